@@ -1,0 +1,57 @@
+"""oracle/tiling.py (numpy restatement) vs fixtures captured from the imported reference
+do_prediction (tests/golden/make_tiling_golden.py; main.py:225-366).  Bit-exact."""
+import json
+import os
+import zlib
+
+import numpy as np
+import pytest
+
+from oracle import tiling
+
+GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "tiling_golden.json")))
+CASES = GOLD["cases"]
+SMALL = [c for c in CASES if c["page_h"] * c["page_w"] <= 1300 * 1300]
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: f"{c['page_h']}x{c['page_w']}_m{c['model_h']}x{c['model_w']}")
+def test_tile_grid_matches_reference_calls(case):
+    tiles, nxf, nyf = tiling.tile_grid(case["page_h"], case["page_w"], case["model_h"], case["model_w"])
+    assert len(tiles) == case["n_calls"] == nxf * nyf
+    assert [[t["x0"], t["y0"]] for t in tiles] == [list(c) for c in case["calls_xy"]]
+
+
+@pytest.mark.parametrize("case", SMALL + [c for c in CASES if (c["page_h"], c["page_w"]) == (3500, 2500)],
+                         ids=lambda c: f"{c['page_h']}x{c['page_w']}_m{c['model_h']}x{c['model_w']}")
+def test_do_prediction_matches_reference_output(case):
+    page = tiling.coord_page(case["page_h"], case["page_w"])
+    fm = tiling.FakeModel(case["model_h"], case["model_w"], case["classes"])
+    res = tiling.do_prediction(True, page, fm)
+    assert str(res.dtype) == case["out_dtype"] and list(res.shape) == case["out_shape"]
+    assert fm.in_dtype == case["predict_in_dtype"] and list(fm.in_shape) == case["predict_in_shape"]
+    assert np.array_equal(res[:, :, 0], res[:, :, 1]) and np.array_equal(res[:, :, 0], res[:, :, 2])
+    for y, x, v in case["probe"]:
+        assert int(res[y, x, 0]) == v
+    assert int(res[:, :, 0].astype(np.int64).sum()) == case["out_sum"]
+    assert zlib.crc32(np.ascontiguousarray(res[:, :, 0]).tobytes()) & 0xFFFFFFFF == case["out_crc32"]
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: f"{c['page_h']}x{c['page_w']}")
+def test_owner_map_covers_page_and_is_last_writer(case):
+    own = tiling.owner_map(case["page_h"], case["page_w"], case["model_h"], case["model_w"])
+    assert own.min() >= 0 and own.max() == case["n_calls"] - 1
+
+
+def test_small_page_is_unsupported_like_reference():
+    # main.py:278/281: page smaller than the model -> negative slice start -> reshape error in the reference
+    fm = tiling.FakeModel(448, 448, 4)
+    with pytest.raises(Exception):
+        tiling.do_prediction(True, tiling.coord_page(300, 500), fm)
+
+
+def test_resize_nearest_rule():
+    a = np.arange(5 * 7).reshape(5, 7)
+    up = tiling.resize_nearest(a, 10, 14)
+    assert up.shape == (10, 14) and np.array_equal(up[::2, ::2], a)
+    dn = tiling.resize_nearest(a, 2, 3)
+    assert np.array_equal(dn, a[[0, 2]][:, [0, 2, 4]])
