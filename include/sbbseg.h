@@ -1,0 +1,144 @@
+/* sbbseg.h -- C ABI of libsbbseg.so: MI355X (gfx950) patch-wise pixel-segmentation inference.
+ *
+ * This is the drop-in boundary for ONE path of qurator-spk/sbb_textline_detection:
+ * `textline_detector.do_prediction()` and the `model.predict()` it calls per 448x448 patch
+ * (reference: qurator/sbb_textline_detector/main.py:225-380).  The reference is Python; its
+ * "FFI" for this path is the Keras model duck type.  A maintainer binds these entry points
+ * with ctypes (the shipped binding is sbb_textline_detection_amd/_capi.py).
+ *
+ * Conventions
+ *   - every function returns 0 on success, non-zero on failure; the message is in
+ *     sbbseg_last_error() (thread-local).  Nothing aborts: the reference's callers rely on
+ *     ordinary Python exceptions (main.py:2061-2157), which the Python shim raises from this.
+ *   - plain pointers and sizes only; host buffers are caller-owned; the library owns only device
+ *     memory behind the opaque handle.  A handle is not thread-safe; distinct handles may be used
+ *     from distinct threads / processes (one process per GPU).
+ *   - "*_dev" variants take device pointers (HBM-resident inputs/outputs, used by bench.py and
+ *     the multi-GPU path); all work is enqueued on the handle's stream (sbbseg_set_stream).
+ */
+#ifndef SBBSEG_H
+#define SBBSEG_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SBBSEG_ABI_VERSION 1
+
+typedef struct sbbseg_ctx sbbseg_ctx;
+
+/* arithmetic mode of a handle */
+#define SBBSEG_PREC_BF16 0   /* bf16 operands, fp32 MFMA accumulate, fp32 epilogue (product path) */
+#define SBBSEG_PREC_F32  1   /* fp32 everything, plain FMA kernels: slow, used to separate plumbing
+                                errors from bf16 rounding in the parity tests */
+
+/* ---- lifecycle: replaces start_new_session_and_model / session.close (main.py:216-223, 428) */
+const char* sbbseg_last_error(void);
+int sbbseg_abi_version(void);
+int sbbseg_device_count(int* count);
+int sbbseg_create(int device, int precision, sbbseg_ctx** out);
+int sbbseg_destroy(sbbseg_ctx* c);                       /* frees all device memory; NULL ok */
+int sbbseg_set_stream(sbbseg_ctx* c, void* hip_stream);  /* NULL -> the handle's own stream */
+int sbbseg_synchronize(sbbseg_ctx* c);
+
+/* ---- plan building: the host-side planner (planner.py) lowers the Keras model_config that the
+ * reference would have handed to keras.models.load_model (main.py:221) into these calls, in
+ * execution order.  Tensors are per-patch NHWC activations; the batch dimension is runtime. */
+
+/* Forms of the network input the kernels consume (both are filled by the ingest kernels):
+ *   SBBSEG_INPUT_C8     [H][W][8]            pixel (y,x) channel c at [y][x][c], channels 3..7 zero
+ *   SBBSEG_INPUT_PAIRS  [H+2p][ceil((W+2p)/2)][8]  zero-padded by p on every side, two horizontal
+ *                       neighbours x 4 channels per 16-byte granule: [y+p][(x+p)>>1][((x+p)&1)*4+c]
+ *                       (lets the 7x7 stride-2 stem run as a 7x4 stride-(2,1) conv over 8 channels) */
+#define SBBSEG_INPUT_C8    0
+#define SBBSEG_INPUT_PAIRS 1
+int sbbseg_set_input(sbbseg_ctx* c, int H, int W, int channels);
+int sbbseg_input_form(sbbseg_ctx* c, int form, int pad, int* tensor_id);
+int sbbseg_add_tensor(sbbseg_ctx* c, int H, int W, int C, int* tensor_id);
+
+typedef struct {
+    int32_t tensor;      /* source tensor id */
+    int32_t channels;    /* channels taken from it (from channel 0), contraction order */
+    int32_t up_shift;    /* 0, or 1 = nearest-neighbour x2 upsampling (UpSampling2D) fused into the gather */
+    int32_t off_y;       /* placement offset of the stored tensor inside the logical one: */
+    int32_t off_x;       /*   logical[y][x] = stored[y-off_y][x-off_x] (zero outside); one_side_pad = (1,1) */
+} sbbseg_conv_src;
+
+typedef struct {
+    int32_t n_src;               /* 1 or 2 (2 = channel concat [src0, src1], Concatenate fused) */
+    sbbseg_conv_src src[2];
+    int32_t kh, kw;
+    int32_t stride_y, stride_x;
+    int32_t pad_top, pad_left;   /* zero padding (ZeroPadding2D / 'same') fused into the gather */
+    int32_t cout;
+    int32_t out_tensor;          /* y = act(scale*conv + shift [+ residual]);  -1 = none */
+    int32_t relu;
+    int32_t residual_tensor;     /* -1 = none (Add fused into the epilogue) */
+    int32_t raw_out_tensor;      /* -1 = none; second output raw_scale*conv + raw_shift, no activation
+                                    (the stem's pre-BN skip f1) */
+} sbbseg_conv_desc;
+
+/* w_hwio: float32 [kh][kw][sum(src.channels)][cout] (Keras kernel layout); scale/shift: float32
+ * [cout] (BatchNorm and bias folded by the caller); raw_*: only if raw_out_tensor >= 0. */
+int sbbseg_add_conv(sbbseg_ctx* c, const sbbseg_conv_desc* d, const float* w_hwio,
+                    const float* scale, const float* shift,
+                    const float* raw_scale, const float* raw_shift);
+int sbbseg_add_maxpool(sbbseg_ctx* c, int src_tensor, int dst_tensor, int k, int stride);
+/* Final 1x1 conv + BN + softmax + argmax (main.py:290) over src_tensor's channels:
+ * w [cin][classes], scale/shift [classes].  Produces u8 labels and (on request) f32 probabilities. */
+int sbbseg_add_head(sbbseg_ctx* c, int src_tensor, int cin, int classes,
+                    const float* w, const float* scale, const float* shift);
+int sbbseg_finalize(sbbseg_ctx* c, int max_batch);
+
+/* ---- queries */
+int sbbseg_model_info(sbbseg_ctx* c, int* H, int* W, int* classes, int* max_batch);
+int sbbseg_num_ops(sbbseg_ctx* c, int* n);
+int sbbseg_op_info(sbbseg_ctx* c, int op, char* name, int name_len, double* flops_per_patch,
+                   double* min_bytes_per_patch);
+int sbbseg_device_bytes(sbbseg_ctx* c, size_t* bytes);
+
+/* ---- seam 2: model.predict (main.py:287-288, 373-374).
+ * x: host float32 [n][H][W][3] already scaled to [0,1]; probs: host float32 [n][H][W][classes]. */
+int sbbseg_predict(sbbseg_ctx* c, const float* x_nhwc, int n, float* probs_nhwc);
+
+/* ---- seam 1, patches=True (main.py:231-366), fused: u8/255 LUT normalise, tile with 10 % margin,
+ * forward, argmax, margin-crop + last-writer-wins stitch.  page: uint8 [Hp][Wp][3];
+ * labels: uint8 [Hp][Wp] (the reference returns this plane replicated x3). */
+int sbbseg_segment_page(sbbseg_ctx* c, const uint8_t* page_hwc, int Hp, int Wp, uint8_t* labels_hw);
+int sbbseg_segment_page_dev(sbbseg_ctx* c, const void* d_page_hwc, int Hp, int Wp, void* d_labels_hw);
+
+/* ---- seam 1, patches=False (main.py:368-380): nearest-resize page to the model size, one forward,
+ * argmax, nearest-resize labels to out_h x out_w (cv2.INTER_NEAREST index rule). */
+int sbbseg_segment_whole(sbbseg_ctx* c, const uint8_t* page_hwc, int Hp, int Wp,
+                         int out_h, int out_w, uint8_t* labels_out);
+
+/* ---- building blocks (multi-GPU sharding, tests).  tile_xy: host int32 [n][2] = (x0, y0) origins.
+ * d_tile_labels: device uint8 [n][H][W]. */
+int sbbseg_tile_grid(int Hp, int Wp, int H, int W, int32_t* tile_xy, int capacity, int* nxf, int* nyf);
+int sbbseg_segment_tiles_dev(sbbseg_ctx* c, const void* d_page_hwc, int Hp, int Wp,
+                             const int32_t* tile_xy, int n_tiles, void* d_tile_labels);
+/* same, for the contiguous range [first_tile, first_tile+n_tiles) of the page's own tile grid in the
+ * reference's call order (x outer, y inner) -- origins come from the closed form, no table upload.
+ * This is the unit of work the multi-GPU path shards. */
+int sbbseg_segment_tile_range_dev(sbbseg_ctx* c, const void* d_page_hwc, int Hp, int Wp,
+                                  int first_tile, int n_tiles, void* d_tile_labels);
+int sbbseg_stitch_dev(sbbseg_ctx* c, const void* d_tile_labels, int Hp, int Wp, void* d_labels_hw);
+/* ingest only (tests): fills both input forms for n tiles and copies form `form` back as float32 */
+int sbbseg_debug_ingest(sbbseg_ctx* c, const uint8_t* page_hwc, int Hp, int Wp, const int32_t* tile_xy,
+                        int n_tiles, int form, float* out, size_t out_floats);
+/* copy an activation tensor of the last run back as float32 [n][H][W][C] (tests) */
+int sbbseg_debug_read_tensor(sbbseg_ctx* c, int tensor_id, int n, float* out, size_t out_floats);
+
+/* ---- per-op timing with HIP events on the handle's stream (bench.py roofline) */
+int sbbseg_profile_enable(sbbseg_ctx* c, int enable);
+int sbbseg_profile_reset(sbbseg_ctx* c);
+/* accumulated since reset: total ms and number of launches for op `op` */
+int sbbseg_profile_get(sbbseg_ctx* c, int op, double* total_ms, int64_t* launches, int64_t* patches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SBBSEG_H */

@@ -1,0 +1,282 @@
+"""ctypes binding of include/sbbseg.h -- the thin layer between the Python host and the HIP library.
+
+There is deliberately no fallback: if libsbbseg.so is missing or a call fails, a RuntimeError is
+raised (the reference's callers expect ordinary Python exceptions, main.py:2061-2157)."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libsbbseg.so")
+
+PREC_BF16, PREC_F32 = 0, 1
+INPUT_C8, INPUT_PAIRS = 0, 1
+
+EXPORTS = [
+    "sbbseg_last_error", "sbbseg_abi_version", "sbbseg_device_count", "sbbseg_create", "sbbseg_destroy",
+    "sbbseg_set_stream", "sbbseg_synchronize", "sbbseg_set_input", "sbbseg_input_form", "sbbseg_add_tensor",
+    "sbbseg_add_conv", "sbbseg_add_maxpool", "sbbseg_add_head", "sbbseg_finalize", "sbbseg_model_info",
+    "sbbseg_num_ops", "sbbseg_op_info", "sbbseg_device_bytes", "sbbseg_predict", "sbbseg_segment_page",
+    "sbbseg_segment_page_dev", "sbbseg_segment_whole", "sbbseg_tile_grid", "sbbseg_segment_tiles_dev",
+    "sbbseg_segment_tile_range_dev", "sbbseg_stitch_dev", "sbbseg_debug_ingest", "sbbseg_debug_read_tensor",
+    "sbbseg_profile_enable", "sbbseg_profile_reset", "sbbseg_profile_get",
+]
+
+
+class ConvSrc(C.Structure):
+    _fields_ = [("tensor", C.c_int32), ("channels", C.c_int32), ("up_shift", C.c_int32),
+                ("off_y", C.c_int32), ("off_x", C.c_int32)]
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [("n_src", C.c_int32), ("src", ConvSrc * 2), ("kh", C.c_int32), ("kw", C.c_int32),
+                ("stride_y", C.c_int32), ("stride_x", C.c_int32), ("pad_top", C.c_int32), ("pad_left", C.c_int32),
+                ("cout", C.c_int32), ("out_tensor", C.c_int32), ("relu", C.c_int32),
+                ("residual_tensor", C.c_int32), ("raw_out_tensor", C.c_int32)]
+
+
+_lib = None
+
+
+def load_library(path: Optional[str] = None):
+    """Load libsbbseg.so (no GPU needed for loading).  Raises if absent."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise RuntimeError(f"{p} not found: build it with `python -m sbb_textline_detection_amd._build` "
+                           "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+    lib = C.CDLL(p)
+    lib.sbbseg_last_error.restype = C.c_char_p
+    vp, i32, f32p = C.c_void_p, C.c_int, C.POINTER(C.c_float)
+    sigs = {
+        "sbbseg_abi_version": [],
+        "sbbseg_device_count": [C.POINTER(C.c_int)],
+        "sbbseg_create": [i32, i32, C.POINTER(vp)],
+        "sbbseg_destroy": [vp],
+        "sbbseg_set_stream": [vp, vp],
+        "sbbseg_synchronize": [vp],
+        "sbbseg_set_input": [vp, i32, i32, i32],
+        "sbbseg_input_form": [vp, i32, i32, C.POINTER(C.c_int)],
+        "sbbseg_add_tensor": [vp, i32, i32, i32, C.POINTER(C.c_int)],
+        "sbbseg_add_conv": [vp, C.POINTER(ConvDesc), vp, vp, vp, vp, vp],
+        "sbbseg_add_maxpool": [vp, i32, i32, i32, i32],
+        "sbbseg_add_head": [vp, i32, i32, i32, vp, vp, vp],
+        "sbbseg_finalize": [vp, i32],
+        "sbbseg_model_info": [vp] + [C.POINTER(C.c_int)] * 4,
+        "sbbseg_num_ops": [vp, C.POINTER(C.c_int)],
+        "sbbseg_op_info": [vp, i32, C.c_char_p, i32, C.POINTER(C.c_double), C.POINTER(C.c_double)],
+        "sbbseg_device_bytes": [vp, C.POINTER(C.c_size_t)],
+        "sbbseg_predict": [vp, vp, i32, vp],
+        "sbbseg_segment_page": [vp, vp, i32, i32, vp],
+        "sbbseg_segment_page_dev": [vp, vp, i32, i32, vp],
+        "sbbseg_segment_whole": [vp, vp, i32, i32, i32, i32, vp],
+        "sbbseg_tile_grid": [i32, i32, i32, i32, vp, i32, C.POINTER(C.c_int), C.POINTER(C.c_int)],
+        "sbbseg_segment_tiles_dev": [vp, vp, i32, i32, vp, i32, vp],
+        "sbbseg_segment_tile_range_dev": [vp, vp, i32, i32, i32, i32, vp],
+        "sbbseg_stitch_dev": [vp, vp, i32, i32, vp],
+        "sbbseg_debug_ingest": [vp, vp, i32, i32, vp, i32, i32, vp, C.c_size_t],
+        "sbbseg_debug_read_tensor": [vp, i32, i32, vp, C.c_size_t],
+        "sbbseg_profile_enable": [vp, i32],
+        "sbbseg_profile_reset": [vp],
+        "sbbseg_profile_get": [vp, i32, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_int64)],
+    }
+    for name, args in sigs.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = C.c_int
+    if lib.sbbseg_abi_version() != 1:
+        raise RuntimeError("libsbbseg ABI version mismatch")
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = "libsbbseg"):
+    if rc != 0:
+        msg = load_library().sbbseg_last_error()
+        raise RuntimeError(f"{what}: {msg.decode('utf-8', 'replace') if msg else 'unknown error'}")
+
+
+def _ptr(a: Optional[np.ndarray]):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class Context:
+    """Owns one sbbseg_ctx (one GPU, one plan)."""
+
+    def __init__(self, device: int = 0, precision: int = PREC_BF16):
+        self.lib = load_library()
+        h = C.c_void_p()
+        check(self.lib.sbbseg_create(device, precision, C.byref(h)), "sbbseg_create")
+        self.h = h
+        self.device, self.precision = device, precision
+        self.tensor_ids = []
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.sbbseg_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- plan upload ---------------------------------------------------------------------------
+    def load_plan(self, plan, max_batch: int):
+        lib, h = self.lib, self.h
+        check(lib.sbbseg_set_input(h, plan.in_h, plan.in_w, 3))
+        ids = []
+        for t in plan.tensors:
+            tid = C.c_int(-1)
+            if t.kind == "input_c8":
+                check(lib.sbbseg_input_form(h, INPUT_C8, 0, C.byref(tid)))
+            elif t.kind == "input_pairs":
+                check(lib.sbbseg_input_form(h, INPUT_PAIRS, t.pad, C.byref(tid)))
+            else:
+                check(lib.sbbseg_add_tensor(h, t.H, t.W, t.C, C.byref(tid)))
+            ids.append(tid.value)
+        self.tensor_ids = ids
+        for s in plan.steps:
+            if s.kind == "conv":
+                d = ConvDesc()
+                d.n_src = len(s.srcs)
+                for k, g in enumerate(s.srcs):
+                    d.src[k] = ConvSrc(ids[g.tensor], g.channels, g.shift, g.off_y, g.off_x)
+                d.kh, d.kw, d.stride_y, d.stride_x = s.kh, s.kw, s.stride_y, s.stride_x
+                d.pad_top, d.pad_left, d.cout = s.pad_top, s.pad_left, s.cout
+                d.out_tensor = ids[s.out] if s.out >= 0 else -1
+                d.relu = int(s.relu)
+                d.residual_tensor = ids[s.residual] if s.residual >= 0 else -1
+                d.raw_out_tensor = ids[s.raw_out] if s.raw_out >= 0 else -1
+                w = np.ascontiguousarray(s.w_hwio, np.float32)
+                sc, sh = np.ascontiguousarray(s.scale, np.float32), np.ascontiguousarray(s.shift, np.float32)
+                rs = None if s.raw_scale is None else np.ascontiguousarray(s.raw_scale, np.float32)
+                rb = None if s.raw_shift is None else np.ascontiguousarray(s.raw_shift, np.float32)
+                check(lib.sbbseg_add_conv(h, C.byref(d), _ptr(w), _ptr(sc), _ptr(sh), _ptr(rs), _ptr(rb)),
+                      f"sbbseg_add_conv({s.name})")
+            elif s.kind == "maxpool":
+                check(lib.sbbseg_add_maxpool(h, ids[s.src], ids[s.dst], s.k, s.stride), f"sbbseg_add_maxpool({s.name})")
+            elif s.kind == "head":
+                w = np.ascontiguousarray(s.w, np.float32)
+                sc, sh = np.ascontiguousarray(s.scale, np.float32), np.ascontiguousarray(s.shift, np.float32)
+                check(lib.sbbseg_add_head(h, ids[s.src], s.cin, s.classes, _ptr(w), _ptr(sc), _ptr(sh)),
+                      f"sbbseg_add_head({s.name})")
+            else:
+                raise RuntimeError(f"unknown plan step {s.kind}")
+        check(lib.sbbseg_finalize(h, int(max_batch)), "sbbseg_finalize")
+
+    # -- queries -------------------------------------------------------------------------------
+    def model_info(self):
+        v = [C.c_int() for _ in range(4)]
+        check(self.lib.sbbseg_model_info(self.h, *[C.byref(x) for x in v]))
+        return tuple(x.value for x in v)          # H, W, classes, max_batch
+
+    def ops(self):
+        n = C.c_int()
+        check(self.lib.sbbseg_num_ops(self.h, C.byref(n)))
+        out = []
+        for i in range(n.value):
+            buf = C.create_string_buffer(128)
+            fl, by = C.c_double(), C.c_double()
+            check(self.lib.sbbseg_op_info(self.h, i, buf, 128, C.byref(fl), C.byref(by)))
+            out.append({"name": buf.value.decode(), "flops": fl.value, "min_bytes": by.value})
+        return out
+
+    def device_bytes(self) -> int:
+        b = C.c_size_t()
+        check(self.lib.sbbseg_device_bytes(self.h, C.byref(b)))
+        return b.value
+
+    def set_stream(self, stream_ptr: int):
+        check(self.lib.sbbseg_set_stream(self.h, C.c_void_p(stream_ptr)))
+
+    def synchronize(self):
+        check(self.lib.sbbseg_synchronize(self.h))
+
+    # -- execution -----------------------------------------------------------------------------
+    def predict(self, x: np.ndarray) -> np.ndarray:
+        H, W, classes, _ = self.model_info()
+        x = np.ascontiguousarray(x, np.float32)
+        if x.ndim != 4 or x.shape[1:] != (H, W, 3):
+            raise ValueError(f"predict expects [n,{H},{W},3], got {x.shape}")
+        out = np.empty((x.shape[0], H, W, classes), np.float32)
+        check(self.lib.sbbseg_predict(self.h, _ptr(x), x.shape[0], _ptr(out)), "sbbseg_predict")
+        return out
+
+    def segment_page(self, page: np.ndarray) -> np.ndarray:
+        page = np.ascontiguousarray(page, np.uint8)
+        if page.ndim != 3 or page.shape[2] != 3:
+            raise ValueError(f"page must be uint8 [H,W,3], got {page.shape}")
+        out = np.empty(page.shape[:2], np.uint8)
+        check(self.lib.sbbseg_segment_page(self.h, _ptr(page), page.shape[0], page.shape[1], _ptr(out)), "sbbseg_segment_page")
+        return out
+
+    def segment_whole(self, page: np.ndarray, out_h: int, out_w: int) -> np.ndarray:
+        page = np.ascontiguousarray(page, np.uint8)
+        out = np.empty((out_h, out_w), np.uint8)
+        check(self.lib.sbbseg_segment_whole(self.h, _ptr(page), page.shape[0], page.shape[1], out_h, out_w, _ptr(out)),
+              "sbbseg_segment_whole")
+        return out
+
+    def segment_page_dev(self, d_page: int, Hp: int, Wp: int, d_labels: int):
+        check(self.lib.sbbseg_segment_page_dev(self.h, C.c_void_p(d_page), Hp, Wp, C.c_void_p(d_labels)), "sbbseg_segment_page_dev")
+
+    def segment_tile_range_dev(self, d_page: int, Hp: int, Wp: int, first: int, n: int, d_tile_labels: int):
+        check(self.lib.sbbseg_segment_tile_range_dev(self.h, C.c_void_p(d_page), Hp, Wp, first, n, C.c_void_p(d_tile_labels)),
+              "sbbseg_segment_tile_range_dev")
+
+    def segment_tiles_dev(self, d_page: int, Hp: int, Wp: int, tile_xy: np.ndarray, d_tile_labels: int):
+        xy = np.ascontiguousarray(tile_xy, np.int32)
+        check(self.lib.sbbseg_segment_tiles_dev(self.h, C.c_void_p(d_page), Hp, Wp, _ptr(xy), xy.shape[0], C.c_void_p(d_tile_labels)),
+              "sbbseg_segment_tiles_dev")
+
+    def stitch_dev(self, d_tile_labels: int, Hp: int, Wp: int, d_labels: int):
+        check(self.lib.sbbseg_stitch_dev(self.h, C.c_void_p(d_tile_labels), Hp, Wp, C.c_void_p(d_labels)), "sbbseg_stitch_dev")
+
+    def debug_ingest(self, page: np.ndarray, tile_xy: np.ndarray, form: int, shape) -> np.ndarray:
+        page = np.ascontiguousarray(page, np.uint8)
+        xy = np.ascontiguousarray(tile_xy, np.int32)
+        out = np.empty((xy.shape[0],) + tuple(shape), np.float32)
+        check(self.lib.sbbseg_debug_ingest(self.h, _ptr(page), page.shape[0], page.shape[1], _ptr(xy), xy.shape[0], form,
+                                           _ptr(out), out.size), "sbbseg_debug_ingest")
+        return out
+
+    def debug_read_tensor(self, plan_tensor: int, n: int, shape) -> np.ndarray:
+        out = np.empty((n,) + tuple(shape), np.float32)
+        check(self.lib.sbbseg_debug_read_tensor(self.h, self.tensor_ids[plan_tensor], n, _ptr(out), out.size),
+              "sbbseg_debug_read_tensor")
+        return out
+
+    # -- profiling -----------------------------------------------------------------------------
+    def profile_enable(self, on: bool):
+        check(self.lib.sbbseg_profile_enable(self.h, int(on)))
+
+    def profile_reset(self):
+        check(self.lib.sbbseg_profile_reset(self.h))
+
+    def profile(self):
+        out = []
+        for i, op in enumerate(self.ops()):
+            ms, ln, pt = C.c_double(), C.c_int64(), C.c_int64()
+            check(self.lib.sbbseg_profile_get(self.h, i, C.byref(ms), C.byref(ln), C.byref(pt)))
+            op.update(total_ms=ms.value, launches=ln.value, patches=pt.value)
+            out.append(op)
+        return out
+
+
+def tile_grid(Hp: int, Wp: int, H: int, W: int):
+    """(tile_xy int32 [n,2], nxf, nyf) from the library's restatement of main.py:246-281."""
+    lib = load_library()
+    nx, ny = C.c_int(), C.c_int()
+    check(lib.sbbseg_tile_grid(Hp, Wp, H, W, None, 0, C.byref(nx), C.byref(ny)), "sbbseg_tile_grid")
+    xy = np.empty((nx.value * ny.value, 2), np.int32)
+    check(lib.sbbseg_tile_grid(Hp, Wp, H, W, _ptr(xy), xy.shape[0], None, None), "sbbseg_tile_grid")
+    return xy, nx.value, ny.value

@@ -1,0 +1,915 @@
+// api.hip -- host side of libsbbseg: the C ABI declared in include/sbbseg.h.
+//
+// Holds the execution plan the Python planner builds (tensors + fused ops), owns all device
+// memory, packs weights into the kernels' contraction order, and drives the per-page pipeline
+//   ingest (u8 -> LUT -> bf16 tiles)  ->  fused conv plan  ->  head (softmax/argmax)  ->  stitch
+// that replaces the reference's per-patch Python loop (main.py:225-380).
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <cmath>
+#include <string>
+#include <vector>
+
+#include "../../include/sbbseg.h"
+#include "internal.h"
+
+using namespace sbbseg;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(const char* fmt, ...)
+{
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return 1;
+}
+
+#define HIPCHK(expr)                                                                                   \
+    do {                                                                                               \
+        hipError_t e_ = (expr);                                                                        \
+        if (e_ != hipSuccess)                                                                          \
+            return fail("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__);   \
+    } while (0)
+
+#define REQUIRE(cond, ...)                    \
+    do {                                      \
+        if (!(cond)) return fail(__VA_ARGS__); \
+    } while (0)
+
+struct Tensor {
+    int H = 0, W = 0, C = 0;
+    size_t elems_per_patch = 0;
+    char* buf = nullptr;          // zero header + data
+    bool is_input_form = false;
+    int form = -1, pad = 0;
+    char* data() const { return buf + kZeroHeaderBytes; }
+};
+
+enum OpType { kConv = 0, kPool = 1, kHead = 2 };
+
+struct ConvOp {
+    sbbseg_conv_desc d;
+    int Ho = 0, Wo = 0;
+    int cout_pad = 0, Ktot = 0, total_ksteps = 0, ksteps[2] = {0, 0};
+    KTabEntry* d_ktab = nullptr;
+    void* d_w = nullptr;
+    float *d_scale = nullptr, *d_shift = nullptr, *d_rscale = nullptr, *d_rshift = nullptr;
+};
+
+struct PoolOp { int src, dst, k, stride, Ho, Wo; };
+
+struct HeadOp {
+    int src, cin, classes;
+    float *d_w = nullptr, *d_scale = nullptr, *d_shift = nullptr;
+};
+
+struct Op {
+    OpType type;
+    std::string name;
+    double flops = 0, min_bytes = 0;
+    ConvOp conv;
+    PoolOp pool;
+    HeadOp head;
+    double prof_ms = 0;
+    int64_t prof_launches = 0, prof_patches = 0;
+};
+
+struct PendingEvent { int op; hipEvent_t a, b; int patches; };
+
+}  // namespace
+
+struct sbbseg_ctx {
+    int device = 0;
+    int precision = kBF16;
+    int elem = 2;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    int in_H = 0, in_W = 0, in_C = 0;
+    std::vector<Tensor> tensors;
+    std::vector<Op> ops;
+    int form_tensor[2] = {-1, -1};
+    int classes = 0, max_batch = 0;
+    bool finalized = false;
+    size_t device_bytes = 0;
+    // run-time buffers
+    float* d_lut = nullptr;
+    int* d_tile_xy = nullptr;          // [max_batch][2]
+    uint8_t* d_batch_labels = nullptr; // [max_batch][H][W] (predict / whole-image path)
+    float* d_probs = nullptr;          // [max_batch][H][W][classes], lazily allocated
+    float* d_xin = nullptr;            // predict(): staged float input, lazily allocated
+    uint8_t* d_page = nullptr; size_t page_cap = 0;
+    uint8_t* d_page_labels = nullptr; size_t page_labels_cap = 0;
+    uint8_t* d_tile_labels = nullptr; size_t tile_labels_cap = 0;
+    int *d_own_x = nullptr, *d_own_y = nullptr; size_t own_cap = 0;
+    int own_Hp = -1, own_Wp = -1, own_nyf = 0;
+    int *d_map = nullptr; size_t map_cap = 0;
+    // profiling
+    bool profiling = false;
+    std::vector<PendingEvent> pending;
+    std::vector<hipEvent_t> free_events;
+};
+
+namespace {
+
+int dmalloc(sbbseg_ctx* c, void** p, size_t bytes)
+{
+    HIPCHK(hipMalloc(p, bytes));
+    c->device_bytes += bytes;
+    return 0;
+}
+
+template <typename T>
+int upload(sbbseg_ctx* c, T** dptr, const T* host, size_t n)
+{
+    if (dmalloc(c, (void**)dptr, n * sizeof(T))) return 1;
+    HIPCHK(hipMemcpy(*dptr, host, n * sizeof(T), hipMemcpyHostToDevice));
+    return 0;
+}
+
+int ensure(sbbseg_ctx* c, void** p, size_t* cap, size_t bytes)
+{
+    if (*cap >= bytes) return 0;
+    if (*p) {
+        HIPCHK(hipStreamSynchronize(c->stream));
+        HIPCHK(hipFree(*p));
+        c->device_bytes -= *cap;
+        *p = nullptr;
+        *cap = 0;
+    }
+    if (dmalloc(c, p, bytes)) return 1;
+    *cap = bytes;
+    return 0;
+}
+
+int margin_of(int W) { return (int)(0.1 * (double)W); }   // main.py:233  int(0.1 * img_width_model)
+
+// per-axis tiles exactly as main.py:246-281: count = ceil(extent/mid); origin t*mid clamped inward
+int axis_tiles(int extent, int tile, int margin, std::vector<int>& origin)
+{
+    const int mid = tile - 2 * margin;
+    if (mid <= 0 || extent < tile) return -1;
+    const int n = (extent + mid - 1) / mid;
+    origin.resize(n);
+    for (int t = 0; t < n; ++t) {
+        int d = t * mid;
+        if (d + tile > extent) d = extent - tile;
+        origin[t] = d;
+    }
+    return n;
+}
+
+// owner table of one axis (closed form of the crop + overwrite order, main.py:294-364)
+void axis_owner(int extent, int tile, int margin, const std::vector<int>& origin, std::vector<int>& own)
+{
+    own.assign(extent, 0);
+    const int n = (int)origin.size();
+    for (int t = 0; t < n; ++t) {
+        const int lo = origin[t] + (t == 0 ? 0 : margin);
+        const int hi = origin[t] + (t == n - 1 ? tile : tile - margin);
+        for (int q = lo; q < hi; ++q) own[q] = (t << 16) | (q - origin[t]);
+    }
+}
+
+// cv2.resize(..., INTER_NEAREST) index rule [EXT OpenCV resizeNN]: min(floor(dst * (1/(dst_len/src_len))), src_len-1)
+void nearest_map(int src_len, int dst_len, std::vector<int>& m)
+{
+    m.resize(dst_len);
+    const double inv = 1.0 / ((double)dst_len / (double)src_len);
+    for (int i = 0; i < dst_len; ++i) {
+        int s = (int)std::floor(i * inv);
+        m[i] = s < src_len - 1 ? s : src_len - 1;
+    }
+}
+
+int get_event(sbbseg_ctx* c, hipEvent_t* e)
+{
+    if (!c->free_events.empty()) {
+        *e = c->free_events.back();
+        c->free_events.pop_back();
+        return 0;
+    }
+    HIPCHK(hipEventCreate(e));
+    return 0;
+}
+
+int resolve_pending(sbbseg_ctx* c)
+{
+    if (c->pending.empty()) return 0;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    for (auto& pe : c->pending) {
+        float ms = 0.f;
+        HIPCHK(hipEventElapsedTime(&ms, pe.a, pe.b));
+        Op& op = c->ops[pe.op];
+        op.prof_ms += ms;
+        op.prof_launches += 1;
+        op.prof_patches += pe.patches;
+        c->free_events.push_back(pe.a);
+        c->free_events.push_back(pe.b);
+    }
+    c->pending.clear();
+    return 0;
+}
+
+// ---- forward pass over n patches whose input forms are already filled -------------------------
+int run_plan(sbbseg_ctx* c, int n, uint8_t* d_labels, float* d_probs)
+{
+    for (size_t i = 0; i < c->ops.size(); ++i) {
+        Op& op = c->ops[i];
+        hipEvent_t ea = nullptr, eb = nullptr;
+        if (c->profiling) {
+            if (get_event(c, &ea) || get_event(c, &eb)) return 1;
+            HIPCHK(hipEventRecord(ea, c->stream));
+        }
+        if (op.type == kConv) {
+            const ConvOp& co = op.conv;
+            ConvParams p;
+            memset(&p, 0, sizeof(p));
+            p.n_src = co.d.n_src;
+            for (int s = 0; s < co.d.n_src; ++s) {
+                const Tensor& t = c->tensors[co.d.src[s].tensor];
+                SrcDesc& sd = p.src[s];
+                sd.base = t.buf;
+                sd.PH = t.H; sd.PW = t.W;
+                sd.pix_bytes = t.C * c->elem;
+                sd.shift = co.d.src[s].up_shift;
+                sd.lim_y = t.H << sd.shift; sd.lim_x = t.W << sd.shift;
+                sd.ksteps = co.ksteps[s];
+            }
+            p.ktab = co.d_ktab; p.w = co.d_w; p.Ktot = co.Ktot; p.total_ksteps = co.total_ksteps;
+            p.Ho = co.Ho; p.Wo = co.Wo; p.M = n * co.Ho * co.Wo;
+            p.sy = co.d.stride_y; p.sx = co.d.stride_x; p.pad_t = co.d.pad_top; p.pad_l = co.d.pad_left;
+            p.cout = co.d.cout; p.scale = co.d_scale; p.shift = co.d_shift;
+            p.out = co.d.out_tensor >= 0 ? c->tensors[co.d.out_tensor].data() : nullptr;
+            p.residual = co.d.residual_tensor >= 0 ? c->tensors[co.d.residual_tensor].data() : nullptr;
+            p.raw_out = co.d.raw_out_tensor >= 0 ? c->tensors[co.d.raw_out_tensor].data() : nullptr;
+            p.raw_scale = co.d_rscale; p.raw_shift = co.d_rshift; p.relu = co.d.relu;
+            HIPCHK(launch_conv(p, c->precision, c->stream));
+        } else if (op.type == kPool) {
+            const PoolOp& po = op.pool;
+            const Tensor& s = c->tensors[po.src];
+            HIPCHK(launch_maxpool(s.data(), c->tensors[po.dst].data(), n, s.H, s.W, s.C, po.k, po.stride, po.Ho, po.Wo,
+                                  c->precision, c->stream));
+        } else {
+            const HeadOp& ho = op.head;
+            const Tensor& s = c->tensors[ho.src];
+            HeadParams hp;
+            hp.src = s.data(); hp.cin = ho.cin; hp.classes = ho.classes; hp.M = n * s.H * s.W;
+            hp.w = ho.d_w; hp.scale = ho.d_scale; hp.shift = ho.d_shift;
+            hp.labels = d_labels; hp.probs = d_probs;
+            HIPCHK(launch_head(hp, c->precision, c->stream));
+        }
+        if (c->profiling) {
+            HIPCHK(hipEventRecord(eb, c->stream));
+            c->pending.push_back({(int)i, ea, eb, n});
+        }
+    }
+    return 0;
+}
+
+int fill_ingest(sbbseg_ctx* c, IngestParams& ip)
+{
+    memset(&ip, 0, sizeof(ip));
+    REQUIRE(c->form_tensor[SBBSEG_INPUT_C8] >= 0, "plan has no C8 input form");
+    const Tensor& c8 = c->tensors[c->form_tensor[SBBSEG_INPUT_C8]];
+    ip.H = c->in_H; ip.W = c->in_W; ip.lut = c->d_lut; ip.c8 = c8.data();
+    if (c->form_tensor[SBBSEG_INPUT_PAIRS] >= 0) {
+        const Tensor& pr = c->tensors[c->form_tensor[SBBSEG_INPUT_PAIRS]];
+        ip.pairs = pr.data(); ip.pad = pr.pad; ip.pairs_w = pr.W;
+    }
+    return 0;
+}
+
+int check_ready(sbbseg_ctx* c)
+{
+    REQUIRE(c != nullptr, "null handle");
+    REQUIRE(c->finalized, "plan not finalized");
+    HIPCHK(hipSetDevice(c->device));
+    return 0;
+}
+
+}  // namespace
+
+// =================================================================================================
+extern "C" {
+
+const char* sbbseg_last_error(void) { return g_err.c_str(); }
+int sbbseg_abi_version(void) { return SBBSEG_ABI_VERSION; }
+
+int sbbseg_device_count(int* count)
+{
+    REQUIRE(count, "null count");
+    HIPCHK(hipGetDeviceCount(count));
+    return 0;
+}
+
+int sbbseg_create(int device, int precision, sbbseg_ctx** out)
+{
+    REQUIRE(out, "null out");
+    REQUIRE(precision == SBBSEG_PREC_BF16 || precision == SBBSEG_PREC_F32, "bad precision %d", precision);
+    int ndev = 0;
+    HIPCHK(hipGetDeviceCount(&ndev));
+    REQUIRE(device >= 0 && device < ndev, "device %d out of range (have %d)", device, ndev);
+    HIPCHK(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, device));
+    REQUIRE(strncmp(prop.gcnArchName, "gfx950", 6) == 0,
+            "libsbbseg is built for gfx950 (MI355X) only; device %d is %s", device, prop.gcnArchName);
+    sbbseg_ctx* c = new sbbseg_ctx();
+    c->device = device;
+    c->precision = precision;
+    c->elem = precision == SBBSEG_PREC_F32 ? 4 : 2;
+    hipError_t e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        delete c;
+        return fail("hipStreamCreate failed: %s", hipGetErrorString(e));
+    }
+    c->stream = c->own_stream;
+    *out = c;
+    return 0;
+}
+
+int sbbseg_destroy(sbbseg_ctx* c)
+{
+    if (!c) return 0;
+    hipSetDevice(c->device);
+    if (c->stream) hipStreamSynchronize(c->stream);
+    for (auto& t : c->tensors)
+        if (t.buf) hipFree(t.buf);
+    for (auto& op : c->ops) {
+        hipFree(op.conv.d_ktab); hipFree(op.conv.d_w); hipFree(op.conv.d_scale); hipFree(op.conv.d_shift);
+        hipFree(op.conv.d_rscale); hipFree(op.conv.d_rshift);
+        hipFree(op.head.d_w); hipFree(op.head.d_scale); hipFree(op.head.d_shift);
+    }
+    hipFree(c->d_lut); hipFree(c->d_tile_xy); hipFree(c->d_batch_labels); hipFree(c->d_probs); hipFree(c->d_xin);
+    hipFree(c->d_page); hipFree(c->d_page_labels); hipFree(c->d_tile_labels);
+    hipFree(c->d_own_x); hipFree(c->d_own_y); hipFree(c->d_map);
+    for (auto& pe : c->pending) { hipEventDestroy(pe.a); hipEventDestroy(pe.b); }
+    for (auto e : c->free_events) hipEventDestroy(e);
+    if (c->own_stream) hipStreamDestroy(c->own_stream);
+    delete c;
+    return 0;
+}
+
+int sbbseg_set_stream(sbbseg_ctx* c, void* hip_stream)
+{
+    REQUIRE(c, "null handle");
+    if (resolve_pending(c)) return 1;
+    c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    return 0;
+}
+
+int sbbseg_synchronize(sbbseg_ctx* c)
+{
+    REQUIRE(c, "null handle");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------- plan building
+int sbbseg_set_input(sbbseg_ctx* c, int H, int W, int channels)
+{
+    REQUIRE(c && !c->finalized, "bad handle / already finalized");
+    REQUIRE(H > 0 && W > 0 && channels == 3, "input must be HxWx3 (got %dx%dx%d)", H, W, channels);
+    c->in_H = H; c->in_W = W; c->in_C = channels;
+    return 0;
+}
+
+int sbbseg_input_form(sbbseg_ctx* c, int form, int pad, int* tensor_id)
+{
+    REQUIRE(c && !c->finalized && tensor_id, "bad handle / already finalized");
+    REQUIRE(c->in_H > 0, "sbbseg_set_input first");
+    REQUIRE(form == SBBSEG_INPUT_C8 || form == SBBSEG_INPUT_PAIRS, "unknown input form %d", form);
+    if (c->form_tensor[form] >= 0) {
+        REQUIRE(c->tensors[c->form_tensor[form]].pad == pad, "input form %d requested with different pad", form);
+        *tensor_id = c->form_tensor[form];
+        return 0;
+    }
+    Tensor t;
+    t.is_input_form = true; t.form = form; t.pad = pad; t.C = 8;
+    if (form == SBBSEG_INPUT_C8) {
+        REQUIRE(pad == 0, "C8 form takes pad 0");
+        t.H = c->in_H; t.W = c->in_W;
+    } else {
+        REQUIRE(pad >= 0, "negative pad");
+        t.H = c->in_H + 2 * pad; t.W = (c->in_W + 2 * pad + 1) / 2;
+    }
+    t.elems_per_patch = (size_t)t.H * t.W * t.C;
+    c->tensors.push_back(t);
+    c->form_tensor[form] = (int)c->tensors.size() - 1;
+    *tensor_id = c->form_tensor[form];
+    return 0;
+}
+
+int sbbseg_add_tensor(sbbseg_ctx* c, int H, int W, int C, int* tensor_id)
+{
+    REQUIRE(c && !c->finalized && tensor_id, "bad handle / already finalized");
+    REQUIRE(H > 0 && W > 0 && C > 0 && C % 8 == 0, "tensor %dx%dx%d: channels must be a positive multiple of 8", H, W, C);
+    Tensor t;
+    t.H = H; t.W = W; t.C = C;
+    t.elems_per_patch = (size_t)H * W * C;
+    c->tensors.push_back(t);
+    *tensor_id = (int)c->tensors.size() - 1;
+    return 0;
+}
+
+int sbbseg_add_conv(sbbseg_ctx* c, const sbbseg_conv_desc* d, const float* w_hwio, const float* scale,
+                    const float* shift, const float* raw_scale, const float* raw_shift)
+{
+    REQUIRE(c && !c->finalized && d && w_hwio && scale && shift, "bad arguments");
+    HIPCHK(hipSetDevice(c->device));
+    REQUIRE(d->n_src == 1 || d->n_src == 2, "n_src must be 1 or 2");
+    REQUIRE(d->cout > 0 && d->cout % 8 == 0, "cout %d must be a positive multiple of 8", d->cout);
+    REQUIRE(d->kh > 0 && d->kw > 0 && d->stride_y > 0 && d->stride_x > 0, "bad kernel/stride");
+    const int ntens = (int)c->tensors.size();
+    int lh = -1, lw = -1, cin_total = 0;
+    for (int s = 0; s < d->n_src; ++s) {
+        const sbbseg_conv_src& cs = d->src[s];
+        REQUIRE(cs.tensor >= 0 && cs.tensor < ntens, "conv source tensor %d undefined", cs.tensor);
+        const Tensor& t = c->tensors[cs.tensor];
+        REQUIRE(cs.channels > 0 && ((cs.channels + 7) / 8) * 8 <= t.C, "conv source takes %d channels of a %d-channel tensor", cs.channels, t.C);
+        REQUIRE(cs.up_shift == 0 || cs.up_shift == 1, "up_shift must be 0 or 1");
+        REQUIRE(!(cs.up_shift && (cs.off_y || cs.off_x)), "offset and upsampling cannot be combined");
+        const int h = (t.H << cs.up_shift) + cs.off_y, w = (t.W << cs.up_shift) + cs.off_x;
+        if (s == 0) { lh = h; lw = w; }
+        REQUIRE(h == lh && w == lw, "concat sources differ in logical size (%dx%d vs %dx%d)", h, w, lh, lw);
+        cin_total += cs.channels;
+    }
+    REQUIRE(d->out_tensor >= 0 || d->raw_out_tensor >= 0, "conv without outputs");
+    int Ho = -1, Wo = -1;
+    for (int which = 0; which < 3; ++which) {
+        const int id = which == 0 ? d->out_tensor : which == 1 ? d->raw_out_tensor : d->residual_tensor;
+        if (id < 0) continue;
+        REQUIRE(id < ntens, "conv output/residual tensor %d undefined", id);
+        const Tensor& t = c->tensors[id];
+        REQUIRE(t.C == d->cout, "conv output tensor has %d channels, cout is %d", t.C, d->cout);
+        if (Ho < 0) { Ho = t.H; Wo = t.W; }
+        REQUIRE(t.H == Ho && t.W == Wo, "conv outputs differ in size");
+    }
+    // the last window must start inside the padded logical input
+    REQUIRE((Ho - 1) * d->stride_y - d->pad_top < lh && (Wo - 1) * d->stride_x - d->pad_left < lw,
+            "conv geometry: output %dx%d does not fit input %dx%d", Ho, Wo, lh, lw);
+
+    Op op;
+    op.type = kConv;
+    ConvOp& co = op.conv;
+    co.d = *d;
+    co.Ho = Ho; co.Wo = Wo;
+    const int bc = c->precision == kBF16 ? conv_tile_bc(d->cout) : 4;
+    co.cout_pad = ((d->cout + bc - 1) / bc) * bc;
+
+    // contraction order: source-major, then tap (ky,kx), then 8-channel granules; each source's
+    // segment padded to whole K-steps (64) with out-of-bounds ("zero") granules.
+    std::vector<KTabEntry> ktab;
+    struct KRef { int s, ky, kx, c0; };
+    std::vector<KRef> kref;
+    for (int s = 0; s < d->n_src; ++s) {
+        const sbbseg_conv_src& cs = d->src[s];
+        const int g8 = (cs.channels + 7) / 8;
+        int granules = 0;
+        for (int ky = 0; ky < d->kh; ++ky)
+            for (int kx = 0; kx < d->kw; ++kx)
+                for (int g = 0; g < g8; ++g) {
+                    KTabEntry e;
+                    e.dy = (int16_t)(ky - cs.off_y);
+                    e.dx = (int16_t)(kx - cs.off_x);
+                    e.coff = g * 8 * c->elem;
+                    ktab.push_back(e);
+                    kref.push_back({s, ky, kx, g * 8});
+                    ++granules;
+                }
+        const int ks = (granules + kGranulesPerStep - 1) / kGranulesPerStep;
+        for (int g = granules; g < ks * kGranulesPerStep; ++g) {
+            KTabEntry e;
+            e.dy = 16000; e.dx = 0; e.coff = 0;
+            ktab.push_back(e);
+            kref.push_back({-1, 0, 0, 0});
+        }
+        co.ksteps[s] = ks;
+        co.total_ksteps += ks;
+    }
+    co.Ktot = co.total_ksteps * kBK;
+    REQUIRE((size_t)co.cout_pad * co.Ktot * c->elem < (size_t)3 << 30, "weight matrix too large");
+
+    // pack weights [cout_pad][Ktot]
+    std::vector<int> cin_base(d->n_src, 0);
+    for (int s = 1; s < d->n_src; ++s) cin_base[s] = cin_base[s - 1] + d->src[s - 1].channels;
+    const size_t wn = (size_t)co.cout_pad * co.Ktot;
+    std::vector<float> wf(wn, 0.f);
+    for (size_t g = 0; g < kref.size(); ++g) {
+        const KRef& r = kref[g];
+        if (r.s < 0) continue;
+        for (int q = 0; q < 8; ++q) {
+            const int ch = r.c0 + q;
+            if (ch >= d->src[r.s].channels) continue;
+            const float* wsrc = w_hwio + ((size_t)(r.ky * d->kw + r.kx) * cin_total + cin_base[r.s] + ch) * d->cout;
+            const size_t k = g * 8 + q;
+            for (int o = 0; o < d->cout; ++o) wf[(size_t)o * co.Ktot + k] = wsrc[o];
+        }
+    }
+    if (c->precision == kBF16) {
+        std::vector<uint16_t> wb(wn);
+        for (size_t i = 0; i < wn; ++i) wb[i] = f32_to_bf16_rne(wf[i]);
+        if (upload(c, (uint16_t**)&co.d_w, wb.data(), wn)) return 1;
+    } else {
+        if (upload(c, (float**)&co.d_w, wf.data(), wn)) return 1;
+    }
+    if (upload(c, &co.d_ktab, ktab.data(), ktab.size())) return 1;
+    std::vector<float> pad_s(co.cout_pad, 0.f), pad_b(co.cout_pad, 0.f);
+    memcpy(pad_s.data(), scale, sizeof(float) * d->cout);
+    memcpy(pad_b.data(), shift, sizeof(float) * d->cout);
+    if (upload(c, &co.d_scale, pad_s.data(), pad_s.size()) || upload(c, &co.d_shift, pad_b.data(), pad_b.size())) return 1;
+    if (d->raw_out_tensor >= 0) {
+        REQUIRE(raw_scale && raw_shift, "raw output needs raw_scale/raw_shift");
+        memcpy(pad_s.data(), raw_scale, sizeof(float) * d->cout);
+        memcpy(pad_b.data(), raw_shift, sizeof(float) * d->cout);
+        if (upload(c, &co.d_rscale, pad_s.data(), pad_s.size()) || upload(c, &co.d_rshift, pad_b.data(), pad_b.size())) return 1;
+    }
+    char nm[96];
+    snprintf(nm, sizeof(nm), "conv%dx%d_s%d_c%dto%d_%dx%d%s%s", d->kh, d->kw, d->stride_y, cin_total, d->cout, Ho, Wo,
+             d->n_src == 2 ? "_cat" : "", d->src[0].up_shift ? "_up" : "");
+    op.name = nm;
+    op.flops = 2.0 * Ho * Wo * d->cout * d->kh * d->kw * cin_total;
+    double bytes = 0;
+    for (int s = 0; s < d->n_src; ++s) {
+        const Tensor& t = c->tensors[d->src[s].tensor];
+        bytes += (double)t.H * t.W * ((d->src[s].channels + 7) / 8 * 8) * c->elem;
+    }
+    const double ob = (double)Ho * Wo * d->cout * c->elem;
+    bytes += (d->out_tensor >= 0 ? ob : 0) + (d->raw_out_tensor >= 0 ? ob : 0) + (d->residual_tensor >= 0 ? ob : 0);
+    op.min_bytes = bytes;
+    c->ops.push_back(op);
+    return 0;
+}
+
+int sbbseg_add_maxpool(sbbseg_ctx* c, int src_tensor, int dst_tensor, int k, int stride)
+{
+    REQUIRE(c && !c->finalized, "bad handle / already finalized");
+    const int ntens = (int)c->tensors.size();
+    REQUIRE(src_tensor >= 0 && src_tensor < ntens && dst_tensor >= 0 && dst_tensor < ntens, "maxpool tensors undefined");
+    const Tensor& s = c->tensors[src_tensor];
+    const Tensor& t = c->tensors[dst_tensor];
+    const int Ho = (s.H - k) / stride + 1, Wo = (s.W - k) / stride + 1;
+    REQUIRE(t.H == Ho && t.W == Wo && t.C == s.C, "maxpool output should be %dx%dx%d", Ho, Wo, s.C);
+    Op op;
+    op.type = kPool;
+    op.pool = {src_tensor, dst_tensor, k, stride, Ho, Wo};
+    char nm[64];
+    snprintf(nm, sizeof(nm), "maxpool%dx%d_s%d_c%d_%dx%d", k, k, stride, s.C, Ho, Wo);
+    op.name = nm;
+    op.flops = 0;
+    op.min_bytes = ((double)s.H * s.W + (double)Ho * Wo) * s.C * c->elem;
+    c->ops.push_back(op);
+    return 0;
+}
+
+int sbbseg_add_head(sbbseg_ctx* c, int src_tensor, int cin, int classes, const float* w, const float* scale,
+                    const float* shift)
+{
+    REQUIRE(c && !c->finalized && w && scale && shift, "bad arguments");
+    HIPCHK(hipSetDevice(c->device));
+    REQUIRE(src_tensor >= 0 && src_tensor < (int)c->tensors.size(), "head source undefined");
+    const Tensor& s = c->tensors[src_tensor];
+    REQUIRE(cin == s.C && cin <= 64, "head cin %d must equal the source channels (%d) and be <= 64", cin, s.C);
+    REQUIRE(classes >= 1 && classes <= 8, "head supports 1..8 classes (got %d)", classes);
+    REQUIRE(s.H == c->in_H && s.W == c->in_W, "head runs at input resolution");
+    REQUIRE(c->classes == 0, "plan already has a head");
+    Op op;
+    op.type = kHead;
+    op.head.src = src_tensor; op.head.cin = cin; op.head.classes = classes;
+    if (upload(c, &op.head.d_w, w, (size_t)cin * classes) || upload(c, &op.head.d_scale, scale, classes) ||
+        upload(c, &op.head.d_shift, shift, classes))
+        return 1;
+    char nm[64];
+    snprintf(nm, sizeof(nm), "head1x1_c%dto%d_softmax_argmax", cin, classes);
+    op.name = nm;
+    op.flops = 2.0 * s.H * s.W * cin * classes;
+    op.min_bytes = (double)s.H * s.W * (cin * c->elem + 1);
+    c->classes = classes;
+    c->ops.push_back(op);
+    return 0;
+}
+
+int sbbseg_finalize(sbbseg_ctx* c, int max_batch)
+{
+    REQUIRE(c && !c->finalized, "bad handle / already finalized");
+    HIPCHK(hipSetDevice(c->device));
+    REQUIRE(max_batch >= 1, "max_batch must be >= 1");
+    REQUIRE(c->classes > 0 && !c->ops.empty() && c->ops.back().type == kHead, "plan must end with a head");
+    c->max_batch = max_batch;
+    for (auto& t : c->tensors) {
+        const size_t bytes = kZeroHeaderBytes + t.elems_per_patch * max_batch * c->elem + 256;
+        REQUIRE(bytes < ((size_t)1 << 32), "tensor %dx%dx%d x batch %d exceeds the 4 GiB gather window", t.H, t.W, t.C, max_batch);
+        if (dmalloc(c, (void**)&t.buf, bytes)) return 1;
+        // input forms rely on their zero borders / zero channels; headers must be zero for every tensor
+        HIPCHK(hipMemset(t.buf, 0, t.is_input_form ? bytes : (size_t)kZeroHeaderBytes));
+    }
+    float lut[256];
+    for (int v = 0; v < 256; ++v) lut[v] = (float)((double)v / 255.0);   // main.py:239 in f64, then Keras' f32 feed
+    if (upload(c, &c->d_lut, lut, 256)) return 1;
+    if (dmalloc(c, (void**)&c->d_tile_xy, sizeof(int) * 2 * max_batch)) return 1;
+    if (dmalloc(c, (void**)&c->d_batch_labels, (size_t)max_batch * c->in_H * c->in_W)) return 1;
+    HIPCHK(hipDeviceSynchronize());
+    c->finalized = true;
+    return 0;
+}
+
+// ----------------------------------------------------------------------------------------- queries
+int sbbseg_model_info(sbbseg_ctx* c, int* H, int* W, int* classes, int* max_batch)
+{
+    REQUIRE(c, "null handle");
+    if (H) *H = c->in_H;
+    if (W) *W = c->in_W;
+    if (classes) *classes = c->classes;
+    if (max_batch) *max_batch = c->max_batch;
+    return 0;
+}
+
+int sbbseg_num_ops(sbbseg_ctx* c, int* n)
+{
+    REQUIRE(c && n, "bad arguments");
+    *n = (int)c->ops.size();
+    return 0;
+}
+
+int sbbseg_op_info(sbbseg_ctx* c, int op, char* name, int name_len, double* flops_per_patch, double* min_bytes_per_patch)
+{
+    REQUIRE(c && op >= 0 && op < (int)c->ops.size(), "op index out of range");
+    if (name && name_len > 0) snprintf(name, name_len, "%s", c->ops[op].name.c_str());
+    if (flops_per_patch) *flops_per_patch = c->ops[op].flops;
+    if (min_bytes_per_patch) *min_bytes_per_patch = c->ops[op].min_bytes;
+    return 0;
+}
+
+int sbbseg_device_bytes(sbbseg_ctx* c, size_t* bytes)
+{
+    REQUIRE(c && bytes, "bad arguments");
+    *bytes = c->device_bytes;
+    return 0;
+}
+
+// -------------------------------------------------------------------------------------- seam 2
+int sbbseg_predict(sbbseg_ctx* c, const float* x_nhwc, int n, float* probs_nhwc)
+{
+    if (check_ready(c)) return 1;
+    REQUIRE(x_nhwc && probs_nhwc && n >= 0, "bad arguments");
+    const size_t per_in = (size_t)c->in_H * c->in_W * 3, per_out = (size_t)c->in_H * c->in_W * c->classes;
+    if (!c->d_xin && dmalloc(c, (void**)&c->d_xin, per_in * c->max_batch * sizeof(float))) return 1;
+    if (!c->d_probs && dmalloc(c, (void**)&c->d_probs, per_out * c->max_batch * sizeof(float))) return 1;
+    IngestParams ip;
+    if (fill_ingest(c, ip)) return 1;
+    for (int done = 0; done < n; done += c->max_batch) {
+        const int nb = n - done < c->max_batch ? n - done : c->max_batch;
+        HIPCHK(hipMemcpyAsync(c->d_xin, x_nhwc + done * per_in, per_in * nb * sizeof(float), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(launch_ingest_f32(c->d_xin, nb, c->in_H, c->in_W, ip.c8, ip.pairs, ip.pad, ip.pairs_w, c->precision, c->stream));
+        if (run_plan(c, nb, c->d_batch_labels, c->d_probs)) return 1;
+        HIPCHK(hipMemcpyAsync(probs_nhwc + done * per_out, c->d_probs, per_out * nb * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+    }
+    return 0;
+}
+
+// -------------------------------------------------------------------------------------- seam 1
+int sbbseg_tile_grid(int Hp, int Wp, int H, int W, int32_t* tile_xy, int capacity, int* nxf, int* nyf)
+{
+    std::vector<int> ox, oy;
+    const int margin = margin_of(W);
+    const int nx = axis_tiles(Wp, W, margin, ox), ny = axis_tiles(Hp, H, margin, oy);
+    REQUIRE(nx > 0 && ny > 0, "page %dx%d is smaller than the model input %dx%d (unsupported by the reference too, main.py:278-281)", Hp, Wp, H, W);
+    if (nxf) *nxf = nx;
+    if (nyf) *nyf = ny;
+    if (tile_xy) {
+        REQUIRE(capacity >= nx * ny, "tile_xy capacity %d < %d tiles", capacity, nx * ny);
+        for (int i = 0; i < nx; ++i)               // x outer, y inner: main.py:259-260
+            for (int j = 0; j < ny; ++j) {
+                tile_xy[2 * (i * ny + j)] = ox[i];
+                tile_xy[2 * (i * ny + j) + 1] = oy[j];
+            }
+    }
+    return 0;
+}
+
+int sbbseg_segment_tiles_dev(sbbseg_ctx* c, const void* d_page_hwc, int Hp, int Wp, const int32_t* tile_xy, int n_tiles,
+                             void* d_tile_labels)
+{
+    if (check_ready(c)) return 1;
+    REQUIRE(d_page_hwc && tile_xy && d_tile_labels && n_tiles >= 0, "bad arguments");
+    for (int t = 0; t < n_tiles; ++t)
+        REQUIRE(tile_xy[2 * t] >= 0 && tile_xy[2 * t] + c->in_W <= Wp && tile_xy[2 * t + 1] >= 0 && tile_xy[2 * t + 1] + c->in_H <= Hp,
+                "tile %d at (%d,%d) leaves the %dx%d page", t, tile_xy[2 * t], tile_xy[2 * t + 1], Hp, Wp);
+    IngestParams ip;
+    if (fill_ingest(c, ip)) return 1;
+    ip.page = (const uint8_t*)d_page_hwc; ip.Hp = Hp; ip.Wp = Wp; ip.tile_xy = c->d_tile_xy;
+    const size_t per = (size_t)c->in_H * c->in_W;
+    for (int done = 0; done < n_tiles; done += c->max_batch) {
+        const int nb = n_tiles - done < c->max_batch ? n_tiles - done : c->max_batch;
+        // explicit origin lists are the slow, general form: the table is re-used per chunk, so wait
+        // for the previous chunk's ingest before overwriting it (the grid form below needs no table)
+        HIPCHK(hipStreamSynchronize(c->stream));
+        HIPCHK(hipMemcpy(c->d_tile_xy, tile_xy + 2 * done, sizeof(int) * 2 * nb, hipMemcpyHostToDevice));
+        ip.n_tiles = nb;
+        HIPCHK(launch_ingest_u8(ip, c->precision, c->stream));
+        if (run_plan(c, nb, (uint8_t*)d_tile_labels + done * per, nullptr)) return 1;
+    }
+    return 0;
+}
+
+int sbbseg_segment_tile_range_dev(sbbseg_ctx* c, const void* d_page_hwc, int Hp, int Wp, int first_tile, int n_tiles,
+                                  void* d_tile_labels)
+{
+    if (check_ready(c)) return 1;
+    REQUIRE(d_page_hwc && d_tile_labels && first_tile >= 0 && n_tiles >= 0, "bad arguments");
+    int nx = 0, ny = 0;
+    if (sbbseg_tile_grid(Hp, Wp, c->in_H, c->in_W, nullptr, 0, &nx, &ny)) return 1;
+    REQUIRE(first_tile + n_tiles <= nx * ny, "tile range [%d,%d) exceeds the %d tiles of the page", first_tile, first_tile + n_tiles, nx * ny);
+    const int margin = margin_of(c->in_W);
+    IngestParams ip;
+    if (fill_ingest(c, ip)) return 1;
+    ip.page = (const uint8_t*)d_page_hwc; ip.Hp = Hp; ip.Wp = Wp; ip.tile_xy = nullptr;
+    ip.grid_nyf = ny; ip.grid_mid_x = c->in_W - 2 * margin; ip.grid_mid_y = c->in_H - 2 * margin;
+    const size_t per = (size_t)c->in_H * c->in_W;
+    for (int done = 0; done < n_tiles; done += c->max_batch) {
+        const int nb = n_tiles - done < c->max_batch ? n_tiles - done : c->max_batch;
+        ip.grid_first = first_tile + done;
+        ip.n_tiles = nb;
+        HIPCHK(launch_ingest_u8(ip, c->precision, c->stream));
+        if (run_plan(c, nb, (uint8_t*)d_tile_labels + done * per, nullptr)) return 1;
+    }
+    return 0;
+}
+
+static int prepare_owner(sbbseg_ctx* c, int Hp, int Wp)
+{
+    if (c->own_Hp == Hp && c->own_Wp == Wp) return 0;
+    std::vector<int> ox, oy, own_x, own_y;
+    const int margin = margin_of(c->in_W);
+    const int nx = axis_tiles(Wp, c->in_W, margin, ox), ny = axis_tiles(Hp, c->in_H, margin, oy);
+    REQUIRE(nx > 0 && ny > 0, "page %dx%d is smaller than the model input", Hp, Wp);
+    axis_owner(Wp, c->in_W, margin, ox, own_x);
+    axis_owner(Hp, c->in_H, margin, oy, own_y);
+    const size_t need = sizeof(int) * (size_t)(Hp > Wp ? Hp : Wp);
+    if (c->own_cap < need) {
+        HIPCHK(hipStreamSynchronize(c->stream));
+        if (c->d_own_x) { HIPCHK(hipFree(c->d_own_x)); HIPCHK(hipFree(c->d_own_y)); c->device_bytes -= 2 * c->own_cap; }
+        c->d_own_x = c->d_own_y = nullptr;
+        if (dmalloc(c, (void**)&c->d_own_x, need) || dmalloc(c, (void**)&c->d_own_y, need)) return 1;
+        c->own_cap = need;
+    }
+    HIPCHK(hipStreamSynchronize(c->stream));   // tables may still be in use by an earlier stitch
+    HIPCHK(hipMemcpy(c->d_own_x, own_x.data(), sizeof(int) * Wp, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(c->d_own_y, own_y.data(), sizeof(int) * Hp, hipMemcpyHostToDevice));
+    c->own_Hp = Hp; c->own_Wp = Wp; c->own_nyf = ny;
+    return 0;
+}
+
+int sbbseg_stitch_dev(sbbseg_ctx* c, const void* d_tile_labels, int Hp, int Wp, void* d_labels_hw)
+{
+    if (check_ready(c)) return 1;
+    REQUIRE(d_tile_labels && d_labels_hw, "bad arguments");
+    if (prepare_owner(c, Hp, Wp)) return 1;
+    HIPCHK(launch_stitch((const uint8_t*)d_tile_labels, c->in_H, c->in_W, c->d_own_x, c->d_own_y, c->own_nyf, Hp, Wp,
+                         (uint8_t*)d_labels_hw, c->stream));
+    return 0;
+}
+
+int sbbseg_segment_page_dev(sbbseg_ctx* c, const void* d_page_hwc, int Hp, int Wp, void* d_labels_hw)
+{
+    if (check_ready(c)) return 1;
+    int nx = 0, ny = 0;
+    if (sbbseg_tile_grid(Hp, Wp, c->in_H, c->in_W, nullptr, 0, &nx, &ny)) return 1;
+    if (ensure(c, (void**)&c->d_tile_labels, &c->tile_labels_cap, (size_t)nx * ny * c->in_H * c->in_W)) return 1;
+    if (sbbseg_segment_tile_range_dev(c, d_page_hwc, Hp, Wp, 0, nx * ny, c->d_tile_labels)) return 1;
+    return sbbseg_stitch_dev(c, c->d_tile_labels, Hp, Wp, d_labels_hw);
+}
+
+int sbbseg_segment_page(sbbseg_ctx* c, const uint8_t* page_hwc, int Hp, int Wp, uint8_t* labels_hw)
+{
+    if (check_ready(c)) return 1;
+    REQUIRE(page_hwc && labels_hw, "bad arguments");
+    REQUIRE(Hp >= c->in_H && Wp >= c->in_W, "page %dx%d is smaller than the model input %dx%d (unsupported by the reference too, main.py:278-281)", Hp, Wp, c->in_H, c->in_W);
+    const size_t pix = (size_t)Hp * Wp;
+    if (ensure(c, (void**)&c->d_page, &c->page_cap, pix * 3)) return 1;
+    if (ensure(c, (void**)&c->d_page_labels, &c->page_labels_cap, pix)) return 1;
+    HIPCHK(hipMemcpyAsync(c->d_page, page_hwc, pix * 3, hipMemcpyHostToDevice, c->stream));
+    if (sbbseg_segment_page_dev(c, c->d_page, Hp, Wp, c->d_page_labels)) return 1;
+    HIPCHK(hipMemcpyAsync(labels_hw, c->d_page_labels, pix, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int sbbseg_segment_whole(sbbseg_ctx* c, const uint8_t* page_hwc, int Hp, int Wp, int out_h, int out_w, uint8_t* labels_out)
+{
+    if (check_ready(c)) return 1;
+    REQUIRE(page_hwc && labels_out && Hp > 0 && Wp > 0 && out_h > 0 && out_w > 0, "bad arguments");
+    const size_t pix = (size_t)Hp * Wp, opix = (size_t)out_h * out_w;
+    if (ensure(c, (void**)&c->d_page, &c->page_cap, pix * 3)) return 1;
+    if (ensure(c, (void**)&c->d_page_labels, &c->page_labels_cap, opix)) return 1;
+    std::vector<int> my, mx, oy, ox;
+    nearest_map(Hp, c->in_H, my);          // model row  -> page row   (main.py:371)
+    nearest_map(Wp, c->in_W, mx);
+    nearest_map(c->in_H, out_h, oy);       // output row -> model row  (main.py:378)
+    nearest_map(c->in_W, out_w, ox);
+    const size_t need = sizeof(int) * (size_t)(c->in_H + c->in_W + out_h + out_w);
+    if (ensure(c, (void**)&c->d_map, &c->map_cap, need)) return 1;
+    int* d_my = c->d_map; int* d_mx = d_my + c->in_H; int* d_oy = d_mx + c->in_W; int* d_ox = d_oy + out_h;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipMemcpy(d_my, my.data(), sizeof(int) * c->in_H, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d_mx, mx.data(), sizeof(int) * c->in_W, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d_oy, oy.data(), sizeof(int) * out_h, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d_ox, ox.data(), sizeof(int) * out_w, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpyAsync(c->d_page, page_hwc, pix * 3, hipMemcpyHostToDevice, c->stream));
+    IngestParams ip;
+    if (fill_ingest(c, ip)) return 1;
+    ip.page = c->d_page; ip.Hp = Hp; ip.Wp = Wp; ip.tile_xy = c->d_tile_xy; ip.n_tiles = 1;
+    ip.map_y = d_my; ip.map_x = d_mx;
+    HIPCHK(launch_ingest_u8(ip, c->precision, c->stream));
+    if (run_plan(c, 1, c->d_batch_labels, nullptr)) return 1;
+    HIPCHK(launch_resize_labels(c->d_batch_labels, c->in_H, c->in_W, d_oy, d_ox, out_h, out_w, c->d_page_labels, c->stream));
+    HIPCHK(hipMemcpyAsync(labels_out, c->d_page_labels, opix, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+// ----------------------------------------------------------------------------------------- debug
+int sbbseg_debug_ingest(sbbseg_ctx* c, const uint8_t* page_hwc, int Hp, int Wp, const int32_t* tile_xy, int n_tiles,
+                        int form, float* out, size_t out_floats)
+{
+    if (check_ready(c)) return 1;
+    REQUIRE(page_hwc && tile_xy && out && n_tiles >= 1 && n_tiles <= c->max_batch, "bad arguments (n_tiles <= max_batch)");
+    REQUIRE(form == SBBSEG_INPUT_C8 || form == SBBSEG_INPUT_PAIRS, "unknown form");
+    REQUIRE(c->form_tensor[form] >= 0, "plan does not use input form %d", form);
+    const Tensor& t = c->tensors[c->form_tensor[form]];
+    const size_t n = t.elems_per_patch * n_tiles;
+    REQUIRE(out_floats >= n, "output buffer too small (%zu < %zu)", out_floats, n);
+    const size_t pix = (size_t)Hp * Wp;
+    if (ensure(c, (void**)&c->d_page, &c->page_cap, pix * 3)) return 1;
+    HIPCHK(hipMemcpyAsync(c->d_page, page_hwc, pix * 3, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipMemcpy(c->d_tile_xy, tile_xy, sizeof(int) * 2 * n_tiles, hipMemcpyHostToDevice));
+    IngestParams ip;
+    if (fill_ingest(c, ip)) return 1;
+    ip.page = c->d_page; ip.Hp = Hp; ip.Wp = Wp; ip.tile_xy = c->d_tile_xy; ip.n_tiles = n_tiles;
+    HIPCHK(launch_ingest_u8(ip, c->precision, c->stream));
+    float* d_tmp = nullptr;
+    HIPCHK(hipMalloc((void**)&d_tmp, n * sizeof(float)));
+    hipError_t e = launch_to_f32(t.data(), d_tmp, n, c->precision, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(out, d_tmp, n * sizeof(float), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    hipFree(d_tmp);
+    HIPCHK(e);
+    return 0;
+}
+
+int sbbseg_debug_read_tensor(sbbseg_ctx* c, int tensor_id, int n, float* out, size_t out_floats)
+{
+    if (check_ready(c)) return 1;
+    REQUIRE(tensor_id >= 0 && tensor_id < (int)c->tensors.size() && out && n >= 1 && n <= c->max_batch, "bad arguments");
+    const Tensor& t = c->tensors[tensor_id];
+    const size_t cnt = t.elems_per_patch * n;
+    REQUIRE(out_floats >= cnt, "output buffer too small (%zu < %zu)", out_floats, cnt);
+    float* d_tmp = nullptr;
+    HIPCHK(hipMalloc((void**)&d_tmp, cnt * sizeof(float)));
+    hipError_t e = launch_to_f32(t.data(), d_tmp, cnt, c->precision, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(out, d_tmp, cnt * sizeof(float), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    hipFree(d_tmp);
+    HIPCHK(e);
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------- profiling
+int sbbseg_profile_enable(sbbseg_ctx* c, int enable)
+{
+    REQUIRE(c, "null handle");
+    if (resolve_pending(c)) return 1;
+    c->profiling = enable != 0;
+    return 0;
+}
+
+int sbbseg_profile_reset(sbbseg_ctx* c)
+{
+    REQUIRE(c, "null handle");
+    if (resolve_pending(c)) return 1;
+    for (auto& op : c->ops) { op.prof_ms = 0; op.prof_launches = 0; op.prof_patches = 0; }
+    return 0;
+}
+
+int sbbseg_profile_get(sbbseg_ctx* c, int op, double* total_ms, int64_t* launches, int64_t* patches)
+{
+    REQUIRE(c && op >= 0 && op < (int)c->ops.size(), "op index out of range");
+    if (resolve_pending(c)) return 1;
+    if (total_ms) *total_ms = c->ops[op].prof_ms;
+    if (launches) *launches = c->ops[op].prof_launches;
+    if (patches) *patches = c->ops[op].prof_patches;
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,99 @@
+// internal.h -- structures shared by the host plan (api.hip) and the gfx950 kernels (kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace sbbseg {
+
+// Every activation buffer starts with a zeroed header; gather lanes that fall into padding (conv
+// zero padding, one_side_pad, K padding) read their 16 bytes from offset 0 of the buffer instead
+// of branching -- global_load_lds cannot predicate per lane.
+constexpr int kZeroHeaderBytes = 256;
+constexpr int kBK = 64;               // contraction elements per K-step (8 granules of 8 bf16 = 16 B)
+constexpr int kGranulesPerStep = 8;
+
+struct SrcDesc {
+    const char* base;     // buffer start (zero header first, data at +kZeroHeaderBytes)
+    int PH, PW;           // stored (physical) height / width per patch
+    int pix_bytes;        // bytes per stored pixel (channels * elem size)
+    int shift;            // nearest upsampling log2 (0|1)
+    int lim_y, lim_x;     // PH << shift, PW << shift
+    int ksteps;           // K-steps contributed by this source
+};
+
+// one entry per 16-byte granule of the contraction axis
+struct KTabEntry {
+    int16_t dy, dx;       // tap offset minus the source's placement offset
+    int32_t coff;         // byte offset of the granule inside the stored pixel
+};
+
+struct ConvParams {
+    SrcDesc src[2];
+    int n_src;
+    const KTabEntry* ktab;    // [total_ksteps * 8]
+    const void* w;            // packed [cout_pad][Ktot] (bf16) -- K order = ktab order
+    int Ktot;                 // total_ksteps * 64
+    int total_ksteps;
+    int M;                    // batch * Ho * Wo output pixels
+    int Ho, Wo;
+    int sy, sx, pad_t, pad_l;
+    int cout;                 // real output channels (multiple of 8)
+    const float* scale;       // [cout_pad]
+    const float* shift;
+    void* out;                // data pointer (header skipped), [M][cout]; may be null
+    const void* residual;     // same shape as out, or null
+    void* raw_out;            // or null
+    const float* raw_scale;
+    const float* raw_shift;
+    int relu;
+};
+
+struct HeadParams {
+    const void* src;          // [M][cin] activations (data pointer)
+    int cin;                  // <= 64, multiple of 8
+    int classes;              // <= 8
+    int M;
+    const float* w;           // [cin][classes]
+    const float* scale;       // [classes]
+    const float* shift;
+    uint8_t* labels;          // [M]
+    float* probs;             // [M][classes] or null
+};
+
+struct IngestParams {
+    const uint8_t* page;      // [Hp][Wp][3] u8 (device)
+    int Hp, Wp;
+    const int* tile_xy;       // device [n][2] explicit origins, or null = closed-form grid below
+    int grid_first, grid_nyf; // grid mode: tile t = grid_first + local index; i = t / nyf, j = t % nyf
+    int grid_mid_x, grid_mid_y; //   origin = min(i*mid_x, Wp-W), min(j*mid_y, Hp-H)   (main.py:262-281)
+    int n_tiles;
+    int H, W;                 // model input size
+    const float* lut;         // [256] float32(v / 255.0)
+    void* c8;                 // data pointer of the C8 form  [n][H][W][8]
+    void* pairs;              // data pointer of the PAIRS form [n][H+2p][PWp][8]; may be null
+    int pad, pairs_w;         // p, ceil((W+2p)/2)
+    const int* map_y;         // optional nearest-resize gather tables (whole-image branch) or null
+    const int* map_x;
+};
+
+enum Precision { kBF16 = 0, kF32 = 1 };
+
+// launchers implemented in kernels.hip ---------------------------------------------------------
+hipError_t launch_conv(const ConvParams& p, int precision, hipStream_t s);
+hipError_t launch_maxpool(const void* src, void* dst, int n, int H, int W, int C, int k, int stride,
+                          int Ho, int Wo, int precision, hipStream_t s);
+hipError_t launch_head(const HeadParams& p, int precision, hipStream_t s);
+hipError_t launch_ingest_u8(const IngestParams& p, int precision, hipStream_t s);
+hipError_t launch_ingest_f32(const float* x, int n, int H, int W, void* c8, void* pairs, int pad,
+                             int pairs_w, int precision, hipStream_t s);
+hipError_t launch_stitch(const uint8_t* tile_labels, int H, int W, const int* own_x, const int* own_y,
+                         int nyf, int Hp, int Wp, uint8_t* out, hipStream_t s);
+hipError_t launch_resize_labels(const uint8_t* labels, int H, int W, const int* map_y, const int* map_x,
+                                int out_h, int out_w, uint8_t* out, hipStream_t s);
+hipError_t launch_to_f32(const void* src, float* dst, size_t n, int precision, hipStream_t s);
+
+int conv_tile_bc(int cout);   // channel-tile width the bf16 conv kernel uses for `cout` (weights are padded to it)
+uint16_t f32_to_bf16_rne(float f);
+float bf16_to_f32(uint16_t h);
+
+}  // namespace sbbseg

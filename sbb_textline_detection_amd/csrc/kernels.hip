@@ -1,0 +1,565 @@
+// kernels.hip -- gfx950 (MI355X, CDNA4) device code of libsbbseg.
+//
+// Hot kernel: conv_igemm_bf16 -- im2col-free implicit-GEMM convolution on MFMA.
+//   D[channel][pixel] = sum_k W[channel][k] * X[pixel][k]     (v_mfma_f32_16x16x32_bf16, fp32 acc)
+//   * the contraction axis k walks (source, tap, channel) in 16-byte granules described by a small
+//     table (KTabEntry); nearest x2 upsampling, channel concat of two sources, zero padding and
+//     the one_side_pad shift are address arithmetic in the gather -- no tensor is materialised
+//   * operands go HBM/L2 -> LDS with global_load_lds_dwordx4 (per-lane source address = gather,
+//     lane-linear LDS image, XOR-swizzled through the *source* granule choice), double buffered
+//   * MFMA "A" operand = weights, "B" = pixels, so a lane ends up with 4 consecutive channels of
+//     one pixel: the NHWC epilogue store is 8 contiguous bytes per lane, BN scale/shift, residual
+//     add and ReLU are applied in fp32 registers.
+// Everything else here (ingest, max-pool, head, stitch, resize) is HBM-bound byte shuffling.
+#include "internal.h"
+
+namespace sbbseg {
+
+typedef __attribute__((ext_vector_type(8))) short bf16x8_t;   // 8 bf16 = one 16-byte granule
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+
+#define GLOBAL_AS __attribute__((address_space(1)))
+#define LDS_AS __attribute__((address_space(3)))
+
+__host__ __device__ inline uint16_t bf16_bits_rne(float f)
+{
+    uint32_t u = __builtin_bit_cast(uint32_t, f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);   // NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+uint16_t f32_to_bf16_rne(float f) { return bf16_bits_rne(f); }
+float bf16_to_f32(uint16_t h) { uint32_t u = (uint32_t)h << 16; return __builtin_bit_cast(float, u); }
+
+__device__ inline float bf16_lo(uint32_t v) { return __builtin_bit_cast(float, v << 16); }
+__device__ inline float bf16_hi(uint32_t v) { return __builtin_bit_cast(float, v & 0xffff0000u); }
+__device__ inline uint32_t pack_bf16x2(float a, float b)
+{
+    uint32_t r;                                   // gfx950 packed RNE convert (no builtin)
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+// ------------------------------------------------------------------------------------------------
+// conv_igemm_bf16
+// ------------------------------------------------------------------------------------------------
+template <int BP, int BC, int WP, int WC>
+struct ConvTile {
+    static constexpr int kThreads = 256;
+    static constexpr int kWPX = BP / WP;          // pixels per wave tile
+    static constexpr int kWCH = BC / WC;          // channels per wave tile
+    static constexpr int kNI = kWPX / 16;
+    static constexpr int kMI = kWCH / 16;
+    static constexpr int kPLoads = BP / 32;       // global_load_lds per thread per K-step, pixels
+    static constexpr int kWLoads = BC / 32;       // ... weights
+    static constexpr int kStageBytes = (BP + BC) * 128;
+    static constexpr int kLdsBytes = 2 * kStageBytes;
+};
+
+template <int BP, int BC, int WP, int WC>
+__global__ __launch_bounds__(256, 2) void conv_igemm_bf16(const ConvParams p)
+{
+    using T = ConvTile<BP, BC, WP, WC>;
+    static_assert(WP * WC == 4, "4 waves");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wp = wave / WC, wc = wave % WC;
+
+    const int n_ct = (p.cout + BC - 1) / BC;
+    const int ctile = blockIdx.x % n_ct;
+    const int ptile = blockIdx.x / n_ct;
+
+    // ---- per-thread gather rows (fixed over the K loop)
+    const int lrow = lane >> 3;                         // row inside an 8-row glds group
+    const int gsrc = (lane & 7) ^ lrow;                 // source granule this lane fetches (swizzle)
+    int r_n[T::kPLoads], r_iy[T::kPLoads], r_ix[T::kPLoads];
+    const int HoWo = p.Ho * p.Wo;
+#pragma unroll
+    for (int j = 0; j < T::kPLoads; ++j) {
+        const int m = ptile * BP + j * 32 + wave * 8 + lrow;
+        if (m < p.M) {
+            const int n = m / HoWo;
+            const int rem = m - n * HoWo;
+            const int oy = rem / p.Wo;
+            const int ox = rem - oy * p.Wo;
+            r_n[j] = n;
+            r_iy[j] = oy * p.sy - p.pad_t;
+            r_ix[j] = ox * p.sx - p.pad_l;
+        } else {
+            r_n[j] = 0;
+            r_iy[j] = -(1 << 20);                       // always out of bounds -> zero granule
+            r_ix[j] = 0;
+        }
+    }
+    // weights: row = ctile*BC + j*32 + wave*8 + lrow ; byte offset of this lane's granule at K-step 0
+    uint32_t w_off[T::kWLoads];
+#pragma unroll
+    for (int j = 0; j < T::kWLoads; ++j)
+        w_off[j] = (uint32_t)((ctile * BC + j * 32 + wave * 8 + lrow) * p.Ktot + gsrc * 8) * 2u;
+    const char* wbase = (const char*)p.w;
+
+    const int nt = p.total_ksteps;
+    KTabEntry e = p.ktab[gsrc];                         // entry of the K-step staged next
+    auto stage = [&](int t, int buf) {
+        // source of this K-step (uniform)
+        const bool s1 = (p.n_src > 1) && (t >= p.src[0].ksteps);
+        const SrcDesc& sd = s1 ? p.src[1] : p.src[0];
+        char* lds_p = smem + buf * T::kStageBytes;
+        char* lds_w = lds_p + BP * 128;
+#pragma unroll
+        for (int j = 0; j < T::kPLoads; ++j) {
+            const int uy = r_iy[j] + e.dy;
+            const int ux = r_ix[j] + e.dx;
+            const bool ok = ((unsigned)uy < (unsigned)sd.lim_y) & ((unsigned)ux < (unsigned)sd.lim_x);
+            const int yy = uy >> sd.shift, xx = ux >> sd.shift;
+            uint32_t off = (uint32_t)((r_n[j] * sd.PH + yy) * sd.PW + xx) * (uint32_t)sd.pix_bytes
+                           + (uint32_t)e.coff + (uint32_t)kZeroHeaderBytes;
+            off = ok ? off : 0u;
+            __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(sd.base + off),
+                                             (LDS_AS void*)(lds_p + (j * 32 + wave * 8) * 128), 16, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < T::kWLoads; ++j) {
+            __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(wbase + w_off[j] + (uint32_t)t * (kBK * 2)),
+                                             (LDS_AS void*)(lds_w + (j * 32 + wave * 8) * 128), 16, 0, 0);
+        }
+        // table entry for the following K-step: in flight under the MFMAs, drained with the glds
+        e = p.ktab[min(t + 1, nt - 1) * kGranulesPerStep + gsrc];
+    };
+
+    f32x4_t acc[T::kMI][T::kNI];
+#pragma unroll
+    for (int mi = 0; mi < T::kMI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < T::kNI; ++ni) acc[mi][ni] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    // LDS read offsets: row r, granule g lives at r*128 + ((g ^ (r & 7)) * 16)
+    const int frow = lane & 15;
+    const int fg = lane >> 4;
+    const int rd_k0 = frow * 128 + (((0 + fg) ^ (frow & 7)) << 4);
+    const int rd_k1 = frow * 128 + (((4 + fg) ^ (frow & 7)) << 4);
+    const int p_rd = (wp * T::kWPX) * 128;
+    const int w_rd = BP * 128 + (wc * T::kWCH) * 128;
+
+    stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    for (int t = 0; t < nt; ++t) {
+        const int cur = t & 1;
+        if (t + 1 < nt) stage(t + 1, cur ^ 1);
+        const char* sb = smem + cur * T::kStageBytes;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int rd = kk ? rd_k1 : rd_k0;
+            bf16x8_t a[T::kMI], b[T::kNI];
+#pragma unroll
+            for (int mi = 0; mi < T::kMI; ++mi)
+                a[mi] = *(const bf16x8_t*)(sb + w_rd + mi * 16 * 128 + rd);
+#pragma unroll
+            for (int ni = 0; ni < T::kNI; ++ni)
+                b[ni] = *(const bf16x8_t*)(sb + p_rd + ni * 16 * 128 + rd);
+#pragma unroll
+            for (int mi = 0; mi < T::kMI; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < T::kNI; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+
+    // ---- epilogue: lane holds channels c0..c0+3 (rows of D) of pixel m (column of D)
+#pragma unroll
+    for (int mi = 0; mi < T::kMI; ++mi) {
+        const int c0 = ctile * BC + wc * T::kWCH + mi * 16 + fg * 4;
+        if (c0 >= p.cout) continue;
+        const float4 sc = *(const float4*)(p.scale + c0);
+        const float4 sh = *(const float4*)(p.shift + c0);
+        float4 rsc = make_float4(1.f, 1.f, 1.f, 1.f), rsh = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p.raw_out) {
+            rsc = *(const float4*)(p.raw_scale + c0);
+            rsh = *(const float4*)(p.raw_shift + c0);
+        }
+#pragma unroll
+        for (int ni = 0; ni < T::kNI; ++ni) {
+            const int m = ptile * BP + wp * T::kWPX + ni * 16 + frow;
+            if (m >= p.M) continue;
+            const f32x4_t v = acc[mi][ni];
+            const size_t o = (size_t)m * p.cout + c0;
+            if (p.raw_out) {
+                uint2 r;
+                r.x = pack_bf16x2(v[0] * rsc.x + rsh.x, v[1] * rsc.y + rsh.y);
+                r.y = pack_bf16x2(v[2] * rsc.z + rsh.z, v[3] * rsc.w + rsh.w);
+                *(uint2*)((uint16_t*)p.raw_out + o) = r;
+            }
+            if (p.out) {
+                float y0 = v[0] * sc.x + sh.x, y1 = v[1] * sc.y + sh.y;
+                float y2 = v[2] * sc.z + sh.z, y3 = v[3] * sc.w + sh.w;
+                if (p.residual) {
+                    const uint2 rr = *(const uint2*)((const uint16_t*)p.residual + o);
+                    y0 += bf16_lo(rr.x); y1 += bf16_hi(rr.x);
+                    y2 += bf16_lo(rr.y); y3 += bf16_hi(rr.y);
+                }
+                if (p.relu) {
+                    y0 = fmaxf(y0, 0.f); y1 = fmaxf(y1, 0.f); y2 = fmaxf(y2, 0.f); y3 = fmaxf(y3, 0.f);
+                }
+                uint2 r;
+                r.x = pack_bf16x2(y0, y1);
+                r.y = pack_bf16x2(y2, y3);
+                *(uint2*)((uint16_t*)p.out + o) = r;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// conv_naive_f32 -- SBBSEG_PREC_F32 handles only: same gather table, plain fp32 FMA.  Slow on
+// purpose-free grounds: it exists to separate plumbing errors from bf16 rounding in parity tests.
+// One thread = one pixel x 4 channels.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void conv_naive_f32(const ConvParams p)
+{
+    const int cgroups = p.cout / 4;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)p.M * cgroups) return;
+    const int m = (int)(idx / cgroups);
+    const int c0 = (int)(idx - (long)m * cgroups) * 4;
+    const int HoWo = p.Ho * p.Wo;
+    const int n = m / HoWo;
+    const int rem = m - n * HoWo;
+    const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+    const int iy0 = oy * p.sy - p.pad_t, ix0 = ox * p.sx - p.pad_l;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    const float* w = (const float*)p.w;
+    int t = 0;
+    for (int s = 0; s < p.n_src; ++s) {
+        const SrcDesc sd = p.src[s];
+        for (int ks = 0; ks < sd.ksteps; ++ks, ++t) {
+            for (int g = 0; g < kGranulesPerStep; ++g) {
+                const KTabEntry e = p.ktab[t * kGranulesPerStep + g];
+                const int uy = iy0 + e.dy, ux = ix0 + e.dx;
+                if (!(((unsigned)uy < (unsigned)sd.lim_y) & ((unsigned)ux < (unsigned)sd.lim_x))) continue;
+                const int yy = uy >> sd.shift, xx = ux >> sd.shift;
+                const float* xp = (const float*)(sd.base + kZeroHeaderBytes +
+                                                 (size_t)((n * sd.PH + yy) * sd.PW + xx) * sd.pix_bytes + e.coff);
+                const int k0 = (t * kGranulesPerStep + g) * 8;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const float xv = xp[q];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) acc[c] = fmaf(xv, w[(size_t)(c0 + c) * p.Ktot + k0 + q], acc[c]);
+                }
+            }
+        }
+    }
+    const size_t o = (size_t)m * p.cout + c0;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        if (p.raw_out) ((float*)p.raw_out)[o + c] = acc[c] * p.raw_scale[c0 + c] + p.raw_shift[c0 + c];
+        if (p.out) {
+            float y = acc[c] * p.scale[c0 + c] + p.shift[c0 + c];
+            if (p.residual) y += ((const float*)p.residual)[o + c];
+            if (p.relu) y = fmaxf(y, 0.f);
+            ((float*)p.out)[o + c] = y;
+        }
+    }
+}
+
+int conv_tile_bc(int cout) { return cout >= 128 ? 128 : (cout > 32 ? 64 : 32); }
+
+template <int BP, int BC, int WP, int WC>
+static hipError_t launch_conv_t(const ConvParams& p, hipStream_t s)
+{
+    using T = ConvTile<BP, BC, WP, WC>;
+    static bool attr_done[64] = {};
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (!attr_done[dev & 63]) {
+        e = hipFuncSetAttribute((const void*)conv_igemm_bf16<BP, BC, WP, WC>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, T::kLdsBytes);
+        if (e != hipSuccess) return e;
+        attr_done[dev & 63] = true;
+    }
+    const int n_ct = (p.cout + BC - 1) / BC;
+    const int n_pt = (p.M + BP - 1) / BP;
+    hipLaunchKernelGGL((conv_igemm_bf16<BP, BC, WP, WC>), dim3(n_ct * n_pt), dim3(256), T::kLdsBytes, s, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_conv(const ConvParams& p, int precision, hipStream_t s)
+{
+    if (precision == kF32) {
+        const long total = (long)p.M * (p.cout / 4);
+        hipLaunchKernelGGL(conv_naive_f32, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, p);
+        return hipGetLastError();
+    }
+    switch (conv_tile_bc(p.cout)) {
+        case 128: return launch_conv_t<128, 128, 2, 2>(p, s);
+        case 64: return launch_conv_t<256, 64, 4, 1>(p, s);
+        default: return launch_conv_t<256, 32, 4, 1>(p, s);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// element helpers for the HBM-bound kernels (E = uint16_t bf16 bits | float)
+// ------------------------------------------------------------------------------------------------
+template <typename E> __device__ inline E to_elem(float v);
+template <> __device__ inline uint16_t to_elem<uint16_t>(float v) { return bf16_bits_rne(v); }
+template <> __device__ inline float to_elem<float>(float v) { return v; }
+template <typename E> __device__ inline float from_elem(E v);
+template <> __device__ inline float from_elem<uint16_t>(uint16_t v) { return __builtin_bit_cast(float, (uint32_t)v << 16); }
+template <> __device__ inline float from_elem<float>(float v) { return v; }
+
+template <typename E> struct alignas(16) Vec8 { E v[8]; };
+template <typename E> struct alignas(sizeof(E) * 4) Vec4 { E v[4]; };
+
+// ------------------------------------------------------------------------------------------------
+// ingest: u8 page -> normalised network input in both forms (main.py:239 `img / 255.0`, 285 slice)
+// one thread per (tile, y, x)
+// ------------------------------------------------------------------------------------------------
+template <typename E>
+__global__ __launch_bounds__(256) void ingest_u8_kernel(const IngestParams p)
+{
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const long per = (long)p.H * p.W;
+    if (idx >= per * p.n_tiles) return;
+    const int t = (int)(idx / per);
+    const int rem = (int)(idx - t * per);
+    const int y = rem / p.W, x = rem - y * p.W;
+    int sy, sx;
+    if (p.map_y) { sy = p.map_y[y]; sx = p.map_x[x]; }
+    else if (p.tile_xy) { sx = p.tile_xy[2 * t] + x; sy = p.tile_xy[2 * t + 1] + y; }
+    else {
+        const int gt = p.grid_first + t;
+        const int gi = gt / p.grid_nyf, gj = gt - gi * p.grid_nyf;
+        sx = min(gi * p.grid_mid_x, p.Wp - p.W) + x;
+        sy = min(gj * p.grid_mid_y, p.Hp - p.H) + y;
+    }
+    const uint8_t* px = p.page + ((size_t)sy * p.Wp + sx) * 3;
+    const E v0 = to_elem<E>(p.lut[px[0]]), v1 = to_elem<E>(p.lut[px[1]]), v2 = to_elem<E>(p.lut[px[2]]);
+    const E z = to_elem<E>(0.f);
+    Vec8<E> o;
+    o.v[0] = v0; o.v[1] = v1; o.v[2] = v2;
+#pragma unroll
+    for (int i = 3; i < 8; ++i) o.v[i] = z;
+    ((Vec8<E>*)p.c8)[idx] = o;
+    if (p.pairs) {
+        const int PH = p.H + 2 * p.pad;
+        const int xp = x + p.pad;
+        E* dst = (E*)p.pairs + (((size_t)t * PH + (y + p.pad)) * p.pairs_w + (xp >> 1)) * 8 + (xp & 1) * 4;
+        Vec4<E> q; q.v[0] = v0; q.v[1] = v1; q.v[2] = v2; q.v[3] = z;
+        *(Vec4<E>*)dst = q;
+    }
+}
+
+template <typename E>
+__global__ __launch_bounds__(256) void ingest_f32_kernel(const float* x, int n, int H, int W, void* c8,
+                                                         void* pairs, int pad, int pairs_w)
+{
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const long per = (long)H * W;
+    if (idx >= per * n) return;
+    const int t = (int)(idx / per);
+    const int rem = (int)(idx - t * per);
+    const int y = rem / W, xx = rem - y * W;
+    const float* px = x + idx * 3;
+    const E v0 = to_elem<E>(px[0]), v1 = to_elem<E>(px[1]), v2 = to_elem<E>(px[2]);
+    const E z = to_elem<E>(0.f);
+    Vec8<E> o;
+    o.v[0] = v0; o.v[1] = v1; o.v[2] = v2;
+#pragma unroll
+    for (int i = 3; i < 8; ++i) o.v[i] = z;
+    ((Vec8<E>*)c8)[idx] = o;
+    if (pairs) {
+        const int PH = H + 2 * pad;
+        const int xp = xx + pad;
+        E* dst = (E*)pairs + (((size_t)t * PH + (y + pad)) * pairs_w + (xp >> 1)) * 8 + (xp & 1) * 4;
+        Vec4<E> q; q.v[0] = v0; q.v[1] = v1; q.v[2] = v2; q.v[3] = z;
+        *(Vec4<E>*)dst = q;
+    }
+}
+
+hipError_t launch_ingest_u8(const IngestParams& p, int precision, hipStream_t s)
+{
+    const long total = (long)p.H * p.W * p.n_tiles;
+    const unsigned grid = (unsigned)((total + 255) / 256);
+    if (precision == kF32) hipLaunchKernelGGL(ingest_u8_kernel<float>, dim3(grid), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(ingest_u8_kernel<uint16_t>, dim3(grid), dim3(256), 0, s, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_ingest_f32(const float* x, int n, int H, int W, void* c8, void* pairs, int pad,
+                             int pairs_w, int precision, hipStream_t s)
+{
+    const long total = (long)H * W * n;
+    const unsigned grid = (unsigned)((total + 255) / 256);
+    if (precision == kF32)
+        hipLaunchKernelGGL(ingest_f32_kernel<float>, dim3(grid), dim3(256), 0, s, x, n, H, W, c8, pairs, pad, pairs_w);
+    else
+        hipLaunchKernelGGL(ingest_f32_kernel<uint16_t>, dim3(grid), dim3(256), 0, s, x, n, H, W, c8, pairs, pad, pairs_w);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// max-pool (valid), NHWC, one thread per (pixel, 8-channel granule)
+// ------------------------------------------------------------------------------------------------
+template <typename E>
+__global__ __launch_bounds__(256) void maxpool_kernel(const E* src, E* dst, int n, int H, int W, int C,
+                                                      int k, int stride, int Ho, int Wo)
+{
+    const int cg = C / 8;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const long total = (long)n * Ho * Wo * cg;
+    if (idx >= total) return;
+    const int g = (int)(idx % cg);
+    long pix = idx / cg;
+    const int ox = (int)(pix % Wo); pix /= Wo;
+    const int oy = (int)(pix % Ho);
+    const int b = (int)(pix / Ho);
+    float m[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) m[i] = -3.0e38f;
+    for (int ky = 0; ky < k; ++ky)
+        for (int kx = 0; kx < k; ++kx) {
+            const Vec8<E> v = *(const Vec8<E>*)(src + (((size_t)b * H + oy * stride + ky) * W + ox * stride + kx) * C + g * 8);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) m[i] = fmaxf(m[i], from_elem<E>(v.v[i]));
+        }
+    Vec8<E> o;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o.v[i] = to_elem<E>(m[i]);
+    *(Vec8<E>*)(dst + (((size_t)b * Ho + oy) * Wo + ox) * C + g * 8) = o;
+}
+
+hipError_t launch_maxpool(const void* src, void* dst, int n, int H, int W, int C, int k, int stride,
+                          int Ho, int Wo, int precision, hipStream_t s)
+{
+    const long total = (long)n * Ho * Wo * (C / 8);
+    const unsigned grid = (unsigned)((total + 255) / 256);
+    if (precision == kF32)
+        hipLaunchKernelGGL(maxpool_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)src, (float*)dst, n, H, W, C, k, stride, Ho, Wo);
+    else
+        hipLaunchKernelGGL(maxpool_kernel<uint16_t>, dim3(grid), dim3(256), 0, s, (const uint16_t*)src, (uint16_t*)dst, n, H, W, C, k, stride, Ho, Wo);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// head: 1x1 conv + BN + softmax + argmax (main.py:290: np.argmax over the softmax output, first
+// maximum wins).  One thread per pixel; weights broadcast from LDS.
+// ------------------------------------------------------------------------------------------------
+template <typename E>
+__global__ __launch_bounds__(256) void head_kernel(const HeadParams p)
+{
+    __shared__ float sw[64 * 8];
+    __shared__ float ss[16];
+    for (int i = threadIdx.x; i < p.cin * p.classes; i += 256) sw[i] = p.w[i];
+    if (threadIdx.x < p.classes) { ss[threadIdx.x] = p.scale[threadIdx.x]; ss[8 + threadIdx.x] = p.shift[threadIdx.x]; }
+    __syncthreads();
+    const int m = blockIdx.x * 256 + threadIdx.x;
+    if (m >= p.M) return;
+    float logit[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) logit[c] = 0.f;
+    const E* src = (const E*)p.src + (size_t)m * p.cin;
+    for (int g = 0; g < p.cin / 8; ++g) {
+        const Vec8<E> v = *(const Vec8<E>*)(src + g * 8);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float xv = from_elem<E>(v.v[i]);
+            const float* wr = sw + (g * 8 + i) * p.classes;
+#pragma unroll
+            for (int c = 0; c < 8; ++c)
+                if (c < p.classes) logit[c] = fmaf(xv, wr[c], logit[c]);
+        }
+    }
+    float mx = -3.0e38f;
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+        if (c < p.classes) { logit[c] = logit[c] * ss[c] + ss[8 + c]; mx = fmaxf(mx, logit[c]); }
+    float pr[8], sum = 0.f;
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+        if (c < p.classes) { pr[c] = expf(logit[c] - mx); sum += pr[c]; }
+    int best = 0;
+    float bestp = -1.f;
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+        if (c < p.classes) {
+            pr[c] = pr[c] / sum;
+            if (pr[c] > bestp) { bestp = pr[c]; best = c; }
+            if (p.probs) p.probs[(size_t)m * p.classes + c] = pr[c];
+        }
+    p.labels[m] = (uint8_t)best;
+}
+
+hipError_t launch_head(const HeadParams& p, int precision, hipStream_t s)
+{
+    const unsigned grid = (unsigned)((p.M + 255) / 256);
+    if (precision == kF32) hipLaunchKernelGGL(head_kernel<float>, dim3(grid), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(head_kernel<uint16_t>, dim3(grid), dim3(256), 0, s, p);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// stitch: page pixel (y,x) takes the label of its owner tile (closed form of the reference's
+// crop-and-overwrite, main.py:294-364).  own_x[x] = (tile column i << 16) | x-inside-tile, own_y alike.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void stitch_kernel(const uint8_t* tile_labels, int H, int W, const int* own_x,
+                                                     const int* own_y, int nyf, int Hp, int Wp, uint8_t* out)
+{
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)Hp * Wp) return;
+    const int y = (int)(idx / Wp), x = (int)(idx - (long)y * Wp);
+    const int ex = own_x[x], ey = own_y[y];
+    const int t = (ex >> 16) * nyf + (ey >> 16);
+    out[idx] = tile_labels[((size_t)t * H + (ey & 0xffff)) * W + (ex & 0xffff)];
+}
+
+hipError_t launch_stitch(const uint8_t* tile_labels, int H, int W, const int* own_x, const int* own_y,
+                         int nyf, int Hp, int Wp, uint8_t* out, hipStream_t s)
+{
+    const long total = (long)Hp * Wp;
+    hipLaunchKernelGGL(stitch_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, tile_labels, H, W,
+                       own_x, own_y, nyf, Hp, Wp, out);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void resize_labels_kernel(const uint8_t* labels, int H, int W, const int* map_y,
+                                                            const int* map_x, int out_h, int out_w, uint8_t* out)
+{
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)out_h * out_w) return;
+    const int y = (int)(idx / out_w), x = (int)(idx - (long)y * out_w);
+    out[idx] = labels[(size_t)map_y[y] * W + map_x[x]];
+}
+
+hipError_t launch_resize_labels(const uint8_t* labels, int H, int W, const int* map_y, const int* map_x,
+                                int out_h, int out_w, uint8_t* out, hipStream_t s)
+{
+    const long total = (long)out_h * out_w;
+    hipLaunchKernelGGL(resize_labels_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, labels, H, W,
+                       map_y, map_x, out_h, out_w, out);
+    return hipGetLastError();
+}
+
+template <typename E>
+__global__ __launch_bounds__(256) void to_f32_kernel(const E* src, float* dst, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dst[i] = from_elem<E>(src[i]);
+}
+
+hipError_t launch_to_f32(const void* src, float* dst, size_t n, int precision, hipStream_t s)
+{
+    const unsigned grid = (unsigned)((n + 255) / 256);
+    if (precision == kF32) hipLaunchKernelGGL(to_f32_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)src, dst, n);
+    else hipLaunchKernelGGL(to_f32_kernel<uint16_t>, dim3(grid), dim3(256), 0, s, (const uint16_t*)src, dst, n);
+    return hipGetLastError();
+}
+
+}  // namespace sbbseg

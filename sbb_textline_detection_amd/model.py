@@ -1,0 +1,135 @@
+"""Model lifecycle behind the reference's seams (``main.py:216-223``, ``227-229``, ``287-288``).
+
+``start_new_session_and_model(path) -> (model, session)`` mirrors the reference method of the same
+name; ``model`` is a :class:`SegModel` with exactly the duck type ``do_prediction`` touches:
+``model.layers[-1].output_shape == (None, H, W, C)`` and ``model.predict(x[N,H,W,3]) -> f32
+[N,H,W,C]`` softmax probabilities.  Inference runs only through libsbbseg (HIP, gfx950); no
+Keras/TF and no CPU fallback.
+
+The reference re-parses its ``.h5`` and rebuilds a TF session for every stage of every page
+(``main.py:386, 442, 492``).  Here loaded models are cached per (file, device, precision);
+``Session.close()`` only drops a reference and :func:`clear_session` (the ``K.clear_session()``
+analogue, ``main.py:2065``) frees device memory.  Set ``SBBSEG_MODEL_CACHE=0`` to free on close.
+"""
+from __future__ import annotations
+
+import os
+from typing import Dict, Optional, Tuple
+
+import numpy as np
+
+from . import _capi
+from .keras_graph import Graph, parse_model_config
+from .planner import Plan, build_plan
+from .weights import load_sbbw
+
+_CACHE: Dict[Tuple, "SegModel"] = {}
+
+
+def default_max_batch() -> int:
+    return int(os.environ.get("SBBSEG_MAX_BATCH", "32"))
+
+
+class SegModel:
+    """A segmentation net resident on one MI355X, duck-typed like the Keras model the reference uses."""
+
+    def __init__(self, model_config, weights, device: int = 0, max_batch: Optional[int] = None,
+                 precision: str = "bf16"):
+        self.graph: Graph = parse_model_config(model_config)
+        self.plan: Plan = build_plan(self.graph, weights)
+        self.layers = self.graph.nodes                     # main.py:227-229 reads layers[-1].output_shape
+        self.device = device
+        self.precision = precision
+        self.max_batch = int(max_batch or default_max_batch())
+        prec = {"bf16": _capi.PREC_BF16, "f32": _capi.PREC_F32}[precision]
+        self._ctx: Optional[_capi.Context] = _capi.Context(device, prec)
+        try:
+            self._ctx.load_plan(self.plan, self.max_batch)
+        except Exception:
+            self._ctx.close()
+            raise
+        self.input_shape = (None,) + tuple(self.graph.input_shape)
+        self.output_shape = (None,) + tuple(self.graph.output_shape)
+
+    # -- seam 2 ------------------------------------------------------------------------------
+    def predict(self, x, batch_size=None, verbose=0):
+        """Keras-compatible: float array [N,H,W,3] in [0,1] -> float32 [N,H,W,C] softmax."""
+        return self.ctx.predict(np.asarray(x))
+
+    # -- fused fast paths of seam 1 -----------------------------------------------------------
+    def segment_page(self, page_u8: np.ndarray) -> np.ndarray:
+        """uint8 [Hp,Wp,3] -> uint8 [Hp,Wp] label map == do_prediction(True, ...)[:, :, 0]."""
+        return self.ctx.segment_page(page_u8)
+
+    def segment_whole(self, page_u8: np.ndarray, out_h: int, out_w: int) -> np.ndarray:
+        """uint8 [Hp,Wp,3] -> uint8 [out_h,out_w] == do_prediction(False, ...)[:, :, 0]."""
+        return self.ctx.segment_whole(page_u8, out_h, out_w)
+
+    @property
+    def ctx(self) -> _capi.Context:
+        if self._ctx is None or self._ctx.h is None:
+            raise RuntimeError("model has been released (session closed)")
+        return self._ctx
+
+    def release(self):
+        if self._ctx is not None:
+            self._ctx.close()
+            self._ctx = None
+
+
+class Session:
+    """Stand-in for the ``tf.InteractiveSession`` the reference closes after each stage (main.py:428)."""
+
+    def __init__(self, model: SegModel, cached: bool):
+        self._model, self._cached, self.closed = model, cached, False
+
+    def close(self):
+        if self.closed:
+            return                       # double close is harmless
+        self.closed = True
+        if not self._cached and self._model is not None:
+            self._model.release()
+        self._model = None
+
+
+def resolve_model_path(path: str) -> str:
+    """The reference is handed ``<dir>/model_*.h5`` (main.py:58-60).  HDF5 cannot be read at inference
+    time here; the offline converter (tools/h5_to_sbbw.py) writes ``<same name>.sbbw`` next to it."""
+    if path.endswith(".sbbw") and os.path.exists(path):
+        return path
+    alt = os.path.splitext(path)[0] + ".sbbw"
+    if os.path.exists(alt):
+        return alt
+    if os.path.exists(path):
+        raise RuntimeError(f"{path}: Keras HDF5 must be converted once with tools/h5_to_sbbw.py "
+                           f"(expected {alt})")
+    raise FileNotFoundError(path)
+
+
+def load_model(path: str, compile: bool = False, device: int = 0, max_batch: Optional[int] = None,
+               precision: str = "bf16") -> SegModel:
+    """``keras.models.load_model(path, compile=False)`` replacement (main.py:221)."""
+    real = resolve_model_path(path)
+    use_cache = os.environ.get("SBBSEG_MODEL_CACHE", "1") != "0"
+    key = (os.path.realpath(real), os.path.getmtime(real), device, precision, int(max_batch or default_max_batch()))
+    if use_cache and key in _CACHE and _CACHE[key]._ctx is not None:
+        return _CACHE[key]
+    cfg, weights = load_sbbw(real)
+    model = SegModel(cfg, weights, device=device, max_batch=max_batch, precision=precision)
+    if use_cache:
+        _CACHE[key] = model
+    model._from_cache = use_cache
+    return model
+
+
+def start_new_session_and_model(model_dir: str, **kw):
+    """Same name / argument / return as ``textline_detector.start_new_session_and_model`` (main.py:216-223)."""
+    model = load_model(model_dir, compile=False, **kw)
+    return model, Session(model, getattr(model, "_from_cache", False))
+
+
+def clear_session():
+    """``K.clear_session()`` analogue (main.py:2065...): free every cached model's device memory."""
+    for m in list(_CACHE.values()):
+        m.release()
+    _CACHE.clear()

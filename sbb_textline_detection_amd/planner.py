@@ -1,0 +1,387 @@
+"""Lower a parsed Keras graph (``keras_graph.Graph``) into the fused op list libsbbseg executes.
+
+What the reference gets from ``keras.models.load_model`` + ``model.predict`` (``main.py:221,
+287-288``) -- ~210 Keras layers run one by one -- becomes ~60 kernels here:
+
+* ``Conv2D -> BatchNormalization -> [Add] -> relu``        one conv, BN/bias folded to fp32
+  scale/shift, residual + ReLU in the epilogue
+* ``UpSampling2D -> Concatenate -> ZeroPadding2D -> Conv2D``  address arithmetic of that conv's gather
+* ``ZeroPadding2D -> Lambda(x[:, :-1, :-1, :])`` (one_side_pad)  a (1,1) placement offset
+* the stem ``ZeroPadding2D(3) -> Conv2D 7x7 s2`` on the 3-channel image  a 7x4 stride-(2,1) conv
+  over the PAIRS input form (two horizontal neighbours x 4 channels per 16-byte granule)
+* final ``Conv2D 1x1 -> BN -> softmax`` (+ the caller's ``np.argmax``, ``main.py:290``)  the head op
+
+The result is plain data (``Plan``); ``_capi.build_context`` feeds it to the C ABI, and
+``tests/plan_interp.py`` can interpret it with numpy to check the lowering against the oracle
+without a GPU.  Nothing here runs arithmetic on activations.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+
+from .keras_graph import Graph, Node
+
+INPUT_C8, INPUT_PAIRS = 0, 1
+
+
+@dataclass
+class Seg:
+    tensor: int          # plan tensor id
+    channels: int
+    shift: int = 0       # nearest x2 upsampling fused into the gather
+    off_y: int = 0
+    off_x: int = 0
+
+
+@dataclass
+class TensorSpec:
+    H: int
+    W: int
+    C: int
+    kind: str = "act"    # act | input_c8 | input_pairs
+    pad: int = 0
+    name: str = ""
+
+
+@dataclass
+class ConvStep:
+    name: str
+    srcs: List[Seg]
+    kh: int
+    kw: int
+    stride_y: int
+    stride_x: int
+    pad_top: int
+    pad_left: int
+    cout: int
+    w_hwio: np.ndarray            # float32 [kh][kw][sum(src channels)][cout]
+    scale: np.ndarray             # float32 [cout]
+    shift: np.ndarray
+    out: int = -1
+    relu: bool = False
+    residual: int = -1
+    raw_out: int = -1
+    raw_scale: Optional[np.ndarray] = None
+    raw_shift: Optional[np.ndarray] = None
+    kind: str = "conv"
+
+
+@dataclass
+class PoolStep:
+    name: str
+    src: int
+    dst: int
+    k: int
+    stride: int
+    kind: str = "maxpool"
+
+
+@dataclass
+class HeadStep:
+    name: str
+    src: int
+    cin: int
+    classes: int
+    w: np.ndarray                 # float32 [cin][classes]
+    scale: np.ndarray
+    shift: np.ndarray
+    kind: str = "head"
+
+
+@dataclass
+class Plan:
+    in_h: int
+    in_w: int
+    classes: int
+    tensors: List[TensorSpec] = field(default_factory=list)
+    steps: List[object] = field(default_factory=list)
+    layer_tensor: Dict[str, int] = field(default_factory=dict)   # Keras layer name -> materialised tensor
+
+    def macs_per_patch(self) -> int:
+        total = 0
+        for s in self.steps:
+            if s.kind == "conv":
+                t = self.tensors[s.out if s.out >= 0 else s.raw_out]
+                total += t.H * t.W * s.cout * s.logical_macs_per_out
+            elif s.kind == "head":
+                t = self.tensors[s.src]
+                total += t.H * t.W * s.cin * s.classes
+        return total
+
+
+class _Pending:
+    """A conv whose epilogue is still being fused."""
+
+    def __init__(self, node: Node, srcs, kh, kw, sy, sx, pt, pl, cout, w, bias, out_hw, logical_taps):
+        self.node = node
+        self.srcs, self.kh, self.kw, self.sy, self.sx, self.pt, self.pl = srcs, kh, kw, sy, sx, pt, pl
+        self.cout, self.w = cout, w
+        self.scale = np.ones(cout, np.float64)
+        self.shift = np.zeros(cout, np.float64) if bias is None else bias.astype(np.float64)
+        self.relu = False
+        self.residual = -1
+        self.raw_needed = False
+        self.raw_scale = self.scale.copy()
+        self.raw_shift = self.shift.copy()
+        self.out_hw = out_hw
+        self.logical_macs_per_out = logical_taps
+        self.emitted_out = -1
+        self.emitted_raw = -1
+        self.stage = "conv"          # conv -> bn -> (add) -> relu
+
+
+class _View:
+    def __init__(self, H, W, segs=None, pad=(0, 0, 0, 0), pending=None, raw_of=None):
+        self.H, self.W = H, W
+        self.segs: List[Seg] = segs or []
+        self.pad = pad                   # pending zero padding (t, b, l, r); H, W include it
+        self.pending: Optional[_Pending] = pending
+        self.raw_of: Optional[_Pending] = raw_of   # the un-normalised output of a pending conv
+
+
+class PlanError(NotImplementedError):
+    pass
+
+
+def build_plan(graph: Graph, weights: Dict[str, np.ndarray]) -> Plan:
+    byn = graph.by_name()
+    consumers: Dict[str, int] = {}
+    for n in graph.nodes:
+        for i in n.inputs:
+            consumers[i] = consumers.get(i, 0) + 1
+
+    in_h, in_w, in_c = graph.input_shape
+    if in_c != 3:
+        raise PlanError("network input must have 3 channels")
+    plan = Plan(in_h, in_w, 0)
+    views: Dict[str, _View] = {}
+    input_forms: Dict[Tuple[int, int], int] = {}
+
+    def new_tensor(H, W, C, name="", kind="act", pad=0):
+        plan.tensors.append(TensorSpec(H, W, C, kind, pad, name))
+        return len(plan.tensors) - 1
+
+    def input_form(form, pad):
+        key = (form, pad)
+        if key not in input_forms:
+            if form == INPUT_C8:
+                input_forms[key] = new_tensor(in_h, in_w, 8, "input_c8", "input_c8", 0)
+            else:
+                if any(k[0] == INPUT_PAIRS for k in input_forms):
+                    raise PlanError("only one PAIRS input form (one padding) is supported")
+                input_forms[key] = new_tensor(in_h + 2 * pad, (in_w + 2 * pad + 1) // 2, 8, "input_pairs", "input_pairs", pad)
+        return input_forms[key]
+
+    def emit(p: _Pending):
+        if p.emitted_out >= 0 or p.emitted_raw >= 0:
+            return
+        oh, ow = p.out_hw
+        p.emitted_out = new_tensor(oh, ow, p.cout, p.node.name)
+        if p.raw_needed:
+            p.emitted_raw = new_tensor(oh, ow, p.cout, p.node.name + ":raw")
+        step = ConvStep(p.node.name, p.srcs, p.kh, p.kw, p.sy, p.sx, p.pt, p.pl, p.cout,
+                        np.ascontiguousarray(p.w, np.float32), p.scale.astype(np.float32), p.shift.astype(np.float32),
+                        out=p.emitted_out, relu=p.relu, residual=p.residual, raw_out=p.emitted_raw,
+                        raw_scale=p.raw_scale.astype(np.float32) if p.raw_needed else None,
+                        raw_shift=p.raw_shift.astype(np.float32) if p.raw_needed else None)
+        step.logical_macs_per_out = p.logical_macs_per_out
+        plan.steps.append(step)
+
+    def materialize(name: str) -> _View:
+        """Make the value of Keras layer `name` a plain stored tensor (emit pending work)."""
+        v = views[name]
+        if v.pending is not None:
+            emit(v.pending)
+            v.segs = [Seg(v.pending.emitted_out, v.pending.cout)]
+            v.pending = None
+        elif v.raw_of is not None:
+            p = v.raw_of
+            if p.emitted_out >= 0 and p.emitted_raw < 0:
+                raise PlanError(f"{name}: raw conv output requested after the conv was emitted")
+            p.raw_needed = True
+            emit(p)
+            v.segs = [Seg(p.emitted_raw, p.cout)]
+            v.raw_of = None
+        if v.segs and len(v.segs) == 1 and v.pad == (0, 0, 0, 0) and not v.segs[0].shift \
+                and not v.segs[0].off_y and not v.segs[0].off_x and v.segs[0].tensor >= 0:
+            plan.layer_tensor[name] = v.segs[0].tensor
+        return v
+
+    def plain_tensor(name: str) -> int:
+        v = materialize(name)
+        s = v.segs
+        if len(s) != 1 or s[0].shift or s[0].off_y or s[0].off_x or v.pad != (0, 0, 0, 0):
+            raise PlanError(f"{name}: needs a plain stored tensor here")
+        return s[0].tensor
+
+    def gatherable(name: str) -> _View:
+        """Value usable as a conv source: stored segments with shift/offset/pad folded."""
+        v = materialize(name)
+        t, b, l, r = v.pad
+        segs = [Seg(s.tensor, s.channels, s.shift, s.off_y + t, s.off_x + l) for s in v.segs]
+        return _View(v.H, v.W, segs)
+
+    for n in graph.nodes:
+        if n.op == "input":
+            views[n.name] = _View(in_h, in_w, [Seg(-1, 3)])        # tensor -1 = the network input
+        elif n.op == "zeropad":
+            src = materialize(n.inputs[0])
+            t, b, l, r = n.attrs["pad"]
+            pt, pb, pl, pr = src.pad
+            views[n.name] = _View(src.H + t + b, src.W + l + r, src.segs, (pt + t, pb + b, pl + l, pr + r))
+        elif n.op == "crop_last":
+            src = views[n.inputs[0]]
+            t, b, l, r = src.pad
+            if b < 1 or r < 1:
+                raise PlanError(f"{n.name}: crop of real data unsupported")
+            views[n.name] = _View(src.H - 1, src.W - 1, src.segs, (t, b - 1, l, r - 1))
+        elif n.op == "upsample":
+            if n.attrs["size"] != (2, 2):
+                raise PlanError(f"{n.name}: only x2 upsampling supported")
+            src = gatherable(n.inputs[0])
+            if any(s.shift or s.off_y or s.off_x for s in src.segs):
+                raise PlanError(f"{n.name}: upsampling of an already transformed view")
+            views[n.name] = _View(src.H * 2, src.W * 2, [Seg(s.tensor, s.channels, 1) for s in src.segs])
+        elif n.op == "concat":
+            parts = [gatherable(i) for i in n.inputs]
+            if len({(p.H, p.W) for p in parts}) != 1:
+                raise PlanError(f"{n.name}: concat inputs differ in size")
+            views[n.name] = _View(parts[0].H, parts[0].W, [s for p in parts for s in p.segs])
+        elif n.op == "conv":
+            src = gatherable(n.inputs[0])
+            kh, kw = n.attrs["kernel"]
+            sy, sx = n.attrs["strides"]
+            oh, ow, cout = n.out_shape
+            if n.attrs["padding"] == "same":
+                pt = max((oh - 1) * sy + kh - src.H, 0) // 2
+                pl = max((ow - 1) * sx + kw - src.W, 0) // 2
+            else:
+                pt = pl = 0
+            w = weights[f"{n.name}/kernel:0"].astype(np.float32)
+            bias = weights[f"{n.name}/bias:0"] if n.attrs["use_bias"] else None
+            segs = src.segs
+            if len(segs) > 2:
+                raise PlanError(f"{n.name}: more than two concatenated sources")
+            # a placement offset shared by every source is just conv padding
+            my, mx = min(s.off_y for s in segs), min(s.off_x for s in segs)
+            segs = [Seg(s.tensor, s.channels, s.shift, s.off_y - my, s.off_x - mx) for s in segs]
+            pt, pl = pt + my, pl + mx
+            if any(s.shift and (s.off_y or s.off_x) for s in segs):
+                raise PlanError(f"{n.name}: upsampled source with a placement offset unsupported")
+            taps = kh * kw * sum(s.channels for s in segs)
+            if any(s.tensor == -1 for s in segs):
+                # a conv that reads the image itself
+                segs = list(segs)
+                for k, s in enumerate(segs):
+                    if s.tensor != -1:
+                        continue
+                    if s.shift:
+                        raise PlanError(f"{n.name}: upsampled network input unsupported")
+                    if sx == 2 and len(segs) == 1:
+                        # stem: fold the horizontal stride into 2-pixel granules of the PAIRS form
+                        pad = s.off_y + pt
+                        if pad != s.off_x + pl:
+                            raise PlanError(f"{n.name}: asymmetric stem padding unsupported")
+                        t_id = input_form(INPUT_PAIRS, pad)
+                        kw2 = (kw + 1) // 2
+                        w2 = np.zeros((kh, kw2, 8, cout), np.float32)
+                        for dx in range(kw):
+                            w2[:, dx // 2, (dx & 1) * 4:(dx & 1) * 4 + 3, :] = w[:, dx, :, :]
+                        segs[k] = Seg(t_id, 8, 0, 0, 0)
+                        w, kw, sx, pt, pl = w2, kw2, 1, 0, 0
+                    elif sx == 1:
+                        segs[k] = Seg(input_form(INPUT_C8, 0), 3, 0, s.off_y, s.off_x)
+                    else:
+                        raise PlanError(f"{n.name}: unsupported conv on the network input")
+            p = _Pending(n, segs, kh, kw, sy, sx, pt, pl, cout, w, bias, (oh, ow), taps)
+            if n.attrs.get("activation", "linear") == "relu":
+                p.relu, p.stage = True, "relu"
+            elif n.attrs.get("activation", "linear") != "linear":
+                raise PlanError(f"{n.name}: inline activation {n.attrs['activation']} unsupported")
+            views[n.name] = _View(oh, ow, pending=p)
+        elif n.op == "bn":
+            src = views[n.inputs[0]]
+            p = src.pending
+            if p is None or p.stage != "conv":
+                raise PlanError(f"{n.name}: BatchNormalization must follow a Conv2D directly")
+            if consumers.get(n.inputs[0], 0) > 1:
+                # somebody else wants the un-normalised conv output (the f1 skip): keep both
+                p.raw_needed = True
+                views[n.inputs[0]] = _View(src.H, src.W, raw_of=p)
+            g = weights[f"{n.name}/gamma:0"].astype(np.float64) if n.attrs["scale"] else 1.0
+            be = weights[f"{n.name}/beta:0"].astype(np.float64) if n.attrs["center"] else 0.0
+            mu = weights[f"{n.name}/moving_mean:0"].astype(np.float64)
+            var = weights[f"{n.name}/moving_variance:0"].astype(np.float64)
+            a = g / np.sqrt(var + n.attrs["eps"])
+            p.scale, p.shift = p.scale * a, (p.shift - mu) * a + be
+            p.stage = "bn"
+            views[n.name] = _View(src.H, src.W, pending=p)
+        elif n.op == "add":
+            if len(n.inputs) != 2:
+                raise PlanError(f"{n.name}: Add of {len(n.inputs)} inputs unsupported")
+            va, vb = views[n.inputs[0]], views[n.inputs[1]]
+            cand = [k for k, v in ((0, va), (1, vb))
+                    if v.pending is not None and v.pending.stage in ("conv", "bn") and not v.pending.relu
+                    and v.pending.residual < 0 and consumers.get(n.inputs[k], 0) == 1]
+            if not cand:
+                raise PlanError(f"{n.name}: Add needs one input that is a conv(+BN) with a single consumer")
+            k = cand[0]
+            other = plain_tensor(n.inputs[1 - k])
+            p = views[n.inputs[k]].pending
+            ot = plan.tensors[other]
+            if (ot.H, ot.W, ot.C) != (p.out_hw[0], p.out_hw[1], p.cout):
+                raise PlanError(f"{n.name}: residual shape mismatch")
+            p.residual, p.stage = other, "add"
+            views[n.name] = _View(va.H, va.W, pending=p)
+        elif n.op == "act":
+            kind = n.attrs["kind"]
+            src = views[n.inputs[0]]
+            if kind == "linear":
+                views[n.name] = src
+            elif kind == "relu":
+                p = src.pending
+                if p is None or p.relu or consumers.get(n.inputs[0], 0) != 1:
+                    raise PlanError(f"{n.name}: relu must follow conv/BN/Add with a single consumer")
+                p.relu, p.stage = True, "relu"
+                views[n.name] = _View(src.H, src.W, pending=p)
+            elif kind == "softmax":
+                p = src.pending
+                if (n.name != graph.output_name or p is None or p.relu or p.residual >= 0 or (p.kh, p.kw) != (1, 1)
+                        or len(p.srcs) != 1 or p.srcs[0].shift or p.srcs[0].off_y or p.srcs[0].off_x
+                        or (p.sy, p.sx) != (1, 1)):
+                    raise PlanError(f"{n.name}: softmax is only supported as the final 1x1-conv head")
+                t_id = p.srcs[0].tensor
+                ts = plan.tensors[t_id]
+                if ts.C != p.srcs[0].channels or ts.C > 64 or p.cout > 8 or (ts.H, ts.W) != (in_h, in_w):
+                    raise PlanError(f"{n.name}: head needs <=64 input channels, <=8 classes, input resolution")
+                plan.steps.append(HeadStep(p.node.name, t_id, ts.C, p.cout,
+                                           np.ascontiguousarray(p.w.reshape(ts.C, p.cout), np.float32),
+                                           p.scale.astype(np.float32), p.shift.astype(np.float32)))
+                plan.classes = p.cout
+                views[n.name] = _View(src.H, src.W)
+        elif n.op == "maxpool":
+            if n.attrs["pool"][0] != n.attrs["pool"][1] or n.attrs["strides"][0] != n.attrs["strides"][1]:
+                raise PlanError(f"{n.name}: non-square pooling unsupported")
+            src_t = plain_tensor(n.inputs[0])
+            oh, ow, c = n.out_shape
+            dst = new_tensor(oh, ow, c, n.name)
+            plan.steps.append(PoolStep(n.name, src_t, dst, n.attrs["pool"][0], n.attrs["strides"][0]))
+            views[n.name] = _View(oh, ow, [Seg(dst, c)])
+            plan.layer_tensor[n.name] = dst
+        elif n.op == "convT":
+            raise PlanError(f"{n.name}: Conv2DTranspose decoders are not used by the sbb models "
+                            "(UpSampling2D is); not lowered yet")
+        else:
+            raise PlanError(f"{n.name}: op {n.op} not lowered")
+
+    if plan.classes == 0:
+        raise PlanError("graph does not end in Conv2D 1x1 -> BatchNormalization -> softmax")
+    for s in plan.steps:
+        if s.kind == "conv":
+            for seg in s.srcs:
+                if seg.tensor < 0:
+                    raise PlanError(f"{s.name}: unresolved network-input source")
+    return plan

@@ -1,0 +1,53 @@
+"""planner.py lowering (fusions, PAIRS stem, one_side_pad offset, head) checked on CPU against the
+unfused oracle through tests/plan_interp.py -- no GPU involved."""
+import numpy as np
+import pytest
+
+from oracle import keras_forward as kf
+from plan_interp import run_plan
+from sbb_textline_detection_amd.keras_graph import parse_model_config, resnet50_unet_config
+from sbb_textline_detection_amd.planner import PlanError, build_plan
+from sbb_textline_detection_amd.synthetic import synthetic_page
+from sbb_textline_detection_amd.weights import synthetic_model, synthetic_weights
+from tools.synth_model import calibrated_model
+
+
+@pytest.mark.parametrize("classes,hw", [(2, (96, 128)), (4, (64, 64))])
+def test_plan_equals_oracle(classes, hw):
+    cfg, w = calibrated_model(classes, hw[0], hw[1], seed=1, calib_hw=64)
+    g = parse_model_config(cfg)
+    plan = build_plan(g, w)
+    page = synthetic_page(300, 400, 5)
+    x = np.stack([page[10:10 + hw[0], 20:20 + hw[1]], page[100:100 + hw[0], 200:200 + hw[1]]]).astype(np.float32) / 255
+    ref = kf.forward(g, w, x)
+    lab, pr, _ = run_plan(plan, x)
+    assert np.abs(ref - pr).max() < 5e-4
+    srt = np.sort(ref, axis=-1)
+    decided = (srt[..., -1] - srt[..., -2]) > 2e-3
+    assert np.array_equal(lab[decided], ref.argmax(-1)[decided])
+
+
+def test_plan_structure_448():
+    cfg, w = synthetic_model(2, 448, 448, 0)
+    plan = build_plan(parse_model_config(cfg), w)
+    kinds = [s.kind for s in plan.steps]
+    assert kinds.count("conv") == 59 and kinds.count("maxpool") == 1 and kinds[-1] == "head"
+    assert plan.macs_per_patch() == 47418195968                       # 47.418 GMAC
+    stem = plan.steps[0]
+    assert (stem.kh, stem.kw, stem.stride_y, stem.stride_x) == (7, 4, 2, 1) and stem.raw_out >= 0
+    dec = {s.name: s for s in plan.steps if s.kind == "conv" and len(s.srcs) == 2}
+    assert len(dec) == 5 and all(s.srcs[0].shift == 1 for s in dec.values())
+    f2 = [s for s in dec.values() if s.srcs[1].off_y == 1]
+    assert len(f2) == 1 and f2[0].srcs[1].off_x == 1                   # one_side_pad became an offset
+    assert sum(1 for s in plan.steps if s.kind == "conv" and s.residual >= 0) == 16
+
+
+def test_unsupported_graph_raises_plan_error():
+    cfg = resnet50_unet_config(2, 64, 64)
+    for layer in cfg["config"]["layers"]:
+        if layer["class_name"] == "UpSampling2D":
+            layer["config"]["size"] = [4, 4]
+            break
+    with pytest.raises((PlanError, ValueError)):
+        g = parse_model_config(cfg)
+        build_plan(g, synthetic_weights(g, 0))
