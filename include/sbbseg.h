@@ -33,7 +33,9 @@ typedef struct sbbseg_ctx sbbseg_ctx;
 /* arithmetic mode of a handle */
 #define SBBSEG_PREC_BF16 0   /* bf16 operands, fp32 MFMA accumulate, fp32 epilogue (product path) */
 #define SBBSEG_PREC_F32  1   /* fp32 everything, plain FMA kernels: slow, used to separate plumbing
-                                errors from bf16 rounding in the parity tests */
+                                errors from 16-bit rounding in the parity tests */
+#define SBBSEG_PREC_F16  2   /* fp16 operands (11-bit significand, saturating stores), same MFMA rate as
+                                bf16, fp32 accumulate/epilogue: 8x finer rounding, range +-65504 */
 
 /* ---- lifecycle: replaces start_new_session_and_model / session.close (main.py:216-223, 428) */
 const char* sbbseg_last_error(void);

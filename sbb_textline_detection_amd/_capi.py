@@ -13,7 +13,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libsbbseg.so")
 
-PREC_BF16, PREC_F32 = 0, 1
+PREC_BF16, PREC_F32, PREC_F16 = 0, 1, 2
 INPUT_C8, INPUT_PAIRS = 0, 1
 
 EXPORTS = [

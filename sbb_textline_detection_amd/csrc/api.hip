@@ -313,7 +313,7 @@ int sbbseg_device_count(int* count)
 int sbbseg_create(int device, int precision, sbbseg_ctx** out)
 {
     REQUIRE(out, "null out");
-    REQUIRE(precision == SBBSEG_PREC_BF16 || precision == SBBSEG_PREC_F32, "bad precision %d", precision);
+    REQUIRE(precision == SBBSEG_PREC_BF16 || precision == SBBSEG_PREC_F32 || precision == SBBSEG_PREC_F16, "bad precision %d", precision);
     int ndev = 0;
     HIPCHK(hipGetDeviceCount(&ndev));
     REQUIRE(device >= 0 && device < ndev, "device %d out of range (have %d)", device, ndev);
@@ -463,7 +463,7 @@ int sbbseg_add_conv(sbbseg_ctx* c, const sbbseg_conv_desc* d, const float* w_hwi
     ConvOp& co = op.conv;
     co.d = *d;
     co.Ho = Ho; co.Wo = Wo;
-    const int bc = c->precision == kBF16 ? conv_tile_bc(d->cout) : 4;
+    const int bc = c->precision != kF32 ? conv_tile_bc(d->cout) : 4;
     co.cout_pad = ((d->cout + bc - 1) / bc) * bc;
 
     // contraction order: source-major, then tap (ky,kx), then 8-channel granules; each source's
@@ -515,9 +515,10 @@ int sbbseg_add_conv(sbbseg_ctx* c, const sbbseg_conv_desc* d, const float* w_hwi
             for (int o = 0; o < d->cout; ++o) wf[(size_t)o * co.Ktot + k] = wsrc[o];
         }
     }
-    if (c->precision == kBF16) {
+    if (c->precision != kF32) {
         std::vector<uint16_t> wb(wn);
-        for (size_t i = 0; i < wn; ++i) wb[i] = f32_to_bf16_rne(wf[i]);
+        if (c->precision == kF16) for (size_t i = 0; i < wn; ++i) wb[i] = f32_to_f16_rne(wf[i]);
+        else for (size_t i = 0; i < wn; ++i) wb[i] = f32_to_bf16_rne(wf[i]);
         if (upload(c, (uint16_t**)&co.d_w, wb.data(), wn)) return 1;
     } else {
         if (upload(c, (float**)&co.d_w, wf.data(), wn)) return 1;

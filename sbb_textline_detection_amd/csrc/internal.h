@@ -76,7 +76,7 @@ struct IngestParams {
     const int* map_x;
 };
 
-enum Precision { kBF16 = 0, kF32 = 1 };
+enum Precision { kBF16 = 0, kF32 = 1, kF16 = 2 };
 
 // launchers implemented in kernels.hip ---------------------------------------------------------
 hipError_t launch_conv(const ConvParams& p, int precision, hipStream_t s);
@@ -94,6 +94,7 @@ hipError_t launch_to_f32(const void* src, float* dst, size_t n, int precision, h
 
 int conv_tile_bc(int cout);   // channel-tile width the bf16 conv kernel uses for `cout` (weights are padded to it)
 uint16_t f32_to_bf16_rne(float f);
+uint16_t f32_to_f16_rne(float f);
 float bf16_to_f32(uint16_t h);
 
 }  // namespace sbbseg

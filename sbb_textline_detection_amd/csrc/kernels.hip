@@ -16,6 +16,8 @@
 namespace sbbseg {
 
 typedef __attribute__((ext_vector_type(8))) short bf16x8_t;   // 8 bf16 = one 16-byte granule
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t; // 8 fp16
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 
 #define GLOBAL_AS __attribute__((address_space(1)))
@@ -30,6 +32,12 @@ __host__ __device__ inline uint16_t bf16_bits_rne(float f)
 }
 uint16_t f32_to_bf16_rne(float f) { return bf16_bits_rne(f); }
 float bf16_to_f32(uint16_t h) { uint32_t u = (uint32_t)h << 16; return __builtin_bit_cast(float, u); }
+uint16_t f32_to_f16_rne(float f)
+{
+    f = f > 65504.f ? 65504.f : (f < -65504.f ? -65504.f : f);
+    _Float16 h = (_Float16)f;
+    return __builtin_bit_cast(uint16_t, h);
+}
 
 __device__ inline float bf16_lo(uint32_t v) { return __builtin_bit_cast(float, v << 16); }
 __device__ inline float bf16_hi(uint32_t v) { return __builtin_bit_cast(float, v & 0xffff0000u); }
@@ -40,8 +48,30 @@ __device__ inline uint32_t pack_bf16x2(float a, float b)
     return r;
 }
 
+// fp16 twins (SBBSEG_PREC_F16): saturate instead of overflowing to inf, round to nearest even
+__device__ inline uint32_t pack_f16x2(float a, float b)
+{
+    a = fminf(fmaxf(a, -65504.f), 65504.f);
+    b = fminf(fmaxf(b, -65504.f), 65504.f);
+    f16x2_t v = {(_Float16)a, (_Float16)b};
+    return __builtin_bit_cast(uint32_t, v);
+}
+__device__ inline float f16_lo(uint32_t v) { return (float)__builtin_bit_cast(f16x2_t, v)[0]; }
+__device__ inline float f16_hi(uint32_t v) { return (float)__builtin_bit_cast(f16x2_t, v)[1]; }
+
+template <bool F16> __device__ inline uint32_t pack2(float a, float b) { return F16 ? pack_f16x2(a, b) : pack_bf16x2(a, b); }
+template <bool F16> __device__ inline float unpack_lo(uint32_t v) { return F16 ? f16_lo(v) : bf16_lo(v); }
+template <bool F16> __device__ inline float unpack_hi(uint32_t v) { return F16 ? f16_hi(v) : bf16_hi(v); }
+template <bool F16> __device__ inline f32x4_t mfma16(bf16x8_t a, bf16x8_t b, f32x4_t c)
+{
+    if constexpr (F16)
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+
 // ------------------------------------------------------------------------------------------------
-// conv_igemm_bf16
+// conv_igemm_mfma  (16-bit operands: bf16 or fp16, fp32 accumulate)
 // ------------------------------------------------------------------------------------------------
 template <int BP, int BC, int WP, int WC>
 struct ConvTile {
@@ -56,8 +86,8 @@ struct ConvTile {
     static constexpr int kLdsBytes = 2 * kStageBytes;
 };
 
-template <int BP, int BC, int WP, int WC>
-__global__ __launch_bounds__(256, 2) void conv_igemm_bf16(const ConvParams p)
+template <int BP, int BC, int WP, int WC, bool F16>
+__global__ __launch_bounds__(256, 2) void conv_igemm_mfma(const ConvParams p)
 {
     using T = ConvTile<BP, BC, WP, WC>;
     static_assert(WP * WC == 4, "4 waves");
@@ -166,7 +196,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_bf16(const ConvParams p)
             for (int mi = 0; mi < T::kMI; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < T::kNI; ++ni)
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+                    acc[mi][ni] = mfma16<F16>(a[mi], b[ni], acc[mi][ni]);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -192,8 +222,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_bf16(const ConvParams p)
             const size_t o = (size_t)m * p.cout + c0;
             if (p.raw_out) {
                 uint2 r;
-                r.x = pack_bf16x2(v[0] * rsc.x + rsh.x, v[1] * rsc.y + rsh.y);
-                r.y = pack_bf16x2(v[2] * rsc.z + rsh.z, v[3] * rsc.w + rsh.w);
+                r.x = pack2<F16>(v[0] * rsc.x + rsh.x, v[1] * rsc.y + rsh.y);
+                r.y = pack2<F16>(v[2] * rsc.z + rsh.z, v[3] * rsc.w + rsh.w);
                 *(uint2*)((uint16_t*)p.raw_out + o) = r;
             }
             if (p.out) {
@@ -201,15 +231,15 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_bf16(const ConvParams p)
                 float y2 = v[2] * sc.z + sh.z, y3 = v[3] * sc.w + sh.w;
                 if (p.residual) {
                     const uint2 rr = *(const uint2*)((const uint16_t*)p.residual + o);
-                    y0 += bf16_lo(rr.x); y1 += bf16_hi(rr.x);
-                    y2 += bf16_lo(rr.y); y3 += bf16_hi(rr.y);
+                    y0 += unpack_lo<F16>(rr.x); y1 += unpack_hi<F16>(rr.x);
+                    y2 += unpack_lo<F16>(rr.y); y3 += unpack_hi<F16>(rr.y);
                 }
                 if (p.relu) {
                     y0 = fmaxf(y0, 0.f); y1 = fmaxf(y1, 0.f); y2 = fmaxf(y2, 0.f); y3 = fmaxf(y3, 0.f);
                 }
                 uint2 r;
-                r.x = pack_bf16x2(y0, y1);
-                r.y = pack_bf16x2(y2, y3);
+                r.x = pack2<F16>(y0, y1);
+                r.y = pack2<F16>(y2, y3);
                 *(uint2*)((uint16_t*)p.out + o) = r;
             }
         }
@@ -271,7 +301,7 @@ __global__ __launch_bounds__(256) void conv_naive_f32(const ConvParams p)
 
 int conv_tile_bc(int cout) { return cout >= 128 ? 128 : (cout > 32 ? 64 : 32); }
 
-template <int BP, int BC, int WP, int WC>
+template <int BP, int BC, int WP, int WC, bool F16>
 static hipError_t launch_conv_t(const ConvParams& p, hipStream_t s)
 {
     using T = ConvTile<BP, BC, WP, WC>;
@@ -280,14 +310,14 @@ static hipError_t launch_conv_t(const ConvParams& p, hipStream_t s)
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
     if (!attr_done[dev & 63]) {
-        e = hipFuncSetAttribute((const void*)conv_igemm_bf16<BP, BC, WP, WC>,
+        e = hipFuncSetAttribute((const void*)conv_igemm_mfma<BP, BC, WP, WC, F16>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, T::kLdsBytes);
         if (e != hipSuccess) return e;
         attr_done[dev & 63] = true;
     }
     const int n_ct = (p.cout + BC - 1) / BC;
     const int n_pt = (p.M + BP - 1) / BP;
-    hipLaunchKernelGGL((conv_igemm_bf16<BP, BC, WP, WC>), dim3(n_ct * n_pt), dim3(256), T::kLdsBytes, s, p);
+    hipLaunchKernelGGL((conv_igemm_mfma<BP, BC, WP, WC, F16>), dim3(n_ct * n_pt), dim3(256), T::kLdsBytes, s, p);
     return hipGetLastError();
 }
 
@@ -298,11 +328,15 @@ hipError_t launch_conv(const ConvParams& p, int precision, hipStream_t s)
         hipLaunchKernelGGL(conv_naive_f32, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, p);
         return hipGetLastError();
     }
-    switch (conv_tile_bc(p.cout)) {
-        case 128: return launch_conv_t<128, 128, 2, 2>(p, s);
-        case 64: return launch_conv_t<256, 64, 4, 1>(p, s);
-        default: return launch_conv_t<256, 32, 4, 1>(p, s);
+    const int bc = conv_tile_bc(p.cout);
+    if (precision == kF16) {
+        if (bc == 128) return launch_conv_t<128, 128, 2, 2, true>(p, s);
+        if (bc == 64) return launch_conv_t<256, 64, 4, 1, true>(p, s);
+        return launch_conv_t<256, 32, 4, 1, true>(p, s);
     }
+    if (bc == 128) return launch_conv_t<128, 128, 2, 2, false>(p, s);
+    if (bc == 64) return launch_conv_t<256, 64, 4, 1, false>(p, s);
+    return launch_conv_t<256, 32, 4, 1, false>(p, s);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -311,9 +345,11 @@ hipError_t launch_conv(const ConvParams& p, int precision, hipStream_t s)
 template <typename E> __device__ inline E to_elem(float v);
 template <> __device__ inline uint16_t to_elem<uint16_t>(float v) { return bf16_bits_rne(v); }
 template <> __device__ inline float to_elem<float>(float v) { return v; }
+template <> __device__ inline _Float16 to_elem<_Float16>(float v) { return (_Float16)fminf(fmaxf(v, -65504.f), 65504.f); }
 template <typename E> __device__ inline float from_elem(E v);
 template <> __device__ inline float from_elem<uint16_t>(uint16_t v) { return __builtin_bit_cast(float, (uint32_t)v << 16); }
 template <> __device__ inline float from_elem<float>(float v) { return v; }
+template <> __device__ inline float from_elem<_Float16>(_Float16 v) { return (float)v; }
 
 template <typename E> struct alignas(16) Vec8 { E v[8]; };
 template <typename E> struct alignas(sizeof(E) * 4) Vec4 { E v[4]; };
@@ -389,6 +425,7 @@ hipError_t launch_ingest_u8(const IngestParams& p, int precision, hipStream_t s)
     const long total = (long)p.H * p.W * p.n_tiles;
     const unsigned grid = (unsigned)((total + 255) / 256);
     if (precision == kF32) hipLaunchKernelGGL(ingest_u8_kernel<float>, dim3(grid), dim3(256), 0, s, p);
+    else if (precision == kF16) hipLaunchKernelGGL(ingest_u8_kernel<_Float16>, dim3(grid), dim3(256), 0, s, p);
     else hipLaunchKernelGGL(ingest_u8_kernel<uint16_t>, dim3(grid), dim3(256), 0, s, p);
     return hipGetLastError();
 }
@@ -400,6 +437,8 @@ hipError_t launch_ingest_f32(const float* x, int n, int H, int W, void* c8, void
     const unsigned grid = (unsigned)((total + 255) / 256);
     if (precision == kF32)
         hipLaunchKernelGGL(ingest_f32_kernel<float>, dim3(grid), dim3(256), 0, s, x, n, H, W, c8, pairs, pad, pairs_w);
+    else if (precision == kF16)
+        hipLaunchKernelGGL(ingest_f32_kernel<_Float16>, dim3(grid), dim3(256), 0, s, x, n, H, W, c8, pairs, pad, pairs_w);
     else
         hipLaunchKernelGGL(ingest_f32_kernel<uint16_t>, dim3(grid), dim3(256), 0, s, x, n, H, W, c8, pairs, pad, pairs_w);
     return hipGetLastError();
@@ -443,6 +482,8 @@ hipError_t launch_maxpool(const void* src, void* dst, int n, int H, int W, int C
     const unsigned grid = (unsigned)((total + 255) / 256);
     if (precision == kF32)
         hipLaunchKernelGGL(maxpool_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)src, (float*)dst, n, H, W, C, k, stride, Ho, Wo);
+    else if (precision == kF16)
+        hipLaunchKernelGGL(maxpool_kernel<_Float16>, dim3(grid), dim3(256), 0, s, (const _Float16*)src, (_Float16*)dst, n, H, W, C, k, stride, Ho, Wo);
     else
         hipLaunchKernelGGL(maxpool_kernel<uint16_t>, dim3(grid), dim3(256), 0, s, (const uint16_t*)src, (uint16_t*)dst, n, H, W, C, k, stride, Ho, Wo);
     return hipGetLastError();
@@ -501,6 +542,7 @@ hipError_t launch_head(const HeadParams& p, int precision, hipStream_t s)
 {
     const unsigned grid = (unsigned)((p.M + 255) / 256);
     if (precision == kF32) hipLaunchKernelGGL(head_kernel<float>, dim3(grid), dim3(256), 0, s, p);
+    else if (precision == kF16) hipLaunchKernelGGL(head_kernel<_Float16>, dim3(grid), dim3(256), 0, s, p);
     else hipLaunchKernelGGL(head_kernel<uint16_t>, dim3(grid), dim3(256), 0, s, p);
     return hipGetLastError();
 }
@@ -558,6 +600,7 @@ hipError_t launch_to_f32(const void* src, float* dst, size_t n, int precision, h
 {
     const unsigned grid = (unsigned)((n + 255) / 256);
     if (precision == kF32) hipLaunchKernelGGL(to_f32_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)src, dst, n);
+    else if (precision == kF16) hipLaunchKernelGGL(to_f32_kernel<_Float16>, dim3(grid), dim3(256), 0, s, (const _Float16*)src, dst, n);
     else hipLaunchKernelGGL(to_f32_kernel<uint16_t>, dim3(grid), dim3(256), 0, s, (const uint16_t*)src, dst, n);
     return hipGetLastError();
 }

@@ -41,7 +41,7 @@ class SegModel:
         self.device = device
         self.precision = precision
         self.max_batch = int(max_batch or default_max_batch())
-        prec = {"bf16": _capi.PREC_BF16, "f32": _capi.PREC_F32}[precision]
+        prec = {"bf16": _capi.PREC_BF16, "f32": _capi.PREC_F32, "f16": _capi.PREC_F16}[precision]
         self._ctx: Optional[_capi.Context] = _capi.Context(device, prec)
         try:
             self._ctx.load_plan(self.plan, self.max_batch)

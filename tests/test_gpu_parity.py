@@ -1,0 +1,178 @@
+"""-m gpu: the HIP path (through libsbbseg's C ABI) against the CPU oracle on the same seeded inputs,
+against the golden fixtures captured from the reference loop, and -- at BASELINE sizes -- through
+size-independent properties.  Forward tolerances are stated in tests/gpu_common.py."""
+import json
+import os
+import zlib
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from gpu_common import TOL_SOFTMAX, compare_probs, make_model, patches_from_page  # noqa: E402
+from oracle import keras_forward as kf  # noqa: E402
+from oracle import tiling  # noqa: E402
+from sbb_textline_detection_amd import _capi, predict  # noqa: E402
+from sbb_textline_detection_amd.synthetic import noise_page, synthetic_page  # noqa: E402
+
+GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "tiling_golden.json")))["cases"]
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "gpu tests need a GPU"
+    return torch
+
+
+# ------------------------------------------------------------------------------------------ ingest
+@pytest.mark.parametrize("precision", ["bf16", "f32"])
+def test_ingest_forms(precision):
+    cfg, w, g, model = make_model(2, 64, 96, precision=precision, calib_hw=64)
+    page = noise_page(200, 300, 1)
+    xy = np.array([[0, 0], [204, 136], [17, 55]], np.int32)
+    c8 = model.ctx.debug_ingest(page, xy, _capi.INPUT_C8, (64, 96, 8))
+    pairs = model.ctx.debug_ingest(page, xy, _capi.INPUT_PAIRS, (64 + 6, (96 + 6 + 1) // 2, 8))
+    import torch
+    for k, (x0, y0) in enumerate(xy):
+        ref = (page[y0:y0 + 64, x0:x0 + 96] / 255.0).astype(np.float32)       # main.py:239, 285
+        if precision == "bf16":
+            ref = torch.from_numpy(ref).to(torch.bfloat16).to(torch.float32).numpy()
+        assert np.array_equal(c8[k, :, :, :3], ref) and not c8[k, :, :, 3:].any()
+        padded = np.zeros((70, 102, 4), np.float32)
+        padded[3:67, 3:99, :3] = ref
+        assert np.array_equal(pairs[k], padded.reshape(70, 51, 8))
+    model.release()
+
+
+# --------------------------------------------------------------------------------- forward, by layer
+@pytest.mark.parametrize("precision", ["f32", "bf16"])
+def test_every_fused_layer_matches_oracle(precision):
+    cfg, w, g, model = make_model(2, 64, 96, seed=2, precision=precision, max_batch=4, calib_hw=64)
+    x8 = patches_from_page(64, 96, 3, seed=4)
+    x = (x8 / 255.0).astype(np.float32)
+    taps = {name: None for name in model.plan.layer_tensor}
+    ref = kf.forward(g, w, x, taps=taps)
+    got = model.predict(x)
+    rel_tol = 2e-4 if precision == "f32" else 0.04
+    worst = ("", 0.0)
+    for name, tid in model.plan.layer_tensor.items():
+        t = model.plan.tensors[tid]
+        a = model.ctx.debug_read_tensor(tid, 3, (t.H, t.W, t.C))
+        r = taps[name]
+        rel = float(np.abs(a - r).max() / (np.abs(r).max() + 1e-6))
+        if rel > worst[1]:
+            worst = (name, rel)
+        assert rel < rel_tol, f"{name}: rel err {rel:.4g} ({precision})"
+    d, mism, bad = compare_probs(ref, got, TOL_SOFTMAX[precision])
+    assert d < TOL_SOFTMAX[precision] and bad == 0, (d, mism, bad, worst)
+    model.release()
+
+
+# ------------------------------------------------------------------------------- seam 2 at full size
+@pytest.mark.parametrize("classes", [2, 4])
+def test_predict_448_matches_oracle(classes):
+    cfg, w, g, model = make_model(classes, 448, 448, seed=classes, precision="bf16", max_batch=4)
+    x = (patches_from_page(448, 448, 2, seed=9) / 255.0).astype(np.float32)
+    ref = kf.forward(g, w, x)
+    got = model.predict(x)
+    assert got.shape == ref.shape and got.dtype == np.float32
+    assert np.allclose(got.sum(-1), 1.0, atol=1e-5)
+    d, mism, bad = compare_probs(ref, got, TOL_SOFTMAX["bf16"])
+    print(f"[448 C={classes}] max|dsoftmax|={d:.4f} label mismatches={mism}/{ref[...,0].size} outside tolerance={bad}")
+    assert d < TOL_SOFTMAX["bf16"] and bad == 0
+    assert mism / ref[..., 0].size < 0.03
+    model.release()
+
+
+# ------------------------------------------------------------ seam 1: fused page path vs oracle loop
+def test_segment_page_matches_oracle_loop():
+    cfg, w, g, model = make_model(2, 224, 224, seed=5, precision="bf16", max_batch=5)
+    page = synthetic_page(500, 610, seed=3)
+    om = kf.OracleModel(cfg, w)
+    ref = tiling.do_prediction(True, page, om)                                   # oracle: main.py:225-366
+    got = predict.do_prediction(True, page, model)
+    assert got.dtype == np.uint8 and got.shape == ref.shape
+    assert np.array_equal(got[:, :, 0], got[:, :, 1]) and np.array_equal(got[:, :, 0], got[:, :, 2])
+    mism = (got[:, :, 0] != ref[:, :, 0]).mean()
+    print(f"[page 500x610, 224 model] label mismatch fraction vs oracle loop: {mism:.5f}")
+    assert mism < 0.03
+    # the f32 check handle must agree with the oracle almost everywhere (only summation order differs)
+    cfg2, w2, g2, m32 = make_model(2, 224, 224, seed=5, precision="f32", max_batch=5)
+    got32 = predict.do_prediction(True, page, m32)
+    assert (got32[:, :, 0] != ref[:, :, 0]).mean() < 5e-4
+    # generic path (float page -> batched model.predict on the GPU -> host stitch) == fused path
+    got_f = predict.do_prediction(True, page.astype(np.float64), model)
+    assert np.array_equal(got_f, got)
+    model.release(); m32.release()
+
+
+def test_whole_image_branch_matches_oracle():
+    cfg, w, g, model = make_model(2, 224, 224, seed=6, precision="f32", max_batch=2)
+    page = synthetic_page(700, 520, seed=8)
+    om = kf.OracleModel(cfg, w)
+    ref = tiling.do_prediction(False, page, om, full_image_shape=(840, 624, 3))
+    got = predict.do_prediction(False, page, model, full_image_shape=(840, 624, 3))
+    assert got.shape == (840, 624, 3) and got.dtype == np.uint8
+    assert (got != ref).mean() < 1e-3
+    model.release()
+
+
+# ------------------------------------------------- stitch / tile ranges vs the reference's own output
+@pytest.mark.parametrize("case", [c for c in GOLD if c["model_h"] == 448],
+                         ids=lambda c: f"{c['page_h']}x{c['page_w']}")
+def test_device_stitch_reproduces_reference_fixture(case, torch_cuda, stitch_model):
+    torch = torch_cuda
+    ph, pw = case["page_h"], case["page_w"]
+    page = tiling.coord_page(ph, pw).astype(np.int64)
+    yy, xx = np.mgrid[0:448, 0:448]
+    tiles = np.empty((case["n_calls"], 448, 448), np.uint8)
+    for k, (x0, y0) in enumerate(case["calls_xy"]):                            # FakeModel's label rule
+        p = page[y0:y0 + 448, x0:x0 + 448]
+        tiles[k] = (k * 5 + yy * 3 + xx * 7 + p[:, :, 0] + 2 * p[:, :, 1]) % 16
+    d_tiles = torch.from_numpy(tiles).cuda()
+    d_out = torch.zeros((ph, pw), dtype=torch.uint8, device="cuda")
+    stitch_model.ctx.stitch_dev(d_tiles.data_ptr(), ph, pw, d_out.data_ptr())
+    stitch_model.ctx.synchronize()
+    out = d_out.cpu().numpy()
+    assert zlib.crc32(out.tobytes()) & 0xFFFFFFFF == case["out_crc32"]
+    assert int(out.astype(np.int64).sum()) == case["out_sum"]
+
+
+@pytest.fixture(scope="module")
+def stitch_model():
+    from sbb_textline_detection_amd.model import SegModel
+    from sbb_textline_detection_amd.weights import synthetic_model
+    cfg, w = synthetic_model(2, 448, 448, seed=0)
+    m = SegModel(cfg, w, device=0, max_batch=8)
+    yield m
+    m.release()
+
+
+# -------------------------------------------------------------- BASELINE config[1]: size-independent
+def test_full_page_properties_3500x2500(torch_cuda, stitch_model):
+    """One 3500x2500 page, 448 model (70 tiles).  The oracle needs ~2 min for this, so check
+    properties instead: determinism, independence of the tile batch size, tile-range sharding ==
+    whole page, and oracle agreement on a sample of tiles."""
+    torch = torch_cuda
+    model = stitch_model
+    page = synthetic_page(3500, 2500, seed=0)
+    a = model.segment_page(page)
+    b = model.segment_page(page)
+    assert a.shape == (3500, 2500) and np.array_equal(a, b)
+    from sbb_textline_detection_amd.model import SegModel
+    from sbb_textline_detection_amd.weights import synthetic_model
+    cfg, w = synthetic_model(2, 448, 448, seed=0)
+    m3 = SegModel(cfg, w, device=0, max_batch=3)
+    assert np.array_equal(m3.segment_page(page), a)
+    # sharded tile ranges, stitched, equal the one-call result
+    d_page = torch.from_numpy(page).cuda()
+    d_tiles = torch.empty((70, 448, 448), dtype=torch.uint8, device="cuda")
+    for first, n in ((0, 23), (23, 23), (46, 24)):
+        m3.ctx.segment_tile_range_dev(d_page.data_ptr(), 3500, 2500, first, n, d_tiles[first:].data_ptr())
+    d_out = torch.empty((3500, 2500), dtype=torch.uint8, device="cuda")
+    m3.ctx.stitch_dev(d_tiles.data_ptr(), 3500, 2500, d_out.data_ptr())
+    m3.ctx.synchronize()
+    assert np.array_equal(d_out.cpu().numpy(), a)
+    m3.release()
