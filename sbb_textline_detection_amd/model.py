@@ -34,7 +34,7 @@ class SegModel:
     """A segmentation net resident on one MI355X, duck-typed like the Keras model the reference uses."""
 
     def __init__(self, model_config, weights, device: int = 0, max_batch: Optional[int] = None,
-                 precision: str = "bf16"):
+                 precision: str = "f16"):
         self.graph: Graph = parse_model_config(model_config)
         self.plan: Plan = build_plan(self.graph, weights)
         self.layers = self.graph.nodes                     # main.py:227-229 reads layers[-1].output_shape
@@ -107,7 +107,7 @@ def resolve_model_path(path: str) -> str:
 
 
 def load_model(path: str, compile: bool = False, device: int = 0, max_batch: Optional[int] = None,
-               precision: str = "bf16") -> SegModel:
+               precision: str = "f16") -> SegModel:
     """``keras.models.load_model(path, compile=False)`` replacement (main.py:221)."""
     real = resolve_model_path(path)
     use_cache = os.environ.get("SBBSEG_MODEL_CACHE", "1") != "0"
