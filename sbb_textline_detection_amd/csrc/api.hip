@@ -512,7 +512,10 @@ int sbbseg_add_conv(sbbseg_ctx* c, const sbbseg_conv_desc* d, const float* w_hwi
             if (ch >= d->src[r.s].channels) continue;
             const float* wsrc = w_hwio + ((size_t)(r.ky * d->kw + r.kx) * cin_total + cin_base[r.s] + ch) * d->cout;
             const size_t k = g * 8 + q;
-            for (int o = 0; o < d->cout; ++o) wf[(size_t)o * co.Ktot + k] = wsrc[o];
+            for (int row = 0; row < co.cout_pad; ++row) {
+                const int o = c->precision != kF32 ? conv_row_channel(row, d->cout) : row;
+                if (o < d->cout) wf[(size_t)row * co.Ktot + k] = wsrc[o];
+            }
         }
     }
     if (c->precision != kF32) {

@@ -92,6 +92,7 @@ hipError_t launch_resize_labels(const uint8_t* labels, int H, int W, const int* 
                                 int out_h, int out_w, uint8_t* out, hipStream_t s);
 hipError_t launch_to_f32(const void* src, float* dst, size_t n, int precision, hipStream_t s);
 
+int conv_row_channel(int row, int cout);   // packed weight row -> output channel (16-bit modes)
 int conv_tile_bc(int cout);   // channel-tile width the bf16 conv kernel uses for `cout` (weights are padded to it)
 uint16_t f32_to_bf16_rne(float f);
 uint16_t f32_to_f16_rne(float f);

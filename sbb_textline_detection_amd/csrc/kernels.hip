@@ -202,45 +202,59 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_mfma(const ConvParams p)
         __syncthreads();
     }
 
-    // ---- epilogue: lane holds channels c0..c0+3 (rows of D) of pixel m (column of D)
+    // ---- epilogue.  Weight rows are packed in the order conv_row_channel() gives, so that the two
+    // MFMA row blocks (2s, 2s+1) of a lane hold 8 CONSECUTIVE channels of one pixel: 16-byte NHWC
+    // stores / residual loads, 64 contiguous bytes per pixel per instruction.
 #pragma unroll
-    for (int mi = 0; mi < T::kMI; ++mi) {
-        const int c0 = ctile * BC + wc * T::kWCH + mi * 16 + fg * 4;
+    for (int s2 = 0; s2 < T::kMI / 2; ++s2) {
+        const int c0 = ctile * BC + wc * T::kWCH + s2 * 32 + fg * 8;
         if (c0 >= p.cout) continue;
-        const float4 sc = *(const float4*)(p.scale + c0);
-        const float4 sh = *(const float4*)(p.shift + c0);
-        float4 rsc = make_float4(1.f, 1.f, 1.f, 1.f), rsh = make_float4(0.f, 0.f, 0.f, 0.f);
+        float sc[8], sh[8], rsc[8], rsh[8];
+        *(float4*)&sc[0] = *(const float4*)(p.scale + c0);
+        *(float4*)&sc[4] = *(const float4*)(p.scale + c0 + 4);
+        *(float4*)&sh[0] = *(const float4*)(p.shift + c0);
+        *(float4*)&sh[4] = *(const float4*)(p.shift + c0 + 4);
         if (p.raw_out) {
-            rsc = *(const float4*)(p.raw_scale + c0);
-            rsh = *(const float4*)(p.raw_shift + c0);
+            *(float4*)&rsc[0] = *(const float4*)(p.raw_scale + c0);
+            *(float4*)&rsc[4] = *(const float4*)(p.raw_scale + c0 + 4);
+            *(float4*)&rsh[0] = *(const float4*)(p.raw_shift + c0);
+            *(float4*)&rsh[4] = *(const float4*)(p.raw_shift + c0 + 4);
         }
 #pragma unroll
         for (int ni = 0; ni < T::kNI; ++ni) {
             const int m = ptile * BP + wp * T::kWPX + ni * 16 + frow;
             if (m >= p.M) continue;
-            const f32x4_t v = acc[mi][ni];
+            float v[8];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { v[q] = acc[2 * s2][ni][q]; v[4 + q] = acc[2 * s2 + 1][ni][q]; }
             const size_t o = (size_t)m * p.cout + c0;
             if (p.raw_out) {
-                uint2 r;
-                r.x = pack2<F16>(v[0] * rsc.x + rsh.x, v[1] * rsc.y + rsh.y);
-                r.y = pack2<F16>(v[2] * rsc.z + rsh.z, v[3] * rsc.w + rsh.w);
-                *(uint2*)((uint16_t*)p.raw_out + o) = r;
+                uint4 r;
+                r.x = pack2<F16>(v[0] * rsc[0] + rsh[0], v[1] * rsc[1] + rsh[1]);
+                r.y = pack2<F16>(v[2] * rsc[2] + rsh[2], v[3] * rsc[3] + rsh[3]);
+                r.z = pack2<F16>(v[4] * rsc[4] + rsh[4], v[5] * rsc[5] + rsh[5]);
+                r.w = pack2<F16>(v[6] * rsc[6] + rsh[6], v[7] * rsc[7] + rsh[7]);
+                *(uint4*)((uint16_t*)p.raw_out + o) = r;
             }
             if (p.out) {
-                float y0 = v[0] * sc.x + sh.x, y1 = v[1] * sc.y + sh.y;
-                float y2 = v[2] * sc.z + sh.z, y3 = v[3] * sc.w + sh.w;
+                float y[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) y[q] = v[q] * sc[q] + sh[q];
                 if (p.residual) {
-                    const uint2 rr = *(const uint2*)((const uint16_t*)p.residual + o);
-                    y0 += unpack_lo<F16>(rr.x); y1 += unpack_hi<F16>(rr.x);
-                    y2 += unpack_lo<F16>(rr.y); y3 += unpack_hi<F16>(rr.y);
+                    const uint4 rr = *(const uint4*)((const uint16_t*)p.residual + o);
+                    y[0] += unpack_lo<F16>(rr.x); y[1] += unpack_hi<F16>(rr.x);
+                    y[2] += unpack_lo<F16>(rr.y); y[3] += unpack_hi<F16>(rr.y);
+                    y[4] += unpack_lo<F16>(rr.z); y[5] += unpack_hi<F16>(rr.z);
+                    y[6] += unpack_lo<F16>(rr.w); y[7] += unpack_hi<F16>(rr.w);
                 }
                 if (p.relu) {
-                    y0 = fmaxf(y0, 0.f); y1 = fmaxf(y1, 0.f); y2 = fmaxf(y2, 0.f); y3 = fmaxf(y3, 0.f);
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) y[q] = fmaxf(y[q], 0.f);
                 }
-                uint2 r;
-                r.x = pack2<F16>(y0, y1);
-                r.y = pack2<F16>(y2, y3);
-                *(uint2*)((uint16_t*)p.out + o) = r;
+                uint4 r;
+                r.x = pack2<F16>(y[0], y[1]); r.y = pack2<F16>(y[2], y[3]);
+                r.z = pack2<F16>(y[4], y[5]); r.w = pack2<F16>(y[6], y[7]);
+                *(uint4*)((uint16_t*)p.out + o) = r;
             }
         }
     }
@@ -300,6 +314,17 @@ __global__ __launch_bounds__(256) void conv_naive_f32(const ConvParams p)
 }
 
 int conv_tile_bc(int cout) { return cout >= 128 ? 128 : (cout > 32 ? 64 : 32); }
+
+// Channel stored in packed weight row `row` (16-bit modes).  Inside each wave tile of WCH channels
+// (64, or 32 when the channel tile is 32) MFMA row block mi, row rho is given channel
+// (mi>>1)*32 + (rho>>2)*8 + (mi&1)*4 + (rho&3): see the epilogue of conv_igemm_mfma.
+int conv_row_channel(int row, int cout)
+{
+    const int wch = conv_tile_bc(cout) == 32 ? 32 : 64;
+    const int base = (row / wch) * wch, t = row % wch;
+    const int mi = t >> 4, rho = t & 15;
+    return base + (mi >> 1) * 32 + (rho >> 2) * 8 + (mi & 1) * 4 + (rho & 3);
+}
 
 template <int BP, int BC, int WP, int WC, bool F16>
 static hipError_t launch_conv_t(const ConvParams& p, hipStream_t s)
