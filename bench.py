@@ -37,6 +37,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--precision", default=os.environ.get("SBBSEG_PRECISION", "f16"), choices=["f16", "bf16"])
     ap.add_argument("--max-batch", type=int, default=int(os.environ.get("SBBSEG_MAX_BATCH", "35")))
+    ap.add_argument("--conv-variant", type=int, default=int(os.environ.get("SBBSEG_CONV_VARIANT", "0")),
+                    help="0 auto, 1 force 4-wave/2-stage conv tiles, 2 force 8-wave/3-stage (A/B only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-patches", type=int, default=8)
     args = ap.parse_args()
@@ -64,6 +66,7 @@ def main():
     model = SegModel(cfg, weights, device=local_rank, max_batch=args.max_batch, precision=args.precision)
     ctx = model.ctx
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    ctx.set_conv_variant(args.conv_variant)
 
     page = synthetic_page(PAGE_H, PAGE_W, seed=rank)
     d_page = torch.from_numpy(page).cuda()

@@ -134,6 +134,10 @@ int sbbseg_debug_ingest(sbbseg_ctx* c, const uint8_t* page_hwc, int Hp, int Wp, 
 /* copy an activation tensor of the last run back as float32 [n][H][W][C] (tests) */
 int sbbseg_debug_read_tensor(sbbseg_ctx* c, int tensor_id, int n, float* out, size_t out_floats);
 
+/* force the conv tile family (A/B benchmarking, tests): 0 auto, 1 = 4 waves / 2 LDS stages,
+ * 2 = 8 waves / 3 LDS stages with counted waits */
+int sbbseg_debug_set_conv_variant(sbbseg_ctx* c, int variant);
+
 /* ---- per-op timing with HIP events on the handle's stream (bench.py roofline) */
 int sbbseg_profile_enable(sbbseg_ctx* c, int enable);
 int sbbseg_profile_reset(sbbseg_ctx* c);

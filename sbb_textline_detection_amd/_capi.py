@@ -23,6 +23,7 @@ EXPORTS = [
     "sbbseg_num_ops", "sbbseg_op_info", "sbbseg_device_bytes", "sbbseg_predict", "sbbseg_segment_page",
     "sbbseg_segment_page_dev", "sbbseg_segment_whole", "sbbseg_tile_grid", "sbbseg_segment_tiles_dev",
     "sbbseg_segment_tile_range_dev", "sbbseg_stitch_dev", "sbbseg_debug_ingest", "sbbseg_debug_read_tensor",
+    "sbbseg_debug_set_conv_variant",
     "sbbseg_profile_enable", "sbbseg_profile_reset", "sbbseg_profile_get",
 ]
 
@@ -82,6 +83,7 @@ def load_library(path: Optional[str] = None):
         "sbbseg_stitch_dev": [vp, vp, i32, i32, vp],
         "sbbseg_debug_ingest": [vp, vp, i32, i32, vp, i32, i32, vp, C.c_size_t],
         "sbbseg_debug_read_tensor": [vp, i32, i32, vp, C.c_size_t],
+        "sbbseg_debug_set_conv_variant": [vp, i32],
         "sbbseg_profile_enable": [vp, i32],
         "sbbseg_profile_reset": [vp],
         "sbbseg_profile_get": [vp, i32, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_int64)],
@@ -254,6 +256,9 @@ class Context:
         check(self.lib.sbbseg_debug_read_tensor(self.h, self.tensor_ids[plan_tensor], n, _ptr(out), out.size),
               "sbbseg_debug_read_tensor")
         return out
+
+    def set_conv_variant(self, variant: int):
+        check(self.lib.sbbseg_debug_set_conv_variant(self.h, int(variant)))
 
     # -- profiling -----------------------------------------------------------------------------
     def profile_enable(self, on: bool):

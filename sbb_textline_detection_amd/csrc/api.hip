@@ -60,6 +60,7 @@ struct ConvOp {
     int Ho = 0, Wo = 0;
     int cout_pad = 0, Ktot = 0, total_ksteps = 0, ksteps[2] = {0, 0};
     KTabEntry* d_ktab = nullptr;
+    KStepRec* d_kstep = nullptr;
     void* d_w = nullptr;
     float *d_scale = nullptr, *d_shift = nullptr, *d_rscale = nullptr, *d_rshift = nullptr;
 };
@@ -113,6 +114,7 @@ struct sbbseg_ctx {
     int *d_map = nullptr; size_t map_cap = 0;
     // profiling
     bool profiling = false;
+    int conv_variant = 0;
     std::vector<PendingEvent> pending;
     std::vector<hipEvent_t> free_events;
 };
@@ -243,7 +245,7 @@ int run_plan(sbbseg_ctx* c, int n, uint8_t* d_labels, float* d_probs)
                 sd.lim_y = t.H << sd.shift; sd.lim_x = t.W << sd.shift;
                 sd.ksteps = co.ksteps[s];
             }
-            p.ktab = co.d_ktab; p.w = co.d_w; p.Ktot = co.Ktot; p.total_ksteps = co.total_ksteps;
+            p.ktab = co.d_ktab; p.kstep = co.d_kstep; p.variant = c->conv_variant; p.w = co.d_w; p.Ktot = co.Ktot; p.total_ksteps = co.total_ksteps;
             p.Ho = co.Ho; p.Wo = co.Wo; p.M = n * co.Ho * co.Wo;
             p.sy = co.d.stride_y; p.sx = co.d.stride_x; p.pad_t = co.d.pad_top; p.pad_l = co.d.pad_left;
             p.cout = co.d.cout; p.scale = co.d_scale; p.shift = co.d_shift;
@@ -344,7 +346,7 @@ int sbbseg_destroy(sbbseg_ctx* c)
     for (auto& t : c->tensors)
         if (t.buf) hipFree(t.buf);
     for (auto& op : c->ops) {
-        hipFree(op.conv.d_ktab); hipFree(op.conv.d_w); hipFree(op.conv.d_scale); hipFree(op.conv.d_shift);
+        hipFree(op.conv.d_ktab); hipFree(op.conv.d_kstep); hipFree(op.conv.d_w); hipFree(op.conv.d_scale); hipFree(op.conv.d_shift);
         hipFree(op.conv.d_rscale); hipFree(op.conv.d_rshift);
         hipFree(op.head.d_w); hipFree(op.head.d_scale); hipFree(op.head.d_shift);
     }
@@ -527,6 +529,17 @@ int sbbseg_add_conv(sbbseg_ctx* c, const sbbseg_conv_desc* d, const float* w_hwi
         if (upload(c, (float**)&co.d_w, wf.data(), wn)) return 1;
     }
     if (upload(c, &co.d_ktab, ktab.data(), ktab.size())) return 1;
+    std::vector<KStepRec> ksteps(co.total_ksteps);
+    for (int t = 0; t < co.total_ksteps; ++t) {
+        const KTabEntry* e = &ktab[(size_t)t * kGranulesPerStep];
+        KStepRec r;
+        r.dy = e[0].dy; r.dx = e[0].dx; r.coff = e[0].coff; r.irregular = 0; r.pad_ = 0;
+        for (int g = 1; g < kGranulesPerStep; ++g)
+            if (e[g].dy != e[0].dy || e[g].dx != e[0].dx || e[g].coff != e[0].coff + 16 * g) r.irregular = 1;
+        if (c->precision == kF32) r.irregular = 1;     // the fp32 check kernel only walks the granule table
+        ksteps[t] = r;
+    }
+    if (upload(c, &co.d_kstep, ksteps.data(), ksteps.size())) return 1;
     std::vector<float> pad_s(co.cout_pad, 0.f), pad_b(co.cout_pad, 0.f);
     memcpy(pad_s.data(), scale, sizeof(float) * d->cout);
     memcpy(pad_b.data(), shift, sizeof(float) * d->cout);
@@ -886,6 +899,13 @@ int sbbseg_debug_read_tensor(sbbseg_ctx* c, int tensor_id, int n, float* out, si
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     hipFree(d_tmp);
     HIPCHK(e);
+    return 0;
+}
+
+int sbbseg_debug_set_conv_variant(sbbseg_ctx* c, int variant)
+{
+    REQUIRE(c && variant >= 0 && variant <= 2, "variant must be 0 (auto), 1 (4-wave/2-stage) or 2 (8-wave/3-stage)");
+    c->conv_variant = variant;
     return 0;
 }
 

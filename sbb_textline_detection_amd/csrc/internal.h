@@ -27,9 +27,20 @@ struct KTabEntry {
     int32_t coff;         // byte offset of the granule inside the stored pixel
 };
 
+// one record per K-step, read through the scalar cache.  Regular step: all 8 granules share the tap
+// (dy,dx) and are channel-consecutive (coff + 16*g).  Irregular: per-granule KTabEntry applies.
+struct KStepRec {
+    int16_t dy, dx;
+    int32_t coff;
+    int32_t irregular;
+    int32_t pad_;
+};
+
 struct ConvParams {
     SrcDesc src[2];
     int n_src;
+    const KStepRec* kstep;    // [total_ksteps]
+    int variant;              // 0 = auto tile choice, 1 = force 4-wave/2-stage, 2 = force 8-wave/3-stage
     const KTabEntry* ktab;    // [total_ksteps * 8]
     const void* w;            // packed [cout_pad][Ktot] (bf16) -- K order = ktab order
     int Ktot;                 // total_ksteps * 64

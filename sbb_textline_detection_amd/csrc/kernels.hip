@@ -73,24 +73,42 @@ template <bool F16> __device__ inline f32x4_t mfma16(bf16x8_t a, bf16x8_t b, f32
 // ------------------------------------------------------------------------------------------------
 // conv_igemm_mfma  (16-bit operands: bf16 or fp16, fp32 accumulate)
 // ------------------------------------------------------------------------------------------------
-template <int BP, int BC, int WP, int WC>
+template <int BP, int BC, int WP, int WC, int NS>
 struct ConvTile {
-    static constexpr int kThreads = 256;
+    static constexpr int kWaves = WP * WC;
+    static constexpr int kThreads = 64 * kWaves;
     static constexpr int kWPX = BP / WP;          // pixels per wave tile
     static constexpr int kWCH = BC / WC;          // channels per wave tile
     static constexpr int kNI = kWPX / 16;
     static constexpr int kMI = kWCH / 16;
-    static constexpr int kPLoads = BP / 32;       // global_load_lds per thread per K-step, pixels
-    static constexpr int kWLoads = BC / 32;       // ... weights
-    static constexpr int kStageBytes = (BP + BC) * 128;
-    static constexpr int kLdsBytes = 2 * kStageBytes;
+    static constexpr int kPLoads = BP / (8 * kWaves);   // global_load_lds per thread per K-step, pixels
+    static constexpr int kWRows = BC > 8 * kWaves ? BC : 8 * kWaves;   // weight rows staged (>= one 8-row group per wave,
+                                                                       // so every wave issues the same number of loads)
+    static constexpr int kWLoads = kWRows / (8 * kWaves);              // ... weights
+    static constexpr int kLoads = kPLoads + kWLoads;
+    static constexpr int kStageBytes = (BP + kWRows) * 128;
+    static constexpr int kLdsBytes = NS * kStageBytes;
+    static_assert(BP % (8 * kWaves) == 0 && kWRows % (8 * kWaves) == 0, "tile rows must split over the waves");
+    static_assert(kMI % 2 == 0, "epilogue pairs MFMA row blocks");
 };
 
-template <int BP, int BC, int WP, int WC, bool F16>
-__global__ __launch_bounds__(256, 2) void conv_igemm_mfma(const ConvParams p)
+template <int N> __device__ inline void wait_vmcnt()
 {
-    using T = ConvTile<BP, BC, WP, WC>;
-    static_assert(WP * WC == 4, "4 waves");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// Pipeline: NS LDS stages, stage t+D (D = NS-1) is issued while stage t is multiplied; the wait
+// at the end of an iteration is COUNTED (stage t+1 landed, later stages stay in flight across the
+// raw s_barrier) -- the vmcnt(0)+__syncthreads() drain of a 2-stage loop is what kept MFMA idle.
+// K-step descriptors come through the scalar cache (uniform address -> s_load, lgkmcnt), so no
+// VGPR-destination VMEM load sits in the loop to force a vmcnt(0).
+template <int BP, int BC, int WP, int WC, int NS, bool F16>
+__global__ __launch_bounds__(64 * WP * WC, (WP * WC) / 4 * (NS == 2 ? 2 : 1))
+void conv_igemm_mfma(const ConvParams p)
+{
+    using T = ConvTile<BP, BC, WP, WC, NS>;
+    constexpr int NW = T::kWaves;
+    constexpr int D = NS - 1;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x;
@@ -102,14 +120,14 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_mfma(const ConvParams p)
     const int ctile = blockIdx.x % n_ct;
     const int ptile = blockIdx.x / n_ct;
 
-    // ---- per-thread gather rows (fixed over the K loop)
+    // ---- per-thread gather rows (fixed over the K loop): row = (j*NW + wave)*8 + lrow
     const int lrow = lane >> 3;                         // row inside an 8-row glds group
     const int gsrc = (lane & 7) ^ lrow;                 // source granule this lane fetches (swizzle)
     int r_n[T::kPLoads], r_iy[T::kPLoads], r_ix[T::kPLoads];
     const int HoWo = p.Ho * p.Wo;
 #pragma unroll
     for (int j = 0; j < T::kPLoads; ++j) {
-        const int m = ptile * BP + j * 32 + wave * 8 + lrow;
+        const int m = ptile * BP + (j * NW + wave) * 8 + lrow;
         if (m < p.M) {
             const int n = m / HoWo;
             const int rem = m - n * HoWo;
@@ -124,40 +142,67 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_mfma(const ConvParams p)
             r_ix[j] = 0;
         }
     }
-    // weights: row = ctile*BC + j*32 + wave*8 + lrow ; byte offset of this lane's granule at K-step 0
     uint32_t w_off[T::kWLoads];
 #pragma unroll
     for (int j = 0; j < T::kWLoads; ++j)
-        w_off[j] = (uint32_t)((ctile * BC + j * 32 + wave * 8 + lrow) * p.Ktot + gsrc * 8) * 2u;
+        w_off[j] = (uint32_t)((ctile * BC + min((j * NW + wave) * 8 + lrow, BC - 1)) * p.Ktot + gsrc * 8) * 2u;
     const char* wbase = (const char*)p.w;
 
     const int nt = p.total_ksteps;
-    KTabEntry e = p.ktab[gsrc];                         // entry of the K-step staged next
+    // both sources' descriptors live in SGPRs for the whole kernel (selected per K-step with
+    // s_cselect); per-row image base offsets are precomputed per source
+    const SrcDesc sd0 = p.src[0];
+    const SrcDesc sd1 = p.n_src > 1 ? p.src[1] : p.src[0];
+    const int ks0 = p.n_src > 1 ? sd0.ksteps : nt;
+    uint32_t r_nb0[T::kPLoads], r_nb1[T::kPLoads];
+#pragma unroll
+    for (int j = 0; j < T::kPLoads; ++j) {
+        r_nb0[j] = (uint32_t)r_n[j] * (uint32_t)(sd0.PH * sd0.PW * sd0.pix_bytes);
+        r_nb1[j] = (uint32_t)r_n[j] * (uint32_t)(sd1.PH * sd1.PW * sd1.pix_bytes);
+    }
+    const __attribute__((address_space(4))) int* kstep_tab =
+        (const __attribute__((address_space(4))) int*)(uintptr_t)p.kstep;
+    // K-step record of the stage issued NEXT, fetched one stage ahead through the scalar cache
+    // (uniform address in the constant address space -> s_load, lgkmcnt): no VGPR-destination
+    // VMEM load sits in the loop, so the counted vmcnt below stays exact.
+    int rec_yx = kstep_tab[0], rec_coff = kstep_tab[1], rec_irr = kstep_tab[2];
     auto stage = [&](int t, int buf) {
-        // source of this K-step (uniform)
-        const bool s1 = (p.n_src > 1) && (t >= p.src[0].ksteps);
-        const SrcDesc& sd = s1 ? p.src[1] : p.src[0];
+        const bool s1 = t >= ks0;
+        const char* base = s1 ? sd1.base : sd0.base;
+        const int rowbytes = s1 ? sd1.PW * sd1.pix_bytes : sd0.PW * sd0.pix_bytes;
+        const int pixb = s1 ? sd1.pix_bytes : sd0.pix_bytes;
+        const int sh = s1 ? sd1.shift : sd0.shift;
+        const unsigned lim_y = s1 ? sd1.lim_y : sd0.lim_y, lim_x = s1 ? sd1.lim_x : sd0.lim_x;
+        int dy = (int)(short)(rec_yx & 0xffff), dx = rec_yx >> 16;
+        int coff = rec_coff + gsrc * 16 + kZeroHeaderBytes;
+        if (rec_irr) {                                         // granules of this step differ in tap
+            const KTabEntry e = p.ktab[t * kGranulesPerStep + gsrc];
+            dy = e.dy; dx = e.dx; coff = e.coff + kZeroHeaderBytes;
+        }
+        {   // prefetch the next record (clamped; harmless re-read on the last stage)
+            const int tn = t + 1 < nt ? t + 1 : t;
+            rec_yx = kstep_tab[tn * 4 + 0]; rec_coff = kstep_tab[tn * 4 + 1]; rec_irr = kstep_tab[tn * 4 + 2];
+        }
         char* lds_p = smem + buf * T::kStageBytes;
         char* lds_w = lds_p + BP * 128;
 #pragma unroll
         for (int j = 0; j < T::kPLoads; ++j) {
-            const int uy = r_iy[j] + e.dy;
-            const int ux = r_ix[j] + e.dx;
-            const bool ok = ((unsigned)uy < (unsigned)sd.lim_y) & ((unsigned)ux < (unsigned)sd.lim_x);
-            const int yy = uy >> sd.shift, xx = ux >> sd.shift;
-            uint32_t off = (uint32_t)((r_n[j] * sd.PH + yy) * sd.PW + xx) * (uint32_t)sd.pix_bytes
-                           + (uint32_t)e.coff + (uint32_t)kZeroHeaderBytes;
+            const int uy = r_iy[j] + dy;
+            const int ux = r_ix[j] + dx;
+            const bool ok = ((unsigned)uy < lim_y) & ((unsigned)ux < lim_x);
+            const int yy = uy >> sh, xx = ux >> sh;
+            // yy, xx < 2^12 and rowbytes, pixb < 2^24: 24-bit multiplies are exact (full-rate VALU)
+            uint32_t off = (s1 ? r_nb1[j] : r_nb0[j]) +
+                           __umul24(yy, rowbytes) + __umul24(xx, pixb) + (uint32_t)coff;
             off = ok ? off : 0u;
-            __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(sd.base + off),
-                                             (LDS_AS void*)(lds_p + (j * 32 + wave * 8) * 128), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(base + off),
+                                             (LDS_AS void*)(lds_p + (j * NW + wave) * 8 * 128), 16, 0, 0);
         }
 #pragma unroll
         for (int j = 0; j < T::kWLoads; ++j) {
             __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(wbase + w_off[j] + (uint32_t)t * (kBK * 2)),
-                                             (LDS_AS void*)(lds_w + (j * 32 + wave * 8) * 128), 16, 0, 0);
+                                             (LDS_AS void*)(lds_w + (j * NW + wave) * 8 * 128), 16, 0, 0);
         }
-        // table entry for the following K-step: in flight under the MFMAs, drained with the glds
-        e = p.ktab[min(t + 1, nt - 1) * kGranulesPerStep + gsrc];
     };
 
     f32x4_t acc[T::kMI][T::kNI];
@@ -174,13 +219,17 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_mfma(const ConvParams p)
     const int p_rd = (wp * T::kWPX) * 128;
     const int w_rd = BP * 128 + (wc * T::kWCH) * 128;
 
-    stage(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    // ---- prologue: D stages in flight, stage 0 landed
+#pragma unroll
+    for (int d = 0; d < D; ++d)
+        if (d < nt) stage(d, d);
+    if (D >= 2 && nt >= 2) wait_vmcnt<T::kLoads*(D >= 2 ? D - 1 : 0)>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
 
+    int cur = 0, nxt = D % NS;
     for (int t = 0; t < nt; ++t) {
-        const int cur = t & 1;
-        if (t + 1 < nt) stage(t + 1, cur ^ 1);
+        if (t + D < nt) stage(t + D, nxt);
         const char* sb = smem + cur * T::kStageBytes;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
@@ -198,8 +247,15 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_mfma(const ConvParams p)
                 for (int ni = 0; ni < T::kNI; ++ni)
                     acc[mi][ni] = mfma16<F16>(a[mi], b[ni], acc[mi][ni]);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        if (t + 1 < nt) {
+            // stage t+1 must have landed; stages t+2..t+D (issued, if they exist) stay in flight
+            if (D >= 2 && t + D < nt) wait_vmcnt<T::kLoads*(D >= 2 ? D - 1 : 0)>();
+            else if (D >= 3 && t + D - 1 < nt) wait_vmcnt<T::kLoads*(D >= 3 ? D - 2 : 0)>();
+            else wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();
+        }
+        cur = cur + 1 == NS ? 0 : cur + 1;
+        nxt = nxt + 1 == NS ? 0 : nxt + 1;
     }
 
     // ---- epilogue.  Weight rows are packed in the order conv_row_channel() gives, so that the two
@@ -326,24 +382,38 @@ int conv_row_channel(int row, int cout)
     return base + (mi >> 1) * 32 + (rho >> 2) * 8 + (mi & 1) * 4 + (rho & 3);
 }
 
-template <int BP, int BC, int WP, int WC, bool F16>
+template <int BP, int BC, int WP, int WC, int NS, bool F16>
 static hipError_t launch_conv_t(const ConvParams& p, hipStream_t s)
 {
-    using T = ConvTile<BP, BC, WP, WC>;
+    using T = ConvTile<BP, BC, WP, WC, NS>;
     static bool attr_done[64] = {};
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
     if (!attr_done[dev & 63]) {
-        e = hipFuncSetAttribute((const void*)conv_igemm_mfma<BP, BC, WP, WC, F16>,
+        e = hipFuncSetAttribute((const void*)conv_igemm_mfma<BP, BC, WP, WC, NS, F16>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, T::kLdsBytes);
         if (e != hipSuccess) return e;
         attr_done[dev & 63] = true;
     }
     const int n_ct = (p.cout + BC - 1) / BC;
     const int n_pt = (p.M + BP - 1) / BP;
-    hipLaunchKernelGGL((conv_igemm_mfma<BP, BC, WP, WC, F16>), dim3(n_ct * n_pt), dim3(256), T::kLdsBytes, s, p);
+    hipLaunchKernelGGL((conv_igemm_mfma<BP, BC, WP, WC, NS, F16>), dim3(n_ct * n_pt), dim3(T::kThreads), T::kLdsBytes, s, p);
     return hipGetLastError();
+}
+
+// Tile choice.  Big layers: 8 waves, 256 pixels x BC channels, 3-stage ring (1 block per CU).
+// Layers too small to give every CU such a block keep the 4-wave / 2-stage tiles (2 blocks per CU).
+template <bool F16>
+static hipError_t launch_conv_16(const ConvParams& p, hipStream_t s)
+{
+    const int bc = conv_tile_bc(p.cout);
+    const int variant = p.variant;
+    const long big_blocks = (long)((p.M + 255) / 256) * ((p.cout + bc - 1) / bc);
+    const bool big = variant == 2 || (variant == 0 && big_blocks >= 192);
+    if (bc == 128) return big ? launch_conv_t<256, 128, 4, 2, 3, F16>(p, s) : launch_conv_t<128, 128, 2, 2, 2, F16>(p, s);
+    if (bc == 64) return big ? launch_conv_t<256, 64, 8, 1, 3, F16>(p, s) : launch_conv_t<256, 64, 4, 1, 2, F16>(p, s);
+    return big ? launch_conv_t<256, 32, 8, 1, 3, F16>(p, s) : launch_conv_t<256, 32, 4, 1, 2, F16>(p, s);
 }
 
 hipError_t launch_conv(const ConvParams& p, int precision, hipStream_t s)
@@ -353,15 +423,7 @@ hipError_t launch_conv(const ConvParams& p, int precision, hipStream_t s)
         hipLaunchKernelGGL(conv_naive_f32, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, p);
         return hipGetLastError();
     }
-    const int bc = conv_tile_bc(p.cout);
-    if (precision == kF16) {
-        if (bc == 128) return launch_conv_t<128, 128, 2, 2, true>(p, s);
-        if (bc == 64) return launch_conv_t<256, 64, 4, 1, true>(p, s);
-        return launch_conv_t<256, 32, 4, 1, true>(p, s);
-    }
-    if (bc == 128) return launch_conv_t<128, 128, 2, 2, false>(p, s);
-    if (bc == 64) return launch_conv_t<256, 64, 4, 1, false>(p, s);
-    return launch_conv_t<256, 32, 4, 1, false>(p, s);
+    return precision == kF16 ? launch_conv_16<true>(p, s) : launch_conv_16<false>(p, s);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -75,6 +75,20 @@ def test_every_fused_layer_matches_oracle(precision):
     model.release()
 
 
+def test_conv_tile_families_agree():
+    """4-wave/2-stage and 8-wave/3-stage conv tiles compute the same sums (only MFMA grouping differs)."""
+    cfg, w, g, model = make_model(2, 224, 224, seed=3, precision="f16", max_batch=6)
+    x = (patches_from_page(224, 224, 5, seed=2) / 255.0).astype(np.float32)
+    model.ctx.set_conv_variant(1)
+    a = model.predict(x)
+    model.ctx.set_conv_variant(2)
+    b = model.predict(x)
+    model.ctx.set_conv_variant(0)
+    c = model.predict(x)
+    assert np.array_equal(a, b) and np.array_equal(a, c)
+    model.release()
+
+
 # ------------------------------------------------------------------------------- seam 2 at full size
 @pytest.mark.parametrize("classes,precision", [(2, "f16"), (4, "f16"), (2, "bf16")])
 def test_predict_448_matches_oracle(classes, precision):
