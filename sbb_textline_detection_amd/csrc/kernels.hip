@@ -402,15 +402,17 @@ static hipError_t launch_conv_t(const ConvParams& p, hipStream_t s)
     return hipGetLastError();
 }
 
-// Tile choice.  Big layers: 8 waves, 256 pixels x BC channels, 3-stage ring (1 block per CU).
-// Layers too small to give every CU such a block keep the 4-wave / 2-stage tiles (2 blocks per CU).
+// Tile choice.  Measured on MI355X (profiles/r01_conv_variants.md): with two 4-wave blocks per CU the
+// 2-stage tiles already hide the staging latency (dec1-3 at 925-980 TFLOP/s); the 8-wave / 3-stage /
+// counted-vmcnt tiles (1 block per CU) are 5-25 % slower on every layer, so they are opt-in only.
 template <bool F16>
 static hipError_t launch_conv_16(const ConvParams& p, hipStream_t s)
 {
     const int bc = conv_tile_bc(p.cout);
     const int variant = p.variant;
     const long big_blocks = (long)((p.M + 255) / 256) * ((p.cout + bc - 1) / bc);
-    const bool big = variant == 2 || (variant == 0 && big_blocks >= 192);
+    const bool big = variant == 2;
+    (void)big_blocks;
     if (bc == 128) return big ? launch_conv_t<256, 128, 4, 2, 3, F16>(p, s) : launch_conv_t<128, 128, 2, 2, 2, F16>(p, s);
     if (bc == 64) return big ? launch_conv_t<256, 64, 8, 1, 3, F16>(p, s) : launch_conv_t<256, 64, 4, 1, 2, F16>(p, s);
     return big ? launch_conv_t<256, 32, 8, 1, 3, F16>(p, s) : launch_conv_t<256, 32, 4, 1, 2, F16>(p, s);
