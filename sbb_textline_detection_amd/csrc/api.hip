@@ -115,6 +115,7 @@ struct sbbseg_ctx {
     // profiling
     bool profiling = false;
     int conv_variant = 0;
+    int num_cus = 256;
     std::vector<PendingEvent> pending;
     std::vector<hipEvent_t> free_events;
 };
@@ -245,7 +246,7 @@ int run_plan(sbbseg_ctx* c, int n, uint8_t* d_labels, float* d_probs)
                 sd.lim_y = t.H << sd.shift; sd.lim_x = t.W << sd.shift;
                 sd.ksteps = co.ksteps[s];
             }
-            p.ktab = co.d_ktab; p.kstep = co.d_kstep; p.variant = c->conv_variant; p.w = co.d_w; p.Ktot = co.Ktot; p.total_ksteps = co.total_ksteps;
+            p.ktab = co.d_ktab; p.kstep = co.d_kstep; p.variant = c->conv_variant & 3; p.persist_blocks = (c->conv_variant & 4) ? 0 : c->num_cus; p.w = co.d_w; p.Ktot = co.Ktot; p.total_ksteps = co.total_ksteps;
             p.Ho = co.Ho; p.Wo = co.Wo; p.M = n * co.Ho * co.Wo;
             p.sy = co.d.stride_y; p.sx = co.d.stride_x; p.pad_t = co.d.pad_top; p.pad_l = co.d.pad_left;
             p.cout = co.d.cout; p.scale = co.d_scale; p.shift = co.d_shift;
@@ -328,6 +329,7 @@ int sbbseg_create(int device, int precision, sbbseg_ctx** out)
     c->device = device;
     c->precision = precision;
     c->elem = precision == SBBSEG_PREC_F32 ? 4 : 2;
+    c->num_cus = prop.multiProcessorCount;
     hipError_t e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
     if (e != hipSuccess) {
         delete c;
@@ -904,7 +906,7 @@ int sbbseg_debug_read_tensor(sbbseg_ctx* c, int tensor_id, int n, float* out, si
 
 int sbbseg_debug_set_conv_variant(sbbseg_ctx* c, int variant)
 {
-    REQUIRE(c && variant >= 0 && variant <= 2, "variant must be 0 (auto), 1 (4-wave/2-stage) or 2 (8-wave/3-stage)");
+    REQUIRE(c && variant >= 0 && variant <= 7 && (variant & 3) != 3, "variant: bits 0-1 = 0 auto | 1 4-wave/2-stage | 2 8-wave/3-stage; bit 2 = one block per tile (non-persistent)");
     c->conv_variant = variant;
     return 0;
 }

@@ -97,11 +97,13 @@ template <int N> __device__ inline void wait_vmcnt()
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-// Pipeline: NS LDS stages, stage t+D (D = NS-1) is issued while stage t is multiplied; the wait
-// at the end of an iteration is COUNTED (stage t+1 landed, later stages stay in flight across the
-// raw s_barrier) -- the vmcnt(0)+__syncthreads() drain of a 2-stage loop is what kept MFMA idle.
-// K-step descriptors come through the scalar cache (uniform address -> s_load, lgkmcnt), so no
-// VGPR-destination VMEM load sits in the loop to force a vmcnt(0).
+// Pipeline: NS LDS stages, stage s+D (D = NS-1) is issued while stage s is multiplied.  Blocks are
+// PERSISTENT: block b walks tiles b, b+G, b+2G, ... and the stage stream runs straight across tile
+// boundaries, so the first K-step of the next tile is in flight while the current tile finishes its
+// MFMAs and runs its epilogue -- short-K layers (1x1 convs, K = 64..512) otherwise spend most of
+// their time filling and draining a 1-4 step pipeline.
+// K-step descriptors come through the scalar cache (uniform address in the constant address space
+// -> s_load, lgkmcnt): no VGPR-destination VMEM load sits in the steady-state loop.
 template <int BP, int BC, int WP, int WC, int NS, bool F16>
 __global__ __launch_bounds__(64 * WP * WC, (WP * WC) / 4 * (NS == 2 ? 2 : 1))
 void conv_igemm_mfma(const ConvParams p)
@@ -117,56 +119,57 @@ void conv_igemm_mfma(const ConvParams p)
     const int wp = wave / WC, wc = wave % WC;
 
     const int n_ct = (p.cout + BC - 1) / BC;
-    const int ctile = blockIdx.x % n_ct;
-    const int ptile = blockIdx.x / n_ct;
+    const int n_tiles = n_ct * ((p.M + BP - 1) / BP);
+    const int G = gridDim.x;
+    const int nt = p.total_ksteps;
+    const int my_tiles = (n_tiles - (int)blockIdx.x + G - 1) / G;
+    const int total = my_tiles * nt;                    // K-steps this block walks
 
-    // ---- per-thread gather rows (fixed over the K loop): row = (j*NW + wave)*8 + lrow
     const int lrow = lane >> 3;                         // row inside an 8-row glds group
     const int gsrc = (lane & 7) ^ lrow;                 // source granule this lane fetches (swizzle)
-    int r_n[T::kPLoads], r_iy[T::kPLoads], r_ix[T::kPLoads];
     const int HoWo = p.Ho * p.Wo;
-#pragma unroll
-    for (int j = 0; j < T::kPLoads; ++j) {
-        const int m = ptile * BP + (j * NW + wave) * 8 + lrow;
-        if (m < p.M) {
-            const int n = m / HoWo;
-            const int rem = m - n * HoWo;
-            const int oy = rem / p.Wo;
-            const int ox = rem - oy * p.Wo;
-            r_n[j] = n;
-            r_iy[j] = oy * p.sy - p.pad_t;
-            r_ix[j] = ox * p.sx - p.pad_l;
-        } else {
-            r_n[j] = 0;
-            r_iy[j] = -(1 << 20);                       // always out of bounds -> zero granule
-            r_ix[j] = 0;
-        }
-    }
-    uint32_t w_off[T::kWLoads];
-#pragma unroll
-    for (int j = 0; j < T::kWLoads; ++j)
-        w_off[j] = (uint32_t)((ctile * BC + min((j * NW + wave) * 8 + lrow, BC - 1)) * p.Ktot + gsrc * 8) * 2u;
-    const char* wbase = (const char*)p.w;
 
-    const int nt = p.total_ksteps;
-    // both sources' descriptors live in SGPRs for the whole kernel (selected per K-step with
-    // s_cselect); per-row image base offsets are precomputed per source
+    // both sources' descriptors live in SGPRs for the whole kernel
     const SrcDesc sd0 = p.src[0];
     const SrcDesc sd1 = p.n_src > 1 ? p.src[1] : p.src[0];
     const int ks0 = p.n_src > 1 ? sd0.ksteps : nt;
-    uint32_t r_nb0[T::kPLoads], r_nb1[T::kPLoads];
-#pragma unroll
-    for (int j = 0; j < T::kPLoads; ++j) {
-        r_nb0[j] = (uint32_t)r_n[j] * (uint32_t)(sd0.PH * sd0.PW * sd0.pix_bytes);
-        r_nb1[j] = (uint32_t)r_n[j] * (uint32_t)(sd1.PH * sd1.PW * sd1.pix_bytes);
-    }
+    const uint32_t img0 = (uint32_t)(sd0.PH * sd0.PW * sd0.pix_bytes), img1 = (uint32_t)(sd1.PH * sd1.PW * sd1.pix_bytes);
+    const char* wbase = (const char*)p.w;
     const __attribute__((address_space(4))) int* kstep_tab =
         (const __attribute__((address_space(4))) int*)(uintptr_t)p.kstep;
-    // K-step record of the stage issued NEXT, fetched one stage ahead through the scalar cache
-    // (uniform address in the constant address space -> s_load, lgkmcnt): no VGPR-destination
-    // VMEM load sits in the loop, so the counted vmcnt below stays exact.
-    int rec_yx = kstep_tab[0], rec_coff = kstep_tab[1], rec_irr = kstep_tab[2];
-    auto stage = [&](int t, int buf) {
+
+    // ---- load side: rows of the tile being STAGED (runs D steps ahead of the compute side)
+    int r_iy[T::kPLoads], r_ix[T::kPLoads];
+    uint32_t r_nb0[T::kPLoads], r_nb1[T::kPLoads], w_off[T::kWLoads];
+    auto setup_rows = [&](int tile) {
+        const int ctile = tile % n_ct, ptile = tile / n_ct;
+#pragma unroll
+        for (int j = 0; j < T::kPLoads; ++j) {
+            const int m = ptile * BP + (j * NW + wave) * 8 + lrow;
+            if (m < p.M) {
+                const int n = m / HoWo;
+                const int rem = m - n * HoWo;
+                const int oy = rem / p.Wo;
+                const int ox = rem - oy * p.Wo;
+                r_iy[j] = oy * p.sy - p.pad_t;
+                r_ix[j] = ox * p.sx - p.pad_l;
+                r_nb0[j] = (uint32_t)n * img0;
+                r_nb1[j] = (uint32_t)n * img1;
+            } else {
+                r_iy[j] = -(1 << 20);                   // always out of bounds -> zero granule
+                r_ix[j] = 0;
+                r_nb0[j] = r_nb1[j] = 0;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < T::kWLoads; ++j)
+            w_off[j] = (uint32_t)((ctile * BC + min((j * NW + wave) * 8 + lrow, BC - 1)) * p.Ktot + gsrc * 8) * 2u;
+    };
+
+    int l_t = 0, l_tile = blockIdx.x, issued = 0;
+    int rec_yx = kstep_tab[0], rec_coff = kstep_tab[1], rec_irr = kstep_tab[2];   // record of the NEXT stage issued
+    auto issue = [&](int buf) {
+        const int t = l_t;
         const bool s1 = t >= ks0;
         const char* base = s1 ? sd1.base : sd0.base;
         const int rowbytes = s1 ? sd1.PW * sd1.pix_bytes : sd0.PW * sd0.pix_bytes;
@@ -179,10 +182,6 @@ void conv_igemm_mfma(const ConvParams p)
             const KTabEntry e = p.ktab[t * kGranulesPerStep + gsrc];
             dy = e.dy; dx = e.dx; coff = e.coff + kZeroHeaderBytes;
         }
-        {   // prefetch the next record (clamped; harmless re-read on the last stage)
-            const int tn = t + 1 < nt ? t + 1 : t;
-            rec_yx = kstep_tab[tn * 4 + 0]; rec_coff = kstep_tab[tn * 4 + 1]; rec_irr = kstep_tab[tn * 4 + 2];
-        }
         char* lds_p = smem + buf * T::kStageBytes;
         char* lds_w = lds_p + BP * 128;
 #pragma unroll
@@ -192,8 +191,7 @@ void conv_igemm_mfma(const ConvParams p)
             const bool ok = ((unsigned)uy < lim_y) & ((unsigned)ux < lim_x);
             const int yy = uy >> sh, xx = ux >> sh;
             // yy, xx < 2^12 and rowbytes, pixb < 2^24: 24-bit multiplies are exact (full-rate VALU)
-            uint32_t off = (s1 ? r_nb1[j] : r_nb0[j]) +
-                           __umul24(yy, rowbytes) + __umul24(xx, pixb) + (uint32_t)coff;
+            uint32_t off = (s1 ? r_nb1[j] : r_nb0[j]) + __umul24(yy, rowbytes) + __umul24(xx, pixb) + (uint32_t)coff;
             off = ok ? off : 0u;
             __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(base + off),
                                              (LDS_AS void*)(lds_p + (j * NW + wave) * 8 * 128), 16, 0, 0);
@@ -203,6 +201,14 @@ void conv_igemm_mfma(const ConvParams p)
             __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(wbase + w_off[j] + (uint32_t)t * (kBK * 2)),
                                              (LDS_AS void*)(lds_w + (j * NW + wave) * 8 * 128), 16, 0, 0);
         }
+        // advance the load side; crossing into the next tile re-derives the gather rows
+        ++issued;
+        if (++l_t == nt) {
+            l_t = 0;
+            l_tile += G;
+            if (l_tile < n_tiles) setup_rows(l_tile);
+        }
+        rec_yx = kstep_tab[l_t * 4 + 0]; rec_coff = kstep_tab[l_t * 4 + 1]; rec_irr = kstep_tab[l_t * 4 + 2];
     };
 
     f32x4_t acc[T::kMI][T::kNI];
@@ -219,17 +225,84 @@ void conv_igemm_mfma(const ConvParams p)
     const int p_rd = (wp * T::kWPX) * 128;
     const int w_rd = BP * 128 + (wc * T::kWCH) * 128;
 
+    // ---- epilogue of one finished tile.  Weight rows are packed in the order conv_row_channel()
+    // gives, so the two MFMA row blocks (2s, 2s+1) of a lane hold 8 CONSECUTIVE channels of one
+    // pixel: 16-byte NHWC stores / residual loads, 64 contiguous bytes per pixel per instruction.
+    auto epilogue = [&](int tile) {
+        const int ctile = tile % n_ct, ptile = tile / n_ct;
+#pragma unroll
+        for (int s2 = 0; s2 < T::kMI / 2; ++s2) {
+            const int c0 = ctile * BC + wc * T::kWCH + s2 * 32 + fg * 8;
+            if (c0 < p.cout) {
+                float sc[8], sh[8], rsc[8], rsh[8];
+                *(float4*)&sc[0] = *(const float4*)(p.scale + c0);
+                *(float4*)&sc[4] = *(const float4*)(p.scale + c0 + 4);
+                *(float4*)&sh[0] = *(const float4*)(p.shift + c0);
+                *(float4*)&sh[4] = *(const float4*)(p.shift + c0 + 4);
+                if (p.raw_out) {
+                    *(float4*)&rsc[0] = *(const float4*)(p.raw_scale + c0);
+                    *(float4*)&rsc[4] = *(const float4*)(p.raw_scale + c0 + 4);
+                    *(float4*)&rsh[0] = *(const float4*)(p.raw_shift + c0);
+                    *(float4*)&rsh[4] = *(const float4*)(p.raw_shift + c0 + 4);
+                }
+#pragma unroll
+                for (int ni = 0; ni < T::kNI; ++ni) {
+                    const int m = ptile * BP + wp * T::kWPX + ni * 16 + frow;
+                    if (m >= p.M) continue;
+                    float v[8];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { v[q] = acc[2 * s2][ni][q]; v[4 + q] = acc[2 * s2 + 1][ni][q]; }
+                    const size_t o = (size_t)m * p.cout + c0;
+                    if (p.raw_out) {
+                        uint4 r;
+                        r.x = pack2<F16>(v[0] * rsc[0] + rsh[0], v[1] * rsc[1] + rsh[1]);
+                        r.y = pack2<F16>(v[2] * rsc[2] + rsh[2], v[3] * rsc[3] + rsh[3]);
+                        r.z = pack2<F16>(v[4] * rsc[4] + rsh[4], v[5] * rsc[5] + rsh[5]);
+                        r.w = pack2<F16>(v[6] * rsc[6] + rsh[6], v[7] * rsc[7] + rsh[7]);
+                        *(uint4*)((uint16_t*)p.raw_out + o) = r;
+                    }
+                    if (p.out) {
+                        float y[8];
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) y[q] = v[q] * sc[q] + sh[q];
+                        if (p.residual) {
+                            const uint4 rr = *(const uint4*)((const uint16_t*)p.residual + o);
+                            y[0] += unpack_lo<F16>(rr.x); y[1] += unpack_hi<F16>(rr.x);
+                            y[2] += unpack_lo<F16>(rr.y); y[3] += unpack_hi<F16>(rr.y);
+                            y[4] += unpack_lo<F16>(rr.z); y[5] += unpack_hi<F16>(rr.z);
+                            y[6] += unpack_lo<F16>(rr.w); y[7] += unpack_hi<F16>(rr.w);
+                        }
+                        if (p.relu) {
+#pragma unroll
+                            for (int q = 0; q < 8; ++q) y[q] = fmaxf(y[q], 0.f);
+                        }
+                        uint4 r;
+                        r.x = pack2<F16>(y[0], y[1]); r.y = pack2<F16>(y[2], y[3]);
+                        r.z = pack2<F16>(y[4], y[5]); r.w = pack2<F16>(y[6], y[7]);
+                        *(uint4*)((uint16_t*)p.out + o) = r;
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int mi = 0; mi < T::kMI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < T::kNI; ++ni) acc[mi][ni] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    };
+
     // ---- prologue: D stages in flight, stage 0 landed
+    if (total == 0) return;
+    setup_rows(l_tile);
 #pragma unroll
     for (int d = 0; d < D; ++d)
-        if (d < nt) stage(d, d);
-    if (D >= 2 && nt >= 2) wait_vmcnt<T::kLoads*(D >= 2 ? D - 1 : 0)>();
+        if (d < total) issue(d);
+    if (D >= 2 && total >= 2) wait_vmcnt<T::kLoads*(D >= 2 ? D - 1 : 0)>();
     else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
 
-    int cur = 0, nxt = D % NS;
-    for (int t = 0; t < nt; ++t) {
-        if (t + D < nt) stage(t + D, nxt);
+    int cur = 0, nxt = D % NS, c_t = 0, c_tile = blockIdx.x;
+    for (int s = 0; s < total; ++s) {
+        if (issued < total) issue(nxt);
         const char* sb = smem + cur * T::kStageBytes;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
@@ -247,72 +320,22 @@ void conv_igemm_mfma(const ConvParams p)
                 for (int ni = 0; ni < T::kNI; ++ni)
                     acc[mi][ni] = mfma16<F16>(a[mi], b[ni], acc[mi][ni]);
         }
-        if (t + 1 < nt) {
-            // stage t+1 must have landed; stages t+2..t+D (issued, if they exist) stay in flight
-            if (D >= 2 && t + D < nt) wait_vmcnt<T::kLoads*(D >= 2 ? D - 1 : 0)>();
-            else if (D >= 3 && t + D - 1 < nt) wait_vmcnt<T::kLoads*(D >= 3 ? D - 2 : 0)>();
+        bool tile_done = false;
+        if (++c_t == nt) {                                  // tile finished: its stores overlap the
+            epilogue(c_tile);                               // next tile's first stage(s), already in flight
+            c_t = 0;
+            c_tile += G;
+            tile_done = true;
+        }
+        if (s + 1 < total) {
+            // stage s+1 must have landed; later issued stages stay in flight across the barrier.
+            // (after an epilogue the counter also holds its stores: drain completely there)
+            if (D >= 2 && !tile_done && s + D < total) wait_vmcnt<T::kLoads*(D >= 2 ? D - 1 : 0)>();
             else wait_vmcnt<0>();
             __builtin_amdgcn_s_barrier();
         }
         cur = cur + 1 == NS ? 0 : cur + 1;
         nxt = nxt + 1 == NS ? 0 : nxt + 1;
-    }
-
-    // ---- epilogue.  Weight rows are packed in the order conv_row_channel() gives, so that the two
-    // MFMA row blocks (2s, 2s+1) of a lane hold 8 CONSECUTIVE channels of one pixel: 16-byte NHWC
-    // stores / residual loads, 64 contiguous bytes per pixel per instruction.
-#pragma unroll
-    for (int s2 = 0; s2 < T::kMI / 2; ++s2) {
-        const int c0 = ctile * BC + wc * T::kWCH + s2 * 32 + fg * 8;
-        if (c0 >= p.cout) continue;
-        float sc[8], sh[8], rsc[8], rsh[8];
-        *(float4*)&sc[0] = *(const float4*)(p.scale + c0);
-        *(float4*)&sc[4] = *(const float4*)(p.scale + c0 + 4);
-        *(float4*)&sh[0] = *(const float4*)(p.shift + c0);
-        *(float4*)&sh[4] = *(const float4*)(p.shift + c0 + 4);
-        if (p.raw_out) {
-            *(float4*)&rsc[0] = *(const float4*)(p.raw_scale + c0);
-            *(float4*)&rsc[4] = *(const float4*)(p.raw_scale + c0 + 4);
-            *(float4*)&rsh[0] = *(const float4*)(p.raw_shift + c0);
-            *(float4*)&rsh[4] = *(const float4*)(p.raw_shift + c0 + 4);
-        }
-#pragma unroll
-        for (int ni = 0; ni < T::kNI; ++ni) {
-            const int m = ptile * BP + wp * T::kWPX + ni * 16 + frow;
-            if (m >= p.M) continue;
-            float v[8];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) { v[q] = acc[2 * s2][ni][q]; v[4 + q] = acc[2 * s2 + 1][ni][q]; }
-            const size_t o = (size_t)m * p.cout + c0;
-            if (p.raw_out) {
-                uint4 r;
-                r.x = pack2<F16>(v[0] * rsc[0] + rsh[0], v[1] * rsc[1] + rsh[1]);
-                r.y = pack2<F16>(v[2] * rsc[2] + rsh[2], v[3] * rsc[3] + rsh[3]);
-                r.z = pack2<F16>(v[4] * rsc[4] + rsh[4], v[5] * rsc[5] + rsh[5]);
-                r.w = pack2<F16>(v[6] * rsc[6] + rsh[6], v[7] * rsc[7] + rsh[7]);
-                *(uint4*)((uint16_t*)p.raw_out + o) = r;
-            }
-            if (p.out) {
-                float y[8];
-#pragma unroll
-                for (int q = 0; q < 8; ++q) y[q] = v[q] * sc[q] + sh[q];
-                if (p.residual) {
-                    const uint4 rr = *(const uint4*)((const uint16_t*)p.residual + o);
-                    y[0] += unpack_lo<F16>(rr.x); y[1] += unpack_hi<F16>(rr.x);
-                    y[2] += unpack_lo<F16>(rr.y); y[3] += unpack_hi<F16>(rr.y);
-                    y[4] += unpack_lo<F16>(rr.z); y[5] += unpack_hi<F16>(rr.z);
-                    y[6] += unpack_lo<F16>(rr.w); y[7] += unpack_hi<F16>(rr.w);
-                }
-                if (p.relu) {
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) y[q] = fmaxf(y[q], 0.f);
-                }
-                uint4 r;
-                r.x = pack2<F16>(y[0], y[1]); r.y = pack2<F16>(y[2], y[3]);
-                r.z = pack2<F16>(y[4], y[5]); r.w = pack2<F16>(y[6], y[7]);
-                *(uint4*)((uint16_t*)p.out + o) = r;
-            }
-        }
     }
 }
 
@@ -398,7 +421,12 @@ static hipError_t launch_conv_t(const ConvParams& p, hipStream_t s)
     }
     const int n_ct = (p.cout + BC - 1) / BC;
     const int n_pt = (p.M + BP - 1) / BP;
-    hipLaunchKernelGGL((conv_igemm_mfma<BP, BC, WP, WC, NS, F16>), dim3(n_ct * n_pt), dim3(T::kThreads), T::kLdsBytes, s, p);
+    const int n_tiles = n_ct * n_pt;
+    // persistent grid: as many blocks as are resident at once (2 per CU for the 4-wave tiles, 1 for
+    // the 8-wave ones); p.persist_blocks == 0 -> one block per tile (A/B)
+    const int resident = p.persist_blocks > 0 ? p.persist_blocks * (NS == 2 ? 2 : 1) : n_tiles;
+    const int grid = n_tiles < resident ? n_tiles : resident;
+    hipLaunchKernelGGL((conv_igemm_mfma<BP, BC, WP, WC, NS, F16>), dim3(grid), dim3(T::kThreads), T::kLdsBytes, s, p);
     return hipGetLastError();
 }
 

@@ -76,16 +76,14 @@ def test_every_fused_layer_matches_oracle(precision):
 
 
 def test_conv_tile_families_agree():
-    """4-wave/2-stage and 8-wave/3-stage conv tiles compute the same sums (only MFMA grouping differs)."""
+    """4-wave/2-stage and 8-wave/3-stage conv tiles, persistent or one block per tile, compute the same sums."""
     cfg, w, g, model = make_model(2, 224, 224, seed=3, precision="f16", max_batch=6)
     x = (patches_from_page(224, 224, 5, seed=2) / 255.0).astype(np.float32)
-    model.ctx.set_conv_variant(1)
-    a = model.predict(x)
-    model.ctx.set_conv_variant(2)
-    b = model.predict(x)
-    model.ctx.set_conv_variant(0)
-    c = model.predict(x)
-    assert np.array_equal(a, b) and np.array_equal(a, c)
+    outs = []
+    for variant in (1, 2, 5, 6, 0):          # bit 2 = one block per tile instead of persistent blocks
+        model.ctx.set_conv_variant(variant)
+        outs.append(model.predict(x))
+    assert all(np.array_equal(outs[0], o) for o in outs[1:])
     model.release()
 
 
