@@ -139,9 +139,9 @@ void conv_igemm_mfma(const ConvParams p)
         (const __attribute__((address_space(4))) int*)(uintptr_t)p.kstep;
 
     // ---- load side: rows of the tile being STAGED (runs D steps ahead of the compute side)
-    int r_iy[T::kPLoads], r_ix[T::kPLoads];
-    uint32_t r_nb0[T::kPLoads], r_nb1[T::kPLoads], w_off[T::kWLoads];
-    auto setup_rows = [&](int tile) {
+    int r_iy[T::kPLoads], r_ix[T::kPLoads], r_n[T::kPLoads];
+    uint32_t w_off[T::kWLoads];
+    auto setup_rows = [&](int tile) __attribute__((always_inline)) {
         const int ctile = tile % n_ct, ptile = tile / n_ct;
 #pragma unroll
         for (int j = 0; j < T::kPLoads; ++j) {
@@ -153,12 +153,11 @@ void conv_igemm_mfma(const ConvParams p)
                 const int ox = rem - oy * p.Wo;
                 r_iy[j] = oy * p.sy - p.pad_t;
                 r_ix[j] = ox * p.sx - p.pad_l;
-                r_nb0[j] = (uint32_t)n * img0;
-                r_nb1[j] = (uint32_t)n * img1;
+                r_n[j] = n;
             } else {
                 r_iy[j] = -(1 << 20);                   // always out of bounds -> zero granule
                 r_ix[j] = 0;
-                r_nb0[j] = r_nb1[j] = 0;
+                r_n[j] = 0;
             }
         }
 #pragma unroll
@@ -168,12 +167,13 @@ void conv_igemm_mfma(const ConvParams p)
 
     int l_t = 0, l_tile = blockIdx.x, issued = 0;
     int rec_yx = kstep_tab[0], rec_coff = kstep_tab[1], rec_irr = kstep_tab[2];   // record of the NEXT stage issued
-    auto issue = [&](int buf) {
+    auto issue = [&](int buf) __attribute__((always_inline)) {
         const int t = l_t;
         const bool s1 = t >= ks0;
         const char* base = s1 ? sd1.base : sd0.base;
         const int rowbytes = s1 ? sd1.PW * sd1.pix_bytes : sd0.PW * sd0.pix_bytes;
         const int pixb = s1 ? sd1.pix_bytes : sd0.pix_bytes;
+        const uint32_t img = s1 ? img1 : img0;
         const int sh = s1 ? sd1.shift : sd0.shift;
         const unsigned lim_y = s1 ? sd1.lim_y : sd0.lim_y, lim_x = s1 ? sd1.lim_x : sd0.lim_x;
         int dy = (int)(short)(rec_yx & 0xffff), dx = rec_yx >> 16;
@@ -191,7 +191,7 @@ void conv_igemm_mfma(const ConvParams p)
             const bool ok = ((unsigned)uy < lim_y) & ((unsigned)ux < lim_x);
             const int yy = uy >> sh, xx = ux >> sh;
             // yy, xx < 2^12 and rowbytes, pixb < 2^24: 24-bit multiplies are exact (full-rate VALU)
-            uint32_t off = (s1 ? r_nb1[j] : r_nb0[j]) + __umul24(yy, rowbytes) + __umul24(xx, pixb) + (uint32_t)coff;
+            uint32_t off = (uint32_t)r_n[j] * img + __umul24(yy, rowbytes) + __umul24(xx, pixb) + (uint32_t)coff;
             off = ok ? off : 0u;
             __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(base + off),
                                              (LDS_AS void*)(lds_p + (j * NW + wave) * 8 * 128), 16, 0, 0);
@@ -228,7 +228,7 @@ void conv_igemm_mfma(const ConvParams p)
     // ---- epilogue of one finished tile.  Weight rows are packed in the order conv_row_channel()
     // gives, so the two MFMA row blocks (2s, 2s+1) of a lane hold 8 CONSECUTIVE channels of one
     // pixel: 16-byte NHWC stores / residual loads, 64 contiguous bytes per pixel per instruction.
-    auto epilogue = [&](int tile) {
+    auto epilogue = [&](int tile) __attribute__((always_inline)) {
         const int ctile = tile % n_ct, ptile = tile / n_ct;
 #pragma unroll
         for (int s2 = 0; s2 < T::kMI / 2; ++s2) {
