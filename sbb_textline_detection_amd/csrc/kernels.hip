@@ -228,6 +228,23 @@ void conv_igemm_mfma(const ConvParams p)
     // ---- epilogue of one finished tile.  Weight rows are packed in the order conv_row_channel()
     // gives, so the two MFMA row blocks (2s, 2s+1) of a lane hold 8 CONSECUTIVE channels of one
     // pixel: 16-byte NHWC stores / residual loads, 64 contiguous bytes per pixel per instruction.
+    // residual tile of the tile being finished: requested BEFORE its last K-step's MFMAs so the HBM
+    // round trip hides under them (a dependent load -> use chain per (s2, ni) in the epilogue cost
+    // several microseconds per tile on the residual layers)
+    uint4 res[T::kMI / 2][T::kNI];
+    auto prefetch_residual = [&](int tile) __attribute__((always_inline)) {
+        const int ctile = tile % n_ct, ptile = tile / n_ct;
+#pragma unroll
+        for (int s2 = 0; s2 < T::kMI / 2; ++s2) {
+            const int c0 = ctile * BC + wc * T::kWCH + s2 * 32 + fg * 8;
+#pragma unroll
+            for (int ni = 0; ni < T::kNI; ++ni) {
+                const int m = ptile * BP + wp * T::kWPX + ni * 16 + frow;
+                if (c0 < p.cout && m < p.M)
+                    res[s2][ni] = *(const uint4*)((const uint16_t*)p.residual + (size_t)m * p.cout + c0);
+            }
+        }
+    };
     auto epilogue = [&](int tile) __attribute__((always_inline)) {
         const int ctile = tile % n_ct, ptile = tile / n_ct;
 #pragma unroll
@@ -266,7 +283,7 @@ void conv_igemm_mfma(const ConvParams p)
 #pragma unroll
                         for (int q = 0; q < 8; ++q) y[q] = v[q] * sc[q] + sh[q];
                         if (p.residual) {
-                            const uint4 rr = *(const uint4*)((const uint16_t*)p.residual + o);
+                            const uint4 rr = res[s2][ni];
                             y[0] += unpack_lo<F16>(rr.x); y[1] += unpack_hi<F16>(rr.x);
                             y[2] += unpack_lo<F16>(rr.y); y[3] += unpack_hi<F16>(rr.y);
                             y[4] += unpack_lo<F16>(rr.z); y[5] += unpack_hi<F16>(rr.z);
@@ -303,6 +320,7 @@ void conv_igemm_mfma(const ConvParams p)
     int cur = 0, nxt = D % NS, c_t = 0, c_tile = blockIdx.x;
     for (int s = 0; s < total; ++s) {
         if (issued < total) issue(nxt);
+        if (p.residual && c_t == nt - 1) prefetch_residual(c_tile);
         const char* sb = smem + cur * T::kStageBytes;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
