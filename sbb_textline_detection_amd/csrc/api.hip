@@ -470,8 +470,11 @@ int sbbseg_add_conv(sbbseg_ctx* c, const sbbseg_conv_desc* d, const float* w_hwi
     const int bc = c->precision != kF32 ? conv_tile_bc(d->cout) : 4;
     co.cout_pad = ((d->cout + bc - 1) / bc) * bc;
 
-    // contraction order: source-major, then tap (ky,kx), then 8-channel granules; each source's
-    // segment padded to whole K-steps (64) with out-of-bounds ("zero") granules.
+    // contraction order: source-major, then 64-channel group, then tap (ky,kx), then the group's
+    // 8-channel granules.  Keeping the 9 taps of one channel group ADJACENT makes the shifted
+    // re-reads of the same pixel rows hit in L2 (measured with tap-outer order: dec1 fetched 2.5 GB
+    // per launch for 70 MB of input).  Each source's segment is padded to whole K-steps (64) with
+    // out-of-bounds ("zero") granules.
     std::vector<KTabEntry> ktab;
     struct KRef { int s, ky, kx, c0; };
     std::vector<KRef> kref;
@@ -479,17 +482,18 @@ int sbbseg_add_conv(sbbseg_ctx* c, const sbbseg_conv_desc* d, const float* w_hwi
         const sbbseg_conv_src& cs = d->src[s];
         const int g8 = (cs.channels + 7) / 8;
         int granules = 0;
-        for (int ky = 0; ky < d->kh; ++ky)
-            for (int kx = 0; kx < d->kw; ++kx)
-                for (int g = 0; g < g8; ++g) {
-                    KTabEntry e;
-                    e.dy = (int16_t)(ky - cs.off_y);
-                    e.dx = (int16_t)(kx - cs.off_x);
-                    e.coff = g * 8 * c->elem;
-                    ktab.push_back(e);
-                    kref.push_back({s, ky, kx, g * 8});
-                    ++granules;
-                }
+        for (int cg = 0; cg < g8; cg += kGranulesPerStep)
+            for (int ky = 0; ky < d->kh; ++ky)
+                for (int kx = 0; kx < d->kw; ++kx)
+                    for (int g = cg; g < g8 && g < cg + kGranulesPerStep; ++g) {
+                        KTabEntry e;
+                        e.dy = (int16_t)(ky - cs.off_y);
+                        e.dx = (int16_t)(kx - cs.off_x);
+                        e.coff = g * 8 * c->elem;
+                        ktab.push_back(e);
+                        kref.push_back({s, ky, kx, g * 8});
+                        ++granules;
+                    }
         const int ks = (granules + kGranulesPerStep - 1) / kGranulesPerStep;
         for (int g = granules; g < ks * kGranulesPerStep; ++g) {
             KTabEntry e;

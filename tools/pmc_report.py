@@ -1,0 +1,51 @@
+"""Join rocprofv3 --pmc CSVs (tools/pmc_run.sh) with the plan's op order and print a per-op table."""
+import csv
+import json
+import os
+import sys
+from collections import defaultdict
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "pmc1"
+root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+ops_json = sys.argv[2] if len(sys.argv) > 2 else None
+
+
+def load(name):
+    rows = defaultdict(dict)
+    meta = {}
+    with open(os.path.join(root, f"{tag}_{name}", "pmc_counter_collection.csv")) as f:
+        for r in csv.DictReader(f):
+            d = int(r["Dispatch_Id"])
+            rows[d][r["Counter_Name"]] = float(r["Counter_Value"])
+            meta[d] = (r["Kernel_Name"], int(r["Grid_Size"]), int(r["Workgroup_Size"]), int(r["VGPR_Count"]),
+                       int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    return rows, meta
+
+
+sq, meta = load("sq")
+fe, meta_f = load("fetch")
+wr, meta_w = load("write")
+# plan kernels only (conv / maxpool / head), in dispatch order; one chunk = 61 ops
+def plan_ids(meta):
+    return [d for d in sorted(meta) if any(s in meta[d][0] for s in ("conv_igemm", "maxpool", "head_kernel"))]
+ids, idf, idw = plan_ids(meta), plan_ids(meta_f), plan_ids(meta_w)
+names = None
+if ops_json:
+    names = [o["name"] for o in json.load(open(ops_json))]
+n_ops = len(names) if names else 61
+# take the LAST full chunk (steady state)
+ids, idf, idw = ids[-n_ops:], idf[-n_ops:], idw[-n_ops:]
+print(f"{'op':46s} {'us':>7s} {'grid':>6s} {'mfma%':>6s} {'wait%':>6s} {'instwait%':>9s} {'active%':>8s} {'ldsconf%':>8s} {'fetchMB':>8s} {'writeMB':>8s} {'GB/s':>7s} {'L2hit%':>6s}")
+for k, (d, df, dw) in enumerate(zip(ids, idf, idw)):
+    c = sq[d]; nm = names[k] if names else meta[d][0][:40]
+    us = meta[d][4] / 1e3
+    wc = c.get("SQ_WAVE_CYCLES", 1) or 1
+    busy = c.get("SQ_BUSY_CYCLES", 1) or 1
+    # SQ_VALU_MFMA_BUSY_CYCLES counts cycles summed over SIMDs? normalise by GRBM-like busy cycles * 4 SIMD * 256 CU
+    gui = fe[df].get("GRBM_GUI_ACTIVE", 0) or 1
+    mfma = c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / (gui * 256 * 4) * 100
+    fetch = fe[df].get("FETCH_SIZE", 0) * 1024 * 2 / 1e6        # gfx950: FETCH_SIZE reads half (MI355X_MICROARCH.md)
+    write = wr[dw].get("WRITE_SIZE", 0) * 1024 / 1e6
+    hit = wr[dw].get("TCC_HIT_sum", 0); miss = wr[dw].get("TCC_MISS_sum", 0)
+    print(f"{nm:46s} {us:7.1f} {meta[d][1]//meta[d][2]:6d} {mfma:6.1f} {c.get('SQ_WAIT_ANY',0)/wc*100:6.1f} {c.get('SQ_WAIT_INST_ANY',0)/wc*100:9.1f} "
+          f"{c.get('SQ_ACTIVE_INST_ANY',0)/wc*100:8.1f} {c.get('SQ_LDS_BANK_CONFLICT',0)/busy*100:8.2f} {fetch:8.1f} {write:8.1f} {(fetch+write)/us*1e3/1e3:7.0f} {hit/(hit+miss+1e-9)*100:6.1f}")
