@@ -36,7 +36,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--precision", default=os.environ.get("SBBSEG_PRECISION", "f16"), choices=["f16", "bf16"])
-    ap.add_argument("--max-batch", type=int, default=int(os.environ.get("SBBSEG_MAX_BATCH", "35")))
+    ap.add_argument("--max-batch", type=int, default=int(os.environ.get("SBBSEG_MAX_BATCH", "70")))
     ap.add_argument("--conv-variant", type=int, default=int(os.environ.get("SBBSEG_CONV_VARIANT", "0")),
                     help="0 auto, 1 force 4-wave/2-stage conv tiles, 2 force 8-wave/3-stage (A/B only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -193,3 +193,17 @@ def test_full_page_properties_3500x2500(torch_cuda, stitch_model):
     m3.ctx.synchronize()
     assert np.array_equal(d_out.cpu().numpy(), a)
     m3.release()
+
+
+def test_sharded_entry_points_single_rank(torch_cuda, stitch_model):
+    """distributed.segment_page_sharded / segment_pages_sharded on one rank == the one-call fused path."""
+    from sbb_textline_detection_amd import distributed as D
+    page = synthetic_page(1000, 900, seed=4)
+    be = D.DeviceBackend(stitch_model)
+    n_tiles = _capi.tile_grid(1000, 900, 448, 448)[0].shape[0]
+    a = D.segment_page_sharded(be, be.to_device(page), n_tiles).cpu().numpy()
+    b = D.segment_pages_sharded(be, [page, page[::-1].copy()]).cpu().numpy()
+    ref = stitch_model.segment_page(page)
+    assert np.array_equal(a, ref) and np.array_equal(b[0], ref)
+    assert np.array_equal(b[1], stitch_model.segment_page(page[::-1].copy()))
+    stitch_model.ctx.set_stream(0)
