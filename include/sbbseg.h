@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SBBSEG_ABI_VERSION 1
+#define SBBSEG_ABI_VERSION 2
 
 typedef struct sbbseg_ctx sbbseg_ctx;
 
@@ -64,30 +64,44 @@ int sbbseg_add_tensor(sbbseg_ctx* c, int H, int W, int C, int* tensor_id);
 typedef struct {
     int32_t tensor;      /* source tensor id */
     int32_t channels;    /* channels taken from it (from channel 0), contraction order */
+    int32_t kh, kw;      /* taps of THIS source */
+    int32_t stride_y, stride_x;   /* input step per output step, 1 or 2 (in the source's logical coordinates) */
+    int32_t pad_top, pad_left;    /* logical input row = oy*stride_y - pad_top + ky  (zero outside) */
     int32_t up_shift;    /* 0, or 1 = nearest-neighbour x2 upsampling (UpSampling2D) fused into the gather */
     int32_t off_y;       /* placement offset of the stored tensor inside the logical one: */
     int32_t off_x;       /*   logical[y][x] = stored[y-off_y][x-off_x] (zero outside); one_side_pad = (1,1) */
 } sbbseg_conv_src;
 
 typedef struct {
-    int32_t n_src;               /* 1 or 2 (2 = channel concat [src0, src1], Concatenate fused) */
+    int32_t n_src;               /* 1 or 2.  2 = channel concat [src0, src1] (Concatenate fused); the two
+                                    sources may have different taps/strides: the planner rewrites a 3x3 conv
+                                    over [UpSampling2D(x), skip] as four output-parity classes, each a 2x2 conv
+                                    over x at its own resolution (taps that hit the same source pixel are
+                                    pre-summed) plus the 3x3 stride-2 conv over the skip */
     sbbseg_conv_src src[2];
-    int32_t kh, kw;
-    int32_t stride_y, stride_x;
-    int32_t pad_top, pad_left;   /* zero padding (ZeroPadding2D / 'same') fused into the gather */
     int32_t cout;
+    int32_t out_h, out_w;        /* output grid of this op */
+    int32_t out_stride_y, out_stride_x, out_off_y, out_off_x;
+                                 /* placement in the output tensor(s): tensor[y*stride+off] = result[y] */
     int32_t out_tensor;          /* y = act(scale*conv + shift [+ residual]);  -1 = none */
     int32_t relu;
     int32_t residual_tensor;     /* -1 = none (Add fused into the epilogue) */
     int32_t raw_out_tensor;      /* -1 = none; second output raw_scale*conv + raw_shift, no activation
                                     (the stem's pre-BN skip f1) */
+    int32_t head_classes;        /* > 0: fuse the network head (1x1 conv + BN + softmax + argmax, main.py:290)
+                                    into this conv's epilogue (needs cout == 32, <= 4 classes, 16-bit mode);
+                                    labels/probabilities are the plan's outputs, out_tensor may be -1 */
+    double algorithmic_macs;     /* MACs per patch of the reference's formulation of this op (for reporting);
+                                    0 = derive from the geometry given here */
 } sbbseg_conv_desc;
 
-/* w_hwio: float32 [kh][kw][sum(src.channels)][cout] (Keras kernel layout); scale/shift: float32
- * [cout] (BatchNorm and bias folded by the caller); raw_*: only if raw_out_tensor >= 0. */
-int sbbseg_add_conv(sbbseg_ctx* c, const sbbseg_conv_desc* d, const float* w_hwio,
+/* w_src0 / w_src1: float32 [kh][kw][channels][cout] per source (Keras kernel layout); scale/shift:
+ * float32 [cout] (BatchNorm and bias folded by the caller); raw_*: only if raw_out_tensor >= 0;
+ * head_w [cout][classes], head_scale/head_shift [classes]: only if head_classes > 0. */
+int sbbseg_add_conv(sbbseg_ctx* c, const sbbseg_conv_desc* d, const float* w_src0, const float* w_src1,
                     const float* scale, const float* shift,
-                    const float* raw_scale, const float* raw_shift);
+                    const float* raw_scale, const float* raw_shift,
+                    const float* head_w, const float* head_scale, const float* head_shift);
 int sbbseg_add_maxpool(sbbseg_ctx* c, int src_tensor, int dst_tensor, int k, int stride);
 /* Final 1x1 conv + BN + softmax + argmax (main.py:290) over src_tensor's channels:
  * w [cin][classes], scale/shift [classes].  Produces u8 labels and (on request) f32 probabilities. */

@@ -29,15 +29,17 @@ EXPORTS = [
 
 
 class ConvSrc(C.Structure):
-    _fields_ = [("tensor", C.c_int32), ("channels", C.c_int32), ("up_shift", C.c_int32),
-                ("off_y", C.c_int32), ("off_x", C.c_int32)]
+    _fields_ = [("tensor", C.c_int32), ("channels", C.c_int32), ("kh", C.c_int32), ("kw", C.c_int32),
+                ("stride_y", C.c_int32), ("stride_x", C.c_int32), ("pad_top", C.c_int32), ("pad_left", C.c_int32),
+                ("up_shift", C.c_int32), ("off_y", C.c_int32), ("off_x", C.c_int32)]
 
 
 class ConvDesc(C.Structure):
-    _fields_ = [("n_src", C.c_int32), ("src", ConvSrc * 2), ("kh", C.c_int32), ("kw", C.c_int32),
-                ("stride_y", C.c_int32), ("stride_x", C.c_int32), ("pad_top", C.c_int32), ("pad_left", C.c_int32),
-                ("cout", C.c_int32), ("out_tensor", C.c_int32), ("relu", C.c_int32),
-                ("residual_tensor", C.c_int32), ("raw_out_tensor", C.c_int32)]
+    _fields_ = [("n_src", C.c_int32), ("src", ConvSrc * 2), ("cout", C.c_int32),
+                ("out_h", C.c_int32), ("out_w", C.c_int32),
+                ("out_stride_y", C.c_int32), ("out_stride_x", C.c_int32), ("out_off_y", C.c_int32), ("out_off_x", C.c_int32),
+                ("out_tensor", C.c_int32), ("relu", C.c_int32), ("residual_tensor", C.c_int32),
+                ("raw_out_tensor", C.c_int32), ("head_classes", C.c_int32), ("algorithmic_macs", C.c_double)]
 
 
 _lib = None
@@ -65,7 +67,7 @@ def load_library(path: Optional[str] = None):
         "sbbseg_set_input": [vp, i32, i32, i32],
         "sbbseg_input_form": [vp, i32, i32, C.POINTER(C.c_int)],
         "sbbseg_add_tensor": [vp, i32, i32, i32, C.POINTER(C.c_int)],
-        "sbbseg_add_conv": [vp, C.POINTER(ConvDesc), vp, vp, vp, vp, vp],
+        "sbbseg_add_conv": [vp, C.POINTER(ConvDesc)] + [vp] * 9,
         "sbbseg_add_maxpool": [vp, i32, i32, i32, i32],
         "sbbseg_add_head": [vp, i32, i32, i32, vp, vp, vp],
         "sbbseg_finalize": [vp, i32],
@@ -92,7 +94,7 @@ def load_library(path: Optional[str] = None):
         fn = getattr(lib, name)
         fn.argtypes = args
         fn.restype = C.c_int
-    if lib.sbbseg_abi_version() != 1:
+    if lib.sbbseg_abi_version() != 2:
         raise RuntimeError("libsbbseg ABI version mismatch")
     if path is None:
         _lib = lib
@@ -142,27 +144,37 @@ class Context:
                 check(lib.sbbseg_input_form(h, INPUT_C8, 0, C.byref(tid)))
             elif t.kind == "input_pairs":
                 check(lib.sbbseg_input_form(h, INPUT_PAIRS, t.pad, C.byref(tid)))
+            elif t.kind == "unused":
+                pass                                   # e.g. the last conv's output when the head is fused
             else:
                 check(lib.sbbseg_add_tensor(h, t.H, t.W, t.C, C.byref(tid)))
             ids.append(tid.value)
         self.tensor_ids = ids
+        f32 = lambda a: None if a is None else np.ascontiguousarray(a, np.float32)
         for s in plan.steps:
             if s.kind == "conv":
                 d = ConvDesc()
                 d.n_src = len(s.srcs)
+                keep = []
                 for k, g in enumerate(s.srcs):
-                    d.src[k] = ConvSrc(ids[g.tensor], g.channels, g.shift, g.off_y, g.off_x)
-                d.kh, d.kw, d.stride_y, d.stride_x = s.kh, s.kw, s.stride_y, s.stride_x
-                d.pad_top, d.pad_left, d.cout = s.pad_top, s.pad_left, s.cout
+                    d.src[k] = ConvSrc(ids[g.tensor], g.channels, g.kh, g.kw, g.stride_y, g.stride_x, g.pad_top,
+                                       g.pad_left, g.shift, g.off_y, g.off_x)
+                    keep.append(f32(g.w))
+                d.cout, d.out_h, d.out_w = s.cout, s.out_h, s.out_w
+                d.out_stride_y, d.out_stride_x = s.out_stride
+                d.out_off_y, d.out_off_x = s.out_off
                 d.out_tensor = ids[s.out] if s.out >= 0 else -1
                 d.relu = int(s.relu)
                 d.residual_tensor = ids[s.residual] if s.residual >= 0 else -1
                 d.raw_out_tensor = ids[s.raw_out] if s.raw_out >= 0 else -1
-                w = np.ascontiguousarray(s.w_hwio, np.float32)
-                sc, sh = np.ascontiguousarray(s.scale, np.float32), np.ascontiguousarray(s.shift, np.float32)
-                rs = None if s.raw_scale is None else np.ascontiguousarray(s.raw_scale, np.float32)
-                rb = None if s.raw_shift is None else np.ascontiguousarray(s.raw_shift, np.float32)
-                check(lib.sbbseg_add_conv(h, C.byref(d), _ptr(w), _ptr(sc), _ptr(sh), _ptr(rs), _ptr(rb)),
+                d.head_classes = s.head.classes if s.head is not None else 0
+                d.algorithmic_macs = float(s.algorithmic_macs)
+                sc, sh, rs, rb = f32(s.scale), f32(s.shift), f32(s.raw_scale), f32(s.raw_shift)
+                hw = hs = hb = None
+                if s.head is not None:
+                    hw, hs, hb = f32(s.head.w), f32(s.head.scale), f32(s.head.shift)
+                check(lib.sbbseg_add_conv(h, C.byref(d), _ptr(keep[0]), _ptr(keep[1]) if len(keep) > 1 else None,
+                                          _ptr(sc), _ptr(sh), _ptr(rs), _ptr(rb), _ptr(hw), _ptr(hs), _ptr(hb)),
                       f"sbbseg_add_conv({s.name})")
             elif s.kind == "maxpool":
                 check(lib.sbbseg_add_maxpool(h, ids[s.src], ids[s.dst], s.k, s.stride), f"sbbseg_add_maxpool({s.name})")

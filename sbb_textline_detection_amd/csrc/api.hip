@@ -57,12 +57,13 @@ enum OpType { kConv = 0, kPool = 1, kHead = 2 };
 
 struct ConvOp {
     sbbseg_conv_desc d;
-    int Ho = 0, Wo = 0;
+    int Ho = 0, Wo = 0, TH = 0, TW = 0;
     int cout_pad = 0, Ktot = 0, total_ksteps = 0, ksteps[2] = {0, 0};
     KTabEntry* d_ktab = nullptr;
     KStepRec* d_kstep = nullptr;
     void* d_w = nullptr;
     float *d_scale = nullptr, *d_shift = nullptr, *d_rscale = nullptr, *d_rshift = nullptr;
+    float *d_head_w = nullptr, *d_head_scale = nullptr, *d_head_shift = nullptr;
 };
 
 struct PoolOp { int src, dst, k, stride, Ho, Wo; };
@@ -245,10 +246,14 @@ int run_plan(sbbseg_ctx* c, int n, uint8_t* d_labels, float* d_probs)
                 sd.shift = co.d.src[s].up_shift;
                 sd.lim_y = t.H << sd.shift; sd.lim_x = t.W << sd.shift;
                 sd.ksteps = co.ksteps[s];
+                sd.sy_shift = co.d.src[s].stride_y == 2; sd.sx_shift = co.d.src[s].stride_x == 2;
             }
             p.ktab = co.d_ktab; p.kstep = co.d_kstep; p.variant = c->conv_variant & 3; p.persist_blocks = (c->conv_variant & 4) ? 0 : c->num_cus; p.w = co.d_w; p.Ktot = co.Ktot; p.total_ksteps = co.total_ksteps;
             p.Ho = co.Ho; p.Wo = co.Wo; p.M = n * co.Ho * co.Wo;
-            p.sy = co.d.stride_y; p.sx = co.d.stride_x; p.pad_t = co.d.pad_top; p.pad_l = co.d.pad_left;
+            p.TH = co.TH; p.TW = co.TW; p.osy = co.d.out_stride_y; p.osx = co.d.out_stride_x;
+            p.ooy = co.d.out_off_y; p.oox = co.d.out_off_x;
+            p.head_classes = co.d.head_classes; p.head_w = co.d_head_w; p.head_scale = co.d_head_scale;
+            p.head_shift = co.d_head_shift; p.labels = d_labels; p.probs = d_probs;
             p.cout = co.d.cout; p.scale = co.d_scale; p.shift = co.d_shift;
             p.out = co.d.out_tensor >= 0 ? c->tensors[co.d.out_tensor].data() : nullptr;
             p.residual = co.d.residual_tensor >= 0 ? c->tensors[co.d.residual_tensor].data() : nullptr;
@@ -350,6 +355,7 @@ int sbbseg_destroy(sbbseg_ctx* c)
     for (auto& op : c->ops) {
         hipFree(op.conv.d_ktab); hipFree(op.conv.d_kstep); hipFree(op.conv.d_w); hipFree(op.conv.d_scale); hipFree(op.conv.d_shift);
         hipFree(op.conv.d_rscale); hipFree(op.conv.d_rshift);
+        hipFree(op.conv.d_head_w); hipFree(op.conv.d_head_scale); hipFree(op.conv.d_head_shift);
         hipFree(op.head.d_w); hipFree(op.head.d_scale); hipFree(op.head.d_shift);
     }
     hipFree(c->d_lut); hipFree(c->d_tile_xy); hipFree(c->d_batch_labels); hipFree(c->d_probs); hipFree(c->d_xin);
@@ -425,70 +431,82 @@ int sbbseg_add_tensor(sbbseg_ctx* c, int H, int W, int C, int* tensor_id)
     return 0;
 }
 
-int sbbseg_add_conv(sbbseg_ctx* c, const sbbseg_conv_desc* d, const float* w_hwio, const float* scale,
-                    const float* shift, const float* raw_scale, const float* raw_shift)
+int sbbseg_add_conv(sbbseg_ctx* c, const sbbseg_conv_desc* d, const float* w_src0, const float* w_src1,
+                    const float* scale, const float* shift, const float* raw_scale, const float* raw_shift,
+                    const float* head_w, const float* head_scale, const float* head_shift)
 {
-    REQUIRE(c && !c->finalized && d && w_hwio && scale && shift, "bad arguments");
+    REQUIRE(c && !c->finalized && d && w_src0 && scale && shift, "bad arguments");
     HIPCHK(hipSetDevice(c->device));
     REQUIRE(d->n_src == 1 || d->n_src == 2, "n_src must be 1 or 2");
+    REQUIRE(d->n_src == 1 || w_src1, "second source needs its weights");
     REQUIRE(d->cout > 0 && d->cout % 8 == 0, "cout %d must be a positive multiple of 8", d->cout);
-    REQUIRE(d->kh > 0 && d->kw > 0 && d->stride_y > 0 && d->stride_x > 0, "bad kernel/stride");
+    REQUIRE(d->out_h > 0 && d->out_w > 0 && d->out_stride_y >= 1 && d->out_stride_x >= 1 && d->out_off_y >= 0 &&
+            d->out_off_x >= 0, "bad output grid / placement");
     const int ntens = (int)c->tensors.size();
-    int lh = -1, lw = -1, cin_total = 0;
     for (int s = 0; s < d->n_src; ++s) {
         const sbbseg_conv_src& cs = d->src[s];
         REQUIRE(cs.tensor >= 0 && cs.tensor < ntens, "conv source tensor %d undefined", cs.tensor);
         const Tensor& t = c->tensors[cs.tensor];
         REQUIRE(cs.channels > 0 && ((cs.channels + 7) / 8) * 8 <= t.C, "conv source takes %d channels of a %d-channel tensor", cs.channels, t.C);
+        REQUIRE(cs.kh > 0 && cs.kw > 0, "bad kernel size");
+        REQUIRE((cs.stride_y == 1 || cs.stride_y == 2) && (cs.stride_x == 1 || cs.stride_x == 2), "strides must be 1 or 2");
         REQUIRE(cs.up_shift == 0 || cs.up_shift == 1, "up_shift must be 0 or 1");
         REQUIRE(!(cs.up_shift && (cs.off_y || cs.off_x)), "offset and upsampling cannot be combined");
-        const int h = (t.H << cs.up_shift) + cs.off_y, w = (t.W << cs.up_shift) + cs.off_x;
-        if (s == 0) { lh = h; lw = w; }
-        REQUIRE(h == lh && w == lw, "concat sources differ in logical size (%dx%d vs %dx%d)", h, w, lh, lw);
-        cin_total += cs.channels;
+        // the last window must start inside the logical input
+        const int lh = (t.H << cs.up_shift) + cs.off_y, lw = (t.W << cs.up_shift) + cs.off_x;
+        REQUIRE((d->out_h - 1) * cs.stride_y - cs.pad_top < lh && (d->out_w - 1) * cs.stride_x - cs.pad_left < lw,
+                "conv geometry: output grid %dx%d does not fit source %d (%dx%d logical)", d->out_h, d->out_w, s, lh, lw);
     }
-    REQUIRE(d->out_tensor >= 0 || d->raw_out_tensor >= 0, "conv without outputs");
-    int Ho = -1, Wo = -1;
+    REQUIRE(d->out_tensor >= 0 || d->raw_out_tensor >= 0 || d->head_classes > 0, "conv without outputs");
+    int TH = -1, TW = -1;
     for (int which = 0; which < 3; ++which) {
         const int id = which == 0 ? d->out_tensor : which == 1 ? d->raw_out_tensor : d->residual_tensor;
         if (id < 0) continue;
         REQUIRE(id < ntens, "conv output/residual tensor %d undefined", id);
         const Tensor& t = c->tensors[id];
         REQUIRE(t.C == d->cout, "conv output tensor has %d channels, cout is %d", t.C, d->cout);
-        if (Ho < 0) { Ho = t.H; Wo = t.W; }
-        REQUIRE(t.H == Ho && t.W == Wo, "conv outputs differ in size");
+        if (TH < 0) { TH = t.H; TW = t.W; }
+        REQUIRE(t.H == TH && t.W == TW, "conv outputs differ in size");
     }
-    // the last window must start inside the padded logical input
-    REQUIRE((Ho - 1) * d->stride_y - d->pad_top < lh && (Wo - 1) * d->stride_x - d->pad_left < lw,
-            "conv geometry: output %dx%d does not fit input %dx%d", Ho, Wo, lh, lw);
+    if (d->head_classes > 0) {
+        REQUIRE(c->precision != kF32, "fused head is a 16-bit-mode feature (the fp32 check path runs the head as its own op)");
+        REQUIRE(d->cout == 32 && d->head_classes <= 4 && head_w && head_scale && head_shift, "fused head needs cout == 32, <= 4 classes and its weights");
+        REQUIRE(c->classes == 0, "plan already has a head");
+        if (TH < 0) { TH = c->in_H; TW = c->in_W; }
+        REQUIRE(TH == c->in_H && TW == c->in_W, "fused head runs at input resolution");
+    }
+    REQUIRE((d->out_h - 1) * d->out_stride_y + d->out_off_y < TH && (d->out_w - 1) * d->out_stride_x + d->out_off_x < TW,
+            "output placement leaves the %dx%d tensor", TH, TW);
+    REQUIRE(d->residual_tensor < 0 || (d->out_stride_y == 1 && d->out_stride_x == 1) || true, "unused");
 
     Op op;
     op.type = kConv;
     ConvOp& co = op.conv;
     co.d = *d;
-    co.Ho = Ho; co.Wo = Wo;
+    co.Ho = d->out_h; co.Wo = d->out_w; co.TH = TH; co.TW = TW;
     const int bc = c->precision != kF32 ? conv_tile_bc(d->cout) : 4;
     co.cout_pad = ((d->cout + bc - 1) / bc) * bc;
 
     // contraction order: source-major, then 64-channel group, then tap (ky,kx), then the group's
-    // 8-channel granules.  Keeping the 9 taps of one channel group ADJACENT makes the shifted
-    // re-reads of the same pixel rows hit in L2 (measured with tap-outer order: dec1 fetched 2.5 GB
-    // per launch for 70 MB of input).  Each source's segment is padded to whole K-steps (64) with
-    // out-of-bounds ("zero") granules.
+    // 8-channel granules.  Keeping the taps of one channel group ADJACENT makes the shifted re-reads
+    // of the same pixel rows hit in L2 (measured with tap-outer order: dec1 fetched 2.5 GB per
+    // launch for 70 MB of input).  Each source's segment is padded to whole K-steps (64) with
+    // out-of-bounds ("zero") granules.  Tap offsets carry the source's padding and placement offset.
     std::vector<KTabEntry> ktab;
     struct KRef { int s, ky, kx, c0; };
     std::vector<KRef> kref;
+    double geo_macs = 0;
     for (int s = 0; s < d->n_src; ++s) {
         const sbbseg_conv_src& cs = d->src[s];
         const int g8 = (cs.channels + 7) / 8;
         int granules = 0;
         for (int cg = 0; cg < g8; cg += kGranulesPerStep)
-            for (int ky = 0; ky < d->kh; ++ky)
-                for (int kx = 0; kx < d->kw; ++kx)
+            for (int ky = 0; ky < cs.kh; ++ky)
+                for (int kx = 0; kx < cs.kw; ++kx)
                     for (int g = cg; g < g8 && g < cg + kGranulesPerStep; ++g) {
                         KTabEntry e;
-                        e.dy = (int16_t)(ky - cs.off_y);
-                        e.dx = (int16_t)(kx - cs.off_x);
+                        e.dy = (int16_t)(ky - cs.pad_top - cs.off_y);
+                        e.dx = (int16_t)(kx - cs.pad_left - cs.off_x);
                         e.coff = g * 8 * c->elem;
                         ktab.push_back(e);
                         kref.push_back({s, ky, kx, g * 8});
@@ -503,22 +521,23 @@ int sbbseg_add_conv(sbbseg_ctx* c, const sbbseg_conv_desc* d, const float* w_hwi
         }
         co.ksteps[s] = ks;
         co.total_ksteps += ks;
+        geo_macs += (double)cs.kh * cs.kw * cs.channels;
     }
     co.Ktot = co.total_ksteps * kBK;
     REQUIRE((size_t)co.cout_pad * co.Ktot * c->elem < (size_t)3 << 30, "weight matrix too large");
 
     // pack weights [cout_pad][Ktot]
-    std::vector<int> cin_base(d->n_src, 0);
-    for (int s = 1; s < d->n_src; ++s) cin_base[s] = cin_base[s - 1] + d->src[s - 1].channels;
     const size_t wn = (size_t)co.cout_pad * co.Ktot;
     std::vector<float> wf(wn, 0.f);
     for (size_t g = 0; g < kref.size(); ++g) {
         const KRef& r = kref[g];
         if (r.s < 0) continue;
+        const sbbseg_conv_src& cs = d->src[r.s];
+        const float* wsrc_base = r.s == 0 ? w_src0 : w_src1;
         for (int q = 0; q < 8; ++q) {
             const int ch = r.c0 + q;
-            if (ch >= d->src[r.s].channels) continue;
-            const float* wsrc = w_hwio + ((size_t)(r.ky * d->kw + r.kx) * cin_total + cin_base[r.s] + ch) * d->cout;
+            if (ch >= cs.channels) continue;
+            const float* wsrc = wsrc_base + ((size_t)(r.ky * cs.kw + r.kx) * cs.channels + ch) * d->cout;
             const size_t k = g * 8 + q;
             for (int row = 0; row < co.cout_pad; ++row) {
                 const int o = c->precision != kF32 ? conv_row_channel(row, d->cout) : row;
@@ -556,17 +575,28 @@ int sbbseg_add_conv(sbbseg_ctx* c, const sbbseg_conv_desc* d, const float* w_hwi
         memcpy(pad_b.data(), raw_shift, sizeof(float) * d->cout);
         if (upload(c, &co.d_rscale, pad_s.data(), pad_s.size()) || upload(c, &co.d_rshift, pad_b.data(), pad_b.size())) return 1;
     }
-    char nm[96];
-    snprintf(nm, sizeof(nm), "conv%dx%d_s%d_c%dto%d_%dx%d%s%s", d->kh, d->kw, d->stride_y, cin_total, d->cout, Ho, Wo,
-             d->n_src == 2 ? "_cat" : "", d->src[0].up_shift ? "_up" : "");
+    if (d->head_classes > 0) {
+        if (upload(c, &co.d_head_w, head_w, (size_t)d->cout * d->head_classes) ||
+            upload(c, &co.d_head_scale, head_scale, d->head_classes) || upload(c, &co.d_head_shift, head_shift, d->head_classes))
+            return 1;
+        c->classes = d->head_classes;
+    }
+    int cin_total = 0;
+    for (int s = 0; s < d->n_src; ++s) cin_total += d->src[s].channels;
+    char nm[128];
+    snprintf(nm, sizeof(nm), "conv%dx%d_c%dto%d_%dx%d%s%s%s%s", d->src[0].kh, d->src[0].kw, cin_total, d->cout, d->out_h, d->out_w,
+             d->n_src == 2 ? "_cat" : "", d->src[0].up_shift ? "_up" : "",
+             (d->out_stride_y > 1 || d->out_stride_x > 1) ? (std::string("_par") + char('0' + d->out_off_y) + char('0' + d->out_off_x)).c_str() : "",
+             d->head_classes > 0 ? "_head" : "");
     op.name = nm;
-    op.flops = 2.0 * Ho * Wo * d->cout * d->kh * d->kw * cin_total;
+    const double macs = d->algorithmic_macs > 0 ? d->algorithmic_macs : (double)d->out_h * d->out_w * d->cout * geo_macs;
+    op.flops = 2.0 * macs;
     double bytes = 0;
     for (int s = 0; s < d->n_src; ++s) {
         const Tensor& t = c->tensors[d->src[s].tensor];
-        bytes += (double)t.H * t.W * ((d->src[s].channels + 7) / 8 * 8) * c->elem;
+        bytes += (double)t.H * t.W * ((d->src[s].channels + 7) / 8 * 8) * c->elem / (d->out_stride_y * d->out_stride_x);
     }
-    const double ob = (double)Ho * Wo * d->cout * c->elem;
+    const double ob = (double)d->out_h * d->out_w * d->cout * c->elem;
     bytes += (d->out_tensor >= 0 ? ob : 0) + (d->raw_out_tensor >= 0 ? ob : 0) + (d->residual_tensor >= 0 ? ob : 0);
     op.min_bytes = bytes;
     c->ops.push_back(op);
@@ -626,7 +656,7 @@ int sbbseg_finalize(sbbseg_ctx* c, int max_batch)
     REQUIRE(c && !c->finalized, "bad handle / already finalized");
     HIPCHK(hipSetDevice(c->device));
     REQUIRE(max_batch >= 1, "max_batch must be >= 1");
-    REQUIRE(c->classes > 0 && !c->ops.empty() && c->ops.back().type == kHead, "plan must end with a head");
+    REQUIRE(c->classes > 0 && !c->ops.empty(), "plan must contain a head (head op or a conv with a fused head)");
     c->max_batch = max_batch;
     for (auto& t : c->tensors) {
         const size_t bytes = kZeroHeaderBytes + t.elems_per_patch * max_batch * c->elem + 256;

@@ -19,6 +19,8 @@ struct SrcDesc {
     int shift;            // nearest upsampling log2 (0|1)
     int lim_y, lim_x;     // PH << shift, PW << shift
     int ksteps;           // K-steps contributed by this source
+    int sy_shift, sx_shift; // log2 of this source's input step per output step (stride 1|2); the
+                          // source's padding and placement offset are folded into the tap table
 };
 
 // one entry per 16-byte granule of the contraction axis
@@ -46,9 +48,11 @@ struct ConvParams {
     const void* w;            // packed [cout_pad][Ktot] (bf16) -- K order = ktab order
     int Ktot;                 // total_ksteps * 64
     int total_ksteps;
-    int M;                    // batch * Ho * Wo output pixels
+    int M;                    // batch * Ho * Wo output pixels of THIS op's output grid
     int Ho, Wo;
-    int sy, sx, pad_t, pad_l;
+    // placement of the op's output grid inside the output tensor(s): tensor[y*osy+ooy][x*osx+oox]
+    // (1,1,0,0 = the whole tensor; the parity-split decoder convs write every second pixel)
+    int TH, TW, osy, osx, ooy, oox;
     int cout;                 // real output channels (multiple of 8)
     const float* scale;       // [cout_pad]
     const float* shift;
@@ -58,6 +62,13 @@ struct ConvParams {
     const float* raw_scale;
     const float* raw_shift;
     int relu;
+    // fused head (cout == 32 tiles only): 1x1 conv + BN + softmax + argmax on the fp32 epilogue values
+    int head_classes;         // 0 = none
+    const float* head_w;      // [cout][classes]
+    const float* head_scale;  // [classes]
+    const float* head_shift;
+    uint8_t* labels;          // [n][TH][TW]
+    float* probs;             // [n][TH][TW][classes] or null
 };
 
 struct HeadParams {

@@ -139,7 +139,7 @@ void conv_igemm_mfma(const ConvParams p)
         (const __attribute__((address_space(4))) int*)(uintptr_t)p.kstep;
 
     // ---- load side: rows of the tile being STAGED (runs D steps ahead of the compute side)
-    int r_iy[T::kPLoads], r_ix[T::kPLoads], r_n[T::kPLoads];
+    int r_oy[T::kPLoads], r_ox[T::kPLoads], r_n[T::kPLoads];   // output coords of the staged rows
     uint32_t w_off[T::kWLoads];
     auto setup_rows = [&](int tile) __attribute__((always_inline)) {
         const int ctile = tile % n_ct, ptile = tile / n_ct;
@@ -151,12 +151,12 @@ void conv_igemm_mfma(const ConvParams p)
                 const int rem = m - n * HoWo;
                 const int oy = rem / p.Wo;
                 const int ox = rem - oy * p.Wo;
-                r_iy[j] = oy * p.sy - p.pad_t;
-                r_ix[j] = ox * p.sx - p.pad_l;
+                r_oy[j] = oy;
+                r_ox[j] = ox;
                 r_n[j] = n;
             } else {
-                r_iy[j] = -(1 << 20);                   // always out of bounds -> zero granule
-                r_ix[j] = 0;
+                r_oy[j] = -(1 << 20);                   // always out of bounds -> zero granule
+                r_ox[j] = 0;
                 r_n[j] = 0;
             }
         }
@@ -175,6 +175,7 @@ void conv_igemm_mfma(const ConvParams p)
         const int pixb = s1 ? sd1.pix_bytes : sd0.pix_bytes;
         const uint32_t img = s1 ? img1 : img0;
         const int sh = s1 ? sd1.shift : sd0.shift;
+        const int ssy = s1 ? sd1.sy_shift : sd0.sy_shift, ssx = s1 ? sd1.sx_shift : sd0.sx_shift;
         const unsigned lim_y = s1 ? sd1.lim_y : sd0.lim_y, lim_x = s1 ? sd1.lim_x : sd0.lim_x;
         int dy = (int)(short)(rec_yx & 0xffff), dx = rec_yx >> 16;
         int coff = rec_coff + gsrc * 16 + kZeroHeaderBytes;
@@ -186,8 +187,8 @@ void conv_igemm_mfma(const ConvParams p)
         char* lds_w = lds_p + BP * 128;
 #pragma unroll
         for (int j = 0; j < T::kPLoads; ++j) {
-            const int uy = r_iy[j] + dy;
-            const int ux = r_ix[j] + dx;
+            const int uy = (r_oy[j] << ssy) + dy;           // dy/dx carry tap - pad - placement offset
+            const int ux = (r_ox[j] << ssx) + dx;
             const bool ok = ((unsigned)uy < lim_y) & ((unsigned)ux < lim_x);
             const int yy = uy >> sh, xx = ux >> sh;
             // yy, xx < 2^12 and rowbytes, pixb < 2^24: 24-bit multiplies are exact (full-rate VALU)
@@ -228,25 +229,46 @@ void conv_igemm_mfma(const ConvParams p)
     // ---- epilogue of one finished tile.  Weight rows are packed in the order conv_row_channel()
     // gives, so the two MFMA row blocks (2s, 2s+1) of a lane hold 8 CONSECUTIVE channels of one
     // pixel: 16-byte NHWC stores / residual loads, 64 contiguous bytes per pixel per instruction.
+    // linear pixel index inside the output tensor(s) for output-grid pixel m (placement: see ConvParams)
+    const bool placed = (p.osy != 1) | (p.osx != 1) | (p.ooy != 0) | (p.oox != 0) | (p.TH != p.Ho) | (p.TW != p.Wo);
+    auto out_pixel = [&](int m) __attribute__((always_inline)) -> int {
+        if (!placed) return m;
+        const int n = m / HoWo;
+        const int rem = m - n * HoWo;
+        const int oy = rem / p.Wo;
+        const int ox = rem - oy * p.Wo;
+        return (n * p.TH + oy * p.osy + p.ooy) * p.TW + ox * p.osx + p.oox;
+    };
+
     // residual tile of the tile being finished: requested BEFORE its last K-step's MFMAs so the HBM
-    // round trip hides under them (a dependent load -> use chain per (s2, ni) in the epilogue cost
-    // several microseconds per tile on the residual layers)
+    // round trip hides under them
     uint4 res[T::kMI / 2][T::kNI];
     auto prefetch_residual = [&](int tile) __attribute__((always_inline)) {
         const int ctile = tile % n_ct, ptile = tile / n_ct;
 #pragma unroll
-        for (int s2 = 0; s2 < T::kMI / 2; ++s2) {
-            const int c0 = ctile * BC + wc * T::kWCH + s2 * 32 + fg * 8;
+        for (int ni = 0; ni < T::kNI; ++ni) {
+            const int m = ptile * BP + wp * T::kWPX + ni * 16 + frow;
+            const int opix = m < p.M ? out_pixel(m) : 0;
 #pragma unroll
-            for (int ni = 0; ni < T::kNI; ++ni) {
-                const int m = ptile * BP + wp * T::kWPX + ni * 16 + frow;
+            for (int s2 = 0; s2 < T::kMI / 2; ++s2) {
+                const int c0 = ctile * BC + wc * T::kWCH + s2 * 32 + fg * 8;
                 if (c0 < p.cout && m < p.M)
-                    res[s2][ni] = *(const uint4*)((const uint16_t*)p.residual + (size_t)m * p.cout + c0);
+                    res[s2][ni] = *(const uint4*)((const uint16_t*)p.residual + (size_t)opix * p.cout + c0);
             }
         }
     };
+
+    // ---- epilogue of one finished tile.  Weight rows are packed in the order conv_row_channel()
+    // gives, so the two MFMA row blocks (2s, 2s+1) of a lane hold 8 CONSECUTIVE channels of one
+    // pixel: 16-byte NHWC stores / residual loads, 64 contiguous bytes per pixel per instruction.
     auto epilogue = [&](int tile) __attribute__((always_inline)) {
         const int ctile = tile % n_ct, ptile = tile / n_ct;
+        int opix[T::kNI];
+#pragma unroll
+        for (int ni = 0; ni < T::kNI; ++ni) {
+            const int m = ptile * BP + wp * T::kWPX + ni * 16 + frow;
+            opix[ni] = m < p.M ? out_pixel(m) : -1;
+        }
 #pragma unroll
         for (int s2 = 0; s2 < T::kMI / 2; ++s2) {
             const int c0 = ctile * BC + wc * T::kWCH + s2 * 32 + fg * 8;
@@ -264,24 +286,21 @@ void conv_igemm_mfma(const ConvParams p)
                 }
 #pragma unroll
                 for (int ni = 0; ni < T::kNI; ++ni) {
-                    const int m = ptile * BP + wp * T::kWPX + ni * 16 + frow;
-                    if (m >= p.M) continue;
-                    float v[8];
+                    float v[8], y[8];
 #pragma unroll
                     for (int q = 0; q < 4; ++q) { v[q] = acc[2 * s2][ni][q]; v[4 + q] = acc[2 * s2 + 1][ni][q]; }
-                    const size_t o = (size_t)m * p.cout + c0;
-                    if (p.raw_out) {
-                        uint4 r;
-                        r.x = pack2<F16>(v[0] * rsc[0] + rsh[0], v[1] * rsc[1] + rsh[1]);
-                        r.y = pack2<F16>(v[2] * rsc[2] + rsh[2], v[3] * rsc[3] + rsh[3]);
-                        r.z = pack2<F16>(v[4] * rsc[4] + rsh[4], v[5] * rsc[5] + rsh[5]);
-                        r.w = pack2<F16>(v[6] * rsc[6] + rsh[6], v[7] * rsc[7] + rsh[7]);
-                        *(uint4*)((uint16_t*)p.raw_out + o) = r;
-                    }
-                    if (p.out) {
-                        float y[8];
 #pragma unroll
-                        for (int q = 0; q < 8; ++q) y[q] = v[q] * sc[q] + sh[q];
+                    for (int q = 0; q < 8; ++q) y[q] = v[q] * sc[q] + sh[q];
+                    const size_t o = (size_t)(opix[ni] < 0 ? 0 : opix[ni]) * p.cout + c0;
+                    if (opix[ni] >= 0) {
+                        if (p.raw_out) {
+                            uint4 r;
+                            r.x = pack2<F16>(v[0] * rsc[0] + rsh[0], v[1] * rsc[1] + rsh[1]);
+                            r.y = pack2<F16>(v[2] * rsc[2] + rsh[2], v[3] * rsc[3] + rsh[3]);
+                            r.z = pack2<F16>(v[4] * rsc[4] + rsh[4], v[5] * rsc[5] + rsh[5]);
+                            r.w = pack2<F16>(v[6] * rsc[6] + rsh[6], v[7] * rsc[7] + rsh[7]);
+                            *(uint4*)((uint16_t*)p.raw_out + o) = r;
+                        }
                         if (p.residual) {
                             const uint4 rr = res[s2][ni];
                             y[0] += unpack_lo<F16>(rr.x); y[1] += unpack_hi<F16>(rr.x);
@@ -289,14 +308,55 @@ void conv_igemm_mfma(const ConvParams p)
                             y[4] += unpack_lo<F16>(rr.z); y[5] += unpack_hi<F16>(rr.z);
                             y[6] += unpack_lo<F16>(rr.w); y[7] += unpack_hi<F16>(rr.w);
                         }
-                        if (p.relu) {
+                    }
+                    if (p.relu) {
 #pragma unroll
-                            for (int q = 0; q < 8; ++q) y[q] = fmaxf(y[q], 0.f);
-                        }
+                        for (int q = 0; q < 8; ++q) y[q] = fmaxf(y[q], 0.f);
+                    }
+                    if (p.out && opix[ni] >= 0) {
                         uint4 r;
                         r.x = pack2<F16>(y[0], y[1]); r.y = pack2<F16>(y[2], y[3]);
                         r.z = pack2<F16>(y[4], y[5]); r.w = pack2<F16>(y[6], y[7]);
                         *(uint4*)((uint16_t*)p.out + o) = r;
+                    }
+                    if constexpr (BC == 32) {
+                        // fused head: the 32 channels of a pixel sit in the 4 lanes {frow + 16*fg}; each
+                        // lane contracts its 8 fp32 channels, two xor-shuffles add the partial logits
+                        // (no 16-bit rounding between the last conv and the softmax)
+                        if (p.head_classes > 0) {
+                            float logit[4];
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) {
+                                float a = 0.f;
+                                if (c < p.head_classes) {
+#pragma unroll
+                                    for (int q = 0; q < 8; ++q) a = fmaf(y[q], p.head_w[(c0 + q) * p.head_classes + c], a);
+                                }
+                                a += __shfl_xor(a, 16);
+                                a += __shfl_xor(a, 32);
+                                logit[c] = a;
+                            }
+                            if (fg == 0 && opix[ni] >= 0) {
+                                float mx = -3.0e38f;
+#pragma unroll
+                                for (int c = 0; c < 4; ++c)
+                                    if (c < p.head_classes) { logit[c] = logit[c] * p.head_scale[c] + p.head_shift[c]; mx = fmaxf(mx, logit[c]); }
+                                float pr[4], sum = 0.f;
+#pragma unroll
+                                for (int c = 0; c < 4; ++c)
+                                    if (c < p.head_classes) { pr[c] = expf(logit[c] - mx); sum += pr[c]; }
+                                int best = 0;
+                                float bestp = -1.f;
+#pragma unroll
+                                for (int c = 0; c < 4; ++c)
+                                    if (c < p.head_classes) {
+                                        pr[c] = pr[c] / sum;
+                                        if (pr[c] > bestp) { bestp = pr[c]; best = c; }      // first maximum wins (np.argmax)
+                                        if (p.probs) p.probs[(size_t)opix[ni] * p.head_classes + c] = pr[c];
+                                    }
+                                p.labels[opix[ni]] = (uint8_t)best;
+                            }
+                        }
                     }
                 }
             }
@@ -373,12 +433,12 @@ __global__ __launch_bounds__(256) void conv_naive_f32(const ConvParams p)
     const int n = m / HoWo;
     const int rem = m - n * HoWo;
     const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
-    const int iy0 = oy * p.sy - p.pad_t, ix0 = ox * p.sx - p.pad_l;
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
     const float* w = (const float*)p.w;
     int t = 0;
     for (int s = 0; s < p.n_src; ++s) {
         const SrcDesc sd = p.src[s];
+        const int iy0 = oy << sd.sy_shift, ix0 = ox << sd.sx_shift;
         for (int ks = 0; ks < sd.ksteps; ++ks, ++t) {
             for (int g = 0; g < kGranulesPerStep; ++g) {
                 const KTabEntry e = p.ktab[t * kGranulesPerStep + g];
@@ -397,7 +457,8 @@ __global__ __launch_bounds__(256) void conv_naive_f32(const ConvParams p)
             }
         }
     }
-    const size_t o = (size_t)m * p.cout + c0;
+    const size_t opix = (size_t)(n * p.TH + oy * p.osy + p.ooy) * p.TW + ox * p.osx + p.oox;
+    const size_t o = opix * p.cout + c0;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
         if (p.raw_out) ((float*)p.raw_out)[o + c] = acc[c] * p.raw_scale[c0 + c] + p.raw_shift[c0 + c];

@@ -34,6 +34,14 @@ class Seg:
     shift: int = 0       # nearest x2 upsampling fused into the gather
     off_y: int = 0
     off_x: int = 0
+    # conv geometry of this source (filled when the segment becomes a conv operand)
+    kh: int = 0
+    kw: int = 0
+    stride_y: int = 1
+    stride_x: int = 1
+    pad_top: int = 0
+    pad_left: int = 0
+    w: Optional[np.ndarray] = None      # float32 [kh][kw][channels][cout]
 
 
 @dataclass
@@ -49,23 +57,22 @@ class TensorSpec:
 @dataclass
 class ConvStep:
     name: str
-    srcs: List[Seg]
-    kh: int
-    kw: int
-    stride_y: int
-    stride_x: int
-    pad_top: int
-    pad_left: int
+    srcs: List[Seg]               # 1 or 2 sources, each with its own taps / stride / padding / weights
     cout: int
-    w_hwio: np.ndarray            # float32 [kh][kw][sum(src channels)][cout]
+    out_h: int                    # output grid of this step ...
+    out_w: int
     scale: np.ndarray             # float32 [cout]
     shift: np.ndarray
+    out_stride: Tuple[int, int] = (1, 1)   # ... and its placement in the output tensor:
+    out_off: Tuple[int, int] = (0, 0)      #     tensor[y*stride+off] = result[y]
     out: int = -1
     relu: bool = False
     residual: int = -1
     raw_out: int = -1
     raw_scale: Optional[np.ndarray] = None
     raw_shift: Optional[np.ndarray] = None
+    head: Optional["HeadStep"] = None      # fused network head (1x1 conv + BN + softmax + argmax)
+    algorithmic_macs: float = 0.0          # MACs per patch in the reference's formulation
     kind: str = "conv"
 
 
@@ -101,15 +108,30 @@ class Plan:
     layer_tensor: Dict[str, int] = field(default_factory=dict)   # Keras layer name -> materialised tensor
 
     def macs_per_patch(self) -> int:
+        """MACs of the reference's formulation (what the roofline counts as algorithmic work)."""
         total = 0
         for s in self.steps:
             if s.kind == "conv":
-                t = self.tensors[s.out if s.out >= 0 else s.raw_out]
-                total += t.H * t.W * s.cout * s.logical_macs_per_out
+                total += s.algorithmic_macs
+                if s.head is not None:
+                    total += s.out_h * s.out_w * s.head.cin * s.head.classes
             elif s.kind == "head":
                 t = self.tensors[s.src]
                 total += t.H * t.W * s.cin * s.classes
-        return total
+        return int(round(total))
+
+    def executed_macs_per_patch(self) -> int:
+        """MACs the kernels actually issue (parity-split decoder convs pre-sum coincident taps)."""
+        total = 0
+        for s in self.steps:
+            if s.kind == "conv":
+                total += s.out_h * s.out_w * s.cout * sum(g.kh * g.kw * g.channels for g in s.srcs)
+                if s.head is not None:
+                    total += s.out_h * s.out_w * s.head.cin * s.head.classes
+            elif s.kind == "head":
+                t = self.tensors[s.src]
+                total += t.H * t.W * s.cin * s.classes
+        return int(total)
 
 
 class _Pending:
@@ -146,7 +168,13 @@ class PlanError(NotImplementedError):
     pass
 
 
-def build_plan(graph: Graph, weights: Dict[str, np.ndarray]) -> Plan:
+# taps of a 3x3 window (index ky = dy+1) that land on source row a+t (+py-1) of a nearest-x2-upsampled
+# tensor, for output-row parity py:  ((2a+py) + dy) >> 1
+_PARITY_TAPS = {(0, 0): (0,), (0, 1): (1, 2), (1, 0): (0, 1), (1, 1): (2,)}
+
+
+def build_plan(graph: Graph, weights: Dict[str, np.ndarray], parity_split: bool = True,
+               fuse_head: bool = True) -> Plan:
     byn = graph.by_name()
     consumers: Dict[str, int] = {}
     for n in graph.nodes:
@@ -182,13 +210,41 @@ def build_plan(graph: Graph, weights: Dict[str, np.ndarray]) -> Plan:
         p.emitted_out = new_tensor(oh, ow, p.cout, p.node.name)
         if p.raw_needed:
             p.emitted_raw = new_tensor(oh, ow, p.cout, p.node.name + ":raw")
-        step = ConvStep(p.node.name, p.srcs, p.kh, p.kw, p.sy, p.sx, p.pt, p.pl, p.cout,
-                        np.ascontiguousarray(p.w, np.float32), p.scale.astype(np.float32), p.shift.astype(np.float32),
-                        out=p.emitted_out, relu=p.relu, residual=p.residual, raw_out=p.emitted_raw,
-                        raw_scale=p.raw_scale.astype(np.float32) if p.raw_needed else None,
-                        raw_shift=p.raw_shift.astype(np.float32) if p.raw_needed else None)
-        step.logical_macs_per_out = p.logical_macs_per_out
-        plan.steps.append(step)
+        cbase, srcs = 0, []
+        for g in p.srcs:
+            srcs.append(Seg(g.tensor, g.channels, g.shift, g.off_y, g.off_x, p.kh, p.kw, p.sy, p.sx, p.pt, p.pl,
+                            np.ascontiguousarray(p.w[:, :, cbase:cbase + g.channels, :], np.float32)))
+            cbase += g.channels
+        common = dict(cout=p.cout, scale=p.scale.astype(np.float32), shift=p.shift.astype(np.float32),
+                      out=p.emitted_out, relu=p.relu, residual=p.residual, raw_out=p.emitted_raw,
+                      raw_scale=p.raw_scale.astype(np.float32) if p.raw_needed else None,
+                      raw_shift=p.raw_shift.astype(np.float32) if p.raw_needed else None)
+        macs = float(oh * ow * p.cout * p.logical_macs_per_out)
+        splittable = (parity_split and srcs[0].shift == 1 and (p.kh, p.kw, p.sy, p.sx, p.pt, p.pl) == (3, 3, 1, 1, 1, 1)
+                      and oh % 2 == 0 and ow % 2 == 0 and p.residual < 0 and not p.raw_needed
+                      and all(not (g.shift and (g.off_y or g.off_x)) for g in srcs))
+        if not splittable:
+            plan.steps.append(ConvStep(p.node.name, srcs, out_h=oh, out_w=ow, algorithmic_macs=macs, **common))
+            return
+        # 3x3 conv over nearest-x2-upsampled sources == four output-parity classes; in each, the taps
+        # that read the same stored pixel are pre-summed: a 2x2 conv at the source's own resolution
+        # (2.25x fewer MACs on that source).  Non-upsampled sources become 3x3 stride-2 convs.
+        for py in (0, 1):
+            for px in (0, 1):
+                psrcs = []
+                for g in srcs:
+                    if g.shift == 1:
+                        w2 = np.zeros((2, 2, g.channels, p.cout), np.float64)
+                        for ty in (0, 1):
+                            for tx in (0, 1):
+                                for ky in _PARITY_TAPS[(py, ty)]:
+                                    for kx in _PARITY_TAPS[(px, tx)]:
+                                        w2[ty, tx] += g.w[ky, kx]
+                        psrcs.append(Seg(g.tensor, g.channels, 0, 0, 0, 2, 2, 1, 1, 1 - py, 1 - px, w2.astype(np.float32)))
+                    else:
+                        psrcs.append(Seg(g.tensor, g.channels, 0, g.off_y, g.off_x, 3, 3, 2, 2, 1 - py, 1 - px, g.w))
+                plan.steps.append(ConvStep(f"{p.node.name}:p{py}{px}", psrcs, out_h=oh // 2, out_w=ow // 2,
+                                           out_stride=(2, 2), out_off=(py, px), algorithmic_macs=macs / 4, **common))
 
     def materialize(name: str) -> _View:
         """Make the value of Keras layer `name` a plain stored tensor (emit pending work)."""
@@ -357,9 +413,21 @@ def build_plan(graph: Graph, weights: Dict[str, np.ndarray]) -> Plan:
                 ts = plan.tensors[t_id]
                 if ts.C != p.srcs[0].channels or ts.C > 64 or p.cout > 8 or (ts.H, ts.W) != (in_h, in_w):
                     raise PlanError(f"{n.name}: head needs <=64 input channels, <=8 classes, input resolution")
-                plan.steps.append(HeadStep(p.node.name, t_id, ts.C, p.cout,
-                                           np.ascontiguousarray(p.w.reshape(ts.C, p.cout), np.float32),
-                                           p.scale.astype(np.float32), p.shift.astype(np.float32)))
+                head = HeadStep(p.node.name, t_id, ts.C, p.cout,
+                                np.ascontiguousarray(p.w.reshape(ts.C, p.cout), np.float32),
+                                p.scale.astype(np.float32), p.shift.astype(np.float32))
+                producers = [st for st in plan.steps if st.kind == "conv" and st.out == t_id]
+                src_layer = p.node.inputs[0]
+                if (fuse_head and producers and ts.C == 32 and p.cout <= 4 and consumers.get(src_layer, 0) == 1
+                        and all(st.raw_out < 0 and st.residual < 0 for st in producers)):
+                    # the head rides in the epilogue of the conv(s) producing its input; that
+                    # tensor is never written (fp32 values go straight into the 1x1 contraction)
+                    for st in producers:
+                        st.head, st.out = head, -1
+                    ts.kind = "unused"
+                    plan.layer_tensor = {k: v for k, v in plan.layer_tensor.items() if v != t_id}
+                else:
+                    plan.steps.append(head)
                 plan.classes = p.cout
                 views[n.name] = _View(src.H, src.W)
         elif n.op == "maxpool":

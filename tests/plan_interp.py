@@ -1,9 +1,10 @@
 """numpy interpreter of a fused ``planner.Plan`` (test helper, CPU only).
 
-Emulates the *semantics* libsbbseg gives each step (gather with upsampling shift / placement offset
-/ zero padding, folded scale+shift, residual, ReLU, PAIRS/C8 input forms) so that the planner's
-lowering can be checked against the unfused oracle without a GPU.  fp32 throughout; convolution
-arithmetic is delegated to the oracle's C conv.  Never used by the product."""
+Emulates the *semantics* libsbbseg gives each step (per-source gather with upsampling shift /
+placement offset / zero padding / stride, folded scale+shift, residual, ReLU, strided output
+placement, fused head, PAIRS/C8 input forms) so that the planner's lowering -- including the
+parity split of the decoder convs -- can be checked against the unfused oracle without a GPU.
+fp32 throughout; convolution arithmetic is delegated to the oracle's C conv.  Never used by the product."""
 import numpy as np
 
 from oracle import keras_forward as kf
@@ -26,45 +27,62 @@ def make_input_forms(plan, x):
     return out
 
 
-def logical_source(plan, vals, seg, LH, LW):
-    a = vals[seg.tensor][..., :seg.channels]
-    if seg.shift:
+def source_conv(plan, vals, g, out_h, out_w):
+    """Contribution of one source to the op's output grid, fp32 [n,out_h,out_w,cout]."""
+    a = vals[g.tensor][..., :g.channels]
+    if g.shift:
         a = np.repeat(np.repeat(a, 2, axis=1), 2, axis=2)
     n, h, w, c = a.shape
-    out = np.zeros((n, LH, LW, c), np.float32)
-    hh, ww = min(h, LH - seg.off_y), min(w, LW - seg.off_x)
-    out[:, seg.off_y:seg.off_y + hh, seg.off_x:seg.off_x + ww] = a[:, :hh, :ww]
-    return out
+    # logical tensor: stored data placed at (off_y, off_x), zero elsewhere, unbounded to the right/bottom
+    need_h = (out_h - 1) * g.stride_y - g.pad_top + g.kh
+    need_w = (out_w - 1) * g.stride_x - g.pad_left + g.kw
+    LH, LW = max(need_h, h + g.off_y), max(need_w, w + g.off_x)
+    logical = np.zeros((n, LH, LW, c), np.float32)
+    logical[:, g.off_y:g.off_y + h, g.off_x:g.off_x + w] = a
+    xin = np.pad(logical, ((0, 0), (g.pad_top, 0), (g.pad_left, 0), (0, 0)))
+    y = kf.conv2d(xin, g.w, None, (g.stride_y, g.stride_x), "valid")
+    return y[:, :out_h, :out_w]
 
 
 def run_plan(plan, x):
     """Returns (labels uint8 [n,H,W], probs float32 [n,H,W,C], vals)."""
-    vals = make_input_forms(plan, np.asarray(x, np.float32))
+    x = np.asarray(x, np.float32)
+    n = x.shape[0]
+    vals = make_input_forms(plan, x)
     labels = probs = None
+
+    def place(tid, z, s):
+        t = plan.tensors[tid]
+        if tid not in vals:
+            vals[tid] = np.zeros((n, t.H, t.W, t.C), np.float32)
+        (sy, sx), (oy, ox) = s.out_stride, s.out_off
+        vals[tid][:, oy::sy, ox::sx][:, :s.out_h, :s.out_w] = z
+
     for s in plan.steps:
         if s.kind == "conv":
-            ot = plan.tensors[s.out if s.out >= 0 else s.raw_out]
-            # logical input extent needed by the last window
-            LH = (ot.H - 1) * s.stride_y - s.pad_top + s.kh
-            LW = (ot.W - 1) * s.stride_x - s.pad_left + s.kw
-            LH = max([LH] + [(plan.tensors[g.tensor].H << g.shift) + g.off_y for g in s.srcs])
-            LW = max([LW] + [(plan.tensors[g.tensor].W << g.shift) + g.off_x for g in s.srcs])
-            xin = np.concatenate([logical_source(plan, vals, g, LH, LW) for g in s.srcs], axis=3)
-            xin = np.pad(xin, ((0, 0), (s.pad_top, s.kh), (s.pad_left, s.kw), (0, 0)))
-            y = kf.conv2d(xin, s.w_hwio, None, (s.stride_y, s.stride_x), "valid")[:, :ot.H, :ot.W]
+            y = sum(source_conv(plan, vals, g, s.out_h, s.out_w) for g in s.srcs)
             if s.raw_out >= 0:
-                vals[s.raw_out] = (y * s.raw_scale + s.raw_shift).astype(np.float32)
+                place(s.raw_out, (y * s.raw_scale + s.raw_shift).astype(np.float32), s)
+            z = y * s.scale + s.shift
+            if s.residual >= 0:
+                (sy, sx), (oy, ox) = s.out_stride, s.out_off
+                z = z + vals[s.residual][:, oy::sy, ox::sx][:, :s.out_h, :s.out_w]
+            if s.relu:
+                z = np.maximum(z, 0)
+            z = z.astype(np.float32)
             if s.out >= 0:
-                z = y * s.scale + s.shift
-                if s.residual >= 0:
-                    z = z + vals[s.residual]
-                if s.relu:
-                    z = np.maximum(z, 0)
-                vals[s.out] = z.astype(np.float32)
+                place(s.out, z, s)
+            if s.head is not None:
+                hd = s.head
+                pr = kf._softmax(((z @ hd.w) * hd.scale + hd.shift).astype(np.float32))
+                if probs is None:
+                    probs = np.zeros((n, plan.in_h, plan.in_w, hd.classes), np.float32)
+                (sy, sx), (oy, ox) = s.out_stride, s.out_off
+                probs[:, oy::sy, ox::sx][:, :s.out_h, :s.out_w] = pr
         elif s.kind == "maxpool":
             vals[s.dst] = kf._maxpool(vals[s.src], (s.k, s.k), (s.stride, s.stride))
         elif s.kind == "head":
             logits = (vals[s.src] @ s.w) * s.scale + s.shift
             probs = kf._softmax(logits.astype(np.float32))
-            labels = np.argmax(probs, axis=3).astype(np.uint8)
+    labels = np.argmax(probs, axis=3).astype(np.uint8)
     return labels, probs, vals

@@ -12,11 +12,12 @@ from sbb_textline_detection_amd.weights import synthetic_model, synthetic_weight
 from tools.synth_model import calibrated_model
 
 
-@pytest.mark.parametrize("classes,hw", [(2, (96, 128)), (4, (64, 64))])
-def test_plan_equals_oracle(classes, hw):
+@pytest.mark.parametrize("classes,hw,parity,fuse", [(2, (96, 128), True, True), (4, (64, 64), True, False),
+                                                     (2, (64, 96), False, True), (4, (64, 64), False, False)])
+def test_plan_equals_oracle(classes, hw, parity, fuse):
     cfg, w = calibrated_model(classes, hw[0], hw[1], seed=1, calib_hw=64)
     g = parse_model_config(cfg)
-    plan = build_plan(g, w)
+    plan = build_plan(g, w, parity_split=parity, fuse_head=fuse)
     page = synthetic_page(300, 400, 5)
     x = np.stack([page[10:10 + hw[0], 20:20 + hw[1]], page[100:100 + hw[0], 200:200 + hw[1]]]).astype(np.float32) / 255
     ref = kf.forward(g, w, x)
@@ -29,17 +30,33 @@ def test_plan_equals_oracle(classes, hw):
 
 def test_plan_structure_448():
     cfg, w = synthetic_model(2, 448, 448, 0)
-    plan = build_plan(parse_model_config(cfg), w)
+    plan = build_plan(parse_model_config(cfg), w, parity_split=False, fuse_head=False)
     kinds = [s.kind for s in plan.steps]
     assert kinds.count("conv") == 59 and kinds.count("maxpool") == 1 and kinds[-1] == "head"
     assert plan.macs_per_patch() == 47418195968                       # 47.418 GMAC
-    stem = plan.steps[0]
-    assert (stem.kh, stem.kw, stem.stride_y, stem.stride_x) == (7, 4, 2, 1) and stem.raw_out >= 0
+    assert plan.executed_macs_per_patch() > plan.macs_per_patch()      # only the stem's zero taps/channels
+    stem = plan.steps[0].srcs[0]
+    assert (stem.kh, stem.kw, stem.stride_y, stem.stride_x) == (7, 4, 2, 1) and plan.steps[0].raw_out >= 0
     dec = {s.name: s for s in plan.steps if s.kind == "conv" and len(s.srcs) == 2}
     assert len(dec) == 5 and all(s.srcs[0].shift == 1 for s in dec.values())
     f2 = [s for s in dec.values() if s.srcs[1].off_y == 1]
     assert len(f2) == 1 and f2[0].srcs[1].off_x == 1                   # one_side_pad became an offset
     assert sum(1 for s in plan.steps if s.kind == "conv" and s.residual >= 0) == 16
+
+
+def test_parity_split_and_fused_head_448():
+    cfg, w = synthetic_model(2, 448, 448, 0)
+    plan = build_plan(parse_model_config(cfg), w)
+    kinds = [s.kind for s in plan.steps]
+    assert kinds.count("conv") == 54 + 5 * 4 and "head" not in kinds    # 5 decoder convs x 4 parity classes
+    assert plan.macs_per_patch() == 47418195968                       # algorithmic work is unchanged ...
+    assert plan.executed_macs_per_patch() < 0.80 * plan.macs_per_patch()   # ... but > 20 % fewer MACs are issued
+    par = [s for s in plan.steps if s.kind == "conv" and s.out_stride == (2, 2)]
+    assert len(par) == 20 and all((s.srcs[0].kh, s.srcs[0].kw, s.srcs[0].shift) == (2, 2, 0) for s in par)
+    assert all((s.srcs[1].kh, s.srcs[1].stride_y) == (3, 2) for s in par)
+    heads = [s for s in par if s.head is not None]
+    assert len(heads) == 4 and all(s.out == -1 and s.cout == 32 for s in heads)
+    assert sum(1 for t in plan.tensors if t.kind == "unused") == 1
 
 
 def test_unsupported_graph_raises_plan_error():
