@@ -116,6 +116,7 @@ struct sbbseg_ctx {
     // profiling
     bool profiling = false;
     int conv_variant = 0;
+    int fused_heads = 0;
     int num_cus = 256;
     std::vector<PendingEvent> pending;
     std::vector<hipEvent_t> free_events;
@@ -471,7 +472,8 @@ int sbbseg_add_conv(sbbseg_ctx* c, const sbbseg_conv_desc* d, const float* w_src
     if (d->head_classes > 0) {
         REQUIRE(c->precision != kF32, "fused head is a 16-bit-mode feature (the fp32 check path runs the head as its own op)");
         REQUIRE(d->cout == 32 && d->head_classes <= 4 && head_w && head_scale && head_shift, "fused head needs cout == 32, <= 4 classes and its weights");
-        REQUIRE(c->classes == 0, "plan already has a head");
+        // several convs may carry the same head (the parity classes of the last decoder conv)
+        REQUIRE(c->classes == 0 || (c->fused_heads > 0 && c->classes == d->head_classes), "plan already has a head");
         if (TH < 0) { TH = c->in_H; TW = c->in_W; }
         REQUIRE(TH == c->in_H && TW == c->in_W, "fused head runs at input resolution");
     }
@@ -580,6 +582,7 @@ int sbbseg_add_conv(sbbseg_ctx* c, const sbbseg_conv_desc* d, const float* w_src
             upload(c, &co.d_head_scale, head_scale, d->head_classes) || upload(c, &co.d_head_shift, head_shift, d->head_classes))
             return 1;
         c->classes = d->head_classes;
+        c->fused_heads += 1;
     }
     int cin_total = 0;
     for (int s = 0; s < d->n_src; ++s) cin_total += d->src[s].channels;
