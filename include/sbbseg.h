@@ -43,7 +43,10 @@ int sbbseg_abi_version(void);
 int sbbseg_device_count(int* count);
 int sbbseg_create(int device, int precision, sbbseg_ctx** out);
 int sbbseg_destroy(sbbseg_ctx* c);                       /* frees all device memory; NULL ok */
-int sbbseg_set_stream(sbbseg_ctx* c, void* hip_stream);  /* NULL -> the handle's own stream */
+/* run on the caller's HIP stream (NULL = the legacy default stream, e.g. torch's current stream when
+ * no stream context is active); SBBSEG_OWN_STREAM returns to the handle's private non-blocking stream */
+#define SBBSEG_OWN_STREAM ((void*)(intptr_t)-1)
+int sbbseg_set_stream(sbbseg_ctx* c, void* hip_stream);
 int sbbseg_synchronize(sbbseg_ctx* c);
 
 /* ---- plan building: the host-side planner (planner.py) lowers the Keras model_config that the

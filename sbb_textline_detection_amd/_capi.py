@@ -210,7 +210,8 @@ class Context:
         return b.value
 
     def set_stream(self, stream_ptr: int):
-        check(self.lib.sbbseg_set_stream(self.h, C.c_void_p(stream_ptr)))
+        """Run on the caller's HIP stream (0 = the legacy default stream); -1 = the handle's own stream."""
+        check(self.lib.sbbseg_set_stream(self.h, C.c_void_p(stream_ptr if stream_ptr >= 0 else 2 ** 64 - 1)))
 
     def synchronize(self):
         check(self.lib.sbbseg_synchronize(self.h))

@@ -373,7 +373,8 @@ int sbbseg_set_stream(sbbseg_ctx* c, void* hip_stream)
 {
     REQUIRE(c, "null handle");
     if (resolve_pending(c)) return 1;
-    c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    // NULL is a real stream (the legacy default stream torch uses unless told otherwise)
+    c->stream = hip_stream == SBBSEG_OWN_STREAM ? c->own_stream : (hipStream_t)hip_stream;
     return 0;
 }
 

@@ -206,4 +206,5 @@ def test_sharded_entry_points_single_rank(torch_cuda, stitch_model):
     ref = stitch_model.segment_page(page)
     assert np.array_equal(a, ref) and np.array_equal(b[0], ref)
     assert np.array_equal(b[1], stitch_model.segment_page(page[::-1].copy()))
-    stitch_model.ctx.set_stream(0)
+    stitch_model.ctx.synchronize()
+    stitch_model.ctx.set_stream(-1)
