@@ -106,6 +106,15 @@ int sbbseg_add_conv(sbbseg_ctx* c, const sbbseg_conv_desc* d, const float* w_src
                     const float* raw_scale, const float* raw_shift,
                     const float* head_w, const float* head_scale, const float* head_shift);
 int sbbseg_add_maxpool(sbbseg_ctx* c, int src_tensor, int dst_tensor, int k, int stride);
+/* Fused network tail (16-bit modes): ReLU(BN(conv3x3 'same' over [UpSampling2D(2)(src0: 64 channels),
+ * network input (3 channels, C8 form)])) -> 32 channels -> 1x1 conv + BN + softmax + argmax, in one
+ * launch that writes only labels (and probabilities on request).  w_src0 [3][3][64][32], w_img
+ * [3][3][3][32] (Keras layout, original 3x3 taps: the library pre-sums them per output parity);
+ * scale/shift [32]; head_w [32][classes], head_scale/head_shift [classes], classes <= 4. */
+int sbbseg_add_tail(sbbseg_ctx* c, int src0_tensor, int img_c8_tensor, const float* w_src0, const float* w_img,
+                    const float* scale, const float* shift, int classes,
+                    const float* head_w, const float* head_scale, const float* head_shift,
+                    double algorithmic_macs);
 /* Final 1x1 conv + BN + softmax + argmax (main.py:290) over src_tensor's channels:
  * w [cin][classes], scale/shift [classes].  Produces u8 labels and (on request) f32 probabilities. */
 int sbbseg_add_head(sbbseg_ctx* c, int src_tensor, int cin, int classes,

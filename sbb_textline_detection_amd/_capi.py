@@ -19,7 +19,7 @@ INPUT_C8, INPUT_PAIRS = 0, 1
 EXPORTS = [
     "sbbseg_last_error", "sbbseg_abi_version", "sbbseg_device_count", "sbbseg_create", "sbbseg_destroy",
     "sbbseg_set_stream", "sbbseg_synchronize", "sbbseg_set_input", "sbbseg_input_form", "sbbseg_add_tensor",
-    "sbbseg_add_conv", "sbbseg_add_maxpool", "sbbseg_add_head", "sbbseg_finalize", "sbbseg_model_info",
+    "sbbseg_add_conv", "sbbseg_add_maxpool", "sbbseg_add_tail", "sbbseg_add_head", "sbbseg_finalize", "sbbseg_model_info",
     "sbbseg_num_ops", "sbbseg_op_info", "sbbseg_device_bytes", "sbbseg_predict", "sbbseg_segment_page",
     "sbbseg_segment_page_dev", "sbbseg_segment_whole", "sbbseg_tile_grid", "sbbseg_segment_tiles_dev",
     "sbbseg_segment_tile_range_dev", "sbbseg_stitch_dev", "sbbseg_debug_ingest", "sbbseg_debug_read_tensor",
@@ -70,6 +70,7 @@ def load_library(path: Optional[str] = None):
         "sbbseg_add_conv": [vp, C.POINTER(ConvDesc)] + [vp] * 9,
         "sbbseg_add_maxpool": [vp, i32, i32, i32, i32],
         "sbbseg_add_head": [vp, i32, i32, i32, vp, vp, vp],
+        "sbbseg_add_tail": [vp, i32, i32, vp, vp, vp, vp, i32, vp, vp, vp, C.c_double],
         "sbbseg_finalize": [vp, i32],
         "sbbseg_model_info": [vp] + [C.POINTER(C.c_int)] * 4,
         "sbbseg_num_ops": [vp, C.POINTER(C.c_int)],
@@ -176,6 +177,11 @@ class Context:
                 check(lib.sbbseg_add_conv(h, C.byref(d), _ptr(keep[0]), _ptr(keep[1]) if len(keep) > 1 else None,
                                           _ptr(sc), _ptr(sh), _ptr(rs), _ptr(rb), _ptr(hw), _ptr(hs), _ptr(hb)),
                       f"sbbseg_add_conv({s.name})")
+            elif s.kind == "tail":
+                arrs = [f32(s.w_src0), f32(s.w_img), f32(s.scale), f32(s.shift), f32(s.head.w), f32(s.head.scale), f32(s.head.shift)]
+                check(lib.sbbseg_add_tail(h, ids[s.src0], ids[s.img], _ptr(arrs[0]), _ptr(arrs[1]), _ptr(arrs[2]), _ptr(arrs[3]),
+                                          s.head.classes, _ptr(arrs[4]), _ptr(arrs[5]), _ptr(arrs[6]), float(s.algorithmic_macs)),
+                      f"sbbseg_add_tail({s.name})")
             elif s.kind == "maxpool":
                 check(lib.sbbseg_add_maxpool(h, ids[s.src], ids[s.dst], s.k, s.stride), f"sbbseg_add_maxpool({s.name})")
             elif s.kind == "head":

@@ -53,7 +53,7 @@ struct Tensor {
     char* data() const { return buf + kZeroHeaderBytes; }
 };
 
-enum OpType { kConv = 0, kPool = 1, kHead = 2 };
+enum OpType { kConv = 0, kPool = 1, kHead = 2, kTail = 3 };
 
 struct ConvOp {
     sbbseg_conv_desc d;
@@ -73,6 +73,12 @@ struct HeadOp {
     float *d_w = nullptr, *d_scale = nullptr, *d_shift = nullptr;
 };
 
+struct TailOp {
+    int src0 = -1, img = -1, classes = 0;
+    void* d_wfrag = nullptr;
+    float *d_scale = nullptr, *d_shift = nullptr, *d_head_w = nullptr, *d_head_scale = nullptr, *d_head_shift = nullptr;
+};
+
 struct Op {
     OpType type;
     std::string name;
@@ -80,6 +86,7 @@ struct Op {
     ConvOp conv;
     PoolOp pool;
     HeadOp head;
+    TailOp tail;
     double prof_ms = 0;
     int64_t prof_launches = 0, prof_patches = 0;
 };
@@ -266,6 +273,15 @@ int run_plan(sbbseg_ctx* c, int n, uint8_t* d_labels, float* d_probs)
             const Tensor& s = c->tensors[po.src];
             HIPCHK(launch_maxpool(s.data(), c->tensors[po.dst].data(), n, s.H, s.W, s.C, po.k, po.stride, po.Ho, po.Wo,
                                   c->precision, c->stream));
+        } else if (op.type == kTail) {
+            const TailOp& to = op.tail;
+            const Tensor& s0 = c->tensors[to.src0];
+            TailParams tp;
+            tp.src0 = s0.buf; tp.img = c->tensors[to.img].buf; tp.PH = s0.H; tp.PW = s0.W; tp.n = n;
+            tp.wfrag = to.d_wfrag; tp.scale = to.d_scale; tp.shift = to.d_shift; tp.classes = to.classes;
+            tp.head_w = to.d_head_w; tp.head_scale = to.d_head_scale; tp.head_shift = to.d_head_shift;
+            tp.labels = d_labels; tp.probs = d_probs;
+            HIPCHK(launch_tail(tp, c->precision, c->num_cus, c->stream));
         } else {
             const HeadOp& ho = op.head;
             const Tensor& s = c->tensors[ho.src];
@@ -358,6 +374,8 @@ int sbbseg_destroy(sbbseg_ctx* c)
         hipFree(op.conv.d_rscale); hipFree(op.conv.d_rshift);
         hipFree(op.conv.d_head_w); hipFree(op.conv.d_head_scale); hipFree(op.conv.d_head_shift);
         hipFree(op.head.d_w); hipFree(op.head.d_scale); hipFree(op.head.d_shift);
+        hipFree(op.tail.d_wfrag); hipFree(op.tail.d_scale); hipFree(op.tail.d_shift); hipFree(op.tail.d_head_w);
+        hipFree(op.tail.d_head_scale); hipFree(op.tail.d_head_shift);
     }
     hipFree(c->d_lut); hipFree(c->d_tile_xy); hipFree(c->d_batch_labels); hipFree(c->d_probs); hipFree(c->d_xin);
     hipFree(c->d_page); hipFree(c->d_page_labels); hipFree(c->d_tile_labels);
@@ -624,6 +642,65 @@ int sbbseg_add_maxpool(sbbseg_ctx* c, int src_tensor, int dst_tensor, int k, int
     op.name = nm;
     op.flops = 0;
     op.min_bytes = ((double)s.H * s.W + (double)Ho * Wo) * s.C * c->elem;
+    c->ops.push_back(op);
+    return 0;
+}
+
+int sbbseg_add_tail(sbbseg_ctx* c, int src0_tensor, int img_c8_tensor, const float* w_src0, const float* w_img,
+                    const float* scale, const float* shift, int classes, const float* head_w, const float* head_scale,
+                    const float* head_shift, double algorithmic_macs)
+{
+    REQUIRE(c && !c->finalized && w_src0 && w_img && scale && shift && head_w && head_scale && head_shift, "bad arguments");
+    HIPCHK(hipSetDevice(c->device));
+    REQUIRE(c->precision != kF32, "the fused tail is a 16-bit-mode kernel");
+    const int ntens = (int)c->tensors.size();
+    REQUIRE(src0_tensor >= 0 && src0_tensor < ntens && img_c8_tensor >= 0 && img_c8_tensor < ntens, "tail tensors undefined");
+    const Tensor& s0 = c->tensors[src0_tensor];
+    const Tensor& im = c->tensors[img_c8_tensor];
+    REQUIRE(s0.C == 64, "fused tail needs a 64-channel upsampled source (got %d)", s0.C);
+    REQUIRE(im.is_input_form && im.form == SBBSEG_INPUT_C8, "fused tail needs the C8 input form as second source");
+    REQUIRE(2 * s0.H == c->in_H && 2 * s0.W == c->in_W && c->in_H % 16 == 0 && c->in_W % 16 == 0, "fused tail: geometry");
+    REQUIRE(classes >= 1 && classes <= 4 && c->classes == 0, "fused tail: 1..4 classes, one head per plan");
+    static const int taps[2][2][2] = {{{0, 0}, {1, 2}}, {{0, 1}, {2, 2}}};   // [parity][t] -> first,last ky summed
+    const int C0 = 64, CO = 32;
+    std::vector<uint16_t> frag((size_t)4 * kTailKSteps * 4 * 64 * 8, 0);
+    for (int q = 0; q < 4; ++q) {
+        const int py = q >> 1, px = q & 1;
+        for (int ks = 0; ks < kTailKSteps; ++ks)
+            for (int kk = 0; kk < 2; ++kk)
+                for (int mi = 0; mi < 2; ++mi)
+                    for (int l = 0; l < 64; ++l) {
+                        const int o = conv_row_channel(mi * 16 + (l & 15), CO);
+                        const int gidx = kk * 4 + (l >> 4);
+                        uint16_t* dst = &frag[((((size_t)q * kTailKSteps + ks) * 4 + kk * 2 + mi) * 64 + l) * 8];
+                        for (int e = 0; e < 8; ++e) {
+                            float v = 0.f;
+                            if (ks < 4) {
+                                const int ty = ks >> 1, tx = ks & 1, ch = gidx * 8 + e;
+                                for (int ky = taps[py][ty][0]; ky <= taps[py][ty][1]; ++ky)
+                                    for (int kx = taps[px][tx][0]; kx <= taps[px][tx][1]; ++kx)
+                                        v += w_src0[((size_t)(ky * 3 + kx) * C0 + ch) * CO + o];
+                            } else {
+                                const int t = (ks - 4) * 8 + gidx;
+                                if (t < 9 && e < 3) v = w_img[((size_t)t * 3 + e) * CO + o];
+                            }
+                            dst[e] = c->precision == kF16 ? f32_to_f16_rne(v) : f32_to_bf16_rne(v);
+                        }
+                    }
+    }
+    Op op;
+    op.type = kTail;
+    op.tail.src0 = src0_tensor; op.tail.img = img_c8_tensor; op.tail.classes = classes;
+    if (upload(c, (uint16_t**)&op.tail.d_wfrag, frag.data(), frag.size()) || upload(c, &op.tail.d_scale, scale, CO) ||
+        upload(c, &op.tail.d_shift, shift, CO) || upload(c, &op.tail.d_head_w, head_w, (size_t)CO * classes) ||
+        upload(c, &op.tail.d_head_scale, head_scale, classes) || upload(c, &op.tail.d_head_shift, head_shift, classes))
+        return 1;
+    char nm[96];
+    snprintf(nm, sizeof(nm), "tail_conv3x3_c67to32_up_cat_head%d_%dx%d", classes, c->in_H, c->in_W);
+    op.name = nm;
+    op.flops = 2.0 * (algorithmic_macs > 0 ? algorithmic_macs : (double)c->in_H * c->in_W * CO * (9.0 * 67 + classes));
+    op.min_bytes = (double)s0.H * s0.W * 64 * c->elem + (double)c->in_H * c->in_W * (8 * c->elem + 1);
+    c->classes = classes;
     c->ops.push_back(op);
     return 0;
 }

@@ -71,6 +71,25 @@ struct ConvParams {
     float* probs;             // [n][TH][TW][classes] or null
 };
 
+// fused network tail: 3x3 conv over [nearest-x2-upsampled src0 (64 ch), image C8 (3 ch)] -> 32 ch
+// -> BN/ReLU -> 1x1 head -> softmax -> argmax, one launch, nothing but labels (and optional
+// probabilities) written.  See dec_tail_fused in kernels.hip.
+struct TailParams {
+    const char* src0;         // buffer start (zero header), [n][PH][PW][64] 16-bit
+    const char* img;          // buffer start (zero header), C8 form [n][2PH][2PW][8]
+    int PH, PW;               // src0 size; output is 2PH x 2PW
+    int n;                    // patches
+    const void* wfrag;        // [4 parities][6 K-steps][2 kk][2 mi][64 lanes] x 16 bytes, MFMA A-fragment order
+    const float* scale;       // [32]
+    const float* shift;
+    int classes;              // <= 4
+    const float* head_w;      // [32][classes]
+    const float* head_scale;
+    const float* head_shift;
+    uint8_t* labels;          // [n][2PH][2PW]
+    float* probs;             // [n][2PH][2PW][classes] or null
+};
+
 struct HeadParams {
     const void* src;          // [M][cin] activations (data pointer)
     int cin;                  // <= 64, multiple of 8
@@ -106,6 +125,8 @@ hipError_t launch_conv(const ConvParams& p, int precision, hipStream_t s);
 hipError_t launch_maxpool(const void* src, void* dst, int n, int H, int W, int C, int k, int stride,
                           int Ho, int Wo, int precision, hipStream_t s);
 hipError_t launch_head(const HeadParams& p, int precision, hipStream_t s);
+hipError_t launch_tail(const TailParams& p, int precision, int num_cus, hipStream_t s);
+constexpr int kTailKSteps = 6;      // 4 taps x 64 channels of src0 + 2 steps for the 9 image taps
 hipError_t launch_ingest_u8(const IngestParams& p, int precision, hipStream_t s);
 hipError_t launch_ingest_f32(const float* x, int n, int H, int W, void* c8, void* pairs, int pad,
                              int pairs_w, int precision, hipStream_t s);

@@ -536,6 +536,251 @@ hipError_t launch_conv(const ConvParams& p, int precision, hipStream_t s)
 }
 
 // ------------------------------------------------------------------------------------------------
+// dec_tail_fused -- the network's last decoder conv and head in one kernel.
+//
+//   y   = ReLU(BN(conv3x3([up2(src0: 64 ch @ H/2 x W/2), image: 3 ch @ H x W])))     32 channels, fp32
+//   out = argmax(softmax(BN(conv1x1(y))))                                            u8 label per pixel
+//
+// The generic implicit-GEMM kernel is address-bound here (32 output channels: 16 MFMAs per 256
+// gathered rows).  This kernel is a direct conv on LDS-staged tiles instead:
+//   * a block owns a 16x16 output tile; its 10x10 src0 halo tile (128 B per pixel) and 18x18
+//     image halo tile (16 B per pixel) are copied to LDS once with global_load_lds (double
+//     buffered across the persistent tile loop) -- every source pixel is fetched once, not 4-9 x
+//   * the four waves are the four output-parity classes (py,px): for a fixed parity the 3x3 taps
+//     on the upsampled src0 collapse to 2x2 taps with pre-summed weights (planner.py), so each
+//     wave runs 4 K-steps of 64 channels on its 8x8 sub-grid + 2 K-steps for the 9 image taps
+//   * the wave's weights (6 K-steps x 32 channels) live in 96 VGPRs in MFMA A-fragment order for
+//     the whole kernel; only pixel fragments are read from LDS (ds_read_b128, XOR-swizzled rows)
+//   * epilogue in registers: scale/shift/ReLU in fp32, the head's 32-channel contraction with two
+//     xor-shuffles, softmax, argmax; labels are assembled in LDS and stored as 16-byte rows.
+// ------------------------------------------------------------------------------------------------
+constexpr int kTailSrcRowPx = 16;                       // LDS row stride of the src0 halo tile (10 used): stride = 0 mod 8
+constexpr int kTailSrcBytes = 10 * kTailSrcRowPx * 128;      // 20 KB
+constexpr int kTailImgRowPx = 32;                       // LDS row stride of the image halo tile (18 used)
+constexpr int kTailImgBytes = 18 * kTailImgRowPx * 16;       // 9 KB
+constexpr int kTailBufBytes = kTailSrcBytes + kTailImgBytes;
+constexpr int kTailConstBytes = 32 * 8 * 4;                  // per channel: scale, shift, head_w[4], pad -> 8 floats
+constexpr int kTailLdsBytes = 2 * kTailBufBytes + 256 + 64 + kTailConstBytes;  // + label tile + zero granule + constants
+
+template <bool F16>
+__global__ __launch_bounds__(256, 2) void dec_tail_fused(const TailParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* lbl_tile = smem + 2 * kTailBufBytes;                 // [16][16] u8
+    char* zero_gran = lbl_tile + 256;                          // 16 zero bytes (image taps 9..15)
+    float* cst = (float*)(zero_gran + 64);                     // [32 channels][8]: scale, shift, head_w[0..3]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int py = wave >> 1, px = wave & 1;
+    const int frow = lane & 15, fg = lane >> 4;
+
+    const int H = 2 * p.PH, W = 2 * p.PW;
+    const int tiles_x = W / 16, tiles_y = H / 16;
+    const int tiles_per_patch = tiles_x * tiles_y;
+    const int n_tiles = p.n * tiles_per_patch;
+    const int G = gridDim.x;
+    const int my_tiles = (n_tiles - (int)blockIdx.x + G - 1) / G;
+    if (my_tiles <= 0) return;
+    if (tid < 4) ((uint32_t*)zero_gran)[tid] = 0u;
+    if (tid < 32) {                                            // epilogue constants stay in LDS (VGPRs hold the weights)
+        cst[tid * 8 + 0] = p.scale[tid];
+        cst[tid * 8 + 1] = p.shift[tid];
+        for (int c = 0; c < 4; ++c) cst[tid * 8 + 2 + c] = c < p.classes ? p.head_w[tid * p.classes + c] : 0.f;
+        cst[tid * 8 + 6] = cst[tid * 8 + 7] = 0.f;
+    }
+
+    // ---- this wave's weights, resident in registers
+    bf16x8_t wf[kTailKSteps * 4];
+    {
+        const uint4* src = (const uint4*)p.wfrag + (size_t)(wave * kTailKSteps * 4) * 64 + lane;
+#pragma unroll
+        for (int f = 0; f < kTailKSteps * 4; ++f) wf[f] = __builtin_bit_cast(bf16x8_t, src[(size_t)f * 64]);
+    }
+    float hsc[4], hsh[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { hsc[c] = c < p.classes ? p.head_scale[c] : 0.f; hsh[c] = c < p.classes ? p.head_shift[c] : 0.f; }
+
+    // ---- LDS read addresses (per lane, tile independent)
+    int src_base[4], img_base[4];
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+        const int i = ni * 16 + frow;                          // pixel of the wave's 8x8 sub-grid
+        const int sy = i >> 3, sx = i & 7;
+        src_base[ni] = (sy + py) * kTailSrcRowPx + (sx + px);                  // + ty*16 + tx
+        img_base[ni] = (2 * sy + py) * kTailImgRowPx + (2 * sx + px);          // + ky*32 + kx
+    }
+    // image taps of this lane's k-chunk: K-step A: tap = kk*4+fg (0..7), K-step B: tap 8 + kk*4+fg (only 8 real)
+    int img_toff[2][2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int t = s * 8 + kk * 4 + fg;
+            img_toff[s][kk] = t < 9 ? (t / 3) * kTailImgRowPx + (t % 3) : -1;
+        }
+
+    auto issue_tile = [&](int tile, int buf) __attribute__((always_inline)) {
+        const int n = tile / tiles_per_patch;
+        const int rem = tile - n * tiles_per_patch;
+        const int ty = rem / tiles_x, tx = rem - ty * tiles_x;
+        const int y0 = ty * 16, x0 = tx * 16;
+        char* lds_src = smem + buf * kTailBufBytes;
+        char* lds_img = lds_src + kTailSrcBytes;
+        // src0 halo: 10 rows x 16 px (10 needed) x 8 granules = 20 wave-instructions of 8 px
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            const int ii = wave + 4 * j;
+            const int r = ii >> 1, c = (ii & 1) * 8 + (lane >> 3);
+            const int g = (lane & 7) ^ (lane >> 3);                       // (hp & 7) == (c & 7) == lane >> 3
+            const int Y = (y0 >> 1) - 1 + r, X = (x0 >> 1) - 1 + c;
+            const bool ok = ((unsigned)Y < (unsigned)p.PH) & ((unsigned)X < (unsigned)p.PW) & (c < 10);
+            uint32_t off = (uint32_t)((n * p.PH + Y) * p.PW + X) * 128u + (uint32_t)(g * 16 + kZeroHeaderBytes);
+            off = ok ? off : 0u;
+            __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(p.src0 + off), (LDS_AS void*)(lds_src + ii * 1024), 16, 0, 0);
+        }
+        // image halo: 18 rows x 32 px (18 needed) x 16 B = 9 wave-instructions of 2 rows
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int ii = wave + 4 * j;
+            if (ii < 9) {
+                const int r = ii * 2 + (lane >> 5), c = lane & 31;
+                const int Y = y0 - 1 + r, X = x0 - 1 + c;
+                const bool ok = ((unsigned)Y < (unsigned)H) & ((unsigned)X < (unsigned)W) & (c < 18);
+                uint32_t off = (uint32_t)((n * H + Y) * W + X) * 16u + (uint32_t)kZeroHeaderBytes;
+                off = ok ? off : 0u;
+                __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(p.img + off), (LDS_AS void*)(lds_img + ii * 1024), 16, 0, 0);
+            }
+        }
+    };
+
+    issue_tile(blockIdx.x, 0);
+    for (int it = 0; it < my_tiles; ++it) {
+        const int tile = blockIdx.x + it * G;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                                        // tile `it` landed; everyone is done with tile it-1
+        if (it + 1 < my_tiles) issue_tile(tile + G, (it + 1) & 1);
+
+        const char* lds_src = smem + (it & 1) * kTailBufBytes;
+        const char* lds_img = lds_src + kTailSrcBytes;
+        f32x4_t acc[2][4];
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+        // src0: K-step ks = tap (ty,tx) of the parity's 2x2 window, 64 channels
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                bf16x8_t b[4];
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) {
+                    const int hp = src_base[ni] + (ks >> 1) * kTailSrcRowPx + (ks & 1);
+                    b[ni] = *(const bf16x8_t*)(lds_src + hp * 128 + (((kk * 4 + fg) ^ (hp & 7)) << 4));
+                }
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                    for (int mi = 0; mi < 2; ++mi)
+                        acc[mi][ni] = mfma16<F16>(wf[(ks * 2 + kk) * 2 + mi], b[ni], acc[mi][ni]);
+            }
+        }
+        // image: two K-steps, one 16-byte granule (8 stored channels, 3 real) per tap
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                bf16x8_t b[4];
+                const int toff = img_toff[s][kk];
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) {
+                    const char* a = toff >= 0 ? lds_img + (img_base[ni] + toff) * 16 : zero_gran;
+                    b[ni] = *(const bf16x8_t*)a;
+                }
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                    for (int mi = 0; mi < 2; ++mi)
+                        acc[mi][ni] = mfma16<F16>(wf[((4 + s) * 2 + kk) * 2 + mi], b[ni], acc[mi][ni]);
+            }
+        }
+
+        // ---- epilogue: BN/ReLU, head, softmax, argmax
+        const int n = tile / tiles_per_patch;
+        const int rem = tile - n * tiles_per_patch;
+        const int tyy = rem / tiles_x, txx = rem - tyy * tiles_x;
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+            float logit[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const float4 c0 = *(const float4*)(cst + (fg * 8 + q) * 8);       // scale, shift, hw0, hw1
+                const float2 c1 = *(const float2*)(cst + (fg * 8 + q) * 8 + 4);   // hw2, hw3
+                const float v = q < 4 ? acc[0][ni][q] : acc[1][ni][q - 4];
+                const float yq = fmaxf(v * c0.x + c0.y, 0.f);
+                logit[0] = fmaf(yq, c0.z, logit[0]); logit[1] = fmaf(yq, c0.w, logit[1]);
+                logit[2] = fmaf(yq, c1.x, logit[2]); logit[3] = fmaf(yq, c1.y, logit[3]);
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                float a = logit[c];
+                a += __shfl_xor(a, 16);
+                a += __shfl_xor(a, 32);
+                logit[c] = a * hsc[c] + hsh[c];
+            }
+            if (fg == 0) {
+                float mx = -3.0e38f;
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    if (c < p.classes) mx = fmaxf(mx, logit[c]);
+                float pr[4], sum = 0.f;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) { pr[c] = c < p.classes ? expf(logit[c] - mx) : 0.f; sum += pr[c]; }
+                int best = 0;
+                float bestp = -1.f;
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    if (c < p.classes) {
+                        pr[c] = pr[c] / sum;
+                        if (pr[c] > bestp) { bestp = pr[c]; best = c; }              // first maximum wins (np.argmax)
+                    }
+                const int i = ni * 16 + frow;
+                const int oy = 2 * (i >> 3) + py, ox = 2 * (i & 7) + px;             // inside the 16x16 tile
+                lbl_tile[oy * 16 + ox] = (char)best;
+                if (p.probs) {
+                    float* dst = p.probs + ((size_t)(n * H + tyy * 16 + oy) * W + txx * 16 + ox) * p.classes;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        if (c < p.classes) dst[c] = pr[c];
+                }
+            }
+        }
+        __syncthreads();
+        if (tid < 16)
+            *(uint4*)(p.labels + (size_t)(n * H + tyy * 16 + tid) * W + txx * 16) = *(const uint4*)(lbl_tile + tid * 16);
+    }
+}
+
+hipError_t launch_tail(const TailParams& p, int precision, int num_cus, hipStream_t s)
+{
+    const int n_tiles = p.n * (p.PH / 8) * (p.PW / 8);
+    const int grid = n_tiles < 2 * num_cus ? n_tiles : 2 * num_cus;
+    if (precision == kF16) {
+        hipError_t e = hipFuncSetAttribute((const void*)dec_tail_fused<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kTailLdsBytes);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(dec_tail_fused<true>, dim3(grid), dim3(256), kTailLdsBytes, s, p);
+    } else {
+        hipError_t e = hipFuncSetAttribute((const void*)dec_tail_fused<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kTailLdsBytes);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(dec_tail_fused<false>, dim3(grid), dim3(256), kTailLdsBytes, s, p);
+    }
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
 // element helpers for the HBM-bound kernels (E = uint16_t bf16 bits | float)
 // ------------------------------------------------------------------------------------------------
 template <typename E> __device__ inline E to_elem(float v);

@@ -99,6 +99,23 @@ class HeadStep:
 
 
 @dataclass
+class TailStep:
+    """Fused network tail: ReLU(BN(conv3x3 over [up2(src0: 64 ch), image 3 ch])) -> head, one kernel."""
+    name: str
+    src0: int                     # 64-channel tensor at half resolution
+    img: int                      # C8 input form
+    w_src0: np.ndarray            # float32 [3][3][64][32] original taps
+    w_img: np.ndarray             # float32 [3][3][3][32]
+    scale: np.ndarray
+    shift: np.ndarray
+    head: HeadStep
+    out_h: int
+    out_w: int
+    algorithmic_macs: float
+    kind: str = "tail"
+
+
+@dataclass
 class Plan:
     in_h: int
     in_w: int
@@ -115,6 +132,8 @@ class Plan:
                 total += s.algorithmic_macs
                 if s.head is not None:
                     total += s.out_h * s.out_w * s.head.cin * s.head.classes
+            elif s.kind == "tail":
+                total += s.algorithmic_macs + s.out_h * s.out_w * s.head.cin * s.head.classes
             elif s.kind == "head":
                 t = self.tensors[s.src]
                 total += t.H * t.W * s.cin * s.classes
@@ -128,6 +147,8 @@ class Plan:
                 total += s.out_h * s.out_w * s.cout * sum(g.kh * g.kw * g.channels for g in s.srcs)
                 if s.head is not None:
                     total += s.out_h * s.out_w * s.head.cin * s.head.classes
+            elif s.kind == "tail":
+                total += s.out_h * s.out_w * (32 * (4 * 64 + 9 * 3) + s.head.cin * s.head.classes)
             elif s.kind == "head":
                 t = self.tensors[s.src]
                 total += t.H * t.W * s.cin * s.classes
@@ -174,7 +195,7 @@ _PARITY_TAPS = {(0, 0): (0,), (0, 1): (1, 2), (1, 0): (0, 1), (1, 1): (2,)}
 
 
 def build_plan(graph: Graph, weights: Dict[str, np.ndarray], parity_split: bool = True,
-               fuse_head: bool = True) -> Plan:
+               fuse_head: bool = True, fuse_tail: bool = True) -> Plan:
     byn = graph.by_name()
     consumers: Dict[str, int] = {}
     for n in graph.nodes:
@@ -220,11 +241,13 @@ def build_plan(graph: Graph, weights: Dict[str, np.ndarray], parity_split: bool 
                       raw_scale=p.raw_scale.astype(np.float32) if p.raw_needed else None,
                       raw_shift=p.raw_shift.astype(np.float32) if p.raw_needed else None)
         macs = float(oh * ow * p.cout * p.logical_macs_per_out)
+        origin = dict(srcs=srcs, geom=(p.kh, p.kw, p.sy, p.sx, p.pt, p.pl), out_hw=(oh, ow), macs=macs, name=p.node.name)
         splittable = (parity_split and srcs[0].shift == 1 and (p.kh, p.kw, p.sy, p.sx, p.pt, p.pl) == (3, 3, 1, 1, 1, 1)
                       and oh % 2 == 0 and ow % 2 == 0 and p.residual < 0 and not p.raw_needed
                       and all(not (g.shift and (g.off_y or g.off_x)) for g in srcs))
         if not splittable:
             plan.steps.append(ConvStep(p.node.name, srcs, out_h=oh, out_w=ow, algorithmic_macs=macs, **common))
+            plan.steps[-1].origin = origin
             return
         # 3x3 conv over nearest-x2-upsampled sources == four output-parity classes; in each, the taps
         # that read the same stored pixel are pre-summed: a 2x2 conv at the source's own resolution
@@ -245,6 +268,7 @@ def build_plan(graph: Graph, weights: Dict[str, np.ndarray], parity_split: bool 
                         psrcs.append(Seg(g.tensor, g.channels, 0, g.off_y, g.off_x, 3, 3, 2, 2, 1 - py, 1 - px, g.w))
                 plan.steps.append(ConvStep(f"{p.node.name}:p{py}{px}", psrcs, out_h=oh // 2, out_w=ow // 2,
                                            out_stride=(2, 2), out_off=(py, px), algorithmic_macs=macs / 4, **common))
+                plan.steps[-1].origin = origin
 
     def materialize(name: str) -> _View:
         """Make the value of Keras layer `name` a plain stored tensor (emit pending work)."""
@@ -418,8 +442,24 @@ def build_plan(graph: Graph, weights: Dict[str, np.ndarray], parity_split: bool 
                                 p.scale.astype(np.float32), p.shift.astype(np.float32))
                 producers = [st for st in plan.steps if st.kind == "conv" and st.out == t_id]
                 src_layer = p.node.inputs[0]
-                if (fuse_head and producers and ts.C == 32 and p.cout <= 4 and consumers.get(src_layer, 0) == 1
-                        and all(st.raw_out < 0 and st.residual < 0 for st in producers)):
+                fusable = (fuse_head and producers and ts.C == 32 and p.cout <= 4 and consumers.get(src_layer, 0) == 1
+                           and all(st.raw_out < 0 and st.residual < 0 for st in producers))
+                org = getattr(producers[0], "origin", None) if producers else None
+                if (fusable and fuse_tail and org is not None and org["geom"] == (3, 3, 1, 1, 1, 1) and len(org["srcs"]) == 2
+                        and org["srcs"][0].shift == 1 and org["srcs"][0].channels == 64
+                        and plan.tensors[org["srcs"][0].tensor].C == 64
+                        and plan.tensors[org["srcs"][1].tensor].kind == "input_c8" and org["srcs"][1].channels == 3
+                        and not org["srcs"][1].off_y and not org["srcs"][1].off_x and producers[0].relu
+                        and org["out_hw"] == (in_h, in_w) and in_h % 16 == 0 and in_w % 16 == 0):
+                    # dedicated kernel for the network tail: LDS halo tiles, weights in registers
+                    st0 = producers[0]
+                    plan.steps = [st for st in plan.steps if st not in producers]
+                    plan.steps.append(TailStep(org["name"] + "+" + p.node.name, org["srcs"][0].tensor, org["srcs"][1].tensor,
+                                               org["srcs"][0].w, org["srcs"][1].w, st0.scale, st0.shift, head,
+                                               in_h, in_w, org["macs"]))
+                    ts.kind = "unused"
+                    plan.layer_tensor = {k: v for k, v in plan.layer_tensor.items() if v != t_id}
+                elif fusable:
                     # the head rides in the epilogue of the conv(s) producing its input; that
                     # tensor is never written (fp32 values go straight into the 1x1 contraction)
                     for st in producers:

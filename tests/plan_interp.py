@@ -79,6 +79,12 @@ def run_plan(plan, x):
                     probs = np.zeros((n, plan.in_h, plan.in_w, hd.classes), np.float32)
                 (sy, sx), (oy, ox) = s.out_stride, s.out_off
                 probs[:, oy::sy, ox::sx][:, :s.out_h, :s.out_w] = pr
+        elif s.kind == "tail":
+            up = np.repeat(np.repeat(vals[s.src0][..., :64], 2, axis=1), 2, axis=2)
+            xin = np.pad(np.concatenate([up, vals[s.img][..., :3]], axis=3), ((0, 0), (1, 1), (1, 1), (0, 0)))
+            w = np.concatenate([s.w_src0, s.w_img], axis=2)
+            z = np.maximum(kf.conv2d(xin, w, None, (1, 1), "valid") * s.scale + s.shift, 0).astype(np.float32)
+            probs = kf._softmax(((z @ s.head.w) * s.head.scale + s.head.shift).astype(np.float32))
         elif s.kind == "maxpool":
             vals[s.dst] = kf._maxpool(vals[s.src], (s.k, s.k), (s.stride, s.stride))
         elif s.kind == "head":

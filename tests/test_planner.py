@@ -17,7 +17,7 @@ from tools.synth_model import calibrated_model
 def test_plan_equals_oracle(classes, hw, parity, fuse):
     cfg, w = calibrated_model(classes, hw[0], hw[1], seed=1, calib_hw=64)
     g = parse_model_config(cfg)
-    plan = build_plan(g, w, parity_split=parity, fuse_head=fuse)
+    plan = build_plan(g, w, parity_split=parity, fuse_head=fuse, fuse_tail=(classes == 2))
     page = synthetic_page(300, 400, 5)
     x = np.stack([page[10:10 + hw[0], 20:20 + hw[1]], page[100:100 + hw[0], 200:200 + hw[1]]]).astype(np.float32) / 255
     ref = kf.forward(g, w, x)
@@ -44,9 +44,20 @@ def test_plan_structure_448():
     assert sum(1 for s in plan.steps if s.kind == "conv" and s.residual >= 0) == 16
 
 
+def test_fused_tail_448():
+    cfg, w = synthetic_model(4, 448, 448, 0)
+    plan = build_plan(parse_model_config(cfg), w)
+    kinds = [s.kind for s in plan.steps]
+    assert kinds.count("tail") == 1 and kinds[-1] == "tail" and "head" not in kinds
+    assert kinds.count("conv") == 54 + 4 * 4                              # dec1-dec4 parity classes; dec5 lives in the tail
+    assert plan.macs_per_patch() == 47418195968 + 448 * 448 * 32 * 2     # (4 classes instead of 2 in the head)
+    tail = plan.steps[-1]
+    assert tail.w_src0.shape == (3, 3, 64, 32) and tail.w_img.shape == (3, 3, 3, 32)
+
+
 def test_parity_split_and_fused_head_448():
     cfg, w = synthetic_model(2, 448, 448, 0)
-    plan = build_plan(parse_model_config(cfg), w)
+    plan = build_plan(parse_model_config(cfg), w, fuse_tail=False)
     kinds = [s.kind for s in plan.steps]
     assert kinds.count("conv") == 54 + 5 * 4 and "head" not in kinds    # 5 decoder convs x 4 parity classes
     assert plan.macs_per_patch() == 47418195968                       # algorithmic work is unchanged ...
