@@ -105,7 +105,10 @@ int sbbseg_add_conv(sbbseg_ctx* c, const sbbseg_conv_desc* d, const float* w_src
                     const float* scale, const float* shift,
                     const float* raw_scale, const float* raw_shift,
                     const float* head_w, const float* head_scale, const float* head_shift);
-int sbbseg_add_maxpool(sbbseg_ctx* c, int src_tensor, int dst_tensor, int k, int stride);
+/* k x k max-pool, 'valid'.  pre_scale/pre_shift [C] (or NULL) + pre_relu: per-channel affine and ReLU
+ * applied to every input element before the max (a BatchNormalization + relu fused into the pool). */
+int sbbseg_add_maxpool(sbbseg_ctx* c, int src_tensor, int dst_tensor, int k, int stride,
+                       const float* pre_scale, const float* pre_shift, int pre_relu);
 /* Fused network tail (16-bit modes): ReLU(BN(conv3x3 'same' over [UpSampling2D(2)(src0: 64 channels),
  * network input (3 channels, C8 form)])) -> 32 channels -> 1x1 conv + BN + softmax + argmax, in one
  * launch that writes only labels (and probabilities on request).  w_src0 [3][3][64][32], w_img

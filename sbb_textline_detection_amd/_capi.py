@@ -68,7 +68,7 @@ def load_library(path: Optional[str] = None):
         "sbbseg_input_form": [vp, i32, i32, C.POINTER(C.c_int)],
         "sbbseg_add_tensor": [vp, i32, i32, i32, C.POINTER(C.c_int)],
         "sbbseg_add_conv": [vp, C.POINTER(ConvDesc)] + [vp] * 9,
-        "sbbseg_add_maxpool": [vp, i32, i32, i32, i32],
+        "sbbseg_add_maxpool": [vp, i32, i32, i32, i32, vp, vp, i32],
         "sbbseg_add_head": [vp, i32, i32, i32, vp, vp, vp],
         "sbbseg_add_tail": [vp, i32, i32, vp, vp, vp, vp, i32, vp, vp, vp, C.c_double],
         "sbbseg_finalize": [vp, i32],
@@ -183,7 +183,9 @@ class Context:
                                           s.head.classes, _ptr(arrs[4]), _ptr(arrs[5]), _ptr(arrs[6]), float(s.algorithmic_macs)),
                       f"sbbseg_add_tail({s.name})")
             elif s.kind == "maxpool":
-                check(lib.sbbseg_add_maxpool(h, ids[s.src], ids[s.dst], s.k, s.stride), f"sbbseg_add_maxpool({s.name})")
+                ps, pb = f32(s.pre_scale), f32(s.pre_shift)
+                check(lib.sbbseg_add_maxpool(h, ids[s.src], ids[s.dst], s.k, s.stride, _ptr(ps), _ptr(pb), int(s.pre_relu)),
+                      f"sbbseg_add_maxpool({s.name})")
             elif s.kind == "head":
                 w = np.ascontiguousarray(s.w, np.float32)
                 sc, sh = np.ascontiguousarray(s.scale, np.float32), np.ascontiguousarray(s.shift, np.float32)

@@ -66,7 +66,7 @@ struct ConvOp {
     float *d_head_w = nullptr, *d_head_scale = nullptr, *d_head_shift = nullptr;
 };
 
-struct PoolOp { int src, dst, k, stride, Ho, Wo; };
+struct PoolOp { int src, dst, k, stride, Ho, Wo; float *d_pre_scale = nullptr, *d_pre_shift = nullptr; int pre_relu = 0; };
 
 struct HeadOp {
     int src, cin, classes;
@@ -272,7 +272,7 @@ int run_plan(sbbseg_ctx* c, int n, uint8_t* d_labels, float* d_probs)
             const PoolOp& po = op.pool;
             const Tensor& s = c->tensors[po.src];
             HIPCHK(launch_maxpool(s.data(), c->tensors[po.dst].data(), n, s.H, s.W, s.C, po.k, po.stride, po.Ho, po.Wo,
-                                  c->precision, c->stream));
+                                  po.d_pre_scale, po.d_pre_shift, po.pre_relu, c->precision, c->stream));
         } else if (op.type == kTail) {
             const TailOp& to = op.tail;
             const Tensor& s0 = c->tensors[to.src0];
@@ -374,6 +374,7 @@ int sbbseg_destroy(sbbseg_ctx* c)
         hipFree(op.conv.d_rscale); hipFree(op.conv.d_rshift);
         hipFree(op.conv.d_head_w); hipFree(op.conv.d_head_scale); hipFree(op.conv.d_head_shift);
         hipFree(op.head.d_w); hipFree(op.head.d_scale); hipFree(op.head.d_shift);
+        hipFree(op.pool.d_pre_scale); hipFree(op.pool.d_pre_shift);
         hipFree(op.tail.d_wfrag); hipFree(op.tail.d_scale); hipFree(op.tail.d_shift); hipFree(op.tail.d_head_w);
         hipFree(op.tail.d_head_scale); hipFree(op.tail.d_head_shift);
     }
@@ -625,7 +626,8 @@ int sbbseg_add_conv(sbbseg_ctx* c, const sbbseg_conv_desc* d, const float* w_src
     return 0;
 }
 
-int sbbseg_add_maxpool(sbbseg_ctx* c, int src_tensor, int dst_tensor, int k, int stride)
+int sbbseg_add_maxpool(sbbseg_ctx* c, int src_tensor, int dst_tensor, int k, int stride, const float* pre_scale,
+                       const float* pre_shift, int pre_relu)
 {
     REQUIRE(c && !c->finalized, "bad handle / already finalized");
     const int ntens = (int)c->tensors.size();
@@ -636,7 +638,13 @@ int sbbseg_add_maxpool(sbbseg_ctx* c, int src_tensor, int dst_tensor, int k, int
     REQUIRE(t.H == Ho && t.W == Wo && t.C == s.C, "maxpool output should be %dx%dx%d", Ho, Wo, s.C);
     Op op;
     op.type = kPool;
-    op.pool = {src_tensor, dst_tensor, k, stride, Ho, Wo};
+    op.pool.src = src_tensor; op.pool.dst = dst_tensor; op.pool.k = k; op.pool.stride = stride; op.pool.Ho = Ho; op.pool.Wo = Wo;
+    if (pre_scale) {
+        REQUIRE(pre_shift, "pre_scale needs pre_shift");
+        HIPCHK(hipSetDevice(c->device));
+        if (upload(c, &op.pool.d_pre_scale, pre_scale, s.C) || upload(c, &op.pool.d_pre_shift, pre_shift, s.C)) return 1;
+        op.pool.pre_relu = pre_relu;
+    }
     char nm[64];
     snprintf(nm, sizeof(nm), "maxpool%dx%d_s%d_c%d_%dx%d", k, k, stride, s.C, Ho, Wo);
     op.name = nm;

@@ -123,7 +123,8 @@ enum Precision { kBF16 = 0, kF32 = 1, kF16 = 2 };
 // launchers implemented in kernels.hip ---------------------------------------------------------
 hipError_t launch_conv(const ConvParams& p, int precision, hipStream_t s);
 hipError_t launch_maxpool(const void* src, void* dst, int n, int H, int W, int C, int k, int stride,
-                          int Ho, int Wo, int precision, hipStream_t s);
+                          int Ho, int Wo, const float* pre_scale, const float* pre_shift, int pre_relu,
+                          int precision, hipStream_t s);
 hipError_t launch_head(const HeadParams& p, int precision, hipStream_t s);
 hipError_t launch_tail(const TailParams& p, int precision, int num_cus, hipStream_t s);
 constexpr int kTailKSteps = 6;      // 4 taps x 64 channels of src0 + 2 steps for the 9 image taps

@@ -888,9 +888,12 @@ hipError_t launch_ingest_f32(const float* x, int n, int H, int W, void* c8, void
 // ------------------------------------------------------------------------------------------------
 // max-pool (valid), NHWC, one thread per (pixel, 8-channel granule)
 // ------------------------------------------------------------------------------------------------
+// optional per-channel affine + ReLU applied to every input element before the max: lets the stem
+// write only its pre-BN tensor (the f1 skip) and the pool apply bn_conv1 + relu on the fly
 template <typename E>
 __global__ __launch_bounds__(256) void maxpool_kernel(const E* src, E* dst, int n, int H, int W, int C,
-                                                      int k, int stride, int Ho, int Wo)
+                                                      int k, int stride, int Ho, int Wo,
+                                                      const float* pre_scale, const float* pre_shift, int pre_relu)
 {
     const int cg = C / 8;
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
@@ -901,14 +904,22 @@ __global__ __launch_bounds__(256) void maxpool_kernel(const E* src, E* dst, int 
     const int ox = (int)(pix % Wo); pix /= Wo;
     const int oy = (int)(pix % Ho);
     const int b = (int)(pix / Ho);
-    float m[8];
+    float m[8], ps[8], pb[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) m[i] = -3.0e38f;
+    for (int i = 0; i < 8; ++i) {
+        m[i] = -3.0e38f;
+        ps[i] = pre_scale ? pre_scale[g * 8 + i] : 1.f;
+        pb[i] = pre_scale ? pre_shift[g * 8 + i] : 0.f;
+    }
     for (int ky = 0; ky < k; ++ky)
         for (int kx = 0; kx < k; ++kx) {
             const Vec8<E> v = *(const Vec8<E>*)(src + (((size_t)b * H + oy * stride + ky) * W + ox * stride + kx) * C + g * 8);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) m[i] = fmaxf(m[i], from_elem<E>(v.v[i]));
+            for (int i = 0; i < 8; ++i) {
+                float x = from_elem<E>(v.v[i]) * ps[i] + pb[i];
+                if (pre_relu) x = fmaxf(x, 0.f);
+                m[i] = fmaxf(m[i], x);
+            }
         }
     Vec8<E> o;
 #pragma unroll
@@ -917,16 +928,17 @@ __global__ __launch_bounds__(256) void maxpool_kernel(const E* src, E* dst, int 
 }
 
 hipError_t launch_maxpool(const void* src, void* dst, int n, int H, int W, int C, int k, int stride,
-                          int Ho, int Wo, int precision, hipStream_t s)
+                          int Ho, int Wo, const float* pre_scale, const float* pre_shift, int pre_relu,
+                          int precision, hipStream_t s)
 {
     const long total = (long)n * Ho * Wo * (C / 8);
     const unsigned grid = (unsigned)((total + 255) / 256);
     if (precision == kF32)
-        hipLaunchKernelGGL(maxpool_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)src, (float*)dst, n, H, W, C, k, stride, Ho, Wo);
+        hipLaunchKernelGGL(maxpool_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)src, (float*)dst, n, H, W, C, k, stride, Ho, Wo, pre_scale, pre_shift, pre_relu);
     else if (precision == kF16)
-        hipLaunchKernelGGL(maxpool_kernel<_Float16>, dim3(grid), dim3(256), 0, s, (const _Float16*)src, (_Float16*)dst, n, H, W, C, k, stride, Ho, Wo);
+        hipLaunchKernelGGL(maxpool_kernel<_Float16>, dim3(grid), dim3(256), 0, s, (const _Float16*)src, (_Float16*)dst, n, H, W, C, k, stride, Ho, Wo, pre_scale, pre_shift, pre_relu);
     else
-        hipLaunchKernelGGL(maxpool_kernel<uint16_t>, dim3(grid), dim3(256), 0, s, (const uint16_t*)src, (uint16_t*)dst, n, H, W, C, k, stride, Ho, Wo);
+        hipLaunchKernelGGL(maxpool_kernel<uint16_t>, dim3(grid), dim3(256), 0, s, (const uint16_t*)src, (uint16_t*)dst, n, H, W, C, k, stride, Ho, Wo, pre_scale, pre_shift, pre_relu);
     return hipGetLastError();
 }
 

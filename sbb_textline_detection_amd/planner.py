@@ -83,6 +83,9 @@ class PoolStep:
     dst: int
     k: int
     stride: int
+    pre_scale: Optional[np.ndarray] = None    # per-channel affine + ReLU applied before the max
+    pre_shift: Optional[np.ndarray] = None
+    pre_relu: bool = False
     kind: str = "maxpool"
 
 
@@ -473,10 +476,29 @@ def build_plan(graph: Graph, weights: Dict[str, np.ndarray], parity_split: bool 
         elif n.op == "maxpool":
             if n.attrs["pool"][0] != n.attrs["pool"][1] or n.attrs["strides"][0] != n.attrs["strides"][1]:
                 raise PlanError(f"{n.name}: non-square pooling unsupported")
-            src_t = plain_tensor(n.inputs[0])
+            pv = views[n.inputs[0]]
+            pp = pv.pending
+            pre = None
+            if (pp is not None and pp.raw_needed and pp.residual < 0 and pp.stage == "relu" and consumers.get(n.inputs[0], 0) == 1
+                    and pp.emitted_out < 0 and np.all(pp.raw_scale != 0)):
+                # the conv's un-normalised output is stored anyway (a skip connection wants it): store
+                # ONLY that, and let the pool apply BN + ReLU on the fly (saves one tensor write + read)
+                a = pp.scale / pp.raw_scale
+                pre = ((a).astype(np.float32), (pp.shift - pp.raw_shift * a).astype(np.float32))
+                pp.scale, pp.shift, pp.relu = pp.raw_scale.copy(), pp.raw_shift.copy(), False
+                pp.raw_needed = False
+                emit(pp)                                         # single output == the raw tensor
+                pp.emitted_raw = pp.emitted_out
+                src_t = pp.emitted_out
+                pv.pending = None
+                plan.tensors[src_t].name += ":raw"
+            else:
+                src_t = plain_tensor(n.inputs[0])
             oh, ow, c = n.out_shape
             dst = new_tensor(oh, ow, c, n.name)
-            plan.steps.append(PoolStep(n.name, src_t, dst, n.attrs["pool"][0], n.attrs["strides"][0]))
+            plan.steps.append(PoolStep(n.name, src_t, dst, n.attrs["pool"][0], n.attrs["strides"][0],
+                                       pre_scale=pre[0] if pre else None, pre_shift=pre[1] if pre else None,
+                                       pre_relu=pre is not None))
             views[n.name] = _View(oh, ow, [Seg(dst, c)])
             plan.layer_tensor[n.name] = dst
         elif n.op == "convT":

@@ -86,7 +86,12 @@ def run_plan(plan, x):
             z = np.maximum(kf.conv2d(xin, w, None, (1, 1), "valid") * s.scale + s.shift, 0).astype(np.float32)
             probs = kf._softmax(((z @ s.head.w) * s.head.scale + s.head.shift).astype(np.float32))
         elif s.kind == "maxpool":
-            vals[s.dst] = kf._maxpool(vals[s.src], (s.k, s.k), (s.stride, s.stride))
+            xin = vals[s.src]
+            if s.pre_scale is not None:
+                xin = xin * s.pre_scale + s.pre_shift
+                if s.pre_relu:
+                    xin = np.maximum(xin, 0)
+            vals[s.dst] = kf._maxpool(xin.astype(np.float32), (s.k, s.k), (s.stride, s.stride))
         elif s.kind == "head":
             logits = (vals[s.src] @ s.w) * s.scale + s.shift
             probs = kf._softmax(logits.astype(np.float32))

@@ -36,7 +36,9 @@ def test_plan_structure_448():
     assert plan.macs_per_patch() == 47418195968                       # 47.418 GMAC
     assert plan.executed_macs_per_patch() > plan.macs_per_patch()      # only the stem's zero taps/channels
     stem = plan.steps[0].srcs[0]
-    assert (stem.kh, stem.kw, stem.stride_y, stem.stride_x) == (7, 4, 2, 1) and plan.steps[0].raw_out >= 0
+    assert (stem.kh, stem.kw, stem.stride_y, stem.stride_x) == (7, 4, 2, 1)
+    # the stem stores only its pre-BN tensor (the f1 skip); bn_conv1 + relu ride in the max-pool
+    assert plan.steps[0].raw_out == -1 and not plan.steps[0].relu and plan.steps[1].kind == "maxpool" and plan.steps[1].pre_relu
     dec = {s.name: s for s in plan.steps if s.kind == "conv" and len(s.srcs) == 2}
     assert len(dec) == 5 and all(s.srcs[0].shift == 1 for s in dec.values())
     f2 = [s for s in dec.values() if s.srcs[1].off_y == 1]
