@@ -122,7 +122,22 @@ void conv_igemm_mfma(const ConvParams p)
     const int n_tiles = n_ct * ((p.M + BP - 1) / BP);
     const int G = gridDim.x;
     const int nt = p.total_ksteps;
-    const int my_tiles = (n_tiles - (int)blockIdx.x + G - 1) / G;
+    // Tile walk of this (persistent) block.  map 0: tiles b, b+G, ... (channel tile fastest): every
+    // XCD keeps ONE channel-tile's weight slab hot -- right when the weights dwarf the L2.
+    // map 1 (small weight matrices): XCD x = b % 8 owns pixel tiles x, x+8, ...; its blocks walk them
+    // channel tile fastest, so the n_ct channel tiles of one pixel tile run on the SAME XCD back to
+    // back and the pixel operand is fetched into that L2 once instead of once per XCD.
+    const int n_pt = (p.M + BP - 1) / BP;
+    const bool pshare = p.tile_map == 1 && (G & 7) == 0;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, GX = G >> 3;
+    const int xcd_tiles = pshare ? ((n_pt - xcd + 7) >> 3) * n_ct : 0;
+    const int my_tiles = pshare ? (slot < xcd_tiles ? (xcd_tiles - slot + GX - 1) / GX : 0)
+                                : (n_tiles - (int)blockIdx.x + G - 1) / G;
+    auto tile_at = [&](int q) __attribute__((always_inline)) -> int {
+        if (!pshare) return blockIdx.x + q * G;
+        const int li = slot + q * GX;
+        return ((li / n_ct) * 8 + xcd) * n_ct + li % n_ct;
+    };
     const int total = my_tiles * nt;                    // K-steps this block walks
 
     const int lrow = lane >> 3;                         // row inside an 8-row glds group
@@ -165,7 +180,7 @@ void conv_igemm_mfma(const ConvParams p)
             w_off[j] = (uint32_t)((ctile * BC + min((j * NW + wave) * 8 + lrow, BC - 1)) * p.Ktot + gsrc * 8) * 2u;
     };
 
-    int l_t = 0, l_tile = blockIdx.x, issued = 0;
+    int l_t = 0, l_q = 0, issued = 0;
     int rec_yx = kstep_tab[0], rec_coff = kstep_tab[1], rec_irr = kstep_tab[2];   // record of the NEXT stage issued
     auto issue = [&](int buf) __attribute__((always_inline)) {
         const int t = l_t;
@@ -206,8 +221,7 @@ void conv_igemm_mfma(const ConvParams p)
         ++issued;
         if (++l_t == nt) {
             l_t = 0;
-            l_tile += G;
-            if (l_tile < n_tiles) setup_rows(l_tile);
+            if (++l_q < my_tiles) setup_rows(tile_at(l_q));
         }
         rec_yx = kstep_tab[l_t * 4 + 0]; rec_coff = kstep_tab[l_t * 4 + 1]; rec_irr = kstep_tab[l_t * 4 + 2];
     };
@@ -369,7 +383,7 @@ void conv_igemm_mfma(const ConvParams p)
 
     // ---- prologue: D stages in flight, stage 0 landed
     if (total == 0) return;
-    setup_rows(l_tile);
+    setup_rows(tile_at(0));
 #pragma unroll
     for (int d = 0; d < D; ++d)
         if (d < total) issue(d);
@@ -377,10 +391,10 @@ void conv_igemm_mfma(const ConvParams p)
     else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
 
-    int cur = 0, nxt = D % NS, c_t = 0, c_tile = blockIdx.x;
+    int cur = 0, nxt = D % NS, c_t = 0, c_q = 0;
     for (int s = 0; s < total; ++s) {
         if (issued < total) issue(nxt);
-        if (p.residual && c_t == nt - 1) prefetch_residual(c_tile);
+        if (p.residual && c_t == nt - 1) prefetch_residual(tile_at(c_q));
         const char* sb = smem + cur * T::kStageBytes;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
@@ -400,9 +414,9 @@ void conv_igemm_mfma(const ConvParams p)
         }
         bool tile_done = false;
         if (++c_t == nt) {                                  // tile finished: its stores overlap the
-            epilogue(c_tile);                               // next tile's first stage(s), already in flight
+            epilogue(tile_at(c_q));                         // next tile's first stage(s), already in flight
             c_t = 0;
-            c_tile += G;
+            ++c_q;
             tile_done = true;
         }
         if (s + 1 < total) {
@@ -504,7 +518,8 @@ static hipError_t launch_conv_t(const ConvParams& p, hipStream_t s)
     // persistent grid: as many blocks as are resident at once (2 per CU for the 4-wave tiles, 1 for
     // the 8-wave ones); p.persist_blocks == 0 -> one block per tile (A/B)
     const int resident = p.persist_blocks > 0 ? p.persist_blocks * (NS == 2 ? 2 : 1) : n_tiles;
-    const int grid = n_tiles < resident ? n_tiles : resident;
+    int grid = n_tiles < resident ? n_tiles : resident;
+    if (p.tile_map == 1 && grid >= 8) grid &= ~7;          // the XCD-grouped walk needs a multiple of 8 blocks
     hipLaunchKernelGGL((conv_igemm_mfma<BP, BC, WP, WC, NS, F16>), dim3(grid), dim3(T::kThreads), T::kLdsBytes, s, p);
     return hipGetLastError();
 }
