@@ -73,6 +73,15 @@ template <bool F16> __device__ inline f32x4_t mfma16(bf16x8_t a, bf16x8_t b, f32
 // ------------------------------------------------------------------------------------------------
 // conv_igemm_mfma  (16-bit operands: bf16 or fp16, fp32 accumulate)
 // ------------------------------------------------------------------------------------------------
+// blocks per CU a tile family is sized for (LDS budget) -> min waves per SIMD for __launch_bounds__
+constexpr int conv_blocks_per_cu(int bp, int bc, int wp, int wc, int ns)
+{
+    const int waves = wp * wc;
+    const int wrows = bc > 8 * waves ? bc : 8 * waves;
+    const int lds = ns * (bp + wrows) * 128;
+    return (2 * lds <= 160 * 1024 && waves == 4) ? 2 : 1;
+}
+
 template <int BP, int BC, int WP, int WC, int NS>
 struct ConvTile {
     static constexpr int kWaves = WP * WC;
@@ -88,6 +97,7 @@ struct ConvTile {
     static constexpr int kLoads = kPLoads + kWLoads;
     static constexpr int kStageBytes = (BP + kWRows) * 128;
     static constexpr int kLdsBytes = NS * kStageBytes;
+    static constexpr int kBlocksPerCU = conv_blocks_per_cu(BP, BC, WP, WC, NS);
     static_assert(BP % (8 * kWaves) == 0 && kWRows % (8 * kWaves) == 0, "tile rows must split over the waves");
     static_assert(kMI % 2 == 0, "epilogue pairs MFMA row blocks");
 };
@@ -105,7 +115,7 @@ template <int N> __device__ inline void wait_vmcnt()
 // K-step descriptors come through the scalar cache (uniform address in the constant address space
 // -> s_load, lgkmcnt): no VGPR-destination VMEM load sits in the steady-state loop.
 template <int BP, int BC, int WP, int WC, int NS, bool F16>
-__global__ __launch_bounds__(64 * WP * WC, (WP * WC) / 4 * (NS == 2 ? 2 : 1))
+__global__ __launch_bounds__(64 * WP * WC, (conv_blocks_per_cu(BP, BC, WP, WC, NS) * (WP * WC) / 4))
 void conv_igemm_mfma(const ConvParams p)
 {
     using T = ConvTile<BP, BC, WP, WC, NS>;
@@ -256,7 +266,8 @@ void conv_igemm_mfma(const ConvParams p)
 
     // residual tile of the tile being finished: requested BEFORE its last K-step's MFMAs so the HBM
     // round trip hides under them
-    uint4 res[T::kMI / 2][T::kNI];
+    constexpr bool kPrefetchRes = (T::kMI / 2) * T::kNI <= 8;      // big wave tiles cannot spare the registers
+    uint4 res[kPrefetchRes ? T::kMI / 2 : 1][kPrefetchRes ? T::kNI : 1];
     auto prefetch_residual = [&](int tile) __attribute__((always_inline)) {
         const int ctile = tile % n_ct, ptile = tile / n_ct;
 #pragma unroll
@@ -266,8 +277,10 @@ void conv_igemm_mfma(const ConvParams p)
 #pragma unroll
             for (int s2 = 0; s2 < T::kMI / 2; ++s2) {
                 const int c0 = ctile * BC + wc * T::kWCH + s2 * 32 + fg * 8;
-                if (c0 < p.cout && m < p.M)
-                    res[s2][ni] = *(const uint4*)((const uint16_t*)p.residual + (size_t)opix * p.cout + c0);
+                if constexpr (kPrefetchRes) {
+                    if (c0 < p.cout && m < p.M)
+                        res[s2][ni] = *(const uint4*)((const uint16_t*)p.residual + (size_t)opix * p.cout + c0);
+                }
             }
         }
     };
@@ -316,7 +329,9 @@ void conv_igemm_mfma(const ConvParams p)
                             *(uint4*)((uint16_t*)p.raw_out + o) = r;
                         }
                         if (p.residual) {
-                            const uint4 rr = res[s2][ni];
+                            uint4 rr;
+                            if constexpr (kPrefetchRes) rr = res[s2][ni];
+                            else rr = *(const uint4*)((const uint16_t*)p.residual + o);
                             y[0] += unpack_lo<F16>(rr.x); y[1] += unpack_hi<F16>(rr.x);
                             y[2] += unpack_lo<F16>(rr.y); y[3] += unpack_hi<F16>(rr.y);
                             y[4] += unpack_lo<F16>(rr.z); y[5] += unpack_hi<F16>(rr.z);
@@ -394,7 +409,7 @@ void conv_igemm_mfma(const ConvParams p)
     int cur = 0, nxt = D % NS, c_t = 0, c_q = 0;
     for (int s = 0; s < total; ++s) {
         if (issued < total) issue(nxt);
-        if (p.residual && c_t == nt - 1) prefetch_residual(tile_at(c_q));
+        if (kPrefetchRes && p.residual && c_t == nt - 1) prefetch_residual(tile_at(c_q));
         const char* sb = smem + cur * T::kStageBytes;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
@@ -517,7 +532,7 @@ static hipError_t launch_conv_t(const ConvParams& p, hipStream_t s)
     const int n_tiles = n_ct * n_pt;
     // persistent grid: as many blocks as are resident at once (2 per CU for the 4-wave tiles, 1 for
     // the 8-wave ones); p.persist_blocks == 0 -> one block per tile (A/B)
-    const int resident = p.persist_blocks > 0 ? p.persist_blocks * (NS == 2 ? 2 : 1) : n_tiles;
+    const int resident = p.persist_blocks > 0 ? p.persist_blocks * T::kBlocksPerCU : n_tiles;
     int grid = n_tiles < resident ? n_tiles : resident;
     if (p.tile_map == 1 && grid >= 8) grid &= ~7;          // the XCD-grouped walk needs a multiple of 8 blocks
     hipLaunchKernelGGL((conv_igemm_mfma<BP, BC, WP, WC, NS, F16>), dim3(grid), dim3(T::kThreads), T::kLdsBytes, s, p);
@@ -535,6 +550,11 @@ static hipError_t launch_conv_16(const ConvParams& p, hipStream_t s)
     const long big_blocks = (long)((p.M + 255) / 256) * ((p.cout + bc - 1) / bc);
     const bool big = variant == 2;
     (void)big_blocks;
+    if (variant == 3) {   // 8 waves, wave tile 128 px x 64 ch (or 64x64 for cout 64), 2 LDS stages, 1 block per CU
+        if (bc == 128 && p.cout % 256 == 0) return launch_conv_t<256, 256, 2, 4, 2, F16>(p, s);
+        if (bc == 128) return launch_conv_t<512, 128, 4, 2, 2, F16>(p, s);
+        if (bc == 64) return launch_conv_t<512, 64, 8, 1, 2, F16>(p, s);
+    }
     if (bc == 128) return big ? launch_conv_t<256, 128, 4, 2, 3, F16>(p, s) : launch_conv_t<128, 128, 2, 2, 2, F16>(p, s);
     if (bc == 64) return big ? launch_conv_t<256, 64, 8, 1, 3, F16>(p, s) : launch_conv_t<256, 64, 4, 1, 2, F16>(p, s);
     return big ? launch_conv_t<256, 32, 8, 1, 3, F16>(p, s) : launch_conv_t<256, 32, 4, 1, 2, F16>(p, s);
