@@ -550,10 +550,19 @@ static hipError_t launch_conv_16(const ConvParams& p, hipStream_t s)
     const long big_blocks = (long)((p.M + 255) / 256) * ((p.cout + bc - 1) / bc);
     const bool big = variant == 2;
     (void)big_blocks;
-    if (variant == 3) {   // 8 waves, wave tile 128 px x 64 ch (or 64x64 for cout 64), 2 LDS stages, 1 block per CU
+    if (variant == 3) {   // force: 8 waves, wave tile 128 px x 64 ch (64x64 for cout 64), 2 LDS stages, 1 block per CU
         if (bc == 128 && p.cout % 256 == 0) return launch_conv_t<256, 256, 2, 4, 2, F16>(p, s);
         if (bc == 128) return launch_conv_t<512, 128, 4, 2, 2, F16>(p, s);
         if (bc == 64) return launch_conv_t<512, 64, 8, 1, 2, F16>(p, s);
+    }
+    if (variant == 0 && bc == 128 && !p.residual) {
+        // auto (measured per layer, profiles/r01_conv_variants.md): the 8-wave tiles with 128x64 wave
+        // tiles (LDS bytes per MFMA x0.75, L2 bytes per MFMA x0.5) win on long-K layers that still
+        // give every CU a block; short-K / residual (HBM-bound) layers and small grids stay on 128x128
+        const long t256 = (long)((p.M + 255) / 256) * (p.cout / 256);
+        const long t512 = (long)((p.M + 511) / 512) * ((p.cout + 127) / 128);
+        if (p.cout % 256 == 0 && p.Ktot >= 512 && t256 >= 200) return launch_conv_t<256, 256, 2, 4, 2, F16>(p, s);
+        if (p.Ktot >= 1024 && t512 >= 200) return launch_conv_t<512, 128, 4, 2, 2, F16>(p, s);
     }
     if (bc == 128) return big ? launch_conv_t<256, 128, 4, 2, 3, F16>(p, s) : launch_conv_t<128, 128, 2, 2, 2, F16>(p, s);
     if (bc == 64) return big ? launch_conv_t<256, 64, 8, 1, 3, F16>(p, s) : launch_conv_t<256, 64, 4, 1, 2, F16>(p, s);

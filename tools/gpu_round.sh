@@ -12,7 +12,7 @@ else
 fi
 SBBSEG_BENCH_OPS=gpurun_out/ops_$TAG.json timeout 600 python bench.py > gpurun_out/bench_$TAG.log 2>&1
 tail -1 gpurun_out/bench_$TAG.log | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('BENCH', d['value'], 'patches/s', d['achieved_tflops_end_to_end'], 'TF e2e; roofline', d['roofline']['kernel'], d['roofline']['achieved'], 'all convs', d['roofline']['all_convs'], 'label', d['label_match'])"
-for v in ${VARIANTS:-3}; do
+for v in ${VARIANTS:-1}; do
   SBBSEG_BENCH_OPS=gpurun_out/ops_${TAG}_v$v.json timeout 300 python bench.py --conv-variant $v --no-cpu-baseline --steps 10 > gpurun_out/bench_${TAG}_v$v.log 2>&1
   tail -1 gpurun_out/bench_${TAG}_v$v.log | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('conv-variant $v', d['value'], 'patches/s', d['roofline']['all_convs'])"
 done
