@@ -714,42 +714,43 @@ __global__ __launch_bounds__(256, 2) void dec_tail_fused(const TailParams p)
 #pragma unroll
             for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
-        // src0: K-step ks = tap (ty,tx) of the parity's 2x2 window, 64 channels
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                bf16x8_t b[4];
+        // 12 half-K-steps: 0..7 = src0 (K-step ks = tap (ty,tx) of the parity's 2x2 window, 64 channels,
+        // two k-halves), 8..11 = image (two K-steps, one 16-byte granule per tap).  The pixel fragments
+        // of step h+1 are requested before the MFMAs of step h (explicit register double buffer: the
+        // LDS latency otherwise sits exposed in front of every group of 8 MFMAs).
+        auto load_b = [&](int h, bf16x8_t (&b)[4]) __attribute__((always_inline)) {
+            if (h < 8) {
+                const int ks = h >> 1, kk = h & 1;
 #pragma unroll
                 for (int ni = 0; ni < 4; ++ni) {
                     const int hp = src_base[ni] + (ks >> 1) * kTailSrcRowPx + (ks & 1);
                     b[ni] = *(const bf16x8_t*)(lds_src + hp * 128 + (((kk * 4 + fg) ^ (hp & 7)) << 4));
                 }
-#pragma unroll
-                for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-                    for (int mi = 0; mi < 2; ++mi)
-                        acc[mi][ni] = mfma16<F16>(wf[(ks * 2 + kk) * 2 + mi], b[ni], acc[mi][ni]);
-            }
-        }
-        // image: two K-steps, one 16-byte granule (8 stored channels, 3 real) per tap
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                bf16x8_t b[4];
-                const int toff = img_toff[s][kk];
+            } else {
+                const int toff = img_toff[(h - 8) >> 1][(h - 8) & 1];
 #pragma unroll
                 for (int ni = 0; ni < 4; ++ni) {
                     const char* a = toff >= 0 ? lds_img + (img_base[ni] + toff) * 16 : zero_gran;
                     b[ni] = *(const bf16x8_t*)a;
                 }
-#pragma unroll
-                for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-                    for (int mi = 0; mi < 2; ++mi)
-                        acc[mi][ni] = mfma16<F16>(wf[((4 + s) * 2 + kk) * 2 + mi], b[ni], acc[mi][ni]);
             }
+        };
+        bf16x8_t b0[4], b1[4];
+        load_b(0, b0);
+#pragma unroll
+        for (int h = 0; h < 12; h += 2) {
+            load_b(h + 1, b1);
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+                    acc[mi][ni] = mfma16<F16>(wf[h * 2 + mi], b0[ni], acc[mi][ni]);
+            if (h + 2 < 12) load_b(h + 2, b0);
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+                    acc[mi][ni] = mfma16<F16>(wf[(h + 1) * 2 + mi], b1[ni], acc[mi][ni]);
         }
 
         // ---- epilogue: BN/ReLU, head, softmax, argmax
