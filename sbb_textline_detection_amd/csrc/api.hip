@@ -64,6 +64,12 @@ struct ConvOp {
     void* d_w = nullptr;
     float *d_scale = nullptr, *d_shift = nullptr, *d_rscale = nullptr, *d_rshift = nullptr;
     float *d_head_w = nullptr, *d_head_scale = nullptr, *d_head_shift = nullptr;
+    // further placement classes merged into this op (parity siblings); class 0 = the fields above
+    int n_cls = 1;
+    void* d_w_cls[4] = {nullptr, nullptr, nullptr, nullptr};
+    KStepRec* d_kstep_cls[4] = {nullptr, nullptr, nullptr, nullptr};
+    KTabEntry* d_ktab_cls[4] = {nullptr, nullptr, nullptr, nullptr};
+    int ooy_cls[4] = {0, 0, 0, 0}, oox_cls[4] = {0, 0, 0, 0};
 };
 
 struct PoolOp { int src, dst, k, stride, Ho, Wo; float *d_pre_scale = nullptr, *d_pre_shift = nullptr; int pre_relu = 0; };
@@ -262,6 +268,11 @@ int run_plan(sbbseg_ctx* c, int n, uint8_t* d_labels, float* d_probs)
             p.Ho = co.Ho; p.Wo = co.Wo; p.M = n * co.Ho * co.Wo;
             p.TH = co.TH; p.TW = co.TW; p.osy = co.d.out_stride_y; p.osx = co.d.out_stride_x;
             p.ooy = co.d.out_off_y; p.oox = co.d.out_off_x;
+            p.n_cls = co.n_cls;
+            for (int q = 0; q < 4; ++q) {
+                p.w_cls[q] = co.d_w_cls[q]; p.kstep_cls[q] = co.d_kstep_cls[q]; p.ktab_cls[q] = co.d_ktab_cls[q];
+                p.ooy_cls[q] = co.ooy_cls[q]; p.oox_cls[q] = co.oox_cls[q];
+            }
             p.head_classes = co.d.head_classes; p.head_w = co.d_head_w; p.head_scale = co.d_head_scale;
             p.head_shift = co.d_head_shift; p.labels = d_labels; p.probs = d_probs;
             p.cout = co.d.cout; p.scale = co.d_scale; p.shift = co.d_shift;
@@ -375,6 +386,7 @@ int sbbseg_destroy(sbbseg_ctx* c)
         hipFree(op.conv.d_ktab); hipFree(op.conv.d_kstep); hipFree(op.conv.d_w); hipFree(op.conv.d_scale); hipFree(op.conv.d_shift);
         hipFree(op.conv.d_rscale); hipFree(op.conv.d_rshift);
         hipFree(op.conv.d_head_w); hipFree(op.conv.d_head_scale); hipFree(op.conv.d_head_shift);
+        for (int q = 1; q < 4; ++q) { hipFree(op.conv.d_w_cls[q]); hipFree(op.conv.d_kstep_cls[q]); hipFree(op.conv.d_ktab_cls[q]); }
         hipFree(op.head.d_w); hipFree(op.head.d_scale); hipFree(op.head.d_shift);
         hipFree(op.pool.d_pre_scale); hipFree(op.pool.d_pre_shift);
         hipFree(op.tail.d_wfrag); hipFree(op.tail.d_scale); hipFree(op.tail.d_shift); hipFree(op.tail.d_head_w);
@@ -624,6 +636,38 @@ int sbbseg_add_conv(sbbseg_ctx* c, const sbbseg_conv_desc* d, const float* w_src
     const double ob = (double)d->out_h * d->out_w * d->cout * c->elem;
     bytes += (d->out_tensor >= 0 ? ob : 0) + (d->raw_out_tensor >= 0 ? ob : 0) + (d->residual_tensor >= 0 ? ob : 0);
     op.min_bytes = bytes;
+    co.d_w_cls[0] = co.d_w; co.d_kstep_cls[0] = co.d_kstep; co.d_ktab_cls[0] = co.d_ktab;
+    co.ooy_cls[0] = d->out_off_y; co.oox_cls[0] = d->out_off_x;
+
+    // Output-placement siblings (same sources, taps geometry and outputs, only padding / placement
+    // offset / weights differ -- the parity classes of one decoder conv) run as ONE launch: bigger
+    // grids (the 256x256 tiles become usable on the small-M layers) and 4x fewer launches.
+    if (c->precision != kF32 && !c->ops.empty() && c->ops.back().type == kConv && !(c->conv_variant & 16)) {
+        Op& prev = c->ops.back();
+        ConvOp& pc = prev.conv;
+        bool same = pc.n_cls < 4 && pc.d.n_src == d->n_src && pc.d.cout == d->cout && pc.d.out_tensor == d->out_tensor &&
+                    pc.d.relu == d->relu && pc.d.residual_tensor < 0 && d->residual_tensor < 0 && pc.d.raw_out_tensor < 0 &&
+                    d->raw_out_tensor < 0 && pc.d.out_h == d->out_h && pc.d.out_w == d->out_w &&
+                    pc.d.out_stride_y == d->out_stride_y && pc.d.out_stride_x == d->out_stride_x &&
+                    (d->out_stride_y > 1 || d->out_stride_x > 1) && pc.d.head_classes == d->head_classes &&
+                    pc.total_ksteps == co.total_ksteps && pc.ksteps[0] == co.ksteps[0];
+        for (int s = 0; same && s < d->n_src; ++s) {
+            const sbbseg_conv_src &x = pc.d.src[s], &y = d->src[s];
+            same = x.tensor == y.tensor && x.channels == y.channels && x.kh == y.kh && x.kw == y.kw && x.stride_y == y.stride_y &&
+                   x.stride_x == y.stride_x && x.up_shift == y.up_shift && x.off_y == y.off_y && x.off_x == y.off_x;
+        }
+        if (same) {
+            const int q = pc.n_cls++;
+            pc.d_w_cls[q] = co.d_w; pc.d_kstep_cls[q] = co.d_kstep; pc.d_ktab_cls[q] = co.d_ktab;
+            pc.ooy_cls[q] = d->out_off_y; pc.oox_cls[q] = d->out_off_x;
+            hipFree(co.d_scale); hipFree(co.d_shift); hipFree(co.d_head_w); hipFree(co.d_head_scale); hipFree(co.d_head_shift);
+            prev.flops += op.flops;
+            prev.min_bytes += op.min_bytes;
+            const size_t pos = prev.name.find("_par");
+            if (pos != std::string::npos) prev.name = prev.name.substr(0, pos) + "_par4" + (d->head_classes > 0 ? "_head" : "");
+            return 0;
+        }
+    }
     c->ops.push_back(op);
     return 0;
 }
@@ -1031,7 +1075,7 @@ int sbbseg_debug_read_tensor(sbbseg_ctx* c, int tensor_id, int n, float* out, si
 
 int sbbseg_debug_set_conv_variant(sbbseg_ctx* c, int variant)
 {
-    REQUIRE(c && variant >= 0 && variant <= 15 && true, "variant: bits 0-1 = 0 auto | 1 4-wave/2-stage | 2 8-wave/3-stage; bit 2 = one block per tile (non-persistent); bit 3 = no XCD-grouped tile walk");
+    REQUIRE(c && variant >= 0 && variant <= 31 && true, "variant: bits 0-1 = 0 auto | 1 4-wave/2-stage | 2 8-wave/3-stage; bit 2 = one block per tile (non-persistent); bit 3 = no XCD-grouped tile walk");
     c->conv_variant = variant;
     return 0;
 }

@@ -63,6 +63,13 @@ struct ConvParams {
     const float* raw_scale;
     const float* raw_shift;
     int relu;
+    // output-placement classes sharing all geometry (the four parity classes of a decoder conv run as
+    // ONE launch): class q has its own weights / tap tables / placement offset; class 0 = the fields above
+    int n_cls;
+    const void* w_cls[4];
+    const KStepRec* kstep_cls[4];
+    const KTabEntry* ktab_cls[4];
+    int ooy_cls[4], oox_cls[4];
     // fused head (cout == 32 tiles only): 1x1 conv + BN + softmax + argmax on the fp32 epilogue values
     int head_classes;         // 0 = none
     const float* head_w;      // [cout][classes]

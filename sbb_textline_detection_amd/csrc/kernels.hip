@@ -129,7 +129,8 @@ void conv_igemm_mfma(const ConvParams p)
     const int wp = wave / WC, wc = wave % WC;
 
     const int n_ct = (p.cout + BC - 1) / BC;
-    const int n_tiles = n_ct * ((p.M + BP - 1) / BP);
+    const int n_pt1 = (p.M + BP - 1) / BP;              // pixel tiles of ONE placement class
+    const int n_tiles = p.n_cls * n_ct * n_pt1;
     const int G = gridDim.x;
     const int nt = p.total_ksteps;
     // Tile walk of this (persistent) block.  map 0: tiles b, b+G, ... (channel tile fastest): every
@@ -137,7 +138,7 @@ void conv_igemm_mfma(const ConvParams p)
     // map 1 (small weight matrices): XCD x = b % 8 owns pixel tiles x, x+8, ...; its blocks walk them
     // channel tile fastest, so the n_ct channel tiles of one pixel tile run on the SAME XCD back to
     // back and the pixel operand is fetched into that L2 once instead of once per XCD.
-    const int n_pt = (p.M + BP - 1) / BP;
+    const int n_pt = p.n_cls * n_pt1;                   // class-major "extended" pixel tiles
     const bool pshare = p.tile_map == 1 && (G & 7) == 0;
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, GX = G >> 3;
     const int xcd_tiles = pshare ? ((n_pt - xcd + 7) >> 3) * n_ct : 0;
@@ -159,15 +160,23 @@ void conv_igemm_mfma(const ConvParams p)
     const SrcDesc sd1 = p.n_src > 1 ? p.src[1] : p.src[0];
     const int ks0 = p.n_src > 1 ? sd0.ksteps : nt;
     const uint32_t img0 = (uint32_t)(sd0.PH * sd0.PW * sd0.pix_bytes), img1 = (uint32_t)(sd1.PH * sd1.PW * sd1.pix_bytes);
+    // load-side class state (weights, tap tables), switched in setup_rows
     const char* wbase = (const char*)p.w;
     const __attribute__((address_space(4))) int* kstep_tab =
         (const __attribute__((address_space(4))) int*)(uintptr_t)p.kstep;
+    const KTabEntry* ktab = p.ktab;
 
     // ---- load side: rows of the tile being STAGED (runs D steps ahead of the compute side)
     int r_oy[T::kPLoads], r_ox[T::kPLoads], r_n[T::kPLoads];   // output coords of the staged rows
     uint32_t w_off[T::kWLoads];
     auto setup_rows = [&](int tile) __attribute__((always_inline)) {
-        const int ctile = tile % n_ct, ptile = tile / n_ct;
+        const int ctile = tile % n_ct, etile = tile / n_ct;
+        const int cls = etile / n_pt1, ptile = etile - cls * n_pt1;
+        if (p.n_cls > 1) {
+            wbase = (const char*)p.w_cls[cls];
+            kstep_tab = (const __attribute__((address_space(4))) int*)(uintptr_t)p.kstep_cls[cls];
+            ktab = p.ktab_cls[cls];
+        }
 #pragma unroll
         for (int j = 0; j < T::kPLoads; ++j) {
             const int m = ptile * BP + (j * NW + wave) * 8 + lrow;
@@ -205,7 +214,7 @@ void conv_igemm_mfma(const ConvParams p)
         int dy = (int)(short)(rec_yx & 0xffff), dx = rec_yx >> 16;
         int coff = rec_coff + gsrc * 16 + kZeroHeaderBytes;
         if (rec_irr) {                                         // granules of this step differ in tap
-            const KTabEntry e = p.ktab[t * kGranulesPerStep + gsrc];
+            const KTabEntry e = ktab[t * kGranulesPerStep + gsrc];
             dy = e.dy; dx = e.dx; coff = e.coff + kZeroHeaderBytes;
         }
         char* lds_p = smem + buf * T::kStageBytes;
@@ -254,14 +263,15 @@ void conv_igemm_mfma(const ConvParams p)
     // gives, so the two MFMA row blocks (2s, 2s+1) of a lane hold 8 CONSECUTIVE channels of one
     // pixel: 16-byte NHWC stores / residual loads, 64 contiguous bytes per pixel per instruction.
     // linear pixel index inside the output tensor(s) for output-grid pixel m (placement: see ConvParams)
-    const bool placed = (p.osy != 1) | (p.osx != 1) | (p.ooy != 0) | (p.oox != 0) | (p.TH != p.Ho) | (p.TW != p.Wo);
-    auto out_pixel = [&](int m) __attribute__((always_inline)) -> int {
+    const bool placed = (p.osy != 1) | (p.osx != 1) | (p.ooy != 0) | (p.oox != 0) | (p.TH != p.Ho) | (p.TW != p.Wo) | (p.n_cls > 1);
+    auto out_pixel = [&](int m, int cls) __attribute__((always_inline)) -> int {
         if (!placed) return m;
         const int n = m / HoWo;
         const int rem = m - n * HoWo;
         const int oy = rem / p.Wo;
         const int ox = rem - oy * p.Wo;
-        return (n * p.TH + oy * p.osy + p.ooy) * p.TW + ox * p.osx + p.oox;
+        const int ooy = p.n_cls > 1 ? p.ooy_cls[cls] : p.ooy, oox = p.n_cls > 1 ? p.oox_cls[cls] : p.oox;
+        return (n * p.TH + oy * p.osy + ooy) * p.TW + ox * p.osx + oox;
     };
 
     // residual tile of the tile being finished: requested BEFORE its last K-step's MFMAs so the HBM
@@ -269,11 +279,12 @@ void conv_igemm_mfma(const ConvParams p)
     constexpr bool kPrefetchRes = (T::kMI / 2) * T::kNI <= 8;      // big wave tiles cannot spare the registers
     uint4 res[kPrefetchRes ? T::kMI / 2 : 1][kPrefetchRes ? T::kNI : 1];
     auto prefetch_residual = [&](int tile) __attribute__((always_inline)) {
-        const int ctile = tile % n_ct, ptile = tile / n_ct;
+        const int ctile = tile % n_ct, etile = tile / n_ct;
+        const int cls = etile / n_pt1, ptile = etile - cls * n_pt1;
 #pragma unroll
         for (int ni = 0; ni < T::kNI; ++ni) {
             const int m = ptile * BP + wp * T::kWPX + ni * 16 + frow;
-            const int opix = m < p.M ? out_pixel(m) : 0;
+            const int opix = m < p.M ? out_pixel(m, cls) : 0;
 #pragma unroll
             for (int s2 = 0; s2 < T::kMI / 2; ++s2) {
                 const int c0 = ctile * BC + wc * T::kWCH + s2 * 32 + fg * 8;
@@ -289,12 +300,13 @@ void conv_igemm_mfma(const ConvParams p)
     // gives, so the two MFMA row blocks (2s, 2s+1) of a lane hold 8 CONSECUTIVE channels of one
     // pixel: 16-byte NHWC stores / residual loads, 64 contiguous bytes per pixel per instruction.
     auto epilogue = [&](int tile) __attribute__((always_inline)) {
-        const int ctile = tile % n_ct, ptile = tile / n_ct;
+        const int ctile = tile % n_ct, etile = tile / n_ct;
+        const int cls = etile / n_pt1, ptile = etile - cls * n_pt1;
         int opix[T::kNI];
 #pragma unroll
         for (int ni = 0; ni < T::kNI; ++ni) {
             const int m = ptile * BP + wp * T::kWPX + ni * 16 + frow;
-            opix[ni] = m < p.M ? out_pixel(m) : -1;
+            opix[ni] = m < p.M ? out_pixel(m, cls) : -1;
         }
 #pragma unroll
         for (int s2 = 0; s2 < T::kMI / 2; ++s2) {
@@ -529,7 +541,7 @@ static hipError_t launch_conv_t(const ConvParams& p, hipStream_t s)
     }
     const int n_ct = (p.cout + BC - 1) / BC;
     const int n_pt = (p.M + BP - 1) / BP;
-    const int n_tiles = n_ct * n_pt;
+    const int n_tiles = p.n_cls * n_ct * n_pt;
     // persistent grid: as many blocks as are resident at once (2 per CU for the 4-wave tiles, 1 for
     // the 8-wave ones); p.persist_blocks == 0 -> one block per tile (A/B)
     const int resident = p.persist_blocks > 0 ? p.persist_blocks * T::kBlocksPerCU : n_tiles;
@@ -559,8 +571,8 @@ static hipError_t launch_conv_16(const ConvParams& p, hipStream_t s)
         // auto (measured per layer, profiles/r01_conv_variants.md): the 8-wave tiles with 128x64 wave
         // tiles (LDS bytes per MFMA x0.75, L2 bytes per MFMA x0.5) win on long-K layers that still
         // give every CU a block; short-K / residual (HBM-bound) layers and small grids stay on 128x128
-        const long t256 = (long)((p.M + 255) / 256) * (p.cout / 256);
-        const long t512 = (long)((p.M + 511) / 512) * ((p.cout + 127) / 128);
+        const long t256 = (long)p.n_cls * ((p.M + 255) / 256) * (p.cout / 256);
+        const long t512 = (long)p.n_cls * ((p.M + 511) / 512) * ((p.cout + 127) / 128);
         if (p.cout % 256 == 0 && p.Ktot >= 512 && t256 >= 200) return launch_conv_t<256, 256, 2, 4, 2, F16>(p, s);
         if (p.Ktot >= 1024 && t512 >= 200) return launch_conv_t<512, 128, 4, 2, 2, F16>(p, s);
     }
