@@ -411,6 +411,7 @@ void conv_igemm_mfma(const ConvParams p)
     // ---- prologue: D stages in flight, stage 0 landed
     if (total == 0) return;
     setup_rows(tile_at(0));
+    rec_yx = kstep_tab[0]; rec_coff = kstep_tab[1]; rec_irr = kstep_tab[2];     // (the first tile's class may not be class 0)
 #pragma unroll
     for (int d = 0; d < D; ++d)
         if (d < total) issue(d);
