@@ -269,6 +269,12 @@ int run_plan(sbbseg_ctx* c, int n, uint8_t* d_labels, float* d_probs)
             p.TH = co.TH; p.TW = co.TW; p.osy = co.d.out_stride_y; p.osx = co.d.out_stride_x;
             p.ooy = co.d.out_off_y; p.oox = co.d.out_off_x;
             p.n_cls = co.n_cls;
+            p.cls_minor = 0;
+            if (co.n_cls > 1 && !(c->conv_variant & 8) && !(c->conv_variant & 4) &&
+                (size_t)co.cout_pad * co.Ktot * c->elem <= ((size_t)2 << 20)) {
+                p.cls_minor = 1;      // small weights: let the classes share their source pixels in one L2
+                p.tile_map = 1;
+            }
             for (int q = 0; q < 4; ++q) {
                 p.w_cls[q] = co.d_w_cls[q]; p.kstep_cls[q] = co.d_kstep_cls[q]; p.ktab_cls[q] = co.d_ktab_cls[q];
                 p.ooy_cls[q] = co.ooy_cls[q]; p.oox_cls[q] = co.oox_cls[q];

@@ -66,6 +66,7 @@ struct ConvParams {
     // output-placement classes sharing all geometry (the four parity classes of a decoder conv run as
     // ONE launch): class q has its own weights / tap tables / placement offset; class 0 = the fields above
     int n_cls;
+    int cls_minor;            // tile order: 0 = class-major, 1 = classes of a pixel tile adjacent (needs tile_map 1)
     const void* w_cls[4];
     const KStepRec* kstep_cls[4];
     const KTabEntry* ktab_cls[4];

@@ -130,7 +130,11 @@ void conv_igemm_mfma(const ConvParams p)
 
     const int n_ct = (p.cout + BC - 1) / BC;
     const int n_pt1 = (p.M + BP - 1) / BP;              // pixel tiles of ONE placement class
-    const int n_tiles = p.n_cls * n_ct * n_pt1;
+    // class-minor order (small weights): the classes of one pixel tile are adjacent and, with the XCD-
+    // grouped walk, on the same XCD -- they read the same source pixels, which then come from one L2.
+    // Pixel tiles are padded to a multiple of 8 per class there (padding tiles are fully masked).
+    const int n_pt1e = p.cls_minor ? (n_pt1 + 7) & ~7 : n_pt1;
+    const int n_tiles = p.n_cls * n_ct * n_pt1e;
     const int G = gridDim.x;
     const int nt = p.total_ksteps;
     // Tile walk of this (persistent) block.  map 0: tiles b, b+G, ... (channel tile fastest): every
@@ -138,7 +142,19 @@ void conv_igemm_mfma(const ConvParams p)
     // map 1 (small weight matrices): XCD x = b % 8 owns pixel tiles x, x+8, ...; its blocks walk them
     // channel tile fastest, so the n_ct channel tiles of one pixel tile run on the SAME XCD back to
     // back and the pixel operand is fetched into that L2 once instead of once per XCD.
-    const int n_pt = p.n_cls * n_pt1;                   // class-major "extended" pixel tiles
+    const int n_pt = p.n_cls * n_pt1e;                  // "extended" pixel tiles (class x pixel tile)
+    auto decode = [&](int tile, int& ctile, int& cls, int& ptile) __attribute__((always_inline)) {
+        ctile = tile % n_ct;
+        const int e = tile / n_ct;
+        if (p.cls_minor) {
+            const int grp = e / (8 * p.n_cls), r = e - grp * 8 * p.n_cls;
+            cls = r >> 3;
+            ptile = grp * 8 + (r & 7);
+        } else {
+            cls = e / n_pt1;
+            ptile = e - cls * n_pt1;
+        }
+    };
     const bool pshare = p.tile_map == 1 && (G & 7) == 0;
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, GX = G >> 3;
     const int xcd_tiles = pshare ? ((n_pt - xcd + 7) >> 3) * n_ct : 0;
@@ -170,8 +186,8 @@ void conv_igemm_mfma(const ConvParams p)
     int r_oy[T::kPLoads], r_ox[T::kPLoads], r_n[T::kPLoads];   // output coords of the staged rows
     uint32_t w_off[T::kWLoads];
     auto setup_rows = [&](int tile) __attribute__((always_inline)) {
-        const int ctile = tile % n_ct, etile = tile / n_ct;
-        const int cls = etile / n_pt1, ptile = etile - cls * n_pt1;
+        int ctile, cls, ptile;
+        decode(tile, ctile, cls, ptile);
         if (p.n_cls > 1) {
             wbase = (const char*)p.w_cls[cls];
             kstep_tab = (const __attribute__((address_space(4))) int*)(uintptr_t)p.kstep_cls[cls];
@@ -279,8 +295,8 @@ void conv_igemm_mfma(const ConvParams p)
     constexpr bool kPrefetchRes = (T::kMI / 2) * T::kNI <= 8;      // big wave tiles cannot spare the registers
     uint4 res[kPrefetchRes ? T::kMI / 2 : 1][kPrefetchRes ? T::kNI : 1];
     auto prefetch_residual = [&](int tile) __attribute__((always_inline)) {
-        const int ctile = tile % n_ct, etile = tile / n_ct;
-        const int cls = etile / n_pt1, ptile = etile - cls * n_pt1;
+        int ctile, cls, ptile;
+        decode(tile, ctile, cls, ptile);
 #pragma unroll
         for (int ni = 0; ni < T::kNI; ++ni) {
             const int m = ptile * BP + wp * T::kWPX + ni * 16 + frow;
@@ -300,8 +316,8 @@ void conv_igemm_mfma(const ConvParams p)
     // gives, so the two MFMA row blocks (2s, 2s+1) of a lane hold 8 CONSECUTIVE channels of one
     // pixel: 16-byte NHWC stores / residual loads, 64 contiguous bytes per pixel per instruction.
     auto epilogue = [&](int tile) __attribute__((always_inline)) {
-        const int ctile = tile % n_ct, etile = tile / n_ct;
-        const int cls = etile / n_pt1, ptile = etile - cls * n_pt1;
+        int ctile, cls, ptile;
+        decode(tile, ctile, cls, ptile);
         int opix[T::kNI];
 #pragma unroll
         for (int ni = 0; ni < T::kNI; ++ni) {
@@ -542,7 +558,7 @@ static hipError_t launch_conv_t(const ConvParams& p, hipStream_t s)
     }
     const int n_ct = (p.cout + BC - 1) / BC;
     const int n_pt = (p.M + BP - 1) / BP;
-    const int n_tiles = p.n_cls * n_ct * n_pt;
+    const int n_tiles = p.n_cls * n_ct * (p.cls_minor ? (n_pt + 7) & ~7 : n_pt);
     // persistent grid: as many blocks as are resident at once (2 per CU for the 4-wave tiles, 1 for
     // the 8-wave ones); p.persist_blocks == 0 -> one block per tile (A/B)
     const int resident = p.persist_blocks > 0 ? p.persist_blocks * T::kBlocksPerCU : n_tiles;
@@ -616,10 +632,10 @@ constexpr int kTailSrcBytes = 10 * kTailSrcRowPx * 128;      // 20 KB
 constexpr int kTailImgRowPx = 32;                       // LDS row stride of the image halo tile (18 used)
 constexpr int kTailImgBytes = 18 * kTailImgRowPx * 16;       // 9 KB
 constexpr int kTailBufBytes = kTailSrcBytes + kTailImgBytes;
-constexpr int kTailConstBytes = 32 * 8 * 4;                  // per channel: scale, shift, head_w[4], pad -> 8 floats
+constexpr int kTailConstBytes = 32 * 8 * 4;                  // per channel: scale, shift, head_w[NC] (row of 4 or 8 floats)
 constexpr int kTailLdsBytes = 2 * kTailBufBytes + 256 + 64 + kTailConstBytes;  // + label tile + zero granule + constants
 
-template <bool F16>
+template <bool F16, int NC>
 __global__ __launch_bounds__(256, 2) void dec_tail_fused(const TailParams p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -641,11 +657,13 @@ __global__ __launch_bounds__(256, 2) void dec_tail_fused(const TailParams p)
     const int my_tiles = (n_tiles - (int)blockIdx.x + G - 1) / G;
     if (my_tiles <= 0) return;
     if (tid < 4) ((uint32_t*)zero_gran)[tid] = 0u;
+    constexpr int CR = NC <= 2 ? 4 : 8;                        // floats per constant row
     if (tid < 32) {                                            // epilogue constants stay in LDS (VGPRs hold the weights)
-        cst[tid * 8 + 0] = p.scale[tid];
-        cst[tid * 8 + 1] = p.shift[tid];
-        for (int c = 0; c < 4; ++c) cst[tid * 8 + 2 + c] = c < p.classes ? p.head_w[tid * p.classes + c] : 0.f;
-        cst[tid * 8 + 6] = cst[tid * 8 + 7] = 0.f;
+        // channel c = fg*8+q lives in row q*4+fg: the four fg lanes groups of one read hit different banks
+        float* row = cst + ((tid & 7) * 4 + (tid >> 3)) * CR;
+        row[0] = p.scale[tid];
+        row[1] = p.shift[tid];
+        for (int c = 0; c < CR - 2; ++c) row[2 + c] = c < p.classes ? p.head_w[tid * p.classes + c] : 0.f;
     }
 
     // ---- this wave's weights, resident in registers
@@ -655,9 +673,9 @@ __global__ __launch_bounds__(256, 2) void dec_tail_fused(const TailParams p)
 #pragma unroll
         for (int f = 0; f < kTailKSteps * 4; ++f) wf[f] = __builtin_bit_cast(bf16x8_t, src[(size_t)f * 64]);
     }
-    float hsc[4], hsh[4];
+    float hsc[NC], hsh[NC];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) { hsc[c] = c < p.classes ? p.head_scale[c] : 0.f; hsh[c] = c < p.classes ? p.head_shift[c] : 0.f; }
+    for (int c = 0; c < NC; ++c) { hsc[c] = c < p.classes ? p.head_scale[c] : 0.f; hsh[c] = c < p.classes ? p.head_shift[c] : 0.f; }
 
     // ---- LDS read addresses (per lane, tile independent)
     int src_base[4], img_base[4];
@@ -772,18 +790,25 @@ __global__ __launch_bounds__(256, 2) void dec_tail_fused(const TailParams p)
         const int tyy = rem / tiles_x, txx = rem - tyy * tiles_x;
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) {
-            float logit[4] = {0.f, 0.f, 0.f, 0.f};
+            float logit[NC];
+#pragma unroll
+            for (int c = 0; c < NC; ++c) logit[c] = 0.f;
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
-                const float4 c0 = *(const float4*)(cst + (fg * 8 + q) * 8);       // scale, shift, hw0, hw1
-                const float2 c1 = *(const float2*)(cst + (fg * 8 + q) * 8 + 4);   // hw2, hw3
+                const float* row = cst + (q * 4 + fg) * CR;
+                const float4 c0 = *(const float4*)row;                            // scale, shift, hw0, hw1
                 const float v = q < 4 ? acc[0][ni][q] : acc[1][ni][q - 4];
                 const float yq = fmaxf(v * c0.x + c0.y, 0.f);
-                logit[0] = fmaf(yq, c0.z, logit[0]); logit[1] = fmaf(yq, c0.w, logit[1]);
-                logit[2] = fmaf(yq, c1.x, logit[2]); logit[3] = fmaf(yq, c1.y, logit[3]);
+                logit[0] = fmaf(yq, c0.z, logit[0]);
+                if constexpr (NC > 1) logit[1] = fmaf(yq, c0.w, logit[1]);
+                if constexpr (NC > 2) {
+                    const float2 c1 = *(const float2*)(row + 4);                  // hw2, hw3
+                    logit[2] = fmaf(yq, c1.x, logit[2]);
+                    logit[3] = fmaf(yq, c1.y, logit[3]);
+                }
             }
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
+            for (int c = 0; c < NC; ++c) {
                 float a = logit[c];
                 a += __shfl_xor(a, 16);
                 a += __shfl_xor(a, 32);
@@ -792,15 +817,15 @@ __global__ __launch_bounds__(256, 2) void dec_tail_fused(const TailParams p)
             if (fg == 0) {
                 float mx = -3.0e38f;
 #pragma unroll
-                for (int c = 0; c < 4; ++c)
+                for (int c = 0; c < NC; ++c)
                     if (c < p.classes) mx = fmaxf(mx, logit[c]);
-                float pr[4], sum = 0.f;
+                float pr[NC], sum = 0.f;
 #pragma unroll
-                for (int c = 0; c < 4; ++c) { pr[c] = c < p.classes ? expf(logit[c] - mx) : 0.f; sum += pr[c]; }
+                for (int c = 0; c < NC; ++c) { pr[c] = c < p.classes ? expf(logit[c] - mx) : 0.f; sum += pr[c]; }
                 int best = 0;
                 float bestp = -1.f;
 #pragma unroll
-                for (int c = 0; c < 4; ++c)
+                for (int c = 0; c < NC; ++c)
                     if (c < p.classes) {
                         pr[c] = pr[c] / sum;
                         if (pr[c] > bestp) { bestp = pr[c]; best = c; }              // first maximum wins (np.argmax)
@@ -811,7 +836,7 @@ __global__ __launch_bounds__(256, 2) void dec_tail_fused(const TailParams p)
                 if (p.probs) {
                     float* dst = p.probs + ((size_t)(n * H + tyy * 16 + oy) * W + txx * 16 + ox) * p.classes;
 #pragma unroll
-                    for (int c = 0; c < 4; ++c)
+                    for (int c = 0; c < NC; ++c)
                         if (c < p.classes) dst[c] = pr[c];
                 }
             }
@@ -826,15 +851,16 @@ hipError_t launch_tail(const TailParams& p, int precision, int num_cus, hipStrea
 {
     const int n_tiles = p.n * (p.PH / 8) * (p.PW / 8);
     const int grid = n_tiles < 2 * num_cus ? n_tiles : 2 * num_cus;
-    if (precision == kF16) {
-        hipError_t e = hipFuncSetAttribute((const void*)dec_tail_fused<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kTailLdsBytes);
+    auto go = [&](auto kern) -> hipError_t {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, kTailLdsBytes);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(dec_tail_fused<true>, dim3(grid), dim3(256), kTailLdsBytes, s, p);
-    } else {
-        hipError_t e = hipFuncSetAttribute((const void*)dec_tail_fused<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kTailLdsBytes);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(dec_tail_fused<false>, dim3(grid), dim3(256), kTailLdsBytes, s, p);
-    }
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), kTailLdsBytes, s, p);
+        return hipSuccess;
+    };
+    hipError_t e;
+    if (precision == kF16) e = p.classes <= 2 ? go(dec_tail_fused<true, 2>) : go(dec_tail_fused<true, 4>);
+    else e = p.classes <= 2 ? go(dec_tail_fused<false, 2>) : go(dec_tail_fused<false, 4>);
+    if (e != hipSuccess) return e;
     return hipGetLastError();
 }
 
