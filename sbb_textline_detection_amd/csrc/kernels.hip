@@ -184,8 +184,6 @@ void conv_igemm_mfma(const ConvParams p)
 
     // ---- load side: rows of the tile being STAGED (runs D steps ahead of the compute side)
     int r_oy[T::kPLoads], r_ox[T::kPLoads], r_n[T::kPLoads];   // output coords of the staged rows
-    uint32_t r_b0[T::kPLoads], r_bd[T::kPLoads];               // byte offset of tap (0,0) in source 0, and (source 1 - source 0)
-                                                               // (two arrays selected by ?: would be demoted to scratch memory)
     uint32_t w_off[T::kWLoads];
     auto setup_rows = [&](int tile) __attribute__((always_inline)) {
         int ctile, cls, ptile;
@@ -206,16 +204,10 @@ void conv_igemm_mfma(const ConvParams p)
                 r_oy[j] = oy;
                 r_ox[j] = ox;
                 r_n[j] = n;
-                r_b0[j] = (uint32_t)n * img0 + (uint32_t)(oy << sd0.sy_shift) * (uint32_t)(sd0.PW * sd0.pix_bytes) +
-                          (uint32_t)(ox << sd0.sx_shift) * (uint32_t)sd0.pix_bytes;
-                r_bd[j] = (uint32_t)n * img1 + (uint32_t)(oy << sd1.sy_shift) * (uint32_t)(sd1.PW * sd1.pix_bytes) +
-                          (uint32_t)(ox << sd1.sx_shift) * (uint32_t)sd1.pix_bytes - r_b0[j];
             } else {
                 r_oy[j] = -(1 << 20);                   // always out of bounds -> zero granule
                 r_ox[j] = 0;
                 r_n[j] = 0;
-                r_b0[j] = 0;
-                r_bd[j] = 0;
             }
         }
 #pragma unroll
@@ -243,33 +235,17 @@ void conv_igemm_mfma(const ConvParams p)
         }
         char* lds_p = smem + buf * T::kStageBytes;
         char* lds_w = lds_p + BP * 128;
-        if (sh == 0) {
-            // stored at the logical resolution (every source of the default plan: the parity split
-            // removed the upsampling): address = per-row base + a uniform tap delta, one VALU add
-            const int delta = dy * rowbytes + dx * pixb + coff;
 #pragma unroll
-            for (int j = 0; j < T::kPLoads; ++j) {
-                const int uy = (r_oy[j] << ssy) + dy;
-                const int ux = (r_ox[j] << ssx) + dx;
-                const bool ok = ((unsigned)uy < lim_y) & ((unsigned)ux < lim_x);
-                const uint32_t rb = r_b0[j] + (s1 ? r_bd[j] : 0u);
-                const uint32_t off = ok ? rb + (uint32_t)delta : 0u;
-                __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(base + off),
-                                                 (LDS_AS void*)(lds_p + (j * NW + wave) * 8 * 128), 16, 0, 0);
-            }
-        } else {
-#pragma unroll
-            for (int j = 0; j < T::kPLoads; ++j) {
-                const int uy = (r_oy[j] << ssy) + dy;           // dy/dx carry tap - pad - placement offset
-                const int ux = (r_ox[j] << ssx) + dx;
-                const bool ok = ((unsigned)uy < lim_y) & ((unsigned)ux < lim_x);
-                const int yy = uy >> sh, xx = ux >> sh;
-                // yy, xx < 2^12 and rowbytes, pixb < 2^24: 24-bit multiplies are exact (full-rate VALU)
-                uint32_t off = (uint32_t)r_n[j] * img + __umul24(yy, rowbytes) + __umul24(xx, pixb) + (uint32_t)coff;
-                off = ok ? off : 0u;
-                __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(base + off),
-                                                 (LDS_AS void*)(lds_p + (j * NW + wave) * 8 * 128), 16, 0, 0);
-            }
+        for (int j = 0; j < T::kPLoads; ++j) {
+            const int uy = (r_oy[j] << ssy) + dy;           // dy/dx carry tap - pad - placement offset
+            const int ux = (r_ox[j] << ssx) + dx;
+            const bool ok = ((unsigned)uy < lim_y) & ((unsigned)ux < lim_x);
+            const int yy = uy >> sh, xx = ux >> sh;
+            // yy, xx < 2^12 and rowbytes, pixb < 2^24: 24-bit multiplies are exact (full-rate VALU)
+            uint32_t off = (uint32_t)r_n[j] * img + __umul24(yy, rowbytes) + __umul24(xx, pixb) + (uint32_t)coff;
+            off = ok ? off : 0u;
+            __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(base + off),
+                                             (LDS_AS void*)(lds_p + (j * NW + wave) * 8 * 128), 16, 0, 0);
         }
 #pragma unroll
         for (int j = 0; j < T::kWLoads; ++j) {
