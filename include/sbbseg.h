@@ -141,6 +141,12 @@ int sbbseg_predict(sbbseg_ctx* c, const float* x_nhwc, int n, float* probs_nhwc)
 int sbbseg_segment_page(sbbseg_ctx* c, const uint8_t* page_hwc, int Hp, int Wp, uint8_t* labels_hw);
 int sbbseg_segment_page_dev(sbbseg_ctx* c, const void* d_page_hwc, int Hp, int Wp, void* d_labels_hw);
 
+/* Same, with the page rescale of get_image_and_scales (main.py:196-214: cv2.resize INTER_NEAREST to Hp x Wp)
+ * fused into the tile gather: page is the STORED image [Hs][Ws][3], labels are [Hp][Wp]; the rescaled
+ * page is never materialised.  Identical to sbbseg_segment_page on the nearest-resized page. */
+int sbbseg_segment_page_scaled(sbbseg_ctx* c, const uint8_t* page_hwc, int Hs, int Ws, int Hp, int Wp,
+                               uint8_t* labels_hw);
+
 /* ---- seam 1, patches=False (main.py:368-380): nearest-resize page to the model size, one forward,
  * argmax, nearest-resize labels to out_h x out_w (cv2.INTER_NEAREST index rule). */
 int sbbseg_segment_whole(sbbseg_ctx* c, const uint8_t* page_hwc, int Hp, int Wp,

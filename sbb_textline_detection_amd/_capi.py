@@ -21,7 +21,7 @@ EXPORTS = [
     "sbbseg_set_stream", "sbbseg_synchronize", "sbbseg_set_input", "sbbseg_input_form", "sbbseg_add_tensor",
     "sbbseg_add_conv", "sbbseg_add_maxpool", "sbbseg_add_tail", "sbbseg_add_head", "sbbseg_finalize", "sbbseg_model_info",
     "sbbseg_num_ops", "sbbseg_op_info", "sbbseg_device_bytes", "sbbseg_predict", "sbbseg_segment_page",
-    "sbbseg_segment_page_dev", "sbbseg_segment_whole", "sbbseg_tile_grid", "sbbseg_segment_tiles_dev",
+    "sbbseg_segment_page_dev", "sbbseg_segment_page_scaled", "sbbseg_segment_whole", "sbbseg_tile_grid", "sbbseg_segment_tiles_dev",
     "sbbseg_segment_tile_range_dev", "sbbseg_stitch_dev", "sbbseg_debug_ingest", "sbbseg_debug_read_tensor",
     "sbbseg_debug_set_conv_variant",
     "sbbseg_profile_enable", "sbbseg_profile_reset", "sbbseg_profile_get",
@@ -79,6 +79,7 @@ def load_library(path: Optional[str] = None):
         "sbbseg_predict": [vp, vp, i32, vp],
         "sbbseg_segment_page": [vp, vp, i32, i32, vp],
         "sbbseg_segment_page_dev": [vp, vp, i32, i32, vp],
+        "sbbseg_segment_page_scaled": [vp, vp, i32, i32, i32, i32, vp],
         "sbbseg_segment_whole": [vp, vp, i32, i32, i32, i32, vp],
         "sbbseg_tile_grid": [i32, i32, i32, i32, vp, i32, C.POINTER(C.c_int), C.POINTER(C.c_int)],
         "sbbseg_segment_tiles_dev": [vp, vp, i32, i32, vp, i32, vp],
@@ -240,6 +241,13 @@ class Context:
             raise ValueError(f"page must be uint8 [H,W,3], got {page.shape}")
         out = np.empty(page.shape[:2], np.uint8)
         check(self.lib.sbbseg_segment_page(self.h, _ptr(page), page.shape[0], page.shape[1], _ptr(out)), "sbbseg_segment_page")
+        return out
+
+    def segment_page_scaled(self, page: np.ndarray, out_h: int, out_w: int) -> np.ndarray:
+        page = np.ascontiguousarray(page, np.uint8)
+        out = np.empty((out_h, out_w), np.uint8)
+        check(self.lib.sbbseg_segment_page_scaled(self.h, _ptr(page), page.shape[0], page.shape[1], out_h, out_w, _ptr(out)),
+              "sbbseg_segment_page_scaled")
         return out
 
     def segment_whole(self, page: np.ndarray, out_h: int, out_w: int) -> np.ndarray:

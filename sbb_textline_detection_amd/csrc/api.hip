@@ -262,7 +262,8 @@ int run_plan(sbbseg_ctx* c, int n, uint8_t* d_labels, float* d_probs)
                 sd.ksteps = co.ksteps[s];
                 sd.sy_shift = co.d.src[s].stride_y == 2; sd.sx_shift = co.d.src[s].stride_x == 2;
             }
-            p.ktab = co.d_ktab; p.kstep = co.d_kstep; p.variant = c->conv_variant & 3; p.persist_blocks = (c->conv_variant & 4) ? 0 : c->num_cus;
+            p.ktab = co.d_ktab; p.kstep = co.d_kstep; p.small_tiles = (c->conv_variant & 16) ? 1 : 0;
+            p.variant = c->conv_variant & 3; p.persist_blocks = (c->conv_variant & 4) ? 0 : c->num_cus;
             p.tile_map = (!(c->conv_variant & 8) && (c->conv_variant & 4) == 0 && co.d.cout > conv_tile_bc(co.d.cout) && p.M >= 256 * 128 &&
                           (size_t)co.cout_pad * co.Ktot * c->elem <= ((size_t)2 << 20)) ? 1 : 0; p.w = co.d_w; p.Ktot = co.Ktot; p.total_ksteps = co.total_ksteps;
             p.Ho = co.Ho; p.Wo = co.Wo; p.M = n * co.Ho * co.Wo;
@@ -901,7 +902,7 @@ int sbbseg_segment_tiles_dev(sbbseg_ctx* c, const void* d_page_hwc, int Hp, int 
                 "tile %d at (%d,%d) leaves the %dx%d page", t, tile_xy[2 * t], tile_xy[2 * t + 1], Hp, Wp);
     IngestParams ip;
     if (fill_ingest(c, ip)) return 1;
-    ip.page = (const uint8_t*)d_page_hwc; ip.Hp = Hp; ip.Wp = Wp; ip.tile_xy = c->d_tile_xy;
+    ip.page = (const uint8_t*)d_page_hwc; ip.Hp = Hp; ip.Wp = Wp; ip.src_Hp = Hp; ip.src_Wp = Wp; ip.tile_xy = c->d_tile_xy;
     const size_t per = (size_t)c->in_H * c->in_W;
     for (int done = 0; done < n_tiles; done += c->max_batch) {
         const int nb = n_tiles - done < c->max_batch ? n_tiles - done : c->max_batch;
@@ -916,10 +917,9 @@ int sbbseg_segment_tiles_dev(sbbseg_ctx* c, const void* d_page_hwc, int Hp, int 
     return 0;
 }
 
-int sbbseg_segment_tile_range_dev(sbbseg_ctx* c, const void* d_page_hwc, int Hp, int Wp, int first_tile, int n_tiles,
-                                  void* d_tile_labels)
+static int tile_range_impl(sbbseg_ctx* c, const void* d_page_hwc, int src_Hp, int src_Wp, const int* d_map_y, const int* d_map_x,
+                           int Hp, int Wp, int first_tile, int n_tiles, void* d_tile_labels)
 {
-    if (check_ready(c)) return 1;
     REQUIRE(d_page_hwc && d_tile_labels && first_tile >= 0 && n_tiles >= 0, "bad arguments");
     int nx = 0, ny = 0;
     if (sbbseg_tile_grid(Hp, Wp, c->in_H, c->in_W, nullptr, 0, &nx, &ny)) return 1;
@@ -927,7 +927,8 @@ int sbbseg_segment_tile_range_dev(sbbseg_ctx* c, const void* d_page_hwc, int Hp,
     const int margin = margin_of(c->in_W);
     IngestParams ip;
     if (fill_ingest(c, ip)) return 1;
-    ip.page = (const uint8_t*)d_page_hwc; ip.Hp = Hp; ip.Wp = Wp; ip.tile_xy = nullptr;
+    ip.page = (const uint8_t*)d_page_hwc; ip.Hp = Hp; ip.Wp = Wp; ip.src_Hp = src_Hp; ip.src_Wp = src_Wp; ip.tile_xy = nullptr;
+    ip.map_y = d_map_y; ip.map_x = d_map_x;
     ip.grid_nyf = ny; ip.grid_mid_x = c->in_W - 2 * margin; ip.grid_mid_y = c->in_H - 2 * margin;
     const size_t per = (size_t)c->in_H * c->in_W;
     for (int done = 0; done < n_tiles; done += c->max_batch) {
@@ -938,6 +939,13 @@ int sbbseg_segment_tile_range_dev(sbbseg_ctx* c, const void* d_page_hwc, int Hp,
         if (run_plan(c, nb, (uint8_t*)d_tile_labels + done * per, nullptr)) return 1;
     }
     return 0;
+}
+
+int sbbseg_segment_tile_range_dev(sbbseg_ctx* c, const void* d_page_hwc, int Hp, int Wp, int first_tile, int n_tiles,
+                                  void* d_tile_labels)
+{
+    if (check_ready(c)) return 1;
+    return tile_range_impl(c, d_page_hwc, Hp, Wp, nullptr, nullptr, Hp, Wp, first_tile, n_tiles, d_tile_labels);
 }
 
 static int prepare_owner(sbbseg_ctx* c, int Hp, int Wp)
@@ -999,6 +1007,33 @@ int sbbseg_segment_page(sbbseg_ctx* c, const uint8_t* page_hwc, int Hp, int Wp, 
     return 0;
 }
 
+int sbbseg_segment_page_scaled(sbbseg_ctx* c, const uint8_t* page_hwc, int Hs, int Ws, int Hp, int Wp, uint8_t* labels_hw)
+{
+    if (check_ready(c)) return 1;
+    REQUIRE(page_hwc && labels_hw && Hs > 0 && Ws > 0, "bad arguments");
+    REQUIRE(Hp >= c->in_H && Wp >= c->in_W, "scaled page %dx%d is smaller than the model input %dx%d", Hp, Wp, c->in_H, c->in_W);
+    const size_t spix = (size_t)Hs * Ws, pix = (size_t)Hp * Wp;
+    if (ensure(c, (void**)&c->d_page, &c->page_cap, spix * 3)) return 1;
+    if (ensure(c, (void**)&c->d_page_labels, &c->page_labels_cap, pix)) return 1;
+    std::vector<int> my, mx;
+    nearest_map(Hs, Hp, my);               // scaled row -> stored row   (main.py:214 -> 112-113)
+    nearest_map(Ws, Wp, mx);
+    if (ensure(c, (void**)&c->d_map, &c->map_cap, sizeof(int) * (size_t)(Hp + Wp))) return 1;
+    int* d_my = c->d_map; int* d_mx = d_my + Hp;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipMemcpy(d_my, my.data(), sizeof(int) * Hp, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d_mx, mx.data(), sizeof(int) * Wp, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpyAsync(c->d_page, page_hwc, spix * 3, hipMemcpyHostToDevice, c->stream));
+    int nx = 0, ny = 0;
+    if (sbbseg_tile_grid(Hp, Wp, c->in_H, c->in_W, nullptr, 0, &nx, &ny)) return 1;
+    if (ensure(c, (void**)&c->d_tile_labels, &c->tile_labels_cap, (size_t)nx * ny * c->in_H * c->in_W)) return 1;
+    if (tile_range_impl(c, c->d_page, Hs, Ws, d_my, d_mx, Hp, Wp, 0, nx * ny, c->d_tile_labels)) return 1;
+    if (sbbseg_stitch_dev(c, c->d_tile_labels, Hp, Wp, c->d_page_labels)) return 1;
+    HIPCHK(hipMemcpyAsync(labels_hw, c->d_page_labels, pix, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
 int sbbseg_segment_whole(sbbseg_ctx* c, const uint8_t* page_hwc, int Hp, int Wp, int out_h, int out_w, uint8_t* labels_out)
 {
     if (check_ready(c)) return 1;
@@ -1022,8 +1057,8 @@ int sbbseg_segment_whole(sbbseg_ctx* c, const uint8_t* page_hwc, int Hp, int Wp,
     HIPCHK(hipMemcpyAsync(c->d_page, page_hwc, pix * 3, hipMemcpyHostToDevice, c->stream));
     IngestParams ip;
     if (fill_ingest(c, ip)) return 1;
-    ip.page = c->d_page; ip.Hp = Hp; ip.Wp = Wp; ip.tile_xy = c->d_tile_xy; ip.n_tiles = 1;
-    ip.map_y = d_my; ip.map_x = d_mx;
+    ip.page = c->d_page; ip.Hp = Hp; ip.Wp = Wp; ip.src_Hp = Hp; ip.src_Wp = Wp; ip.tile_xy = nullptr; ip.n_tiles = 1;
+    ip.whole = 1; ip.map_y = d_my; ip.map_x = d_mx;
     HIPCHK(launch_ingest_u8(ip, c->precision, c->stream));
     if (run_plan(c, 1, c->d_batch_labels, nullptr)) return 1;
     HIPCHK(launch_resize_labels(c->d_batch_labels, c->in_H, c->in_W, d_oy, d_ox, out_h, out_w, c->d_page_labels, c->stream));
@@ -1050,7 +1085,7 @@ int sbbseg_debug_ingest(sbbseg_ctx* c, const uint8_t* page_hwc, int Hp, int Wp, 
     HIPCHK(hipMemcpy(c->d_tile_xy, tile_xy, sizeof(int) * 2 * n_tiles, hipMemcpyHostToDevice));
     IngestParams ip;
     if (fill_ingest(c, ip)) return 1;
-    ip.page = c->d_page; ip.Hp = Hp; ip.Wp = Wp; ip.tile_xy = c->d_tile_xy; ip.n_tiles = n_tiles;
+    ip.page = c->d_page; ip.Hp = Hp; ip.Wp = Wp; ip.src_Hp = Hp; ip.src_Wp = Wp; ip.tile_xy = c->d_tile_xy; ip.n_tiles = n_tiles;
     HIPCHK(launch_ingest_u8(ip, c->precision, c->stream));
     float* d_tmp = nullptr;
     HIPCHK(hipMalloc((void**)&d_tmp, n * sizeof(float)));

@@ -43,6 +43,7 @@ struct ConvParams {
     int n_src;
     const KStepRec* kstep;    // [total_ksteps]
     int variant;              // 0 = auto tile choice, 1 = force 4-wave/2-stage, 2 = force 8-wave/3-stage
+    int small_tiles;          // A/B: 64x128 tiles (3 blocks per CU) on short-K layers
     int tile_map;             // 0 = channel tile per XCD (big weights), 1 = pixel tiles grouped per XCD (small weights)
     int persist_blocks;       // CUs of the device (persistent grid = resident blocks); 0 = one block per tile
     const KTabEntry* ktab;    // [total_ksteps * 8]
@@ -112,8 +113,10 @@ struct HeadParams {
 };
 
 struct IngestParams {
-    const uint8_t* page;      // [Hp][Wp][3] u8 (device)
-    int Hp, Wp;
+    const uint8_t* page;      // [src_Hp][src_Wp][3] u8 (device)
+    int Hp, Wp;               // size of the (virtual) page the tile grid lives on
+    int src_Hp, src_Wp;       // size of the stored page (== Hp, Wp unless a nearest-resize map is given)
+    int whole;                // 1: one patch = the whole page resized to the model input (maps indexed by model coords)
     const int* tile_xy;       // device [n][2] explicit origins, or null = closed-form grid below
     int grid_first, grid_nyf; // grid mode: tile t = grid_first + local index; i = t / nyf, j = t % nyf
     int grid_mid_x, grid_mid_y; //   origin = min(i*mid_x, Wp-W), min(j*mid_y, Hp-H)   (main.py:262-281)

@@ -79,7 +79,8 @@ constexpr int conv_blocks_per_cu(int bp, int bc, int wp, int wc, int ns)
     const int waves = wp * wc;
     const int wrows = bc > 8 * waves ? bc : 8 * waves;
     const int lds = ns * (bp + wrows) * 128;
-    return (2 * lds <= 160 * 1024 && waves == 4) ? 2 : 1;
+    if (waves != 4) return 1;
+    return 3 * lds <= 160 * 1024 ? 3 : (2 * lds <= 160 * 1024 ? 2 : 1);
 }
 
 template <int BP, int BC, int WP, int WC, int NS>
@@ -244,6 +245,7 @@ void conv_igemm_mfma(const ConvParams p)
             // yy, xx < 2^12 and rowbytes, pixb < 2^24: 24-bit multiplies are exact (full-rate VALU)
             uint32_t off = (uint32_t)r_n[j] * img + __umul24(yy, rowbytes) + __umul24(xx, pixb) + (uint32_t)coff;
             off = ok ? off : 0u;
+            // (a non-temporal policy on these loads was measured 5-35 % slower: the tap re-reads live in L2)
             __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(base + off),
                                              (LDS_AS void*)(lds_p + (j * NW + wave) * 8 * 128), 16, 0, 0);
         }
@@ -584,6 +586,7 @@ static hipError_t launch_conv_16(const ConvParams& p, hipStream_t s)
         if (bc == 128) return launch_conv_t<512, 128, 4, 2, 2, F16>(p, s);
         if (bc == 64) return launch_conv_t<512, 64, 8, 1, 2, F16>(p, s);
     }
+    if (p.small_tiles && bc == 128 && p.Ktot <= 256) return launch_conv_t<64, 128, 2, 2, 2, F16>(p, s);   // 3 blocks per CU (A/B)
     if (variant == 0 && bc == 128 && !p.residual) {
         // auto (measured per layer, profiles/r01_conv_variants.md): the 8-wave tiles with 128x64 wave
         // tiles (LDS bytes per MFMA x0.75, L2 bytes per MFMA x0.5) win on long-K layers that still
@@ -892,16 +895,20 @@ __global__ __launch_bounds__(256) void ingest_u8_kernel(const IngestParams p)
     const int t = (int)(idx / per);
     const int rem = (int)(idx - t * per);
     const int y = rem / p.W, x = rem - y * p.W;
-    int sy, sx;
-    if (p.map_y) { sy = p.map_y[y]; sx = p.map_x[x]; }
-    else if (p.tile_xy) { sx = p.tile_xy[2 * t] + x; sy = p.tile_xy[2 * t + 1] + y; }
+    int vy, vx;                                   // position on the (virtual) page
+    if (p.whole) { vy = y; vx = x; }
+    else if (p.tile_xy) { vx = p.tile_xy[2 * t] + x; vy = p.tile_xy[2 * t + 1] + y; }
     else {
         const int gt = p.grid_first + t;
         const int gi = gt / p.grid_nyf, gj = gt - gi * p.grid_nyf;
-        sx = min(gi * p.grid_mid_x, p.Wp - p.W) + x;
-        sy = min(gj * p.grid_mid_y, p.Hp - p.H) + y;
+        vx = min(gi * p.grid_mid_x, p.Wp - p.W) + x;
+        vy = min(gj * p.grid_mid_y, p.Hp - p.H) + y;
     }
-    const uint8_t* px = p.page + ((size_t)sy * p.Wp + sx) * 3;
+    // optional nearest-neighbour rescale (cv2.INTER_NEAREST index tables): the rescaled page of
+    // get_image_and_scales (main.py:196-214) / the resize of the whole-image branch (main.py:371)
+    // is never materialised, the tiles are gathered straight from the stored page
+    const int sy = p.map_y ? p.map_y[vy] : vy, sx = p.map_x ? p.map_x[vx] : vx;
+    const uint8_t* px = p.page + ((size_t)sy * p.src_Wp + sx) * 3;
     const E v0 = to_elem<E>(p.lut[px[0]]), v1 = to_elem<E>(p.lut[px[1]]), v2 = to_elem<E>(p.lut[px[2]]);
     const E z = to_elem<E>(0.f);
     Vec8<E> o;

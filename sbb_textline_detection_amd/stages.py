@@ -1,0 +1,128 @@
+"""The three stage wrappers that call the hot path and the steps either side of
+it that section 8(f) ranks next, with the reference's names and call pattern:
+
+    get_image_and_scales            main.py:196-214   upscale rule (2800 px high, or x1.2), INTER_NEAREST
+    otsu_copy                       main.py:178-194   per-channel Otsu, channel-0 result in all 3 channels (quirk kept)
+    extract_page   (model part)     main.py:384-392   border model, patches=False
+    extract_text_regions            main.py:439-454   Otsu'd page, layout model (4 classes), patches=True
+    textline_contours               main.py:490-503   textline model, patches=True, returns channel 0
+
+The cv2 contour / morphology post-processing of extract_page (main.py:394-426) is out of scope; the
+page box falls back to the full image exactly like the reference's own `except` branch (main.py:417-419).
+"""
+from __future__ import annotations
+
+import gc
+from typing import Optional, Tuple
+
+import numpy as np
+
+from .model import SegModel, start_new_session_and_model
+from .predict import do_prediction
+
+
+def scaled_size(h: int, w: int) -> Tuple[int, int]:
+    """main.py:201-207: pages under 2500 px go to 2800 px height, everything else x1.2 (aspect kept)."""
+    if h < 2500:
+        hi = 2800
+    else:
+        hi = int(h * 1.2)
+    return hi, int(hi * w / float(h))
+
+
+def otsu_threshold_u8(ch: np.ndarray) -> int:
+    """cv2.threshold(..., THRESH_BINARY + THRESH_OTSU) threshold value [EXT: OpenCV getThreshVal_Otsu_8u]."""
+    hist = np.bincount(ch.reshape(-1), minlength=256).astype(np.float64)
+    n = hist.sum()
+    p = hist / n
+    mu = float((np.arange(256) * p).sum())
+    q1 = 0.0
+    mu1 = 0.0
+    best, best_sigma = 0, 0.0
+    eps = np.finfo(np.float32).eps
+    for i in range(256):
+        pi = p[i]
+        mu1 *= q1
+        q1 += pi
+        q2 = 1.0 - q1
+        if min(q1, q2) < eps or max(q1, q2) > 1.0 - eps:
+            continue
+        mu1 = (mu1 + i * pi) / q1
+        mu2 = (mu - q1 * mu1) / q2
+        sigma = q1 * q2 * (mu1 - mu2) ** 2
+        if sigma > best_sigma:
+            best_sigma, best = sigma, i
+    return best
+
+
+def otsu_copy(img: np.ndarray) -> np.ndarray:
+    """main.py:178-194.  Thresholds of all three channels are computed, but the channel-0 result is
+    written to all three output channels (reference quirk, lines 191-193).  float64 HxWx3, values 0/255."""
+    t = otsu_threshold_u8(np.ascontiguousarray(img[:, :, 0], np.uint8))
+    b = np.where(img[:, :, 0] > t, 255.0, 0.0)
+    return np.repeat(b[:, :, None], 3, axis=2)
+
+
+class InferenceStages:
+    """The model-running part of ``textline_detector.run()`` (main.py:2056-2107)."""
+
+    def __init__(self, model_page_dir: str, model_region_dir: str, model_textline_dir: str, device: int = 0,
+                 model_kwargs: Optional[dict] = None):
+        self.model_page_dir, self.model_region_dir, self.model_textline_dir = model_page_dir, model_region_dir, model_textline_dir
+        self.kw = dict(model_kwargs or {}, device=device)
+        self.image = None
+        self.scale_y = self.scale_x = 1.0
+
+    def get_image_and_scales(self, image_u8: np.ndarray) -> None:
+        """Records the upscaled geometry (main.py:196-214).  The upscaled page itself is not built:
+        the tile gather reads the stored page through the nearest-neighbour index tables."""
+        self.image_stored = np.ascontiguousarray(image_u8, np.uint8)
+        h, w = image_u8.shape[:2]
+        self.img_hight_int, self.img_width_int = scaled_size(h, w)
+        self.scale_y = self.img_hight_int / float(h)
+        self.scale_x = self.img_width_int / float(w)
+
+    def _scaled_page(self):
+        from .predict import resize_nearest
+        return resize_nearest(self.image_stored, self.img_hight_int, self.img_width_int)
+
+    def extract_page_mask(self) -> np.ndarray:
+        """Border model on the whole page (main.py:384-392): uint8 [H,W,3] at the *scaled* size."""
+        model, session = start_new_session_and_model(self.model_page_dir, **self.kw)
+        try:
+            img = self._scaled_page()
+            return do_prediction(False, img, model, full_image_shape=img.shape)
+        finally:
+            session.close()
+            gc.collect()
+
+    def extract_text_regions(self, img_u8: np.ndarray) -> np.ndarray:
+        model, session = start_new_session_and_model(self.model_region_dir, **self.kw)
+        try:
+            img = otsu_copy(img_u8).astype(np.uint8)                      # main.py:443-444
+            return do_prediction(True, img, model)                         # main.py:447
+        finally:
+            session.close()
+            gc.collect()
+
+    def textline_contours(self, img_u8: Optional[np.ndarray] = None) -> np.ndarray:
+        """main.py:490-503.  With img_u8=None the stored page is segmented through the fused rescale
+        (identical to running on the upscaled page)."""
+        model, session = start_new_session_and_model(self.model_textline_dir, **self.kw)
+        try:
+            if img_u8 is None and isinstance(model, SegModel):
+                return model.ctx.segment_page_scaled(self.image_stored, self.img_hight_int, self.img_width_int)
+            img = (self._scaled_page() if img_u8 is None else img_u8).astype(np.uint8)
+            return do_prediction(True, img, model)[:, :, 0]
+        finally:
+            session.close()
+            gc.collect()
+
+    def run(self, image_u8: np.ndarray):
+        """border -> (full-page box) -> layout -> textline; returns the three label maps."""
+        self.get_image_and_scales(image_u8)
+        page_mask = self.extract_page_mask()
+        page = self._scaled_page()                                         # box = whole image (main.py:417-419 fallback)
+        regions = self.extract_text_regions(page)
+        textlines = self.textline_contours(page)
+        return page_mask, regions, textlines

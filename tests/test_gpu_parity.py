@@ -208,3 +208,51 @@ def test_sharded_entry_points_single_rank(torch_cuda, stitch_model):
     assert np.array_equal(b[1], stitch_model.segment_page(page[::-1].copy()))
     stitch_model.ctx.synchronize()
     stitch_model.ctx.set_stream(-1)
+
+
+def test_scaled_page_equals_resized_page(stitch_model):
+    """get_image_and_scales fused into the gather: segment_page_scaled(stored page) == segment_page(resized page)."""
+    from sbb_textline_detection_amd.predict import resize_nearest
+    from sbb_textline_detection_amd.stages import scaled_size
+    page = synthetic_page(900, 700, seed=6)
+    hs, ws = 1200, 933
+    a = stitch_model.ctx.segment_page_scaled(page, hs, ws)
+    b = stitch_model.segment_page(np.ascontiguousarray(resize_nearest(page, hs, ws)))
+    assert a.shape == (hs, ws) and np.array_equal(a, b)
+    assert scaled_size(900, 700) == (2800, 2177)
+
+
+def test_three_model_pipeline(tmp_path):
+    """BASELINE config[2]: border (whole image, 2 classes) + layout (Otsu'd page, 4 classes) + textline
+    (2 classes) through the stage wrappers, models loaded from .sbbw files via the reference's .h5 paths."""
+    from sbb_textline_detection_amd import clear_session, stages
+    from sbb_textline_detection_amd.weights import save_sbbw
+    from tools.synth_model import calibrated_model
+    specs = {"model_page_mixed_best": 2, "model_strukturerkennung": 4, "model_textline_new": 2}      # main.py:58-60
+    models = {}
+    for name, classes in specs.items():
+        cfg, w = calibrated_model(classes, 224, 224, seed=classes)
+        save_sbbw(str(tmp_path / (name + ".sbbw")), cfg, w)
+        models[name] = (cfg, w)
+    st = stages.InferenceStages(*[str(tmp_path / (n + ".h5")) for n in specs], model_kwargs={"max_batch": 16})
+    page = synthetic_page(520, 400, seed=9)                                   # < 2500 high -> upscaled to 2800 x 2153
+    mask, regions, lines = st.run(page)
+    hs, ws = stages.scaled_size(520, 400)
+    assert mask.shape == (hs, ws, 3) and regions.shape == (hs, ws, 3) and lines.shape == (hs, ws)
+    assert mask.dtype == regions.dtype == lines.dtype == np.uint8
+    assert regions.max() <= 3 and lines.max() <= 1 and mask.max() <= 1
+    # fused-rescale textline path == the same stage on the materialised upscaled page
+    lines2 = st.textline_contours(None)
+    assert np.array_equal(lines, lines2)
+    # spot-check the layout stage against the oracle on a crop of the upscaled, Otsu'd page
+    from sbb_textline_detection_amd.predict import resize_nearest
+    up = resize_nearest(page, hs, ws)
+    ots = stages.otsu_copy(up).astype(np.uint8)
+    cfg, w = models["model_strukturerkennung"]
+    om = kf.OracleModel(cfg, w)
+    crop = ots[:448, :448]
+    ref = tiling.do_prediction(True, crop, om)[:, :, 0]
+    from sbb_textline_detection_amd.model import load_model
+    got = predict.do_prediction(True, crop, load_model(str(tmp_path / "model_strukturerkennung.h5"), max_batch=16))[:, :, 0]
+    assert (ref != got).mean() < 0.06
+    clear_session()
