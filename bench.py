@@ -39,6 +39,9 @@ def main():
     ap.add_argument("--max-batch", type=int, default=int(os.environ.get("SBBSEG_MAX_BATCH", "70")))
     ap.add_argument("--conv-variant", type=int, default=int(os.environ.get("SBBSEG_CONV_VARIANT", "0")),
                     help="0 auto, 1 force 4-wave/2-stage conv tiles, 2 force 8-wave/3-stage (A/B only)")
+    ap.add_argument("--workload", default="page", choices=["page", "pipeline3", "batch64"],
+                    help="page = BASELINE configs[1] (default, the metric's config); pipeline3 = configs[2] (border whole-image "
+                         "+ layout + textline on one page); batch64 = configs[3] (64 pages of 4000x3000 sharded over the ranks)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-patches", type=int, default=8)
     args = ap.parse_args()
@@ -75,10 +78,54 @@ def main():
     from sbb_textline_detection_amd import _capi
     tiles_per_page = _capi.tile_grid(PAGE_H, PAGE_W, MODEL_HW, MODEL_HW)[0].shape[0]
 
+    scaling = "weak"
+    workload_desc = (f"one {PAGE_H}x{PAGE_W} page per GPU per step, textline model (ResNet-50-U-Net, {CLASSES} classes, "
+                     f"seeded synthetic weights), margin 0.1 -> {tiles_per_page} tiles of 448x448")
+    tiles_per_step = tiles_per_page * world
+
     def step():
         ctx.segment_page_dev(d_page.data_ptr(), PAGE_H, PAGE_W, d_labels.data_ptr())
         if world > 1:
             dist.all_gather_into_tensor(d_all.view(-1), d_labels.view(-1))
+
+    if args.workload == "pipeline3":
+        # configs[2]: the three stage models on one page (model load excluded, models stay resident)
+        from sbb_textline_detection_amd.stages import otsu_copy
+        cfg_b, w_b = calibrated_model(2, MODEL_HW, MODEL_HW, seed=11)
+        cfg_l, w_l = calibrated_model(4, MODEL_HW, MODEL_HW, seed=12)
+        m_border = SegModel(cfg_b, w_b, device=local_rank, max_batch=1, precision=args.precision)
+        m_layout = SegModel(cfg_l, w_l, device=local_rank, max_batch=args.max_batch, precision=args.precision)
+        for m in (m_border, m_layout):
+            m.ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        d_otsu = torch.from_numpy(otsu_copy(page).astype(np.uint8)).cuda()
+        d_lab2 = torch.empty((PAGE_H, PAGE_W), dtype=torch.uint8, device="cuda")
+        tiles_per_step = (1 + 2 * tiles_per_page) * world
+        workload_desc = (f"three-model pipeline on one {PAGE_H}x{PAGE_W} page per GPU: border (whole image, 1 forward) + layout "
+                         f"(Otsu'd page, 4 classes, {tiles_per_page} tiles) + textline ({tiles_per_page} tiles); models resident")
+
+        def step():  # noqa: F811
+            m_border.segment_whole(page, PAGE_H, PAGE_W)                       # host page in / host mask out (1 forward)
+            m_layout.ctx.segment_page_dev(d_otsu.data_ptr(), PAGE_H, PAGE_W, d_lab2.data_ptr())
+            ctx.segment_page_dev(d_page.data_ptr(), PAGE_H, PAGE_W, d_labels.data_ptr())
+    elif args.workload == "batch64":
+        # configs[3]: 64 pages of 4000x3000, whole pages per rank, one all-gather of the masks per step
+        BH, BW, NPAGES = 4000, 3000, 64
+        from sbb_textline_detection_amd.distributed import shard_block
+        first, count, block = shard_block(NPAGES, rank, world)
+        pages = [torch.from_numpy(synthetic_page(BH, BW, seed=100 + first + k)).cuda() for k in range(count)]
+        d_mine = torch.empty((block, BH, BW), dtype=torch.uint8, device="cuda")
+        d_everything = torch.empty((world * block, BH, BW), dtype=torch.uint8, device="cuda") if world > 1 else None
+        tpp = _capi.tile_grid(BH, BW, MODEL_HW, MODEL_HW)[0].shape[0]
+        tiles_per_step = tpp * NPAGES
+        scaling = "strong"
+        workload_desc = (f"{NPAGES} pages of {BH}x{BW} ({tpp} tiles each) sharded as whole pages over the ranks, textline model, "
+                         f"one RCCL all-gather of the u8 masks per step")
+
+        def step():  # noqa: F811
+            for k in range(count):
+                ctx.segment_page_dev(pages[k].data_ptr(), BH, BW, d_mine[k].data_ptr())
+            if world > 1:
+                dist.all_gather_into_tensor(d_everything.view(-1), d_mine.view(-1))
 
     def fence():
         if world > 1:
@@ -97,7 +144,7 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    total_tiles = tiles_per_page * args.steps * world
+    total_tiles = tiles_per_step * args.steps
     value = total_tiles / dt
 
     # ---- roofline of the dominant kernel: per-launch HIP events on the library's stream ----------
@@ -172,11 +219,10 @@ def main():
         out = {
             "metric": "segmented patches/sec (448x448x3) per GPU + per-pixel label-map match vs ref",
             "value": round(value, 2), "unit": "patches/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": scaling,
             "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
-            "config": {"workload": f"one {PAGE_H}x{PAGE_W} page per GPU per step, textline model (ResNet-50-U-Net, "
-                                   f"{CLASSES} classes, seeded synthetic weights), margin 0.1 -> {tiles_per_page} tiles of 448x448",
-                       "tiles_per_step_per_gpu": tiles_per_page, "max_batch": args.max_batch,
+            "config": {"workload": workload_desc, "workload_id": args.workload,
+                       "tiles_per_step": tiles_per_step, "max_batch": args.max_batch,
                        "exchange": "all_gather of u8 label maps over RCCL" if world > 1 else "none (1 GPU)",
                        "flops_per_patch": 2 * model.plan.macs_per_patch()},
             "patches_per_s_per_gpu": round(value / world, 2),
