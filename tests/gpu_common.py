@@ -19,8 +19,8 @@ TOL_SOFTMAX = {"bf16": 0.60, "f16": 0.15, "f32": 2e-3}
 TOL_LAYER_REL = {"bf16": 0.25, "f16": 0.04, "f32": 2e-4}
 
 
-def make_model(classes, h, w, seed=0, precision="f16", max_batch=8, calib_hw=None):
-    cfg, weights = calibrated_model(classes, h, w, seed=seed, calib_hw=calib_hw or min(160, max(h, w)))
+def make_model(classes, h, w, seed=0, precision="f16", max_batch=8, calib_hw=None, decisive=False):
+    cfg, weights = calibrated_model(classes, h, w, seed=seed, calib_hw=calib_hw or min(160, max(h, w)), decisive=decisive)
     graph = parse_model_config(cfg)
     model = SegModel(cfg, weights, device=0, max_batch=max_batch, precision=precision)
     return cfg, weights, graph, model

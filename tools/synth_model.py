@@ -77,10 +77,36 @@ def forward_torch(graph, weights, x_nhwc, dtype=torch.float32, calibrate_bn=Fals
     return vals[graph.output_name].permute(0, 2, 3, 1).contiguous().to(torch.float32).numpy()
 
 
-def calibrated_model(n_classes=2, height=448, width=448, seed=0, calib_hw=160, calib_batch=2):
-    """(model_config, weights): seeded weights with BN statistics calibrated on synthetic pages."""
+def _make_decisive(graph, w, strength=6.0):
+    """Give the seeded net a trained-like, *decisive* output: strengthen the direct image path of the
+    last decoder conv (its concat takes the network input) into a few channels and let the head read
+    them, so that logit differences follow ink vs. paper (bimodal) instead of being noise around 0.
+    The deep path still contributes; BN statistics are calibrated afterwards as usual."""
+    byn = graph.by_name()
+    node = byn[graph.output_name]
+    chain = []
+    while node.op != "concat":
+        if node.op == "conv":
+            chain.append(node)
+        node = byn[node.inputs[0]]
+    head, tail = chain[0], chain[1]
+    kt = w[f"{tail.name}/kernel:0"]                      # [3][3][C_up + 3][32]; the image channels come last
+    kh = w[f"{head.name}/kernel:0"]                      # [1][1][32][classes]
+    for j in range(8):
+        sgn = 1.0 if j % 2 == 0 else -1.0
+        kt[1, 1, -3:, j] += sgn * strength / 3.0
+        for c in range(kh.shape[3]):
+            kh[0, 0, j, c] += sgn * (2.0 if c % 2 == 0 else -2.0)
+
+
+def calibrated_model(n_classes=2, height=448, width=448, seed=0, calib_hw=160, calib_batch=2, decisive=False):
+    """(model_config, weights): seeded weights with BN statistics calibrated on synthetic pages.
+    ``decisive``: see :func:`_make_decisive` (a trained net's outputs are decisive; plain random
+    weights give a worst-case, noise-like label map where every pixel is a potential near-tie)."""
     cfg = resnet50_unet_config(n_classes, height, width)
     w = synthetic_weights(parse_model_config(cfg), seed)
+    if decisive:
+        _make_decisive(parse_model_config(cfg), w)
     cal_cfg = resnet50_unet_config(n_classes, calib_hw, calib_hw)
     cal_graph = parse_model_config(cal_cfg)
     page = synthetic_page(calib_hw * 2, calib_hw * calib_batch, seed=seed + 1000)
