@@ -442,21 +442,41 @@ void conv_igemm_mfma(const ConvParams p)
         if (issued < total) issue(nxt);
         if (kPrefetchRes && p.residual && c_t == nt - 1) prefetch_residual(tile_at(c_q));
         const char* sb = smem + cur * T::kStageBytes;
+        {
+            // The K-step's MFMAs run in phases of (k-half kk, group of <= 4 pixel blocks); the LDS
+            // fragments of phase i+1 are requested BEFORE the MFMAs of phase i (register double
+            // buffer).  hipcc on its own emits "all ds_reads, lgkmcnt(0), all MFMAs" per k-half, which
+            // leaves the matrix pipe idle while all 8 waves of the block read LDS in lockstep.
+            constexpr int NIH = T::kNI >= 8 ? T::kNI / 2 : T::kNI;     // pixel blocks per phase
+            constexpr int NH = T::kNI / NIH;
+            constexpr int NP = 2 * NH;
+            bf16x8_t a[2][T::kMI], b[2][NIH];
+            auto load_a = [&](int kk, bf16x8_t (&dst)[T::kMI]) __attribute__((always_inline)) {
+                const int rd = kk ? rd_k1 : rd_k0;
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            const int rd = kk ? rd_k1 : rd_k0;
-            bf16x8_t a[T::kMI], b[T::kNI];
+                for (int mi = 0; mi < T::kMI; ++mi) dst[mi] = *(const bf16x8_t*)(sb + w_rd + mi * 16 * 128 + rd);
+            };
+            auto load_b = [&](int kk, int h, bf16x8_t (&dst)[NIH]) __attribute__((always_inline)) {
+                const int rd = kk ? rd_k1 : rd_k0;
 #pragma unroll
-            for (int mi = 0; mi < T::kMI; ++mi)
-                a[mi] = *(const bf16x8_t*)(sb + w_rd + mi * 16 * 128 + rd);
+                for (int q = 0; q < NIH; ++q) dst[q] = *(const bf16x8_t*)(sb + p_rd + (h * NIH + q) * 16 * 128 + rd);
+            };
+            load_a(0, a[0]);
+            load_b(0, 0, b[0]);
 #pragma unroll
-            for (int ni = 0; ni < T::kNI; ++ni)
-                b[ni] = *(const bf16x8_t*)(sb + p_rd + ni * 16 * 128 + rd);
+            for (int ph = 0; ph < NP; ++ph) {
+                const int kk = ph / NH, h = ph % NH;
+                if (ph + 1 < NP) {
+                    const int nkk = (ph + 1) / NH, nh = (ph + 1) % NH;
+                    if (nh == 0) load_a(nkk, a[nkk & 1]);
+                    load_b(nkk, nh, b[(ph + 1) & 1]);
+                }
 #pragma unroll
-            for (int mi = 0; mi < T::kMI; ++mi)
+                for (int mi = 0; mi < T::kMI; ++mi)
 #pragma unroll
-                for (int ni = 0; ni < T::kNI; ++ni)
-                    acc[mi][ni] = mfma16<F16>(a[mi], b[ni], acc[mi][ni]);
+                    for (int q = 0; q < NIH; ++q)
+                        acc[mi][h * NIH + q] = mfma16<F16>(a[kk & 1][mi], b[ph & 1][q], acc[mi][h * NIH + q]);
+            }
         }
         bool tile_done = false;
         if (++c_t == nt) {                                  // tile finished: its stores overlap the
@@ -586,6 +606,9 @@ static hipError_t launch_conv_16(const ConvParams& p, hipStream_t s)
         if (bc == 128) return launch_conv_t<512, 128, 4, 2, 2, F16>(p, s);
         if (bc == 64) return launch_conv_t<512, 64, 8, 1, 2, F16>(p, s);
     }
+    if ((p.tune & 2) && variant == 0 && bc == 128 && !p.residual && p.cout % 256 == 0 && p.Ktot >= 512 &&
+        (long)p.n_cls * ((p.M + 255) / 256) * (p.cout / 256) >= 200)
+        return launch_conv_t<256, 256, 4, 2, 2, F16>(p, s);     // A/B: 64 px x 128 ch wave tiles
     if (p.small_tiles && bc == 128 && p.Ktot <= 256) return launch_conv_t<64, 128, 2, 2, 2, F16>(p, s);   // 3 blocks per CU (A/B)
     if (variant == 0 && bc == 128 && !p.residual) {
         // auto (measured per layer, profiles/r01_conv_variants.md): the 8-wave tiles with 128x64 wave
