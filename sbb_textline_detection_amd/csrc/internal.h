@@ -43,8 +43,6 @@ struct ConvParams {
     int n_src;
     const KStepRec* kstep;    // [total_ksteps]
     int variant;              // 0 = auto tile choice, 1 = force 4-wave/2-stage, 2 = force 8-wave/3-stage
-    int tune;                 // A/B bit field (bit 0: s_setprio around the MFMA cluster, bit 1: 4x2 wave arrangement)
-    int small_tiles;          // A/B: 64x128 tiles (3 blocks per CU) on short-K layers
     int tile_map;             // 0 = channel tile per XCD (big weights), 1 = pixel tiles grouped per XCD (small weights)
     int persist_blocks;       // CUs of the device (persistent grid = resident blocks); 0 = one block per tile
     const KTabEntry* ktab;    // [total_ksteps * 8]

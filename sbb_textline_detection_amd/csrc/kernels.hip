@@ -606,10 +606,6 @@ static hipError_t launch_conv_16(const ConvParams& p, hipStream_t s)
         if (bc == 128) return launch_conv_t<512, 128, 4, 2, 2, F16>(p, s);
         if (bc == 64) return launch_conv_t<512, 64, 8, 1, 2, F16>(p, s);
     }
-    if ((p.tune & 2) && variant == 0 && bc == 128 && !p.residual && p.cout % 256 == 0 && p.Ktot >= 512 &&
-        (long)p.n_cls * ((p.M + 255) / 256) * (p.cout / 256) >= 200)
-        return launch_conv_t<256, 256, 4, 2, 2, F16>(p, s);     // A/B: 64 px x 128 ch wave tiles
-    if (p.small_tiles && bc == 128 && p.Ktot <= 256) return launch_conv_t<64, 128, 2, 2, 2, F16>(p, s);   // 3 blocks per CU (A/B)
     if (variant == 0 && bc == 128 && !p.residual) {
         // auto (measured per layer, profiles/r01_conv_variants.md): the 8-wave tiles with 128x64 wave
         // tiles (LDS bytes per MFMA x0.75, L2 bytes per MFMA x0.5) win on long-K layers that still
