@@ -185,6 +185,15 @@ def main():
                           "frac": round(conv_flops / (conv_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4),
                           "share_of_gpu_time": round(conv_ms / tot_ms, 4)},
         }
+        # HBM-side traffic of that launch from the committed rocprofv3 PMC passes of this same command
+        # (tools/pmc_run.sh; counters need their own runs, see profiles/): bytes per launch
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01s_pmc_summary.json")))["ops"].get(dom["name"])
+            if pmc and abs(dom["patches"] / dom["launches"] - 70) < 1e-6:
+                roofline["traffic"] = round(pmc["fetch_bytes"] + pmc["write_bytes"])
+                roofline["traffic_source"] = "profiles/r01s_pmc_summary.json (FETCH_SIZE x2 + WRITE_SIZE per launch, L2 hit %.0f %%)" % pmc["l2_hit_pct"]
+        except Exception:
+            pass
         for o in prof:
             if o["launches"]:
                 per_op.append({"name": o["name"], "ms_per_launch": round(o["total_ms"] / o["launches"], 4),
