@@ -262,7 +262,8 @@ int run_plan(sbbseg_ctx* c, int n, uint8_t* d_labels, float* d_probs)
                 sd.ksteps = co.ksteps[s];
                 sd.sy_shift = co.d.src[s].stride_y == 2; sd.sx_shift = co.d.src[s].stride_x == 2;
             }
-            p.ktab = co.d_ktab; p.kstep = co.d_kstep; p.variant = c->conv_variant & 3; p.persist_blocks = (c->conv_variant & 4) ? 0 : c->num_cus;
+            p.ktab = co.d_ktab; p.kstep = co.d_kstep; p.half_stages = (c->conv_variant & 16) ? 1 : 0;
+            p.variant = c->conv_variant & 3; p.persist_blocks = (c->conv_variant & 4) ? 0 : c->num_cus;
             p.tile_map = (!(c->conv_variant & 8) && (c->conv_variant & 4) == 0 && co.d.cout > conv_tile_bc(co.d.cout) && p.M >= 256 * 128 &&
                           (size_t)co.cout_pad * co.Ktot * c->elem <= ((size_t)2 << 20)) ? 1 : 0; p.w = co.d_w; p.Ktot = co.Ktot; p.total_ksteps = co.total_ksteps;
             p.Ho = co.Ho; p.Wo = co.Wo; p.M = n * co.Ho * co.Wo;
@@ -1115,7 +1116,7 @@ int sbbseg_debug_read_tensor(sbbseg_ctx* c, int tensor_id, int n, float* out, si
 
 int sbbseg_debug_set_conv_variant(sbbseg_ctx* c, int variant)
 {
-    REQUIRE(c && variant >= 0 && variant <= 15, "variant: bits 0-1 = 0 auto | 1 4-wave/2-stage | 2 8-wave/3-stage; bit 2 = one block per tile (non-persistent); bit 3 = no XCD-grouped tile walk");
+    REQUIRE(c && variant >= 0 && variant <= 31, "variant: bits 0-1 = 0 auto | 1 4-wave/2-stage | 2 8-wave/3-stage; bit 2 = one block per tile (non-persistent); bit 3 = no XCD-grouped tile walk");
     c->conv_variant = variant;
     return 0;
 }

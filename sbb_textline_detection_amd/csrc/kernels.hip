@@ -83,25 +83,42 @@ constexpr int conv_blocks_per_cu(int bp, int bc, int wp, int wc, int ns)
     return 3 * lds <= 160 * 1024 ? 3 : (2 * lds <= 160 * 1024 ? 2 : 1);
 }
 
-template <int BP, int BC, int WP, int WC, int NS>
+template <int BP, int BC, int WP, int WC, int NS, int GS = 8>
 struct ConvTile {
+    // GS = 16-byte granules of the contraction axis per LDS stage: 8 (a whole 64-element K-step) or 4
+    // (half a K-step: twice as many, half as big stages -> deeper prefetch in the same LDS)
     static constexpr int kWaves = WP * WC;
     static constexpr int kThreads = 64 * kWaves;
+    static constexpr int kRowBytes = GS * 16;
+    static constexpr int kRowsPerInstr = 64 / GS;             // rows one global_load_lds wave-instruction fills
+    static constexpr int kStagesPerKStep = 8 / GS;
     static constexpr int kWPX = BP / WP;          // pixels per wave tile
     static constexpr int kWCH = BC / WC;          // channels per wave tile
     static constexpr int kNI = kWPX / 16;
     static constexpr int kMI = kWCH / 16;
-    static constexpr int kPLoads = BP / (8 * kWaves);   // global_load_lds per thread per K-step, pixels
-    static constexpr int kWRows = BC > 8 * kWaves ? BC : 8 * kWaves;   // weight rows staged (>= one 8-row group per wave,
-                                                                       // so every wave issues the same number of loads)
-    static constexpr int kWLoads = kWRows / (8 * kWaves);              // ... weights
+    static constexpr int kPLoads = BP / (kRowsPerInstr * kWaves);   // global_load_lds per thread per stage, pixels
+    static constexpr int kWRows = BC > kRowsPerInstr * kWaves ? BC : kRowsPerInstr * kWaves;   // weight rows staged (>= one
+                                                  // row group per wave, so every wave issues the same number of loads)
+    static constexpr int kWLoads = kWRows / (kRowsPerInstr * kWaves);   // ... weights
     static constexpr int kLoads = kPLoads + kWLoads;
-    static constexpr int kStageBytes = (BP + kWRows) * 128;
+    static constexpr int kStageBytes = (BP + kWRows) * kRowBytes;
     static constexpr int kLdsBytes = NS * kStageBytes;
-    static constexpr int kBlocksPerCU = conv_blocks_per_cu(BP, BC, WP, WC, NS);
-    static_assert(BP % (8 * kWaves) == 0 && kWRows % (8 * kWaves) == 0, "tile rows must split over the waves");
+    static constexpr int kBlocksPerCU = (kWaves == 4 && 3 * kLdsBytes <= 160 * 1024) ? 3 : (kWaves == 4 && 2 * kLdsBytes <= 160 * 1024) ? 2 : 1;
+    static_assert(GS == 8 || GS == 4, "stage = whole or half K-step");
+    static_assert(BP % (kRowsPerInstr * kWaves) == 0 && kWRows % (kRowsPerInstr * kWaves) == 0, "tile rows must split over the waves");
     static_assert(kMI % 2 == 0, "epilogue pairs MFMA row blocks");
 };
+
+// blocks per CU a tile family is sized for (LDS budget) -> min waves per SIMD for __launch_bounds__
+constexpr int conv_blocks_per_cu(int bp, int bc, int wp, int wc, int ns, int gs)
+{
+    const int waves = wp * wc;
+    const int rpi = 64 / gs;
+    const int wrows = bc > rpi * waves ? bc : rpi * waves;
+    const int lds = ns * (bp + wrows) * gs * 16;
+    if (waves != 4) return 1;
+    return 3 * lds <= 160 * 1024 ? 3 : (2 * lds <= 160 * 1024 ? 2 : 1);
+}
 
 template <int N> __device__ inline void wait_vmcnt()
 {
@@ -115,11 +132,12 @@ template <int N> __device__ inline void wait_vmcnt()
 // their time filling and draining a 1-4 step pipeline.
 // K-step descriptors come through the scalar cache (uniform address in the constant address space
 // -> s_load, lgkmcnt): no VGPR-destination VMEM load sits in the steady-state loop.
-template <int BP, int BC, int WP, int WC, int NS, bool F16>
-__global__ __launch_bounds__(64 * WP * WC, (conv_blocks_per_cu(BP, BC, WP, WC, NS) * (WP * WC) / 4))
+template <int BP, int BC, int WP, int WC, int NS, bool F16, int GS = 8>
+__global__ __launch_bounds__(64 * WP * WC, (conv_blocks_per_cu(BP, BC, WP, WC, NS, GS) * (WP * WC) / 4))
 void conv_igemm_mfma(const ConvParams p)
 {
-    using T = ConvTile<BP, BC, WP, WC, NS>;
+    using T = ConvTile<BP, BC, WP, WC, NS, GS>;
+    constexpr int RPI = T::kRowsPerInstr, RB = T::kRowBytes, SPK = T::kStagesPerKStep;
     constexpr int NW = T::kWaves;
     constexpr int D = NS - 1;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -166,10 +184,16 @@ void conv_igemm_mfma(const ConvParams p)
         const int li = slot + q * GX;
         return ((li / n_ct) * 8 + xcd) * n_ct + li % n_ct;
     };
-    const int total = my_tiles * nt;                    // K-steps this block walks
+    const int nts = nt * SPK;                           // LDS stages per tile
+    const int total = my_tiles * nts;                   // stages this block walks
 
-    const int lrow = lane >> 3;                         // row inside an 8-row glds group
-    const int gsrc = (lane & 7) ^ lrow;                 // source granule this lane fetches (swizzle)
+    // one global_load_lds wave-instruction fills RPI rows x GS granules; the LDS image is lane-linear,
+    // the XOR swizzle is applied through the SOURCE granule each lane fetches.  Row r keeps granule g
+    // at slot g ^ swz(r): swz = r & 7 for 128-byte rows, {0,2,3,1}[(r >> 2) & 3] for 64-byte rows
+    // (both brute-forced conflict-free for the four 16-lane groups of ds_read_b128).
+    const int lrow = lane / GS;                         // row inside the instruction's row group
+    const int lswz = GS == 8 ? lrow : ((0x78 >> (2 * ((lrow >> 2) & 3))) & 3);
+    const int gsrc = (lane % GS) ^ lswz;                // source granule (within the stage) this lane fetches
     const int HoWo = p.Ho * p.Wo;
 
     // both sources' descriptors live in SGPRs for the whole kernel
@@ -196,7 +220,7 @@ void conv_igemm_mfma(const ConvParams p)
         }
 #pragma unroll
         for (int j = 0; j < T::kPLoads; ++j) {
-            const int m = ptile * BP + (j * NW + wave) * 8 + lrow;
+            const int m = ptile * BP + (j * NW + wave) * RPI + lrow;
             if (m < p.M) {
                 const int n = m / HoWo;
                 const int rem = m - n * HoWo;
@@ -213,10 +237,10 @@ void conv_igemm_mfma(const ConvParams p)
         }
 #pragma unroll
         for (int j = 0; j < T::kWLoads; ++j)
-            w_off[j] = (uint32_t)((ctile * BC + min((j * NW + wave) * 8 + lrow, BC - 1)) * p.Ktot + gsrc * 8) * 2u;
+            w_off[j] = (uint32_t)((ctile * BC + min((j * NW + wave) * RPI + lrow, BC - 1)) * p.Ktot + gsrc * 8) * 2u;
     };
 
-    int l_t = 0, l_q = 0, issued = 0;
+    int l_t = 0, l_h = 0, l_q = 0, issued = 0;          // load side: K-step, stage inside it, tile
     int rec_yx = kstep_tab[0], rec_coff = kstep_tab[1], rec_irr = kstep_tab[2];   // record of the NEXT stage issued
     auto issue = [&](int buf) __attribute__((always_inline)) {
         const int t = l_t;
@@ -228,14 +252,15 @@ void conv_igemm_mfma(const ConvParams p)
         const int sh = s1 ? sd1.shift : sd0.shift;
         const int ssy = s1 ? sd1.sy_shift : sd0.sy_shift, ssx = s1 ? sd1.sx_shift : sd0.sx_shift;
         const unsigned lim_y = s1 ? sd1.lim_y : sd0.lim_y, lim_x = s1 ? sd1.lim_x : sd0.lim_x;
+        const int gfull = l_h * GS + gsrc;                     // granule inside the 64-element K-step
         int dy = (int)(short)(rec_yx & 0xffff), dx = rec_yx >> 16;
-        int coff = rec_coff + gsrc * 16 + kZeroHeaderBytes;
+        int coff = rec_coff + gfull * 16 + kZeroHeaderBytes;
         if (rec_irr) {                                         // granules of this step differ in tap
-            const KTabEntry e = ktab[t * kGranulesPerStep + gsrc];
+            const KTabEntry e = ktab[t * kGranulesPerStep + gfull];
             dy = e.dy; dx = e.dx; coff = e.coff + kZeroHeaderBytes;
         }
         char* lds_p = smem + buf * T::kStageBytes;
-        char* lds_w = lds_p + BP * 128;
+        char* lds_w = lds_p + BP * RB;
 #pragma unroll
         for (int j = 0; j < T::kPLoads; ++j) {
             const int uy = (r_oy[j] << ssy) + dy;           // dy/dx carry tap - pad - placement offset
@@ -247,20 +272,23 @@ void conv_igemm_mfma(const ConvParams p)
             off = ok ? off : 0u;
             // (a non-temporal policy on these loads was measured 5-35 % slower: the tap re-reads live in L2)
             __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(base + off),
-                                             (LDS_AS void*)(lds_p + (j * NW + wave) * 8 * 128), 16, 0, 0);
+                                             (LDS_AS void*)(lds_p + (j * NW + wave) * 1024), 16, 0, 0);
         }
 #pragma unroll
         for (int j = 0; j < T::kWLoads; ++j) {
-            __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(wbase + w_off[j] + (uint32_t)t * (kBK * 2)),
-                                             (LDS_AS void*)(lds_w + (j * NW + wave) * 8 * 128), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(wbase + w_off[j] + (uint32_t)(t * (kBK * 2) + l_h * GS * 16)),
+                                             (LDS_AS void*)(lds_w + (j * NW + wave) * 1024), 16, 0, 0);
         }
         // advance the load side; crossing into the next tile re-derives the gather rows
         ++issued;
-        if (++l_t == nt) {
-            l_t = 0;
-            if (++l_q < my_tiles) setup_rows(tile_at(l_q));
+        if (++l_h == SPK) {
+            l_h = 0;
+            if (++l_t == nt) {
+                l_t = 0;
+                if (++l_q < my_tiles) setup_rows(tile_at(l_q));
+            }
+            rec_yx = kstep_tab[l_t * 4 + 0]; rec_coff = kstep_tab[l_t * 4 + 1]; rec_irr = kstep_tab[l_t * 4 + 2];
         }
-        rec_yx = kstep_tab[l_t * 4 + 0]; rec_coff = kstep_tab[l_t * 4 + 1]; rec_irr = kstep_tab[l_t * 4 + 2];
     };
 
     f32x4_t acc[T::kMI][T::kNI];
@@ -272,10 +300,11 @@ void conv_igemm_mfma(const ConvParams p)
     // LDS read offsets: row r, granule g lives at r*128 + ((g ^ (r & 7)) * 16)
     const int frow = lane & 15;
     const int fg = lane >> 4;
-    const int rd_k0 = frow * 128 + (((0 + fg) ^ (frow & 7)) << 4);
-    const int rd_k1 = frow * 128 + (((4 + fg) ^ (frow & 7)) << 4);
-    const int p_rd = (wp * T::kWPX) * 128;
-    const int w_rd = BP * 128 + (wc * T::kWCH) * 128;
+    const int fswz = GS == 8 ? (frow & 7) : ((0x78 >> (2 * ((frow >> 2) & 3))) & 3);
+    const int rd_k0 = frow * RB + (((0 + fg) ^ fswz) << 4);
+    const int rd_k1 = frow * RB + (((4 + fg) ^ fswz) << 4);        // second k-half of a whole-K-step stage (GS == 8)
+    const int p_rd = (wp * T::kWPX) * RB;
+    const int w_rd = BP * RB + (wc * T::kWCH) * RB;
 
     // ---- epilogue of one finished tile.  Weight rows are packed in the order conv_row_channel()
     // gives, so the two MFMA row blocks (2s, 2s+1) of a lane hold 8 CONSECUTIVE channels of one
@@ -433,14 +462,14 @@ void conv_igemm_mfma(const ConvParams p)
 #pragma unroll
     for (int d = 0; d < D; ++d)
         if (d < total) issue(d);
-    if (D >= 2 && total >= 2) wait_vmcnt<T::kLoads*(D >= 2 ? D - 1 : 0)>();
+    if (D >= 2 && total >= D) wait_vmcnt<T::kLoads*(D >= 2 ? D - 1 : 0)>();     // stage 0 landed, D-1 stages stay in flight
     else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
 
     int cur = 0, nxt = D % NS, c_t = 0, c_q = 0;
     for (int s = 0; s < total; ++s) {
         if (issued < total) issue(nxt);
-        if (kPrefetchRes && p.residual && c_t == nt - 1) prefetch_residual(tile_at(c_q));
+        if (kPrefetchRes && p.residual && c_t == nts - 1) prefetch_residual(tile_at(c_q));
         const char* sb = smem + cur * T::kStageBytes;
         {
             // The K-step's MFMAs run in phases of (k-half kk, group of <= 4 pixel blocks); the LDS
@@ -449,17 +478,17 @@ void conv_igemm_mfma(const ConvParams p)
             // leaves the matrix pipe idle while all 8 waves of the block read LDS in lockstep.
             constexpr int NIH = T::kNI >= 8 ? T::kNI / 2 : T::kNI;     // pixel blocks per phase
             constexpr int NH = T::kNI / NIH;
-            constexpr int NP = 2 * NH;
+            constexpr int NP = (GS / 4) * NH;                      // k-halves per stage x pixel-block groups
             bf16x8_t a[2][T::kMI], b[2][NIH];
             auto load_a = [&](int kk, bf16x8_t (&dst)[T::kMI]) __attribute__((always_inline)) {
                 const int rd = kk ? rd_k1 : rd_k0;
 #pragma unroll
-                for (int mi = 0; mi < T::kMI; ++mi) dst[mi] = *(const bf16x8_t*)(sb + w_rd + mi * 16 * 128 + rd);
+                for (int mi = 0; mi < T::kMI; ++mi) dst[mi] = *(const bf16x8_t*)(sb + w_rd + mi * 16 * RB + rd);
             };
             auto load_b = [&](int kk, int h, bf16x8_t (&dst)[NIH]) __attribute__((always_inline)) {
                 const int rd = kk ? rd_k1 : rd_k0;
 #pragma unroll
-                for (int q = 0; q < NIH; ++q) dst[q] = *(const bf16x8_t*)(sb + p_rd + (h * NIH + q) * 16 * 128 + rd);
+                for (int q = 0; q < NIH; ++q) dst[q] = *(const bf16x8_t*)(sb + p_rd + (h * NIH + q) * 16 * RB + rd);
             };
             load_a(0, a[0]);
             load_b(0, 0, b[0]);
@@ -479,7 +508,7 @@ void conv_igemm_mfma(const ConvParams p)
             }
         }
         bool tile_done = false;
-        if (++c_t == nt) {                                  // tile finished: its stores overlap the
+        if (++c_t == nts) {                                 // tile finished: its stores overlap the
             epilogue(tile_at(c_q));                         // next tile's first stage(s), already in flight
             c_t = 0;
             ++c_q;
@@ -564,16 +593,16 @@ int conv_row_channel(int row, int cout)
     return base + (mi >> 1) * 32 + (rho >> 2) * 8 + (mi & 1) * 4 + (rho & 3);
 }
 
-template <int BP, int BC, int WP, int WC, int NS, bool F16>
+template <int BP, int BC, int WP, int WC, int NS, bool F16, int GS = 8>
 static hipError_t launch_conv_t(const ConvParams& p, hipStream_t s)
 {
-    using T = ConvTile<BP, BC, WP, WC, NS>;
+    using T = ConvTile<BP, BC, WP, WC, NS, GS>;
     static bool attr_done[64] = {};
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
     if (!attr_done[dev & 63]) {
-        e = hipFuncSetAttribute((const void*)conv_igemm_mfma<BP, BC, WP, WC, NS, F16>,
+        e = hipFuncSetAttribute((const void*)conv_igemm_mfma<BP, BC, WP, WC, NS, F16, GS>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, T::kLdsBytes);
         if (e != hipSuccess) return e;
         attr_done[dev & 63] = true;
@@ -586,7 +615,7 @@ static hipError_t launch_conv_t(const ConvParams& p, hipStream_t s)
     const int resident = p.persist_blocks > 0 ? p.persist_blocks * T::kBlocksPerCU : n_tiles;
     int grid = n_tiles < resident ? n_tiles : resident;
     if (p.tile_map == 1 && grid >= 8) grid &= ~7;          // the XCD-grouped walk needs a multiple of 8 blocks
-    hipLaunchKernelGGL((conv_igemm_mfma<BP, BC, WP, WC, NS, F16>), dim3(grid), dim3(T::kThreads), T::kLdsBytes, s, p);
+    hipLaunchKernelGGL((conv_igemm_mfma<BP, BC, WP, WC, NS, F16, GS>), dim3(grid), dim3(T::kThreads), T::kLdsBytes, s, p);
     return hipGetLastError();
 }
 
@@ -601,6 +630,12 @@ static hipError_t launch_conv_16(const ConvParams& p, hipStream_t s)
     const long big_blocks = (long)((p.M + 255) / 256) * ((p.cout + bc - 1) / bc);
     const bool big = variant == 2;
     (void)big_blocks;
+    if (p.half_stages) {   // A/B: half-K-step stages, 4-deep ring (3 stages in flight across the barriers)
+        const long t256 = (long)p.n_cls * ((p.M + 255) / 256) * (p.cout / 256);
+        if (bc == 128 && !p.residual && p.cout % 256 == 0 && p.Ktot >= 512 && t256 >= 200) return launch_conv_t<256, 256, 2, 4, 4, F16, 4>(p, s);
+        if (bc == 128) return launch_conv_t<128, 128, 2, 2, 4, F16, 4>(p, s);
+        if (bc == 64) return launch_conv_t<256, 64, 4, 1, 4, F16, 4>(p, s);
+    }
     if (variant == 3) {   // force: 8 waves, wave tile 128 px x 64 ch (64x64 for cout 64), 2 LDS stages, 1 block per CU
         if (bc == 128 && p.cout % 256 == 0) return launch_conv_t<256, 256, 2, 4, 2, F16>(p, s);
         if (bc == 128) return launch_conv_t<512, 128, 4, 2, 2, F16>(p, s);
