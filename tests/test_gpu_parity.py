@@ -271,3 +271,32 @@ def test_three_model_pipeline(tmp_path):
     got = predict.do_prediction(True, crop, load_model(str(tmp_path / "model_strukturerkennung.h5"), max_batch=16))[:, :, 0]
     assert (ref != got).mean() < 0.06
     clear_session()
+
+
+def test_c_abi_error_paths_do_not_abort(stitch_model):
+    """Bad arguments come back as return codes / RuntimeError (the reference's callers rely on
+    ordinary exceptions, main.py:2061-2157) and leave the handle usable."""
+    m = stitch_model
+    with pytest.raises(RuntimeError, match="smaller than the model"):
+        m.segment_page(np.zeros((300, 500, 3), np.uint8))
+    with pytest.raises(ValueError):
+        m.predict(np.zeros((1, 100, 100, 3), np.float32))
+    with pytest.raises(RuntimeError):
+        m.ctx.debug_read_tensor(0, 10 ** 6, (1, 1, 1))
+    with pytest.raises(RuntimeError, match="variant"):
+        m.ctx.set_conv_variant(999)
+    page = synthetic_page(448, 448, seed=1)              # 448x448 page -> 4 identical clamped tiles (SURVEY 8a-3)
+    lab = m.segment_page(page)
+    assert lab.shape == (448, 448)
+    one = m.predict((page[None] / 255.0).astype(np.float32)).argmax(-1)[0].astype(np.uint8)
+    assert np.array_equal(lab, one)
+
+
+def test_batch_one_and_four_classes():
+    cfg, w, g, model = make_model(4, 224, 224, seed=8, precision="f16", max_batch=1)
+    page = synthetic_page(400, 460, seed=2)
+    a = predict.do_prediction(True, page, model)
+    cfg2, w2, g2, m7 = make_model(4, 224, 224, seed=8, precision="f16", max_batch=7)
+    b = predict.do_prediction(True, page, m7)
+    assert np.array_equal(a, b) and a.max() <= 3
+    model.release(); m7.release()
