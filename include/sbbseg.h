@@ -169,8 +169,12 @@ int sbbseg_debug_ingest(sbbseg_ctx* c, const uint8_t* page_hwc, int Hp, int Wp, 
 /* copy an activation tensor of the last run back as float32 [n][H][W][C] (tests) */
 int sbbseg_debug_read_tensor(sbbseg_ctx* c, int tensor_id, int n, float* out, size_t out_floats);
 
-/* force the conv tile family (A/B benchmarking, tests): 0 auto, 1 = 4 waves / 2 LDS stages,
- * 2 = 8 waves / 3 LDS stages with counted waits */
+/* A/B knobs of the conv kernel (benchmarking, tests; results never depend on them).  bits 0-1: tile
+ * family (0 auto, 1 = 4 waves / 2 LDS stages, 2 = 8 waves / 3 stages, 3 = big 8-wave tiles);
+ * bit 2 = one block per tile instead of persistent blocks; bit 3 = no XCD-grouped tile walk;
+ * bit 4 = half-K-step stages in a 4-deep ring; bit 5 = XCD-grouped tile walk on single-class layers too;
+ * bit 6 = drain the epilogue stores before the next barrier; bit 7 = half-line (64-byte) epilogue stores; bits 8-15 = with bit 5: K limit (units of
+ * 64) up to which every block walks a contiguous run of tiles (0 = keep the current limit) */
 int sbbseg_debug_set_conv_variant(sbbseg_ctx* c, int variant);
 
 /* ---- per-op timing with HIP events on the handle's stream (bench.py roofline) */

@@ -120,6 +120,12 @@ constexpr int conv_blocks_per_cu(int bp, int bc, int wp, int wc, int ns, int gs)
     return 3 * lds <= 160 * 1024 ? 3 : (2 * lds <= 160 * 1024 ? 2 : 1);
 }
 
+// value of lane (l ^ 8) inside each row of 16 lanes (DPP row_ror:8)
+__device__ inline uint32_t row_ror8(uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xf, 0xf, false);
+}
+
 template <int N> __device__ inline void wait_vmcnt()
 {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -174,14 +180,22 @@ void conv_igemm_mfma(const ConvParams p)
             ptile = e - cls * n_pt1;
         }
     };
-    const bool pshare = p.tile_map == 1 && (G & 7) == 0;
+    // map 2 (short-K layers): as map 1, but every block owns a CONTIGUOUS run of its XCD's list, so the
+    // channel tiles of one pixel tile run back to back in the SAME block.  Blocks of a short-K layer
+    // march in lockstep; under map 1 the sibling blocks miss on the same pixel rows at the same moment
+    // and the rows are fetched from HBM once per channel tile (PMC: fetch = n_ct x the input tensor).
+    const bool pshare = p.tile_map >= 1 && (G & 7) == 0;
+    const bool contig = p.tile_map == 2;
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, GX = G >> 3;
     const int xcd_tiles = pshare ? ((n_pt - xcd + 7) >> 3) * n_ct : 0;
-    const int my_tiles = pshare ? (slot < xcd_tiles ? (xcd_tiles - slot + GX - 1) / GX : 0)
-                                : (n_tiles - (int)blockIdx.x + G - 1) / G;
+    const int run_lo = contig ? (int)((long long)slot * xcd_tiles / GX) : 0;
+    const int run_hi = contig ? (int)((long long)(slot + 1) * xcd_tiles / GX) : 0;
+    const int my_tiles = !pshare ? (n_tiles - (int)blockIdx.x + G - 1) / G
+                         : contig ? run_hi - run_lo
+                                  : (slot < xcd_tiles ? (xcd_tiles - slot + GX - 1) / GX : 0);
     auto tile_at = [&](int q) __attribute__((always_inline)) -> int {
         if (!pshare) return blockIdx.x + q * G;
-        const int li = slot + q * GX;
+        const int li = contig ? run_lo + q : slot + q * GX;
         return ((li / n_ct) * 8 + xcd) * n_ct + li % n_ct;
     };
     const int nts = nt * SPK;                           // LDS stages per tile
@@ -346,14 +360,90 @@ void conv_igemm_mfma(const ConvParams p)
     // ---- epilogue of one finished tile.  Weight rows are packed in the order conv_row_channel()
     // gives, so the two MFMA row blocks (2s, 2s+1) of a lane hold 8 CONSECUTIVE channels of one
     // pixel: 16-byte NHWC stores / residual loads, 64 contiguous bytes per pixel per instruction.
-    auto epilogue = [&](int tile) __attribute__((always_inline)) {
+    // Returns true when this wave issued EXACTLY kEpiStores (x2 with a raw copy) store instructions:
+    // a full interior tile with a plain 16-bit output.  The caller may then leave those stores in
+    // flight behind a counted wait (vmcnt retires loads and stores in issue order on gfx9-family
+    // parts, and the staging loads were issued before the stores).
+    auto epilogue = [&](int tile) __attribute__((always_inline)) -> bool {
         int ctile, cls, ptile;
         decode(tile, ctile, cls, ptile);
+        const bool full = (ptile * BP + (wp + 1) * T::kWPX <= p.M) && (ctile * BC + (wc + 1) * T::kWCH <= p.cout) &&
+                          p.out != nullptr && !(BC == 32 && p.head_classes > 0);
         int opix[T::kNI];
 #pragma unroll
         for (int ni = 0; ni < T::kNI; ++ni) {
             const int m = ptile * BP + wp * T::kWPX + ni * 16 + frow;
             opix[ni] = m < p.M ? out_pixel(m, cls) : -1;
+        }
+        if constexpr (T::kMI % 4 == 0) {
+            // Full interior tile: whole-line stores.  A lane holds 8 channels of pixel `frow` from row-block
+            // pair s2 (A) and from pair s2+1 (B); lanes frow and frow^8 swap "B of the low pixel" against
+            // "A of the high pixel" (one DPP row rotate), after which each store instruction writes 8
+            // pixels x 128 contiguous, line-aligned bytes instead of 16 pixels x 64 (half lines).
+            if (full && !p.raw_out && !(p.variant_flags & 2)) {
+                const bool hi = (frow & 8) != 0;
+#pragma unroll
+                for (int sp = 0; sp < T::kMI / 4; ++sp) {
+                    const int cA = ctile * BC + wc * T::kWCH + sp * 64 + fg * 8;
+                    const int cst = cA + (hi ? 32 : 0);
+                    float sc[2][8], sh[2][8];
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        *(float4*)&sc[h][0] = *(const float4*)(p.scale + cA + h * 32);
+                        *(float4*)&sc[h][4] = *(const float4*)(p.scale + cA + h * 32 + 4);
+                        *(float4*)&sh[h][0] = *(const float4*)(p.shift + cA + h * 32);
+                        *(float4*)&sh[h][4] = *(const float4*)(p.shift + cA + h * 32 + 4);
+                    }
+#pragma unroll
+                    for (int ni = 0; ni < T::kNI; ++ni) {
+                        uint4 r[2];
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            const int s2 = sp * 2 + h;
+                            float y[8];
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                y[q] = acc[2 * s2][ni][q] * sc[h][q] + sh[h][q];
+                                y[4 + q] = acc[2 * s2 + 1][ni][q] * sc[h][4 + q] + sh[h][4 + q];
+                            }
+                            if (p.residual) {
+                                uint4 rr;
+                                if constexpr (kPrefetchRes) rr = res[s2][ni];
+                                else rr = *(const uint4*)((const uint16_t*)p.residual + (size_t)opix[ni] * p.cout + cA + h * 32);
+                                y[0] += unpack_lo<F16>(rr.x); y[1] += unpack_hi<F16>(rr.x);
+                                y[2] += unpack_lo<F16>(rr.y); y[3] += unpack_hi<F16>(rr.y);
+                                y[4] += unpack_lo<F16>(rr.z); y[5] += unpack_hi<F16>(rr.z);
+                                y[6] += unpack_lo<F16>(rr.w); y[7] += unpack_hi<F16>(rr.w);
+                            }
+                            if (p.relu) {
+#pragma unroll
+                                for (int q = 0; q < 8; ++q) y[q] = fmaxf(y[q], 0.f);
+                            }
+                            r[h].x = pack2<F16>(y[0], y[1]); r[h].y = pack2<F16>(y[2], y[3]);
+                            r[h].z = pack2<F16>(y[4], y[5]); r[h].w = pack2<F16>(y[6], y[7]);
+                        }
+                        uint4 give, recv;
+                        give.x = hi ? r[0].x : r[1].x; give.y = hi ? r[0].y : r[1].y;
+                        give.z = hi ? r[0].z : r[1].z; give.w = hi ? r[0].w : r[1].w;
+                        recv.x = row_ror8(give.x); recv.y = row_ror8(give.y);
+                        recv.z = row_ror8(give.z); recv.w = row_ror8(give.w);
+                        const int o_other = (int)row_ror8((uint32_t)opix[ni]);
+                        const int pix0 = hi ? o_other : opix[ni], pix1 = hi ? opix[ni] : o_other;
+                        uint4 st0, st1;
+                        st0.x = hi ? recv.x : r[0].x; st0.y = hi ? recv.y : r[0].y;
+                        st0.z = hi ? recv.z : r[0].z; st0.w = hi ? recv.w : r[0].w;
+                        st1.x = hi ? r[1].x : recv.x; st1.y = hi ? r[1].y : recv.y;
+                        st1.z = hi ? r[1].z : recv.z; st1.w = hi ? r[1].w : recv.w;
+                        *(uint4*)((uint16_t*)p.out + (size_t)pix0 * p.cout + cst) = st0;
+                        *(uint4*)((uint16_t*)p.out + (size_t)pix1 * p.cout + cst) = st1;
+                    }
+                }
+#pragma unroll
+                for (int mi = 0; mi < T::kMI; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < T::kNI; ++ni) acc[mi][ni] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+                return true;
+            }
         }
 #pragma unroll
         for (int s2 = 0; s2 < T::kMI / 2; ++s2) {
@@ -453,7 +543,9 @@ void conv_igemm_mfma(const ConvParams p)
         for (int mi = 0; mi < T::kMI; ++mi)
 #pragma unroll
             for (int ni = 0; ni < T::kNI; ++ni) acc[mi][ni] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        return full;
     };
+    constexpr int kEpiStores = (T::kMI / 2) * T::kNI;             // store instructions per wave per output tensor
 
     // ---- prologue: D stages in flight, stage 0 landed
     if (total == 0) return;
@@ -507,17 +599,25 @@ void conv_igemm_mfma(const ConvParams p)
                         acc[mi][h * NIH + q] = mfma16<F16>(a[kk & 1][mi], b[ph & 1][q], acc[mi][h * NIH + q]);
             }
         }
-        bool tile_done = false;
+        bool tile_done = false, counted = false;
         if (++c_t == nts) {                                 // tile finished: its stores overlap the
-            epilogue(tile_at(c_q));                         // next tile's first stage(s), already in flight
+            counted = epilogue(tile_at(c_q));               // next tile's first stage(s), already in flight
             c_t = 0;
             ++c_q;
             tile_done = true;
         }
         if (s + 1 < total) {
-            // stage s+1 must have landed; later issued stages stay in flight across the barrier.
-            // (after an epilogue the counter also holds its stores: drain completely there)
-            if (D >= 2 && !tile_done && s + D < total) wait_vmcnt<T::kLoads*(D >= 2 ? D - 1 : 0)>();
+            // stage s+1 must have landed; later issued stages stay in flight across the barrier, and
+            // so do the stores of a tile that just finished (they are younger than every staging
+            // load): a short-K layer otherwise pays a load AND a store round trip per tile, in series.
+            constexpr int kAhead = T::kLoads * (D >= 2 ? D - 1 : 0);
+            const bool ring_full = D < 2 || s + D < total;          // D-1 younger stages really are in flight
+            if (tile_done) {
+                if (counted && ring_full && !(p.variant_flags & 1)) {
+                    if (p.raw_out) wait_vmcnt<kAhead + 2 * kEpiStores>();
+                    else wait_vmcnt<kAhead + kEpiStores>();
+                } else wait_vmcnt<0>();
+            } else if (D >= 2 && ring_full) wait_vmcnt<kAhead>();
             else wait_vmcnt<0>();
             __builtin_amdgcn_s_barrier();
         }
@@ -614,7 +714,7 @@ static hipError_t launch_conv_t(const ConvParams& p, hipStream_t s)
     // the 8-wave ones); p.persist_blocks == 0 -> one block per tile (A/B)
     const int resident = p.persist_blocks > 0 ? p.persist_blocks * T::kBlocksPerCU : n_tiles;
     int grid = n_tiles < resident ? n_tiles : resident;
-    if (p.tile_map == 1 && grid >= 8) grid &= ~7;          // the XCD-grouped walk needs a multiple of 8 blocks
+    if (p.tile_map >= 1) grid = (grid + 7) & ~7;          // the XCD-grouped walk needs a multiple of 8 blocks
     hipLaunchKernelGGL((conv_igemm_mfma<BP, BC, WP, WC, NS, F16, GS>), dim3(grid), dim3(T::kThreads), T::kLdsBytes, s, p);
     return hipGetLastError();
 }
