@@ -90,22 +90,27 @@ def main():
 
     if args.workload == "pipeline3":
         # configs[2]: the three stage models on one page (model load excluded, models stay resident)
-        from sbb_textline_detection_amd.stages import otsu_copy
         cfg_b, w_b = calibrated_model(2, MODEL_HW, MODEL_HW, seed=11)
         cfg_l, w_l = calibrated_model(4, MODEL_HW, MODEL_HW, seed=12)
         m_border = SegModel(cfg_b, w_b, device=local_rank, max_batch=1, precision=args.precision)
         m_layout = SegModel(cfg_l, w_l, device=local_rank, max_batch=args.max_batch, precision=args.precision)
         for m in (m_border, m_layout):
             m.ctx.set_stream(torch.cuda.current_stream().cuda_stream)
-        d_otsu = torch.from_numpy(otsu_copy(page).astype(np.uint8)).cuda()
+        d_thr = torch.zeros(1, dtype=torch.int32, device="cuda")
+        d_tiles2 = torch.empty((tiles_per_page, MODEL_HW, MODEL_HW), dtype=torch.uint8, device="cuda")
         d_lab2 = torch.empty((PAGE_H, PAGE_W), dtype=torch.uint8, device="cuda")
         tiles_per_step = (1 + 2 * tiles_per_page) * world
         workload_desc = (f"three-model pipeline on one {PAGE_H}x{PAGE_W} page per GPU: border (whole image, 1 forward) + layout "
-                         f"(Otsu'd page, 4 classes, {tiles_per_page} tiles) + textline ({tiles_per_page} tiles); models resident")
+                         f"(device Otsu + binarising gather, 4 classes, {tiles_per_page} tiles) + textline ({tiles_per_page} tiles); models resident")
 
         def step():  # noqa: F811
             m_border.segment_whole(page, PAGE_H, PAGE_W)                       # host page in / host mask out (1 forward)
-            m_layout.ctx.segment_page_dev(d_otsu.data_ptr(), PAGE_H, PAGE_W, d_lab2.data_ptr())
+            # layout stage = otsu_copy + do_prediction (main.py:443-447): histogram, threshold and the
+            # binarising gather all run on the device inside the timed step
+            m_layout.ctx.otsu_dev(d_page.data_ptr(), PAGE_H, PAGE_W, d_thr.data_ptr())
+            m_layout.ctx.segment_tile_range_bin_dev(d_page.data_ptr(), PAGE_H, PAGE_W, 0, tiles_per_page, d_thr.data_ptr(),
+                                                    d_tiles2.data_ptr())
+            m_layout.ctx.stitch_dev(d_tiles2.data_ptr(), PAGE_H, PAGE_W, d_lab2.data_ptr())
             ctx.segment_page_dev(d_page.data_ptr(), PAGE_H, PAGE_W, d_labels.data_ptr())
     elif args.workload == "batch64":
         # configs[3]: 64 pages of 4000x3000, whole pages per rank, one all-gather of the masks per step

@@ -147,6 +147,20 @@ int sbbseg_segment_page_dev(sbbseg_ctx* c, const void* d_page_hwc, int Hp, int W
 int sbbseg_segment_page_scaled(sbbseg_ctx* c, const uint8_t* page_hwc, int Hs, int Ws, int Hp, int Wp,
                                uint8_t* labels_hw);
 
+/* The layout stage's caller fused in: extract_text_regions (main.py:439-447) = otsu_copy (main.py:178-194:
+ * cv2.threshold(channel 0, THRESH_BINARY + THRESH_OTSU), the channel-0 result written to all three
+ * channels) + astype(uint8) + do_prediction(patches=True), on the page rescaled to Hp x Wp as above
+ * (Hs == Hp and Ws == Wp: no rescale).  Histogram and threshold run on the device; the binarised page
+ * is never materialised (the tile gather compares channel 0 with the threshold).  *threshold (may be
+ * NULL) receives the Otsu threshold. */
+int sbbseg_segment_page_otsu(sbbseg_ctx* c, const uint8_t* page_hwc, int Hs, int Ws, int Hp, int Wp,
+                             uint8_t* labels_hw, int* threshold);
+/* building blocks of the same for sharded runs: threshold of a device page into a device int, and a
+ * tile range gathered through that threshold */
+int sbbseg_otsu_dev(sbbseg_ctx* c, const void* d_page_hwc, int Hp, int Wp, int* d_threshold);
+int sbbseg_segment_tile_range_bin_dev(sbbseg_ctx* c, const void* d_page_hwc, int Hp, int Wp, int first_tile,
+                                      int n_tiles, const int* d_threshold, void* d_tile_labels);
+
 /* ---- seam 1, patches=False (main.py:368-380): nearest-resize page to the model size, one forward,
  * argmax, nearest-resize labels to out_h x out_w (cv2.INTER_NEAREST index rule). */
 int sbbseg_segment_whole(sbbseg_ctx* c, const uint8_t* page_hwc, int Hp, int Wp,

@@ -21,7 +21,8 @@ EXPORTS = [
     "sbbseg_set_stream", "sbbseg_synchronize", "sbbseg_set_input", "sbbseg_input_form", "sbbseg_add_tensor",
     "sbbseg_add_conv", "sbbseg_add_maxpool", "sbbseg_add_tail", "sbbseg_add_head", "sbbseg_finalize", "sbbseg_model_info",
     "sbbseg_num_ops", "sbbseg_op_info", "sbbseg_device_bytes", "sbbseg_predict", "sbbseg_segment_page",
-    "sbbseg_segment_page_dev", "sbbseg_segment_page_scaled", "sbbseg_segment_whole", "sbbseg_tile_grid", "sbbseg_segment_tiles_dev",
+    "sbbseg_segment_page_dev", "sbbseg_segment_page_scaled", "sbbseg_segment_page_otsu", "sbbseg_otsu_dev",
+    "sbbseg_segment_tile_range_bin_dev", "sbbseg_segment_whole", "sbbseg_tile_grid", "sbbseg_segment_tiles_dev",
     "sbbseg_segment_tile_range_dev", "sbbseg_stitch_dev", "sbbseg_debug_ingest", "sbbseg_debug_read_tensor",
     "sbbseg_debug_set_conv_variant",
     "sbbseg_profile_enable", "sbbseg_profile_reset", "sbbseg_profile_get",
@@ -80,6 +81,9 @@ def load_library(path: Optional[str] = None):
         "sbbseg_segment_page": [vp, vp, i32, i32, vp],
         "sbbseg_segment_page_dev": [vp, vp, i32, i32, vp],
         "sbbseg_segment_page_scaled": [vp, vp, i32, i32, i32, i32, vp],
+        "sbbseg_segment_page_otsu": [vp, vp, i32, i32, i32, i32, vp, C.POINTER(C.c_int)],
+        "sbbseg_otsu_dev": [vp, vp, i32, i32, vp],
+        "sbbseg_segment_tile_range_bin_dev": [vp, vp, i32, i32, i32, i32, vp, vp],
         "sbbseg_segment_whole": [vp, vp, i32, i32, i32, i32, vp],
         "sbbseg_tile_grid": [i32, i32, i32, i32, vp, i32, C.POINTER(C.c_int), C.POINTER(C.c_int)],
         "sbbseg_segment_tiles_dev": [vp, vp, i32, i32, vp, i32, vp],
@@ -249,6 +253,26 @@ class Context:
         check(self.lib.sbbseg_segment_page_scaled(self.h, _ptr(page), page.shape[0], page.shape[1], out_h, out_w, _ptr(out)),
               "sbbseg_segment_page_scaled")
         return out
+
+    def segment_page_otsu(self, page: np.ndarray, out_h: int = 0, out_w: int = 0):
+        """extract_text_regions (main.py:439-447) in one call: (optional nearest rescale to out_h x out_w) +
+        otsu_copy + do_prediction(patches=True).  Returns (labels uint8 [out_h, out_w], Otsu threshold)."""
+        page = np.ascontiguousarray(page, np.uint8)
+        if page.ndim != 3 or page.shape[2] != 3:
+            raise ValueError(f"page must be uint8 [H,W,3], got {page.shape}")
+        out_h, out_w = (out_h or page.shape[0]), (out_w or page.shape[1])
+        out = np.empty((out_h, out_w), np.uint8)
+        thr = C.c_int(0)
+        check(self.lib.sbbseg_segment_page_otsu(self.h, _ptr(page), page.shape[0], page.shape[1], out_h, out_w, _ptr(out),
+                                                C.byref(thr)), "sbbseg_segment_page_otsu")
+        return out, int(thr.value)
+
+    def otsu_dev(self, d_page: int, Hp: int, Wp: int, d_threshold: int):
+        check(self.lib.sbbseg_otsu_dev(self.h, C.c_void_p(d_page), Hp, Wp, C.c_void_p(d_threshold)), "sbbseg_otsu_dev")
+
+    def segment_tile_range_bin_dev(self, d_page: int, Hp: int, Wp: int, first: int, n: int, d_threshold: int, d_tile_labels: int):
+        check(self.lib.sbbseg_segment_tile_range_bin_dev(self.h, C.c_void_p(d_page), Hp, Wp, first, n, C.c_void_p(d_threshold),
+                                                         C.c_void_p(d_tile_labels)), "sbbseg_segment_tile_range_bin_dev")
 
     def segment_whole(self, page: np.ndarray, out_h: int, out_w: int) -> np.ndarray:
         page = np.ascontiguousarray(page, np.uint8)

@@ -116,6 +116,7 @@ struct sbbseg_ctx {
     size_t device_bytes = 0;
     // run-time buffers
     float* d_lut = nullptr;
+    unsigned* d_hist = nullptr;   // [256] channel-0 histogram + [1] Otsu threshold (int) behind it
     int* d_tile_xy = nullptr;          // [max_batch][2]
     uint8_t* d_batch_labels = nullptr; // [max_batch][H][W] (predict / whole-image path)
     float* d_probs = nullptr;          // [max_batch][H][W][classes], lazily allocated
@@ -406,7 +407,7 @@ int sbbseg_destroy(sbbseg_ctx* c)
         hipFree(op.tail.d_wfrag); hipFree(op.tail.d_scale); hipFree(op.tail.d_shift); hipFree(op.tail.d_head_w);
         hipFree(op.tail.d_head_scale); hipFree(op.tail.d_head_shift);
     }
-    hipFree(c->d_lut); hipFree(c->d_tile_xy); hipFree(c->d_batch_labels); hipFree(c->d_probs); hipFree(c->d_xin);
+    hipFree(c->d_lut); hipFree(c->d_hist); hipFree(c->d_tile_xy); hipFree(c->d_batch_labels); hipFree(c->d_probs); hipFree(c->d_xin);
     hipFree(c->d_page); hipFree(c->d_page_labels); hipFree(c->d_tile_labels);
     hipFree(c->d_own_x); hipFree(c->d_own_y); hipFree(c->d_map);
     for (auto& pe : c->pending) { hipEventDestroy(pe.a); hipEventDestroy(pe.b); }
@@ -817,6 +818,7 @@ int sbbseg_finalize(sbbseg_ctx* c, int max_batch)
     float lut[256];
     for (int v = 0; v < 256; ++v) lut[v] = (float)((double)v / 255.0);   // main.py:239 in f64, then Keras' f32 feed
     if (upload(c, &c->d_lut, lut, 256)) return 1;
+    if (dmalloc(c, (void**)&c->d_hist, 257 * sizeof(unsigned))) return 1;
     if (dmalloc(c, (void**)&c->d_tile_xy, sizeof(int) * 2 * max_batch)) return 1;
     if (dmalloc(c, (void**)&c->d_batch_labels, (size_t)max_batch * c->in_H * c->in_W)) return 1;
     HIPCHK(hipDeviceSynchronize());
@@ -925,7 +927,7 @@ int sbbseg_segment_tiles_dev(sbbseg_ctx* c, const void* d_page_hwc, int Hp, int 
 }
 
 static int tile_range_impl(sbbseg_ctx* c, const void* d_page_hwc, int src_Hp, int src_Wp, const int* d_map_y, const int* d_map_x,
-                           int Hp, int Wp, int first_tile, int n_tiles, void* d_tile_labels)
+                           int Hp, int Wp, int first_tile, int n_tiles, void* d_tile_labels, const int* d_bin_thr = nullptr)
 {
     REQUIRE(d_page_hwc && d_tile_labels && first_tile >= 0 && n_tiles >= 0, "bad arguments");
     int nx = 0, ny = 0;
@@ -935,7 +937,7 @@ static int tile_range_impl(sbbseg_ctx* c, const void* d_page_hwc, int src_Hp, in
     IngestParams ip;
     if (fill_ingest(c, ip)) return 1;
     ip.page = (const uint8_t*)d_page_hwc; ip.Hp = Hp; ip.Wp = Wp; ip.src_Hp = src_Hp; ip.src_Wp = src_Wp; ip.tile_xy = nullptr;
-    ip.map_y = d_map_y; ip.map_x = d_map_x;
+    ip.map_y = d_map_y; ip.map_x = d_map_x; ip.bin_thr = d_bin_thr;
     ip.grid_nyf = ny; ip.grid_mid_x = c->in_W - 2 * margin; ip.grid_mid_y = c->in_H - 2 * margin;
     const size_t per = (size_t)c->in_H * c->in_W;
     for (int done = 0; done < n_tiles; done += c->max_batch) {
@@ -1038,6 +1040,59 @@ int sbbseg_segment_page_scaled(sbbseg_ctx* c, const uint8_t* page_hwc, int Hs, i
     if (sbbseg_stitch_dev(c, c->d_tile_labels, Hp, Wp, c->d_page_labels)) return 1;
     HIPCHK(hipMemcpyAsync(labels_hw, c->d_page_labels, pix, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int sbbseg_otsu_dev(sbbseg_ctx* c, const void* d_page_hwc, int Hp, int Wp, int* d_threshold)
+{
+    if (check_ready(c)) return 1;
+    REQUIRE(d_page_hwc && d_threshold && Hp > 0 && Wp > 0, "bad arguments");
+    HIPCHK(launch_otsu((const uint8_t*)d_page_hwc, Wp, Hp, Wp, nullptr, nullptr, c->d_hist, d_threshold, c->num_cus, c->stream));
+    return 0;
+}
+
+int sbbseg_segment_tile_range_bin_dev(sbbseg_ctx* c, const void* d_page_hwc, int Hp, int Wp, int first_tile, int n_tiles,
+                                      const int* d_threshold, void* d_tile_labels)
+{
+    if (check_ready(c)) return 1;
+    REQUIRE(d_threshold, "bad arguments");
+    return tile_range_impl(c, d_page_hwc, Hp, Wp, nullptr, nullptr, Hp, Wp, first_tile, n_tiles, d_tile_labels, d_threshold);
+}
+
+int sbbseg_segment_page_otsu(sbbseg_ctx* c, const uint8_t* page_hwc, int Hs, int Ws, int Hp, int Wp, uint8_t* labels_hw,
+                             int* threshold)
+{
+    if (check_ready(c)) return 1;
+    REQUIRE(page_hwc && labels_hw && Hs > 0 && Ws > 0, "bad arguments");
+    REQUIRE(Hp >= c->in_H && Wp >= c->in_W, "page %dx%d is smaller than the model input %dx%d", Hp, Wp, c->in_H, c->in_W);
+    const size_t spix = (size_t)Hs * Ws, pix = (size_t)Hp * Wp;
+    const bool scaled = Hs != Hp || Ws != Wp;
+    if (ensure(c, (void**)&c->d_page, &c->page_cap, spix * 3)) return 1;
+    if (ensure(c, (void**)&c->d_page_labels, &c->page_labels_cap, pix)) return 1;
+    int *d_my = nullptr, *d_mx = nullptr;
+    if (scaled) {
+        std::vector<int> my, mx;
+        nearest_map(Hs, Hp, my);           // scaled row -> stored row   (main.py:214 -> 112-113)
+        nearest_map(Ws, Wp, mx);
+        if (ensure(c, (void**)&c->d_map, &c->map_cap, sizeof(int) * (size_t)(Hp + Wp))) return 1;
+        d_my = c->d_map; d_mx = d_my + Hp;
+        HIPCHK(hipStreamSynchronize(c->stream));
+        HIPCHK(hipMemcpy(d_my, my.data(), sizeof(int) * Hp, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(d_mx, mx.data(), sizeof(int) * Wp, hipMemcpyHostToDevice));
+    }
+    HIPCHK(hipMemcpyAsync(c->d_page, page_hwc, spix * 3, hipMemcpyHostToDevice, c->stream));
+    int* d_thr = (int*)(c->d_hist + 256);
+    HIPCHK(launch_otsu(c->d_page, Ws, Hp, Wp, d_my, d_mx, c->d_hist, d_thr, c->num_cus, c->stream));
+    int nx = 0, ny = 0;
+    if (sbbseg_tile_grid(Hp, Wp, c->in_H, c->in_W, nullptr, 0, &nx, &ny)) return 1;
+    if (ensure(c, (void**)&c->d_tile_labels, &c->tile_labels_cap, (size_t)nx * ny * c->in_H * c->in_W)) return 1;
+    if (tile_range_impl(c, c->d_page, Hs, Ws, d_my, d_mx, Hp, Wp, 0, nx * ny, c->d_tile_labels, d_thr)) return 1;
+    if (sbbseg_stitch_dev(c, c->d_tile_labels, Hp, Wp, c->d_page_labels)) return 1;
+    HIPCHK(hipMemcpyAsync(labels_hw, c->d_page_labels, pix, hipMemcpyDeviceToHost, c->stream));
+    int thr = 0;
+    HIPCHK(hipMemcpyAsync(&thr, d_thr, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (threshold) *threshold = thr;
     return 0;
 }
 

@@ -129,6 +129,7 @@ struct IngestParams {
     int pad, pairs_w;         // p, ceil((W+2p)/2)
     const int* map_y;         // optional nearest-resize gather tables (whole-image branch) or null
     const int* map_x;
+    const int* bin_thr;       // device int: binarise channel 0 at this (Otsu) threshold into all 3 channels, or null
 };
 
 enum Precision { kBF16 = 0, kF32 = 1, kF16 = 2 };
@@ -142,6 +143,8 @@ hipError_t launch_head(const HeadParams& p, int precision, hipStream_t s);
 hipError_t launch_tail(const TailParams& p, int precision, int num_cus, hipStream_t s);
 constexpr int kTailKSteps = 6;      // 4 taps x 64 channels of src0 + 2 steps for the 9 image taps
 hipError_t launch_ingest_u8(const IngestParams& p, int precision, hipStream_t s);
+hipError_t launch_otsu(const uint8_t* page, int src_Wp, int Hp, int Wp, const int* map_y, const int* map_x,
+                       unsigned* hist, int* thr, int num_cus, hipStream_t s);
 hipError_t launch_ingest_f32(const float* x, int n, int H, int W, void* c8, void* pairs, int pad,
                              int pairs_w, int precision, hipStream_t s);
 hipError_t launch_stitch(const uint8_t* tile_labels, int H, int W, const int* own_x, const int* own_y,

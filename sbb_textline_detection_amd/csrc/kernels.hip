@@ -1063,7 +1063,14 @@ __global__ __launch_bounds__(256) void ingest_u8_kernel(const IngestParams p)
     // is never materialised, the tiles are gathered straight from the stored page
     const int sy = p.map_y ? p.map_y[vy] : vy, sx = p.map_x ? p.map_x[vx] : vx;
     const uint8_t* px = p.page + ((size_t)sy * p.src_Wp + sx) * 3;
-    const E v0 = to_elem<E>(p.lut[px[0]]), v1 = to_elem<E>(p.lut[px[1]]), v2 = to_elem<E>(p.lut[px[2]]);
+    E v0, v1, v2;
+    if (p.bin_thr) {
+        // otsu_copy + astype(uint8) + /255 (main.py:178-194, 443-444, 239): channel 0 binarised at the
+        // page's Otsu threshold lands in all three channels (reference quirk, lines 191-193): 0.0 or 1.0
+        v0 = v1 = v2 = to_elem<E>((int)px[0] > *p.bin_thr ? 1.f : 0.f);
+    } else {
+        v0 = to_elem<E>(p.lut[px[0]]); v1 = to_elem<E>(p.lut[px[1]]); v2 = to_elem<E>(p.lut[px[2]]);
+    }
     const E z = to_elem<E>(0.f);
     Vec8<E> o;
     o.v[0] = v0; o.v[1] = v1; o.v[2] = v2;
@@ -1106,6 +1113,84 @@ __global__ __launch_bounds__(256) void ingest_f32_kernel(const float* x, int n, 
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Otsu threshold of channel 0 of the (virtually rescaled) page -- cv2.threshold(img[:,:,0], 0, 255,
+// THRESH_BINARY + THRESH_OTSU) of otsu_copy (main.py:178-194).  Pass 1: 256-bin histogram, an HBM-bound
+// scan (runs of equal bytes are counted in registers first: document pages are mostly one value, and
+// same-address LDS atomics serialise).  Pass 2: one thread walks the 256 bins in the order and
+// precision OpenCV's getThreshVal_Otsu_8u does [EXT], fp64, no FMA contraction.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void hist_u8_kernel(const uint8_t* page, int src_Wp, int Hp, int Wp,
+                                                      const int* map_y, const int* map_x, unsigned* hist)
+{
+    __shared__ unsigned h[256];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    constexpr int RUN = 16;
+    const long total = (long)Hp * Wp;
+    for (long base = ((long)blockIdx.x * 256 + threadIdx.x) * RUN; base < total; base += (long)gridDim.x * 256 * RUN) {
+        int y = (int)(base / Wp), x = (int)(base - (long)y * Wp);
+        const uint8_t* row = page + (size_t)(map_y ? map_y[y] : y) * src_Wp * 3;
+        int prev = -1;
+        unsigned cnt = 0;
+        for (int i = 0; i < RUN && base + i < total; ++i) {
+            const int v = row[(size_t)(map_x ? map_x[x] : x) * 3];
+            if (v != prev) {
+                if (cnt) atomicAdd(&h[prev], cnt);
+                prev = v;
+                cnt = 0;
+            }
+            ++cnt;
+            if (++x == Wp) {
+                x = 0;
+                if (++y < Hp) row = page + (size_t)(map_y ? map_y[y] : y) * src_Wp * 3;
+            }
+        }
+        if (cnt) atomicAdd(&h[prev], cnt);
+    }
+    __syncthreads();
+    if (h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], h[threadIdx.x]);
+}
+
+__global__ void otsu_threshold_kernel(const unsigned* hist, long n_pixels, int* thr)
+{
+#pragma clang fp contract(off)
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const double scale = 1.0 / (double)n_pixels;
+    double mu = 0.0;
+    for (int i = 0; i < 256; ++i) mu += (double)i * (double)hist[i];
+    mu *= scale;
+    const double eps = (double)1.1920928955078125e-07f;      // FLT_EPSILON
+    double mu1 = 0.0, q1 = 0.0, max_sigma = 0.0;
+    int max_val = 0;
+    for (int i = 0; i < 256; ++i) {
+        const double p_i = (double)hist[i] * scale;
+        mu1 *= q1;
+        q1 += p_i;
+        const double q2 = 1.0 - q1;
+        if (fmin(q1, q2) < eps || fmax(q1, q2) > 1.0 - eps) continue;
+        mu1 = (mu1 + (double)i * p_i) / q1;
+        const double mu2 = (mu - q1 * mu1) / q2;
+        const double d = mu1 - mu2;
+        const double sigma = q1 * q2 * d * d;
+        if (sigma > max_sigma) { max_sigma = sigma; max_val = i; }
+    }
+    *thr = max_val;
+}
+
+hipError_t launch_otsu(const uint8_t* page, int src_Wp, int Hp, int Wp, const int* map_y, const int* map_x,
+                       unsigned* hist, int* thr, int num_cus, hipStream_t s)
+{
+    hipError_t e = hipMemsetAsync(hist, 0, 256 * sizeof(unsigned), s);
+    if (e != hipSuccess) return e;
+    const long total = (long)Hp * Wp;
+    long blocks = (total + 256 * 16 - 1) / (256 * 16);
+    if (blocks > 8L * num_cus) blocks = 8L * num_cus;
+    hipLaunchKernelGGL(hist_u8_kernel, dim3((unsigned)blocks), dim3(256), 0, s, page, src_Wp, Hp, Wp, map_y, map_x, hist);
+    hipLaunchKernelGGL(otsu_threshold_kernel, dim3(1), dim3(64), 0, s, hist, total, thr);
+    return hipGetLastError();
+}
+
 hipError_t launch_ingest_u8(const IngestParams& p, int precision, hipStream_t s)
 {
     const long total = (long)p.H * p.W * p.n_tiles;
@@ -1141,7 +1226,12 @@ __global__ __launch_bounds__(256) void maxpool_kernel(const E* src, E* dst, int 
                                                       const float* pre_scale, const float* pre_shift, int pre_relu)
 {
     const int cg = C / 8;
-    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    // Blocks are dealt round-robin to the 8 XCDs; give every XCD one CONTIGUOUS eighth of the output
+    // raster, so the input rows shared by vertically adjacent windows (blocks a few indices apart)
+    // meet in ONE L2 instead of being fetched by two (PMC: fetch was 1.43x the input tensor).
+    const unsigned nwg = gridDim.x, xcd = blockIdx.x & 7, q8 = nwg >> 3, r8 = nwg & 7;
+    const unsigned wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (blockIdx.x >> 3);
+    const long idx = (long)wg * 256 + threadIdx.x;
     const long total = (long)n * Ho * Wo * cg;
     if (idx >= total) return;
     const int g = (int)(idx % cg);

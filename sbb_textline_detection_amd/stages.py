@@ -31,25 +31,29 @@ def scaled_size(h: int, w: int) -> Tuple[int, int]:
 
 
 def otsu_threshold_u8(ch: np.ndarray) -> int:
-    """cv2.threshold(..., THRESH_BINARY + THRESH_OTSU) threshold value [EXT: OpenCV getThreshVal_Otsu_8u]."""
-    hist = np.bincount(ch.reshape(-1), minlength=256).astype(np.float64)
-    n = hist.sum()
-    p = hist / n
-    mu = float((np.arange(256) * p).sum())
-    q1 = 0.0
-    mu1 = 0.0
-    best, best_sigma = 0, 0.0
-    eps = np.finfo(np.float32).eps
+    """cv2.threshold(..., THRESH_BINARY + THRESH_OTSU) threshold value [EXT: OpenCV getThreshVal_Otsu_8u]:
+    mean from the integer first moment times 1/N, probabilities h[i] * (1/N), strict `>` (first maximum).
+    Host mirror of the device kernel (csrc/kernels.hip otsu_threshold_kernel), for foreign model objects."""
+    h = np.bincount(np.ascontiguousarray(ch, np.uint8).reshape(-1), minlength=256)
+    scale = 1.0 / float(h.sum())
+    mu = 0.0
     for i in range(256):
-        pi = p[i]
+        mu += float(i) * float(h[i])
+    mu *= scale
+    q1 = mu1 = best_sigma = 0.0
+    best = 0
+    eps = float(np.finfo(np.float32).eps)
+    for i in range(256):
+        p_i = float(h[i]) * scale
         mu1 *= q1
-        q1 += pi
+        q1 += p_i
         q2 = 1.0 - q1
         if min(q1, q2) < eps or max(q1, q2) > 1.0 - eps:
             continue
-        mu1 = (mu1 + i * pi) / q1
+        mu1 = (mu1 + float(i) * p_i) / q1
         mu2 = (mu - q1 * mu1) / q2
-        sigma = q1 * q2 * (mu1 - mu2) ** 2
+        d = mu1 - mu2
+        sigma = q1 * q2 * d * d
         if sigma > best_sigma:
             best_sigma, best = sigma, i
     return best
@@ -96,10 +100,18 @@ class InferenceStages:
             session.close()
             gc.collect()
 
-    def extract_text_regions(self, img_u8: np.ndarray) -> np.ndarray:
+    def extract_text_regions(self, img_u8: Optional[np.ndarray] = None) -> np.ndarray:
+        """main.py:439-454.  On a SegModel the whole wrapper is one library call: histogram, Otsu threshold,
+        binarising tile gather (and, with img_u8=None, the rescale of the stored page), forward, stitch."""
         model, session = start_new_session_and_model(self.model_region_dir, **self.kw)
         try:
-            img = otsu_copy(img_u8).astype(np.uint8)                      # main.py:443-444
+            if isinstance(model, SegModel):
+                if img_u8 is None:
+                    lab, self.otsu_threshold = model.ctx.segment_page_otsu(self.image_stored, self.img_hight_int, self.img_width_int)
+                else:
+                    lab, self.otsu_threshold = model.ctx.segment_page_otsu(np.ascontiguousarray(img_u8, np.uint8))
+                return np.repeat(lab[:, :, None], 3, axis=2)               # main.py:366 layout: 3 equal channels
+            img = otsu_copy(self._scaled_page() if img_u8 is None else img_u8).astype(np.uint8)   # main.py:443-444
             return do_prediction(True, img, model)                         # main.py:447
         finally:
             session.close()
@@ -122,7 +134,8 @@ class InferenceStages:
         """border -> (full-page box) -> layout -> textline; returns the three label maps."""
         self.get_image_and_scales(image_u8)
         page_mask = self.extract_page_mask()
-        page = self._scaled_page()                                         # box = whole image (main.py:417-419 fallback)
-        regions = self.extract_text_regions(page)
-        textlines = self.textline_contours(page)
+        # box = whole image (main.py:417-419 fallback): both patch stages read the stored page through
+        # the fused rescale, the upscaled page is never built
+        regions = self.extract_text_regions()
+        textlines = self.textline_contours()
         return page_mask, regions, textlines

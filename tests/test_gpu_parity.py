@@ -259,15 +259,21 @@ def test_three_model_pipeline(tmp_path):
     # fused-rescale textline path == the same stage on the materialised upscaled page
     lines2 = st.textline_contours(None)
     assert np.array_equal(lines, lines2)
-    # spot-check the layout stage against the oracle on a crop of the upscaled, Otsu'd page
+    # the fused layout stage (device histogram + Otsu + binarising gather through the rescale) ==
+    # the reference's sequence on materialised arrays: resize -> otsu_copy -> astype(uint8) -> do_prediction
+    from oracle import stage_glue
     from sbb_textline_detection_amd.predict import resize_nearest
     up = resize_nearest(page, hs, ws)
-    ots = stages.otsu_copy(up).astype(np.uint8)
+    ots = stage_glue.otsu_copy(up).astype(np.uint8)
+    assert st.otsu_threshold == stage_glue.otsu_threshold(up[:, :, 0])
+    from sbb_textline_detection_amd.model import load_model
+    regions2 = predict.do_prediction(True, ots, load_model(str(tmp_path / "model_strukturerkennung.h5"), max_batch=16))
+    assert np.array_equal(regions, regions2)
+    # spot-check the layout stage against the oracle on a crop of the upscaled, Otsu'd page
     cfg, w = models["model_strukturerkennung"]
     om = kf.OracleModel(cfg, w)
     crop = ots[:448, :448]
     ref = tiling.do_prediction(True, crop, om)[:, :, 0]
-    from sbb_textline_detection_amd.model import load_model
     got = predict.do_prediction(True, crop, load_model(str(tmp_path / "model_strukturerkennung.h5"), max_batch=16))[:, :, 0]
     assert (ref != got).mean() < 0.06
     clear_session()
@@ -300,3 +306,58 @@ def test_batch_one_and_four_classes():
     b = predict.do_prediction(True, page, m7)
     assert np.array_equal(a, b) and a.max() <= 3
     model.release(); m7.release()
+
+
+def test_device_otsu_threshold_and_binarised_gather(stitch_model):
+    """otsu_copy on the device: histogram + getThreshVal_Otsu_8u arithmetic == the oracle's
+    threshold bit for bit, and the binarising tile gather == segmenting the host-binarised page."""
+    from oracle import stage_glue
+    from sbb_textline_detection_amd.predict import resize_nearest
+    m = stitch_model
+    rng = np.random.RandomState(3)
+    cases = [synthetic_page(600, 520, seed=1), synthetic_page(901, 777, seed=2),
+             rng.randint(0, 256, (500, 470, 3)).astype(np.uint8),                       # flat histogram
+             np.full((460, 450, 3), 200, np.uint8)]                                     # constant page -> threshold 0
+    cases[1][:, :, 1] = 255 - cases[1][:, :, 1]                                          # only channel 0 may matter
+    for page in cases:
+        lab, thr = m.ctx.segment_page_otsu(page)
+        assert thr == stage_glue.otsu_threshold(page[:, :, 0])
+        ref = m.segment_page(stage_glue.otsu_copy(page).astype(np.uint8))
+        assert np.array_equal(lab, ref)
+    page = cases[0]
+    hs, ws = 812, 703                                                                    # through the nearest rescale
+    lab, thr = m.ctx.segment_page_otsu(page, hs, ws)
+    up = resize_nearest(page, hs, ws)
+    assert thr == stage_glue.otsu_threshold(up[:, :, 0])
+    assert np.array_equal(lab, m.segment_page(stage_glue.otsu_copy(up).astype(np.uint8)))
+
+
+def test_device_otsu_building_blocks(stitch_model):
+    """sbbseg_otsu_dev + sbbseg_segment_tile_range_bin_dev (the sharded form) == the one-call form."""
+    import torch
+    from oracle import stage_glue
+    m = stitch_model
+    page = synthetic_page(700, 640, seed=5)
+    Hp, Wp = page.shape[:2]
+    H, W, _, _ = m.ctx.model_info()
+    d_page = torch.from_numpy(page).cuda()
+    d_thr = torch.zeros(1, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    m.ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    try:
+        m.ctx.otsu_dev(d_page.data_ptr(), Hp, Wp, d_thr.data_ptr())
+        from sbb_textline_detection_amd._capi import tile_grid
+        _, nx, ny = tile_grid(Hp, Wp, H, W)
+        n = nx * ny
+        d_tiles = torch.empty((n, H, W), dtype=torch.uint8, device="cuda")
+        half = n // 2
+        m.ctx.segment_tile_range_bin_dev(d_page.data_ptr(), Hp, Wp, 0, half, d_thr.data_ptr(), d_tiles.data_ptr())
+        m.ctx.segment_tile_range_bin_dev(d_page.data_ptr(), Hp, Wp, half, n - half, d_thr.data_ptr(), d_tiles[half:].data_ptr())
+        d_lab = torch.empty((Hp, Wp), dtype=torch.uint8, device="cuda")
+        m.ctx.stitch_dev(d_tiles.data_ptr(), Hp, Wp, d_lab.data_ptr())
+        torch.cuda.synchronize()
+    finally:
+        m.ctx.set_stream(-1)
+    assert int(d_thr.item()) == stage_glue.otsu_threshold(page[:, :, 0])
+    lab, _ = m.ctx.segment_page_otsu(page)
+    assert np.array_equal(d_lab.cpu().numpy(), lab)
