@@ -18,7 +18,7 @@ INPUT_C8, INPUT_PAIRS = 0, 1
 
 EXPORTS = [
     "sbbseg_last_error", "sbbseg_abi_version", "sbbseg_device_count", "sbbseg_create", "sbbseg_destroy",
-    "sbbseg_set_stream", "sbbseg_synchronize", "sbbseg_set_input", "sbbseg_input_form", "sbbseg_add_tensor",
+    "sbbseg_set_stream", "sbbseg_set_lanes", "sbbseg_synchronize", "sbbseg_set_input", "sbbseg_input_form", "sbbseg_add_tensor",
     "sbbseg_add_conv", "sbbseg_add_maxpool", "sbbseg_add_tail", "sbbseg_add_head", "sbbseg_finalize", "sbbseg_model_info",
     "sbbseg_num_ops", "sbbseg_op_info", "sbbseg_device_bytes", "sbbseg_predict", "sbbseg_segment_page",
     "sbbseg_segment_page_dev", "sbbseg_segment_page_scaled", "sbbseg_segment_page_otsu", "sbbseg_otsu_dev",
@@ -65,6 +65,7 @@ def load_library(path: Optional[str] = None):
         "sbbseg_destroy": [vp],
         "sbbseg_set_stream": [vp, vp],
         "sbbseg_synchronize": [vp],
+        "sbbseg_set_lanes": [vp, i32],
         "sbbseg_set_input": [vp, i32, i32, i32],
         "sbbseg_input_form": [vp, i32, i32, C.POINTER(C.c_int)],
         "sbbseg_add_tensor": [vp, i32, i32, i32, C.POINTER(C.c_int)],
@@ -228,6 +229,10 @@ class Context:
 
     def synchronize(self):
         check(self.lib.sbbseg_synchronize(self.h))
+
+    def set_lanes(self, lanes: int):
+        """1 = one stream; 2 (default) = chunks of >= 16 tiles run as two concurrent halves (see sbbseg.h)."""
+        check(self.lib.sbbseg_set_lanes(self.h, int(lanes)), "sbbseg_set_lanes")
 
     # -- execution -----------------------------------------------------------------------------
     def predict(self, x: np.ndarray) -> np.ndarray:

@@ -47,7 +47,8 @@ int fail(const char* fmt, ...)
 struct Tensor {
     int H = 0, W = 0, C = 0;
     size_t elems_per_patch = 0;
-    char* buf = nullptr;          // zero header + data
+    char* buf = nullptr;          // zero header + data (of the lane in use)
+    char* lane_buf[2] = {nullptr, nullptr};
     bool is_input_form = false;
     int form = -1, pad = 0;
     char* data() const { return buf + kZeroHeaderBytes; }
@@ -107,6 +108,11 @@ struct sbbseg_ctx {
     int elem = 2;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
+    // second lane: its own activation buffers and stream; a chunk of tiles is split over the two lanes so
+    // that one half's launch tails (few tiles left, most CUs idle) are filled by the other half's kernels
+    hipStream_t lane_stream = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    int lanes = 2, lane1_batch = 0;
     int in_H = 0, in_W = 0, in_C = 0;
     std::vector<Tensor> tensors;
     std::vector<Op> ops;
@@ -340,6 +346,25 @@ int fill_ingest(sbbseg_ctx* c, IngestParams& ip)
     return 0;
 }
 
+constexpr int kMinLaneTiles = 8;      // a lane gets at least this many tiles, else the chunk runs whole on lane 0
+
+// activation buffers and stream of lane L become the ones run_plan / fill_ingest see
+struct LaneScope {
+    sbbseg_ctx* c; hipStream_t saved;
+    LaneScope(sbbseg_ctx* c_, int lane) : c(c_), saved(c_->stream)
+    {
+        if (lane == 1) {
+            for (auto& t : c->tensors) t.buf = t.lane_buf[1];
+            c->stream = c->lane_stream;
+        }
+    }
+    ~LaneScope()
+    {
+        for (auto& t : c->tensors) t.buf = t.lane_buf[0];
+        c->stream = saved;
+    }
+};
+
 int check_ready(sbbseg_ctx* c)
 {
     REQUIRE(c != nullptr, "null handle");
@@ -386,6 +411,13 @@ int sbbseg_create(int device, int precision, sbbseg_ctx** out)
         return fail("hipStreamCreate failed: %s", hipGetErrorString(e));
     }
     c->stream = c->own_stream;
+    e = hipStreamCreateWithFlags(&c->lane_stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming);
+    if (e != hipSuccess) {
+        sbbseg_destroy(c);
+        return fail("lane stream/event creation failed: %s", hipGetErrorString(e));
+    }
     *out = c;
     return 0;
 }
@@ -395,8 +427,11 @@ int sbbseg_destroy(sbbseg_ctx* c)
     if (!c) return 0;
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
-    for (auto& t : c->tensors)
-        if (t.buf) hipFree(t.buf);
+    if (c->lane_stream) hipStreamSynchronize(c->lane_stream);
+    for (auto& t : c->tensors) {
+        hipFree(t.lane_buf[0]);
+        hipFree(t.lane_buf[1]);
+    }
     for (auto& op : c->ops) {
         hipFree(op.conv.d_ktab); hipFree(op.conv.d_kstep); hipFree(op.conv.d_w); hipFree(op.conv.d_scale); hipFree(op.conv.d_shift);
         hipFree(op.conv.d_rscale); hipFree(op.conv.d_rshift);
@@ -413,6 +448,9 @@ int sbbseg_destroy(sbbseg_ctx* c)
     for (auto& pe : c->pending) { hipEventDestroy(pe.a); hipEventDestroy(pe.b); }
     for (auto e : c->free_events) hipEventDestroy(e);
     if (c->own_stream) hipStreamDestroy(c->own_stream);
+    if (c->lane_stream) hipStreamDestroy(c->lane_stream);
+    if (c->ev_fork) hipEventDestroy(c->ev_fork);
+    if (c->ev_join) hipEventDestroy(c->ev_join);
     delete c;
     return 0;
 }
@@ -423,6 +461,14 @@ int sbbseg_set_stream(sbbseg_ctx* c, void* hip_stream)
     if (resolve_pending(c)) return 1;
     // NULL is a real stream (the legacy default stream torch uses unless told otherwise)
     c->stream = hip_stream == SBBSEG_OWN_STREAM ? c->own_stream : (hipStream_t)hip_stream;
+    return 0;
+}
+
+int sbbseg_set_lanes(sbbseg_ctx* c, int lanes)
+{
+    REQUIRE(c && (lanes == 1 || lanes == 2), "lanes must be 1 or 2");
+    REQUIRE(!(c->finalized && lanes == 2 && c->lane1_batch == 0), "the second lane was not allocated at finalize (lanes was 1 or max_batch < 16)");
+    c->lanes = lanes;
     return 0;
 }
 
@@ -811,10 +857,18 @@ int sbbseg_finalize(sbbseg_ctx* c, int max_batch)
     for (auto& t : c->tensors) {
         const size_t bytes = kZeroHeaderBytes + t.elems_per_patch * max_batch * c->elem + 256;
         REQUIRE(bytes < ((size_t)1 << 32), "tensor %dx%dx%d x batch %d exceeds the 4 GiB gather window", t.H, t.W, t.C, max_batch);
-        if (dmalloc(c, (void**)&t.buf, bytes)) return 1;
+        if (dmalloc(c, (void**)&t.lane_buf[0], bytes)) return 1;
+        t.buf = t.lane_buf[0];
         // input forms rely on their zero borders / zero channels; headers must be zero for every tensor
         HIPCHK(hipMemset(t.buf, 0, t.is_input_form ? bytes : (size_t)kZeroHeaderBytes));
     }
+    c->lane1_batch = (c->lanes == 2 && max_batch >= 2 * kMinLaneTiles) ? (max_batch + 1) / 2 : 0;
+    if (c->lane1_batch)
+        for (auto& t : c->tensors) {
+            const size_t bytes = kZeroHeaderBytes + t.elems_per_patch * c->lane1_batch * c->elem + 256;
+            if (dmalloc(c, (void**)&t.lane_buf[1], bytes)) return 1;
+            HIPCHK(hipMemset(t.lane_buf[1], 0, t.is_input_form ? bytes : (size_t)kZeroHeaderBytes));
+        }
     float lut[256];
     for (int v = 0; v < 256; ++v) lut[v] = (float)((double)v / 255.0);   // main.py:239 in f64, then Keras' f32 feed
     if (upload(c, &c->d_lut, lut, 256)) return 1;
@@ -940,12 +994,32 @@ static int tile_range_impl(sbbseg_ctx* c, const void* d_page_hwc, int src_Hp, in
     ip.map_y = d_map_y; ip.map_x = d_map_x; ip.bin_thr = d_bin_thr;
     ip.grid_nyf = ny; ip.grid_mid_x = c->in_W - 2 * margin; ip.grid_mid_y = c->in_H - 2 * margin;
     const size_t per = (size_t)c->in_H * c->in_W;
+    auto run_chunk = [&](int lane, int first, int nb) -> int {
+        LaneScope scope(c, lane);
+        IngestParams lp = ip;
+        if (fill_ingest(c, lp)) return 1;          // (input-form pointers of this lane)
+        lp.page = ip.page; lp.Hp = ip.Hp; lp.Wp = ip.Wp; lp.src_Hp = ip.src_Hp; lp.src_Wp = ip.src_Wp; lp.tile_xy = nullptr;
+        lp.map_y = ip.map_y; lp.map_x = ip.map_x; lp.bin_thr = ip.bin_thr;
+        lp.grid_nyf = ip.grid_nyf; lp.grid_mid_x = ip.grid_mid_x; lp.grid_mid_y = ip.grid_mid_y;
+        lp.grid_first = first_tile + first;
+        lp.n_tiles = nb;
+        HIPCHK(launch_ingest_u8(lp, c->precision, c->stream));
+        return run_plan(c, nb, (uint8_t*)d_tile_labels + first * per, nullptr);
+    };
     for (int done = 0; done < n_tiles; done += c->max_batch) {
         const int nb = n_tiles - done < c->max_batch ? n_tiles - done : c->max_batch;
-        ip.grid_first = first_tile + done;
-        ip.n_tiles = nb;
-        HIPCHK(launch_ingest_u8(ip, c->precision, c->stream));
-        if (run_plan(c, nb, (uint8_t*)d_tile_labels + done * per, nullptr)) return 1;
+        const bool two = c->lane1_batch > 0 && c->lanes == 2 && !c->profiling && nb >= 2 * kMinLaneTiles;
+        if (!two) {
+            if (run_chunk(0, done, nb)) return 1;
+            continue;
+        }
+        const int na = (nb + 1) / 2, nb2 = nb - na;            // nb2 <= lane1_batch
+        HIPCHK(hipEventRecord(c->ev_fork, c->stream));         // page / threshold / earlier chunks are ordered before
+        HIPCHK(hipStreamWaitEvent(c->lane_stream, c->ev_fork, 0));
+        if (run_chunk(0, done, na)) return 1;
+        if (run_chunk(1, done + na, nb2)) return 1;           // (starting lane 1 later -- after lane 0's op k -- measured 3-14 % slower)
+        HIPCHK(hipEventRecord(c->ev_join, c->lane_stream));
+        HIPCHK(hipStreamWaitEvent(c->stream, c->ev_join, 0));
     }
     return 0;
 }

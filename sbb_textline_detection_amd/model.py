@@ -46,6 +46,7 @@ class SegModel:
         prec = {"bf16": _capi.PREC_BF16, "f32": _capi.PREC_F32, "f16": _capi.PREC_F16}[precision]
         self._ctx: Optional[_capi.Context] = _capi.Context(device, prec)
         try:
+            self._ctx.set_lanes(int(os.environ.get("SBBSEG_LANES", "2")))   # before finalize: 1 skips the second buffer set
             self._ctx.load_plan(self.plan, self.max_batch)
         except Exception:
             self._ctx.close()

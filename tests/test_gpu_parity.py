@@ -361,3 +361,20 @@ def test_device_otsu_building_blocks(stitch_model):
     assert int(d_thr.item()) == stage_glue.otsu_threshold(page[:, :, 0])
     lab, _ = m.ctx.segment_page_otsu(page)
     assert np.array_equal(d_lab.cpu().numpy(), lab)
+
+
+def test_two_lanes_equal_one_lane():
+    """The two-lane split of a chunk (second half on a private stream with its own buffers) changes
+    nothing but the schedule: identical label maps, for plain / rescaled / Otsu page entry points."""
+    cfg, w, g, model = make_model(2, 224, 224, seed=3, precision="f16", max_batch=40)
+    page = synthetic_page(1400, 1100, seed=7)                      # 8 x 7 = 56 tiles at 224: chunks of 40 + 16
+    outs = {}
+    for lanes in (2, 1, 2):
+        model.ctx.set_lanes(lanes)
+        outs[lanes] = (model.segment_page(page), model.ctx.segment_page_scaled(page, 1500, 1201),
+                       model.ctx.segment_page_otsu(page)[0])
+        if lanes == 1:
+            ref = outs[1]
+    for a, b in zip(outs[2], ref):
+        assert np.array_equal(a, b)
+    model.release()
