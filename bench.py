@@ -181,6 +181,9 @@ def main():
             "avg_launch_ms": round(dom["total_ms"] / dom["launches"], 4),
             "patches_per_launch": dom["patches"] / dom["launches"],
             "flops_per_launch": dom["flops"] * dom["patches"] / dom["launches"],
+            "launch_mode": "per-launch HIP events in a profiling pass right after the timed region: one 70-tile launch per op on "
+                           "one lane (exclusive GPU).  The timed region runs the same kernels as two concurrent 35-tile halves "
+                           "(lanes=2, +5 % throughput), where per-launch durations overlap and are not separable",
             "flops_note": "algorithmic FLOPs (reference formulation: 2*MACs of the 3x3 conv over the upsampled+"
                           "concatenated input); the parity-split kernels issue 13/18 of them as MFMA work",
             "conv3x3_stages": {"achieved": round(k3_flops / (k3_ms * 1e-3) / 1e12, 2),
@@ -237,6 +240,7 @@ def main():
             "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
             "config": {"workload": workload_desc, "workload_id": args.workload,
                        "tiles_per_step": tiles_per_step, "max_batch": args.max_batch,
+                       "lanes": int(os.environ.get("SBBSEG_LANES", "2")),
                        "exchange": "all_gather of u8 label maps over RCCL" if world > 1 else "none (1 GPU)",
                        "flops_per_patch": 2 * model.plan.macs_per_patch()},
             "patches_per_s_per_gpu": round(value / world, 2),
