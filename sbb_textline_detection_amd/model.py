@@ -38,7 +38,8 @@ class SegModel:
         self.graph: Graph = parse_model_config(model_config)
         self.plan: Plan = build_plan(self.graph, weights, parity_split=os.environ.get("SBBSEG_PARITY_SPLIT", "1") != "0",
                                      fuse_head=precision != "f32" and os.environ.get("SBBSEG_FUSE_HEAD", "1") != "0",
-                                     fuse_tail=os.environ.get("SBBSEG_FUSE_TAIL", "1") != "0")
+                                     fuse_tail=os.environ.get("SBBSEG_FUSE_TAIL", "1") != "0",
+                                     merge_shortcut=os.environ.get("SBBSEG_MERGE_SHORTCUT", "1") != "0")
         self.layers = self.graph.nodes                     # main.py:227-229 reads layers[-1].output_shape
         self.device = device
         self.precision = precision

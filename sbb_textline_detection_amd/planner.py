@@ -177,6 +177,8 @@ class _Pending:
         self.emitted_out = -1
         self.emitted_raw = -1
         self.stage = "conv"          # conv -> bn -> (add) -> relu
+        self.multi = None            # merged convs: explicit per-source Segs (geometry + weights)
+        self.name = node.name
 
 
 class _View:
@@ -198,7 +200,7 @@ _PARITY_TAPS = {(0, 0): (0,), (0, 1): (1, 2), (1, 0): (0, 1), (1, 1): (2,)}
 
 
 def build_plan(graph: Graph, weights: Dict[str, np.ndarray], parity_split: bool = True,
-               fuse_head: bool = True, fuse_tail: bool = True) -> Plan:
+               fuse_head: bool = True, fuse_tail: bool = True, merge_shortcut: bool = True) -> Plan:
     byn = graph.by_name()
     consumers: Dict[str, int] = {}
     for n in graph.nodes:
@@ -231,25 +233,28 @@ def build_plan(graph: Graph, weights: Dict[str, np.ndarray], parity_split: bool 
         if p.emitted_out >= 0 or p.emitted_raw >= 0:
             return
         oh, ow = p.out_hw
-        p.emitted_out = new_tensor(oh, ow, p.cout, p.node.name)
+        p.emitted_out = new_tensor(oh, ow, p.cout, p.name)
         if p.raw_needed:
             p.emitted_raw = new_tensor(oh, ow, p.cout, p.node.name + ":raw")
         cbase, srcs = 0, []
-        for g in p.srcs:
-            srcs.append(Seg(g.tensor, g.channels, g.shift, g.off_y, g.off_x, p.kh, p.kw, p.sy, p.sx, p.pt, p.pl,
-                            np.ascontiguousarray(p.w[:, :, cbase:cbase + g.channels, :], np.float32)))
-            cbase += g.channels
+        if p.multi is not None:
+            srcs = list(p.multi)                       # sources with their own geometry and (pre-scaled) weights
+        else:
+            for g in p.srcs:
+                srcs.append(Seg(g.tensor, g.channels, g.shift, g.off_y, g.off_x, p.kh, p.kw, p.sy, p.sx, p.pt, p.pl,
+                                np.ascontiguousarray(p.w[:, :, cbase:cbase + g.channels, :], np.float32)))
+                cbase += g.channels
         common = dict(cout=p.cout, scale=p.scale.astype(np.float32), shift=p.shift.astype(np.float32),
                       out=p.emitted_out, relu=p.relu, residual=p.residual, raw_out=p.emitted_raw,
                       raw_scale=p.raw_scale.astype(np.float32) if p.raw_needed else None,
                       raw_shift=p.raw_shift.astype(np.float32) if p.raw_needed else None)
         macs = float(oh * ow * p.cout * p.logical_macs_per_out)
         origin = dict(srcs=srcs, geom=(p.kh, p.kw, p.sy, p.sx, p.pt, p.pl), out_hw=(oh, ow), macs=macs, name=p.node.name)
-        splittable = (parity_split and srcs[0].shift == 1 and (p.kh, p.kw, p.sy, p.sx, p.pt, p.pl) == (3, 3, 1, 1, 1, 1)
+        splittable = (parity_split and p.multi is None and srcs[0].shift == 1 and (p.kh, p.kw, p.sy, p.sx, p.pt, p.pl) == (3, 3, 1, 1, 1, 1)
                       and oh % 2 == 0 and ow % 2 == 0 and p.residual < 0 and not p.raw_needed
                       and all(not (g.shift and (g.off_y or g.off_x)) for g in srcs))
         if not splittable:
-            plan.steps.append(ConvStep(p.node.name, srcs, out_h=oh, out_w=ow, algorithmic_macs=macs, **common))
+            plan.steps.append(ConvStep(p.name, srcs, out_h=oh, out_w=ow, algorithmic_macs=macs, **common))
             plan.steps[-1].origin = origin
             return
         # 3x3 conv over nearest-x2-upsampled sources == four output-parity classes; in each, the taps
@@ -411,6 +416,30 @@ def build_plan(graph: Graph, weights: Dict[str, np.ndarray], parity_split: bool 
                     and v.pending.residual < 0 and consumers.get(n.inputs[k], 0) == 1]
             if not cand:
                 raise PlanError(f"{n.name}: Add needs one input that is a conv(+BN) with a single consumer")
+            pa, pb = va.pending, vb.pending
+            if (merge_shortcut and len(cand) == 2 and pa.multi is None and pb.multi is None and len(pa.srcs) == 1
+                    and len(pb.srcs) == 1 and not pa.raw_needed and not pb.raw_needed and pa.cout == pb.cout
+                    and pa.out_hw == pb.out_hw and not pa.srcs[0].shift and not pb.srcs[0].shift
+                    and pa.srcs[0].tensor >= 0 and pb.srcs[0].tensor >= 0):
+                # projection-shortcut block: BN_a(conv_a(x)) + BN_b(conv_b(y)) is ONE conv over two sources
+                # with the BN scales folded into the weight rows (exact algebra):
+                #   sum_k (s_a W_a)[c,k] x[k] + sum_k (s_b W_b)[c,k] y[k] + (shift_a + shift_b)
+                # -> the shortcut tensor is never written or re-read as a residual, one launch instead of two
+                segs = []
+                for q in (pa, pb):
+                    g = q.srcs[0]
+                    wq = (q.w.astype(np.float64) * q.scale[None, None, None, :]).astype(np.float32)
+                    segs.append(Seg(g.tensor, g.channels, 0, g.off_y, g.off_x, q.kh, q.kw, q.sy, q.sx, q.pt, q.pl,
+                                    np.ascontiguousarray(wq)))
+                pa.multi = segs
+                pa.srcs = [Seg(g.tensor, g.channels, 0, g.off_y, g.off_x) for g in segs]
+                pa.shift = pa.shift + pb.shift
+                pa.scale = np.ones(pa.cout, np.float64)
+                pa.logical_macs_per_out += pb.logical_macs_per_out
+                pa.name = f"{pa.node.name}+{pb.node.name}"
+                pa.stage = "add"
+                views[n.name] = _View(va.H, va.W, pending=pa)
+                continue
             k = cand[0]
             other = plain_tensor(n.inputs[1 - k])
             p = views[n.inputs[k]].pending

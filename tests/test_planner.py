@@ -30,7 +30,7 @@ def test_plan_equals_oracle(classes, hw, parity, fuse):
 
 def test_plan_structure_448():
     cfg, w = synthetic_model(2, 448, 448, 0)
-    plan = build_plan(parse_model_config(cfg), w, parity_split=False, fuse_head=False)
+    plan = build_plan(parse_model_config(cfg), w, parity_split=False, fuse_head=False, merge_shortcut=False)
     kinds = [s.kind for s in plan.steps]
     assert kinds.count("conv") == 59 and kinds.count("maxpool") == 1 and kinds[-1] == "head"
     assert plan.macs_per_patch() == 47418195968                       # 47.418 GMAC
@@ -44,6 +44,15 @@ def test_plan_structure_448():
     f2 = [s for s in dec.values() if s.srcs[1].off_y == 1]
     assert len(f2) == 1 and f2[0].srcs[1].off_x == 1                   # one_side_pad became an offset
     assert sum(1 for s in plan.steps if s.kind == "conv" and s.residual >= 0) == 16
+    # projection-shortcut blocks merged: shortcut conv + conv c + Add = one two-source conv, BN scales in the weights
+    merged = build_plan(parse_model_config(cfg), w, parity_split=False, fuse_head=False)
+    convs = [s for s in merged.steps if s.kind == "conv"]
+    assert len(convs) == 55 and sum(1 for s in convs if s.residual >= 0) == 12
+    two = [s for s in convs if len(s.srcs) == 2 and not s.srcs[0].shift]
+    assert len(two) == 4 and all(np.all(s.scale == 1.0) and s.relu for s in two)
+    assert [(s.srcs[0].channels, s.srcs[1].channels, s.cout, s.srcs[1].stride_y) for s in two] == \
+        [(64, 64, 256, 1), (128, 256, 512, 2), (256, 512, 1024, 2), (512, 1024, 2048, 2)]
+    assert merged.macs_per_patch() == 47418195968
 
 
 def test_fused_tail_448():
@@ -51,7 +60,7 @@ def test_fused_tail_448():
     plan = build_plan(parse_model_config(cfg), w)
     kinds = [s.kind for s in plan.steps]
     assert kinds.count("tail") == 1 and kinds[-1] == "tail" and "head" not in kinds
-    assert kinds.count("conv") == 54 + 4 * 4                              # dec1-dec4 parity classes; dec5 lives in the tail
+    assert kinds.count("conv") == 50 + 4 * 4                              # dec1-dec4 parity classes; dec5 lives in the tail
     assert plan.macs_per_patch() == 47418195968 + 448 * 448 * 32 * 2     # (4 classes instead of 2 in the head)
     tail = plan.steps[-1]
     assert tail.w_src0.shape == (3, 3, 64, 32) and tail.w_img.shape == (3, 3, 3, 32)
@@ -61,7 +70,7 @@ def test_parity_split_and_fused_head_448():
     cfg, w = synthetic_model(2, 448, 448, 0)
     plan = build_plan(parse_model_config(cfg), w, fuse_tail=False)
     kinds = [s.kind for s in plan.steps]
-    assert kinds.count("conv") == 54 + 5 * 4 and "head" not in kinds    # 5 decoder convs x 4 parity classes
+    assert kinds.count("conv") == 50 + 5 * 4 and "head" not in kinds    # 5 decoder convs x 4 parity classes
     assert plan.macs_per_patch() == 47418195968                       # algorithmic work is unchanged ...
     assert plan.executed_macs_per_patch() < 0.80 * plan.macs_per_patch()   # ... but > 20 % fewer MACs are issued
     par = [s for s in plan.steps if s.kind == "conv" and s.out_stride == (2, 2)]
