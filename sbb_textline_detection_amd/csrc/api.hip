@@ -71,6 +71,7 @@ struct ConvOp {
     KStepRec* d_kstep_cls[4] = {nullptr, nullptr, nullptr, nullptr};
     KTabEntry* d_ktab_cls[4] = {nullptr, nullptr, nullptr, nullptr};
     int ooy_cls[4] = {0, 0, 0, 0}, oox_cls[4] = {0, 0, 0, 0};
+    uint16_t* d_stem_wfrag = nullptr;     // non-null: the op is the network stem and runs stem_conv_pairs
 };
 
 struct PoolOp { int src, dst, k, stride, Ho, Wo; float *d_pre_scale = nullptr, *d_pre_shift = nullptr; int pre_relu = 0; };
@@ -301,7 +302,16 @@ int run_plan(sbbseg_ctx* c, int n, uint8_t* d_labels, float* d_probs)
             p.residual = co.d.residual_tensor >= 0 ? c->tensors[co.d.residual_tensor].data() : nullptr;
             p.raw_out = co.d.raw_out_tensor >= 0 ? c->tensors[co.d.raw_out_tensor].data() : nullptr;
             p.raw_scale = co.d_rscale; p.raw_shift = co.d_rshift; p.relu = co.d.relu;
-            HIPCHK(launch_conv(p, c->precision, c->stream));
+            if (co.d_stem_wfrag && !(c->conv_variant & 3)) {
+                const Tensor& st = c->tensors[co.d.src[0].tensor];
+                StemParams sp;
+                sp.pairs = st.buf; sp.PHt = st.H; sp.PWt = st.W; sp.n = n; sp.Ho = co.Ho; sp.Wo = co.Wo;
+                sp.wfrag = co.d_stem_wfrag; sp.scale = co.d_scale; sp.shift = co.d_shift; sp.relu = co.d.relu;
+                sp.out = c->tensors[co.d.out_tensor].data();
+                HIPCHK(launch_stem(sp, c->precision, c->num_cus, c->stream));
+            } else {
+                HIPCHK(launch_conv(p, c->precision, c->stream));
+            }
         } else if (op.type == kPool) {
             const PoolOp& po = op.pool;
             const Tensor& s = c->tensors[po.src];
@@ -435,7 +445,7 @@ int sbbseg_destroy(sbbseg_ctx* c)
     for (auto& op : c->ops) {
         hipFree(op.conv.d_ktab); hipFree(op.conv.d_kstep); hipFree(op.conv.d_w); hipFree(op.conv.d_scale); hipFree(op.conv.d_shift);
         hipFree(op.conv.d_rscale); hipFree(op.conv.d_rshift);
-        hipFree(op.conv.d_head_w); hipFree(op.conv.d_head_scale); hipFree(op.conv.d_head_shift);
+        hipFree(op.conv.d_head_w); hipFree(op.conv.d_head_scale); hipFree(op.conv.d_head_shift); hipFree(op.conv.d_stem_wfrag);
         for (int q = 1; q < 4; ++q) { hipFree(op.conv.d_w_cls[q]); hipFree(op.conv.d_kstep_cls[q]); hipFree(op.conv.d_ktab_cls[q]); }
         hipFree(op.head.d_w); hipFree(op.head.d_scale); hipFree(op.head.d_shift);
         hipFree(op.pool.d_pre_scale); hipFree(op.pool.d_pre_shift);
@@ -699,6 +709,33 @@ int sbbseg_add_conv(sbbseg_ctx* c, const sbbseg_conv_desc* d, const float* w_src
     op.min_bytes = bytes;
     co.d_w_cls[0] = co.d_w; co.d_kstep_cls[0] = co.d_kstep; co.d_ktab_cls[0] = co.d_ktab;
     co.ooy_cls[0] = d->out_off_y; co.oox_cls[0] = d->out_off_x;
+
+    // the network stem (7 rows x 4 two-pixel granules on the PAIRS form -> 64 channels) has its own kernel
+    {
+        const sbbseg_conv_src& cs = d->src[0];
+        const Tensor& st = c->tensors[cs.tensor];
+        const char* env = getenv("SBBSEG_STEM_KERNEL");
+        if (c->precision != kF32 && !(env && env[0] == '0') && d->n_src == 1 && st.is_input_form && st.form == SBBSEG_INPUT_PAIRS &&
+            cs.channels == 8 && cs.kh == 7 && cs.kw == 4 && cs.stride_y == 2 && cs.stride_x == 1 && cs.pad_top == 0 && cs.pad_left == 0 &&
+            cs.up_shift == 0 && cs.off_y == 0 && cs.off_x == 0 && d->cout == 64 && d->out_h % 16 == 0 && d->out_w % 16 == 0 &&
+            st.H >= 2 * d->out_h + 5 && st.W >= d->out_w + 3 &&
+            d->residual_tensor < 0 && d->raw_out_tensor < 0 && d->head_classes == 0 && d->out_tensor >= 0 && d->out_stride_y == 1 &&
+            d->out_stride_x == 1 && d->out_off_y == 0 && d->out_off_x == 0 && TH == d->out_h && TW == d->out_w) {
+            std::vector<uint16_t> frag((size_t)7 * 4 * 64 * 8);
+            for (int ky = 0; ky < 7; ++ky)
+                for (int mi = 0; mi < 4; ++mi)
+                    for (int l = 0; l < 64; ++l) {
+                        const int o = conv_row_channel(mi * 16 + (l & 15), 64);
+                        const int g = l >> 4;                                   // two-pixel granule = kernel column pair
+                        for (int e = 0; e < 8; ++e) {
+                            const float v = w_src0[(((size_t)ky * 4 + g) * 8 + e) * 64 + o];
+                            frag[((((size_t)ky * 4 + mi) * 64) + l) * 8 + e] = c->precision == kF16 ? f32_to_f16_rne(v) : f32_to_bf16_rne(v);
+                        }
+                    }
+            if (upload(c, &co.d_stem_wfrag, frag.data(), frag.size())) return 1;
+            op.name = "stem_" + op.name;
+        }
+    }
 
     // Output-placement siblings (same sources, taps geometry and outputs, only padding / placement
     // offset / weights differ -- the parity classes of one decoder conv) run as ONE launch: bigger
@@ -1006,8 +1043,11 @@ static int tile_range_impl(sbbseg_ctx* c, const void* d_page_hwc, int src_Hp, in
         HIPCHK(launch_ingest_u8(lp, c->precision, c->stream));
         return run_plan(c, nb, (uint8_t*)d_tile_labels + first * per, nullptr);
     };
-    for (int done = 0; done < n_tiles; done += c->max_batch) {
-        const int nb = n_tiles - done < c->max_batch ? n_tiles - done : c->max_batch;
+    // chunks of equal size (108 tiles at max_batch 70 -> 54 + 54, not 70 + 38): launches shrink evenly
+    const int n_chunks = (n_tiles + c->max_batch - 1) / c->max_batch;
+    const int chunk = n_chunks ? (n_tiles + n_chunks - 1) / n_chunks : 0;
+    for (int done = 0; done < n_tiles; done += chunk) {
+        const int nb = n_tiles - done < chunk ? n_tiles - done : chunk;
         const bool two = c->lane1_batch > 0 && c->lanes == 2 && !c->profiling && nb >= 2 * kMinLaneTiles;
         if (!two) {
             if (run_chunk(0, done, nb)) return 1;

@@ -101,6 +101,20 @@ struct TailParams {
     float* probs;             // [n][2PH][2PW][classes] or null
 };
 
+// Network stem: 7x7 stride-2 conv on the image in the PAIRS input form (7 rows x 4 two-pixel granules
+// of 8 values) -> 64 channels, per-channel affine (+ ReLU), 16-bit NHWC.  See stem_conv_pairs.
+struct StemParams {
+    const char* pairs;        // buffer start (zero header), [n][PHt][PWt][8] 16-bit
+    int PHt, PWt;             // padded rows, two-pixel granules per row
+    int n;                    // patches
+    int Ho, Wo;               // output size, multiples of 16
+    const void* wfrag;        // [7 ky][4 mi][64 lanes] x 16 bytes, MFMA A-fragment order, rows = conv_row_channel
+    const float* scale;       // [64]
+    const float* shift;
+    int relu;
+    void* out;                // data pointer [n][Ho][Wo][64]
+};
+
 struct HeadParams {
     const void* src;          // [M][cin] activations (data pointer)
     int cin;                  // <= 64, multiple of 8
@@ -141,6 +155,7 @@ hipError_t launch_maxpool(const void* src, void* dst, int n, int H, int W, int C
                           int precision, hipStream_t s);
 hipError_t launch_head(const HeadParams& p, int precision, hipStream_t s);
 hipError_t launch_tail(const TailParams& p, int precision, int num_cus, hipStream_t s);
+hipError_t launch_stem(const StemParams& p, int precision, int num_cus, hipStream_t s);
 constexpr int kTailKSteps = 6;      // 4 taps x 64 channels of src0 + 2 steps for the 9 image taps
 hipError_t launch_ingest_u8(const IngestParams& p, int precision, hipStream_t s);
 hipError_t launch_otsu(const uint8_t* page, int src_Wp, int Hp, int Wp, const int* map_y, const int* map_x,

@@ -357,6 +357,28 @@ void conv_igemm_mfma(const ConvParams p)
         }
     };
 
+    // epilogue constants of the tile being finished, requested like the residual BEFORE the next
+    // stage's loads are issued: vmcnt retires in order, so a load issued in the epilogue itself would
+    // only return after the whole next stage has landed -- one extra round trip per tile on short-K layers
+    constexpr bool kPrefetchConst = kPrefetchRes;
+    float csc[kPrefetchConst ? T::kMI / 2 : 1][8], csh[kPrefetchConst ? T::kMI / 2 : 1][8];
+    auto prefetch_consts = [&](int tile) __attribute__((always_inline)) {
+        int ctile, cls, ptile;
+        decode(tile, ctile, cls, ptile);
+#pragma unroll
+        for (int s2 = 0; s2 < T::kMI / 2; ++s2) {
+            const int c0 = ctile * BC + wc * T::kWCH + s2 * 32 + fg * 8;
+            if constexpr (kPrefetchConst) {
+                if (c0 < p.cout) {
+                    *(float4*)&csc[s2][0] = *(const float4*)(p.scale + c0);
+                    *(float4*)&csc[s2][4] = *(const float4*)(p.scale + c0 + 4);
+                    *(float4*)&csh[s2][0] = *(const float4*)(p.shift + c0);
+                    *(float4*)&csh[s2][4] = *(const float4*)(p.shift + c0 + 4);
+                }
+            }
+        }
+    };
+
     // ---- epilogue of one finished tile.  Weight rows are packed in the order conv_row_channel()
     // gives, so the two MFMA row blocks (2s, 2s+1) of a lane hold 8 CONSECUTIVE channels of one
     // pixel: 16-byte NHWC stores / residual loads, 64 contiguous bytes per pixel per instruction.
@@ -389,10 +411,15 @@ void conv_igemm_mfma(const ConvParams p)
                     float sc[2][8], sh[2][8];
 #pragma unroll
                     for (int h = 0; h < 2; ++h) {
-                        *(float4*)&sc[h][0] = *(const float4*)(p.scale + cA + h * 32);
-                        *(float4*)&sc[h][4] = *(const float4*)(p.scale + cA + h * 32 + 4);
-                        *(float4*)&sh[h][0] = *(const float4*)(p.shift + cA + h * 32);
-                        *(float4*)&sh[h][4] = *(const float4*)(p.shift + cA + h * 32 + 4);
+                        if constexpr (kPrefetchConst) {
+#pragma unroll
+                            for (int q = 0; q < 8; ++q) { sc[h][q] = csc[sp * 2 + h][q]; sh[h][q] = csh[sp * 2 + h][q]; }
+                        } else {
+                            *(float4*)&sc[h][0] = *(const float4*)(p.scale + cA + h * 32);
+                            *(float4*)&sc[h][4] = *(const float4*)(p.scale + cA + h * 32 + 4);
+                            *(float4*)&sh[h][0] = *(const float4*)(p.shift + cA + h * 32);
+                            *(float4*)&sh[h][4] = *(const float4*)(p.shift + cA + h * 32 + 4);
+                        }
                     }
 #pragma unroll
                     for (int ni = 0; ni < T::kNI; ++ni) {
@@ -450,10 +477,15 @@ void conv_igemm_mfma(const ConvParams p)
             const int c0 = ctile * BC + wc * T::kWCH + s2 * 32 + fg * 8;
             if (c0 < p.cout) {
                 float sc[8], sh[8], rsc[8], rsh[8];
-                *(float4*)&sc[0] = *(const float4*)(p.scale + c0);
-                *(float4*)&sc[4] = *(const float4*)(p.scale + c0 + 4);
-                *(float4*)&sh[0] = *(const float4*)(p.shift + c0);
-                *(float4*)&sh[4] = *(const float4*)(p.shift + c0 + 4);
+                if constexpr (kPrefetchConst) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) { sc[q] = csc[s2][q]; sh[q] = csh[s2][q]; }
+                } else {
+                    *(float4*)&sc[0] = *(const float4*)(p.scale + c0);
+                    *(float4*)&sc[4] = *(const float4*)(p.scale + c0 + 4);
+                    *(float4*)&sh[0] = *(const float4*)(p.shift + c0);
+                    *(float4*)&sh[4] = *(const float4*)(p.shift + c0 + 4);
+                }
                 if (p.raw_out) {
                     *(float4*)&rsc[0] = *(const float4*)(p.raw_scale + c0);
                     *(float4*)&rsc[4] = *(const float4*)(p.raw_scale + c0 + 4);
@@ -560,8 +592,11 @@ void conv_igemm_mfma(const ConvParams p)
 
     int cur = 0, nxt = D % NS, c_t = 0, c_q = 0;
     for (int s = 0; s < total; ++s) {
+        if (c_t == nts - 1) {                               // last stage of a tile: its epilogue inputs go first
+            if (kPrefetchConst) prefetch_consts(tile_at(c_q));
+            if (kPrefetchRes && p.residual) prefetch_residual(tile_at(c_q));
+        }
         if (issued < total) issue(nxt);
-        if (kPrefetchRes && p.residual && c_t == nts - 1) prefetch_residual(tile_at(c_q));
         const char* sb = smem + cur * T::kStageBytes;
         {
             // The K-step's MFMAs run in phases of (k-half kk, group of <= 4 pixel blocks); the LDS
@@ -1018,6 +1053,149 @@ hipError_t launch_tail(const TailParams& p, int precision, int num_cus, hipStrea
     if (precision == kF16) e = p.classes <= 2 ? go(dec_tail_fused<true, 2>) : go(dec_tail_fused<true, 4>);
     else e = p.classes <= 2 ? go(dec_tail_fused<false, 2>) : go(dec_tail_fused<false, 4>);
     if (e != hipSuccess) return e;
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// stem_conv_pairs -- the network's first conv (7x7, stride 2, 3 -> 64 channels) as a direct conv on an
+// LDS halo tile.  The generic kernel gathers 8 differently-placed granules per 128-byte row here (the
+// per-granule tap table) and re-fetches every input row ~3.5x across XCDs; this one copies the
+// 37-row x 19-granule input halo of a 16x16 output tile to LDS once (12 KB, double buffered over a
+// persistent tile loop), keeps all 7 x 64-channel weight fragments in 112 VGPRs, and reads one
+// ds_read_b128 per (kernel row, 16-pixel output row): lane (pixel x, granule g) reads granule x + g
+// of input row 2y + ky -- consecutive 16-byte slots, conflict-free for any row stride.  Each wave
+// owns 4 output rows x 64 channels; epilogue = scale/shift(/ReLU), whole-line 16-bit stores.
+// ------------------------------------------------------------------------------------------------
+constexpr int kStemRowSlots = 20;                       // granules per LDS row (19 used)
+constexpr int kStemRows = 37;                           // 2*16 + 5
+constexpr int kStemInstr = (kStemRows * kStemRowSlots + 63) / 64;      // wave-instructions per halo tile (12)
+constexpr int kStemBufBytes = kStemInstr * 1024;
+constexpr int kStemLdsBytes = 2 * kStemBufBytes + 512;  // + scale[64], shift[64]
+constexpr int kStemStores = 8;                          // store instructions per wave per tile
+
+template <bool F16>
+__global__ __launch_bounds__(256, 2) void stem_conv_pairs(const StemParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int frow = lane & 15, fg = lane >> 4;
+    const int tiles_x = p.Wo / 16, tiles_y = p.Ho / 16;
+    const int tiles_per_patch = tiles_x * tiles_y;
+    const int n_tiles = p.n * tiles_per_patch;
+    const int G = gridDim.x;
+    const int my_tiles = (n_tiles - (int)blockIdx.x + G - 1) / G;
+    if (my_tiles <= 0) return;
+
+    // epilogue constants live in LDS: a global load in the epilogue would queue behind the next tile's
+    // halo loads (vmcnt retires in order) and stall every tile for one memory round trip
+    float* cst = (float*)(smem + 2 * kStemBufBytes);
+    if (tid < 64) { cst[tid] = p.scale[tid]; cst[64 + tid] = p.shift[tid]; }
+    bf16x8_t wf[7][4];
+    {
+        const uint4* src = (const uint4*)p.wfrag + lane;
+#pragma unroll
+        for (int ky = 0; ky < 7; ++ky)
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) wf[ky][mi] = __builtin_bit_cast(bf16x8_t, src[(size_t)(ky * 4 + mi) * 64]);
+    }
+
+    auto issue_tile = [&](int tile, int buf) __attribute__((always_inline)) {
+        const int n = tile / tiles_per_patch;
+        const int rem = tile - n * tiles_per_patch;
+        const int ty = rem / tiles_x, tx = rem - ty * tiles_x;
+        char* lds = smem + buf * kStemBufBytes;
+#pragma unroll
+        for (int j = 0; j < kStemInstr / 4; ++j) {
+            const int ii = wave + 4 * j;
+            const int slot = ii * 64 + lane;
+            const int r = slot / kStemRowSlots, cc = slot - r * kStemRowSlots;
+            const int Y = 32 * ty + r, X = 16 * tx + cc;          // (granule 19 of a row is never read: whatever lies there)
+            uint32_t off = (uint32_t)((n * p.PHt + Y) * p.PWt + X) * 16u + (uint32_t)kZeroHeaderBytes;
+            off = r < kStemRows ? off : 0u;
+            __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(p.pairs + off), (LDS_AS void*)(lds + ii * 1024), 16, 0, 0);
+        }
+    };
+
+    const bool hi = (frow & 8) != 0;
+    issue_tile(blockIdx.x, 0);
+    for (int it = 0; it < my_tiles; ++it) {
+        const int tile = blockIdx.x + it * G;
+        // the halo loads of tile `it` are older than the previous tile's stores: leave those in flight
+        if (it == 0) wait_vmcnt<0>();
+        else wait_vmcnt<kStemStores>();
+        __syncthreads();                                        // tile `it` landed; everyone is done with tile it-1
+        if (it + 1 < my_tiles) issue_tile(tile + G, (it + 1) & 1);
+
+        const char* lds = smem + (it & 1) * kStemBufBytes;
+        f32x4_t acc[4][4];
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ky = 0; ky < 7; ++ky) {
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+                const int row = 2 * (wave * 4 + ni) + ky;
+                const bf16x8_t b = *(const bf16x8_t*)(lds + (row * kStemRowSlots + frow + fg) * 16);
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi) acc[mi][ni] = mfma16<F16>(wf[ky][mi], b, acc[mi][ni]);
+            }
+        }
+
+        // ---- epilogue (same lane swap as conv_igemm_mfma's full-tile path: 8 pixels x 128 B per store)
+        const int n = tile / tiles_per_patch;
+        const int rem = tile - n * tiles_per_patch;
+        const int ty = rem / tiles_x, tx = rem - ty * tiles_x;
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+            const int oy = ty * 16 + wave * 4 + ni;
+            const size_t pix0 = ((size_t)n * p.Ho + oy) * p.Wo + tx * 16 + (frow & 7);
+            uint4 r[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int c0 = h * 32 + fg * 8;
+                float sc[8], sh[8], y[8];
+                *(float4*)&sc[0] = *(const float4*)(cst + c0);
+                *(float4*)&sc[4] = *(const float4*)(cst + c0 + 4);
+                *(float4*)&sh[0] = *(const float4*)(cst + 64 + c0);
+                *(float4*)&sh[4] = *(const float4*)(cst + 64 + c0 + 4);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    y[q] = acc[2 * h][ni][q] * sc[q] + sh[q];
+                    y[4 + q] = acc[2 * h + 1][ni][q] * sc[4 + q] + sh[4 + q];
+                }
+                if (p.relu) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) y[q] = fmaxf(y[q], 0.f);
+                }
+                r[h].x = pack2<F16>(y[0], y[1]); r[h].y = pack2<F16>(y[2], y[3]);
+                r[h].z = pack2<F16>(y[4], y[5]); r[h].w = pack2<F16>(y[6], y[7]);
+            }
+            uint4 give, recv, st0, st1;
+            give.x = hi ? r[0].x : r[1].x; give.y = hi ? r[0].y : r[1].y;
+            give.z = hi ? r[0].z : r[1].z; give.w = hi ? r[0].w : r[1].w;
+            recv.x = row_ror8(give.x); recv.y = row_ror8(give.y);
+            recv.z = row_ror8(give.z); recv.w = row_ror8(give.w);
+            st0.x = hi ? recv.x : r[0].x; st0.y = hi ? recv.y : r[0].y;
+            st0.z = hi ? recv.z : r[0].z; st0.w = hi ? recv.w : r[0].w;
+            st1.x = hi ? r[1].x : recv.x; st1.y = hi ? r[1].y : recv.y;
+            st1.z = hi ? r[1].z : recv.z; st1.w = hi ? r[1].w : recv.w;
+            const int cst = (hi ? 32 : 0) + fg * 8;
+            *(uint4*)((uint16_t*)p.out + pix0 * 64 + cst) = st0;
+            *(uint4*)((uint16_t*)p.out + (pix0 + 8) * 64 + cst) = st1;
+        }
+    }
+}
+
+hipError_t launch_stem(const StemParams& p, int precision, int num_cus, hipStream_t s)
+{
+    const int n_tiles = p.n * (p.Ho / 16) * (p.Wo / 16);
+    const int grid = n_tiles < 2 * num_cus ? n_tiles : 2 * num_cus;
+    if (precision == kF16) hipLaunchKernelGGL(stem_conv_pairs<true>, dim3(grid), dim3(256), kStemLdsBytes, s, p);
+    else hipLaunchKernelGGL(stem_conv_pairs<false>, dim3(grid), dim3(256), kStemLdsBytes, s, p);
     return hipGetLastError();
 }
 
