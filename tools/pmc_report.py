@@ -27,7 +27,7 @@ fe, meta_f = load("fetch")
 wr, meta_w = load("write")
 # plan kernels only (conv / maxpool / head), in dispatch order; one chunk = 61 ops
 def plan_ids(meta):
-    return [d for d in sorted(meta) if any(s in meta[d][0] for s in ("conv_igemm", "maxpool", "head_kernel", "dec_tail"))]
+    return [d for d in sorted(meta) if any(s in meta[d][0] for s in ("conv_igemm", "maxpool", "head_kernel", "dec_tail", "stem_conv"))]
 ids, idf, idw = plan_ids(meta), plan_ids(meta_f), plan_ids(meta_w)
 names = None
 if ops_json:
