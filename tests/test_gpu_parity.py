@@ -377,4 +377,17 @@ def test_two_lanes_equal_one_lane():
             ref = outs[1]
     for a, b in zip(outs[2], ref):
         assert np.array_equal(a, b)
+    # the same on torch's current (legacy default) stream with device-resident buffers: how bench.py and the
+    # sharded backend drive the library; the second lane forks from / joins that stream with events
+    import torch
+    d_page = torch.from_numpy(page).cuda()
+    d_lab = torch.zeros(page.shape[:2], dtype=torch.uint8, device="cuda")
+    model.ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    try:
+        for _ in range(3):
+            model.ctx.segment_page_dev(d_page.data_ptr(), page.shape[0], page.shape[1], d_lab.data_ptr())
+        got = d_lab.cpu().numpy()                      # (.cpu() synchronises the current stream only)
+    finally:
+        model.ctx.set_stream(-1)
+    assert np.array_equal(got, ref[0])
     model.release()
