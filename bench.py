@@ -36,7 +36,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--precision", default=os.environ.get("SBBSEG_PRECISION", "f16"), choices=["f16", "bf16"])
-    ap.add_argument("--max-batch", type=int, default=int(os.environ.get("SBBSEG_MAX_BATCH", "70")))
+    ap.add_argument("--max-batch", type=int, default=int(os.environ.get("SBBSEG_MAX_BATCH", "0")),
+                    help="tiles per chunk (0 = one page per chunk: 70 for the 3500x2500 page, 108 for the 4000x3000 pages of batch64)")
     ap.add_argument("--conv-variant", type=int, default=int(os.environ.get("SBBSEG_CONV_VARIANT", "0")),
                     help="0 auto, 1 force 4-wave/2-stage conv tiles, 2 force 8-wave/3-stage (A/B only)")
     ap.add_argument("--workload", default="page", choices=["page", "pipeline3", "batch64"],
@@ -45,6 +46,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-patches", type=int, default=8)
     args = ap.parse_args()
+    if args.max_batch <= 0:
+        args.max_batch = 108 if args.workload == "batch64" else 70
 
     import torch
     import torch.distributed as dist
