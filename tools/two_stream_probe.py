@@ -50,7 +50,30 @@ def bench_pages(k, steps=20):
     print("pages in flight", k, "ms/step %.3f" % ms, "patches/s %.0f" % (k * n / ms * 1e3), flush=True)
     for m in models: m.release()
 
-for split in (1, 2):
-    bench(split)
-for k in (1, 2, 3):
-    bench_pages(k)
+def bench_pages_offset(frac, steps=20):
+    """two whole pages in flight on two handles (one lane each), the second stream started `frac` of a page later"""
+    os.environ["SBBSEG_LANES"] = "1"
+    models = [SegModel(cfg, w, device=0, max_batch=n, precision="f16") for _ in range(2)]
+    streams = [torch.cuda.Stream() for _ in range(2)]
+    outs = [torch.empty((n, 448, 448), dtype=torch.uint8, device="cuda") for _ in range(2)]
+    for m, s in zip(models, streams):
+        m.ctx.set_stream(s.cuda_stream)
+    def run(steps):
+        if frac > 0:
+            models[1].ctx.segment_tile_range_dev(d_page.data_ptr(), 3500, 2500, 0, max(1, int(n * frac)), outs[1].data_ptr())
+        for _ in range(steps):
+            for m, o in zip(models, outs):
+                m.ctx.segment_tile_range_dev(d_page.data_ptr(), 3500, 2500, 0, n, o.data_ptr())
+    run(3)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(steps)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    print("2 pages in flight, offset %.2f page: ms/step %.3f" % (frac, ms), "patches/s %.0f" % ((2 * n * steps + (n * frac if frac else 0)) / (ms * steps) * 1e3), flush=True)
+    for m in models: m.release()
+    os.environ.pop("SBBSEG_LANES")
+
+bench(2)
+for f in (0.0, 0.25, 0.5):
+    bench_pages_offset(f)
