@@ -1403,48 +1403,97 @@ __global__ __launch_bounds__(256) void maxpool_kernel(const E* src, E* dst, int 
                                                       int k, int stride, int Ho, int Wo,
                                                       const float* pre_scale, const float* pre_shift, int pre_relu)
 {
+    // one thread = 8 channels x up to 4 horizontally adjacent outputs: the windows of neighbours overlap
+    // (k - stride shared columns), so the strip is read once -- (3*stride + k) columns instead of 4*k
+    constexpr int OX = 4;
     const int cg = C / 8;
+    const int wq = (Wo + OX - 1) / OX;
     // Blocks are dealt round-robin to the 8 XCDs; give every XCD one CONTIGUOUS eighth of the output
     // raster, so the input rows shared by vertically adjacent windows (blocks a few indices apart)
     // meet in ONE L2 instead of being fetched by two (PMC: fetch was 1.43x the input tensor).
     const unsigned nwg = gridDim.x, xcd = blockIdx.x & 7, q8 = nwg >> 3, r8 = nwg & 7;
     const unsigned wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (blockIdx.x >> 3);
-    const long idx = (long)wg * 256 + threadIdx.x;
-    const long total = (long)n * Ho * Wo * cg;
+    const unsigned idx = wg * 256u + threadIdx.x;
+    const unsigned total = (unsigned)n * Ho * wq * cg;
     if (idx >= total) return;
     const int g = (int)(idx % cg);
-    long pix = idx / cg;
-    const int ox = (int)(pix % Wo); pix /= Wo;
+    unsigned pix = idx / cg;
+    const int oq = (int)(pix % wq); pix /= wq;
     const int oy = (int)(pix % Ho);
     const int b = (int)(pix / Ho);
-    float m[8], ps[8], pb[8];
+    const int ox0 = oq * OX;
+    const int nout = min(OX, Wo - ox0);
+    float m[OX][8], ps[8], pb[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-        m[i] = -3.0e38f;
         ps[i] = pre_scale ? pre_scale[g * 8 + i] : 1.f;
         pb[i] = pre_scale ? pre_shift[g * 8 + i] : 0.f;
-    }
-    for (int ky = 0; ky < k; ++ky)
-        for (int kx = 0; kx < k; ++kx) {
-            const Vec8<E> v = *(const Vec8<E>*)(src + (((size_t)b * H + oy * stride + ky) * W + ox * stride + kx) * C + g * 8);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                float x = from_elem<E>(v.v[i]) * ps[i] + pb[i];
-                if (pre_relu) x = fmaxf(x, 0.f);
-                m[i] = fmaxf(m[i], x);
+        for (int o = 0; o < OX; ++o) m[o][i] = -3.0e38f;
+    }
+    const int ncol = (nout - 1) * stride + k;                   // input columns of the strip
+    if (k == 3 && stride == 2 && nout == OX) {
+        // the ResNet stem pool, full strip: all 27 loads are independent -> issue them back to back
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const E* row = src + (((size_t)b * H + oy * 2 + ky) * W + ox0 * 2) * C + g * 8;
+            Vec8<E> v[9];
+#pragma unroll
+            for (int c = 0; c < 9; ++c) v[c] = *(const Vec8<E>*)(row + (size_t)c * C);
+#pragma unroll
+            for (int c = 0; c < 9; ++c) {
+                float x[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    x[i] = from_elem<E>(v[c].v[i]) * ps[i] + pb[i];
+                    if (pre_relu) x[i] = fmaxf(x[i], 0.f);
+                }
+#pragma unroll
+                for (int o = 0; o < OX; ++o) {
+                    if (c >= 2 * o && c < 2 * o + 3) {
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) m[o][i] = fmaxf(m[o][i], x[i]);
+                    }
+                }
             }
         }
-    Vec8<E> o;
+    } else
+    for (int ky = 0; ky < k; ++ky) {
+        const E* row = src + (((size_t)b * H + oy * stride + ky) * W + ox0 * stride) * C + g * 8;
+        for (int c = 0; c < ncol; ++c) {
+            const Vec8<E> v = *(const Vec8<E>*)(row + (size_t)c * C);
+            float x[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) o.v[i] = to_elem<E>(m[i]);
-    *(Vec8<E>*)(dst + (((size_t)b * Ho + oy) * Wo + ox) * C + g * 8) = o;
+            for (int i = 0; i < 8; ++i) {
+                x[i] = from_elem<E>(v.v[i]) * ps[i] + pb[i];
+                if (pre_relu) x[i] = fmaxf(x[i], 0.f);
+            }
+#pragma unroll
+            for (int o = 0; o < OX; ++o) {
+                const int kx = c - o * stride;                     // column c inside output o's window?
+                if (o < nout && kx >= 0 && kx < k) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) m[o][i] = fmaxf(m[o][i], x[i]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 0; o < OX; ++o) {
+        if (o < nout) {
+            Vec8<E> r;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) r.v[i] = to_elem<E>(m[o][i]);
+            *(Vec8<E>*)(dst + (((size_t)b * Ho + oy) * Wo + ox0 + o) * C + g * 8) = r;
+        }
+    }
 }
 
 hipError_t launch_maxpool(const void* src, void* dst, int n, int H, int W, int C, int k, int stride,
                           int Ho, int Wo, const float* pre_scale, const float* pre_shift, int pre_relu,
                           int precision, hipStream_t s)
 {
-    const long total = (long)n * Ho * Wo * (C / 8);
+    const long total = (long)n * Ho * ((Wo + 3) / 4) * (C / 8);
     const unsigned grid = (unsigned)((total + 255) / 256);
     if (precision == kF32)
         hipLaunchKernelGGL(maxpool_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)src, (float*)dst, n, H, W, C, k, stride, Ho, Wo, pre_scale, pre_shift, pre_relu);
