@@ -72,6 +72,7 @@ struct ConvOp {
     KTabEntry* d_ktab_cls[4] = {nullptr, nullptr, nullptr, nullptr};
     int ooy_cls[4] = {0, 0, 0, 0}, oox_cls[4] = {0, 0, 0, 0};
     uint16_t* d_stem_wfrag = nullptr;     // non-null: the op is the network stem and runs stem_conv_pairs
+    uint16_t* d_d64_wfrag = nullptr;      // non-null: 3x3 s1 64->64 conv, runs conv3x3_c64_direct
 };
 
 struct PoolOp { int src, dst, k, stride, Ho, Wo; float *d_pre_scale = nullptr, *d_pre_shift = nullptr; int pre_relu = 0; };
@@ -309,6 +310,12 @@ int run_plan(sbbseg_ctx* c, int n, uint8_t* d_labels, float* d_probs)
                 sp.wfrag = co.d_stem_wfrag; sp.scale = co.d_scale; sp.shift = co.d_shift; sp.relu = co.d.relu;
                 sp.out = c->tensors[co.d.out_tensor].data();
                 HIPCHK(launch_stem(sp, c->precision, c->num_cus, c->stream));
+            } else if (co.d_d64_wfrag && !(c->conv_variant & 3)) {
+                const Tensor& st = c->tensors[co.d.src[0].tensor];
+                Direct64Params dp;
+                dp.src = st.buf; dp.n = n; dp.H = st.H; dp.W = st.W; dp.wfrag = co.d_d64_wfrag;
+                dp.scale = co.d_scale; dp.shift = co.d_shift; dp.relu = co.d.relu; dp.out = c->tensors[co.d.out_tensor].data();
+                HIPCHK(launch_direct64(dp, c->precision, c->num_cus, c->stream));
             } else {
                 HIPCHK(launch_conv(p, c->precision, c->stream));
             }
@@ -445,7 +452,7 @@ int sbbseg_destroy(sbbseg_ctx* c)
     for (auto& op : c->ops) {
         hipFree(op.conv.d_ktab); hipFree(op.conv.d_kstep); hipFree(op.conv.d_w); hipFree(op.conv.d_scale); hipFree(op.conv.d_shift);
         hipFree(op.conv.d_rscale); hipFree(op.conv.d_rshift);
-        hipFree(op.conv.d_head_w); hipFree(op.conv.d_head_scale); hipFree(op.conv.d_head_shift); hipFree(op.conv.d_stem_wfrag);
+        hipFree(op.conv.d_head_w); hipFree(op.conv.d_head_scale); hipFree(op.conv.d_head_shift); hipFree(op.conv.d_stem_wfrag); hipFree(op.conv.d_d64_wfrag);
         for (int q = 1; q < 4; ++q) { hipFree(op.conv.d_w_cls[q]); hipFree(op.conv.d_kstep_cls[q]); hipFree(op.conv.d_ktab_cls[q]); }
         hipFree(op.head.d_w); hipFree(op.head.d_scale); hipFree(op.head.d_shift);
         hipFree(op.pool.d_pre_scale); hipFree(op.pool.d_pre_shift);
@@ -734,6 +741,28 @@ int sbbseg_add_conv(sbbseg_ctx* c, const sbbseg_conv_desc* d, const float* w_src
                     }
             if (upload(c, &co.d_stem_wfrag, frag.data(), frag.size())) return 1;
             op.name = "stem_" + op.name;
+        }
+        // 3x3 / stride 1 / pad 1, 64 -> 64 channels: direct conv on an LDS halo tile, weights in registers
+        const char* env2 = getenv("SBBSEG_DIRECT64_KERNEL");
+        if (c->precision != kF32 && !(env2 && env2[0] == '0') && d->n_src == 1 && !st.is_input_form && st.C == 64 && cs.channels == 64 &&
+            cs.kh == 3 && cs.kw == 3 && cs.stride_y == 1 && cs.stride_x == 1 && cs.pad_top == 1 && cs.pad_left == 1 && cs.up_shift == 0 &&
+            cs.off_y == 0 && cs.off_x == 0 && d->cout == 64 && d->out_h == st.H && d->out_w == st.W && d->residual_tensor < 0 &&
+            d->raw_out_tensor < 0 && d->head_classes == 0 && d->out_tensor >= 0 && d->out_stride_y == 1 && d->out_stride_x == 1 &&
+            d->out_off_y == 0 && d->out_off_x == 0 && TH == d->out_h && TW == d->out_w) {
+            std::vector<uint16_t> frag((size_t)9 * 2 * 4 * 64 * 8);
+            for (int t = 0; t < 9; ++t)
+                for (int kk = 0; kk < 2; ++kk)
+                    for (int mi = 0; mi < 4; ++mi)
+                        for (int l = 0; l < 64; ++l) {
+                            const int o = conv_row_channel(mi * 16 + (l & 15), 64);
+                            const int chb = (kk * 4 + (l >> 4)) * 8;
+                            for (int e = 0; e < 8; ++e) {
+                                const float v = w_src0[((size_t)t * 64 + chb + e) * 64 + o];
+                                frag[(((((size_t)t * 2 + kk) * 4 + mi) * 64) + l) * 8 + e] = c->precision == kF16 ? f32_to_f16_rne(v) : f32_to_bf16_rne(v);
+                            }
+                        }
+            if (upload(c, &co.d_d64_wfrag, frag.data(), frag.size())) return 1;
+            op.name = "direct_" + op.name;
         }
     }
 

@@ -115,6 +115,18 @@ struct StemParams {
     void* out;                // data pointer [n][Ho][Wo][64]
 };
 
+// 3x3 stride-1 'same' conv, 64 -> 64 channels (the ResNet stage-2 bottleneck convs), as a direct conv on an
+// LDS halo tile with the weights resident in registers.  See conv3x3_c64_direct.
+struct Direct64Params {
+    const char* src;          // buffer start (zero header), [n][H][W][64] 16-bit
+    int n, H, W;
+    const void* wfrag;        // [9 taps][2 kk][4 mi][64 lanes] x 16 bytes, MFMA A-fragment order, rows = conv_row_channel
+    const float* scale;       // [64]
+    const float* shift;
+    int relu;
+    void* out;                // data pointer [n][H][W][64]
+};
+
 struct HeadParams {
     const void* src;          // [M][cin] activations (data pointer)
     int cin;                  // <= 64, multiple of 8
@@ -156,6 +168,7 @@ hipError_t launch_maxpool(const void* src, void* dst, int n, int H, int W, int C
 hipError_t launch_head(const HeadParams& p, int precision, hipStream_t s);
 hipError_t launch_tail(const TailParams& p, int precision, int num_cus, hipStream_t s);
 hipError_t launch_stem(const StemParams& p, int precision, int num_cus, hipStream_t s);
+hipError_t launch_direct64(const Direct64Params& p, int precision, int num_cus, hipStream_t s);
 constexpr int kTailKSteps = 6;      // 4 taps x 64 channels of src0 + 2 steps for the 9 image taps
 hipError_t launch_ingest_u8(const IngestParams& p, int precision, hipStream_t s);
 hipError_t launch_otsu(const uint8_t* page, int src_Wp, int Hp, int Wp, const int* map_y, const int* map_x,

@@ -1200,6 +1200,155 @@ hipError_t launch_stem(const StemParams& p, int precision, int num_cus, hipStrea
 }
 
 // ------------------------------------------------------------------------------------------------
+// conv3x3_c64_direct -- 3x3 / stride 1 / pad 1, 64 -> 64 channels (three layers at 111x111 in the sbb
+// nets).  The implicit-GEMM kernel is staging-bound here: 64 output channels amortise a gathered pixel
+// row over 4 MFMAs only, and every pixel row is re-staged for each of the 9 taps.  Same recipe as the
+// stem: a block owns an 8 x 16 output tile, copies its 10 x 18 pixel halo (128 B per pixel, XOR-swizzled
+// granules, 23 KB, double buffered over a persistent tile loop) once, and runs all 9 taps from it.  Wave
+// (wp, wc) owns 4 output rows x 32 channels and keeps its 9 x 2 x 2 weight fragments in 144 VGPRs.
+// ------------------------------------------------------------------------------------------------
+constexpr int kD64HaloW = 18, kD64HaloH = 10;
+constexpr int kD64Rows = kD64HaloW * kD64HaloH;                 // 180 pixel rows of 128 B
+constexpr int kD64Instr = 24;                                   // wave-instructions of 8 rows (192 >= 180)
+constexpr int kD64BufBytes = kD64Instr * 1024;
+constexpr int kD64LdsBytes = 2 * kD64BufBytes + 512;            // + scale[64], shift[64]
+
+template <bool F16>
+__global__ __launch_bounds__(256, 2) void conv3x3_c64_direct(const Direct64Params p)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wp = wave >> 1, wc = wave & 1;
+    const int frow = lane & 15, fg = lane >> 4;
+    const int tiles_x = (p.W + 15) / 16, tiles_y = (p.H + 7) / 8;
+    const int tiles_per_patch = tiles_x * tiles_y;
+    const int n_tiles = p.n * tiles_per_patch;
+    const int G = gridDim.x;
+    const int my_tiles = (n_tiles - (int)blockIdx.x + G - 1) / G;
+    if (my_tiles <= 0) return;
+    float* cst = (float*)(smem + 2 * kD64BufBytes);
+    if (tid < 64) { cst[tid] = p.scale[tid]; cst[64 + tid] = p.shift[tid]; }
+
+    bf16x8_t wf[9][2][2];                                       // [tap][kk][mi of this wave]
+    {
+        const uint4* src = (const uint4*)p.wfrag + lane;
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+                    wf[t][kk][m] = __builtin_bit_cast(bf16x8_t, src[(size_t)((t * 2 + kk) * 4 + wc * 2 + m) * 64]);
+    }
+
+    const int lrow = lane >> 3;
+    const int gsrc = (lane & 7) ^ lrow;                         // swizzle: halo row j keeps granule g at slot g ^ (j & 7)
+    auto issue_tile = [&](int tile, int buf) __attribute__((always_inline)) {
+        const int n = tile / tiles_per_patch;
+        const int rem = tile - n * tiles_per_patch;
+        const int ty = rem / tiles_x, tx = rem - ty * tiles_x;
+        char* lds = smem + buf * kD64BufBytes;
+#pragma unroll
+        for (int j = 0; j < kD64Instr / 4; ++j) {
+            const int ii = wave + 4 * j;
+            const int hr = ii * 8 + lrow;                       // halo row index = hy * 18 + hx
+            const int hy = hr / kD64HaloW, hx = hr - hy * kD64HaloW;
+            const int Y = ty * 8 - 1 + hy, X = tx * 16 - 1 + hx;
+            const bool ok = ((unsigned)Y < (unsigned)p.H) & ((unsigned)X < (unsigned)p.W) & (hr < kD64Rows);
+            uint32_t off = (uint32_t)((n * p.H + Y) * p.W + X) * 128u + (uint32_t)(gsrc * 16 + kZeroHeaderBytes);
+            off = ok ? off : 0u;
+            __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(p.src + off), (LDS_AS void*)(lds + ii * 1024), 16, 0, 0);
+        }
+    };
+
+    // halo row of output pixel (r, x) = (wp*4 + ni, frow) for tap (0,0); + ky*18 + kx per tap
+    int hbase[4];
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) hbase[ni] = (wp * 4 + ni) * kD64HaloW + frow;
+
+    issue_tile(blockIdx.x, 0);
+    bool prev_full = false;
+    for (int it = 0; it < my_tiles; ++it) {
+        const int tile = blockIdx.x + it * G;
+        // the halo copies of tile `it` are older than the previous tile's stores (4 per wave when that tile
+        // was full): leave those in flight
+        if (prev_full) wait_vmcnt<4>();
+        else wait_vmcnt<0>();
+        __syncthreads();
+        if (it + 1 < my_tiles) issue_tile(tile + G, (it + 1) & 1);
+
+        const char* lds = smem + (it & 1) * kD64BufBytes;
+        f32x4_t acc[2][4];
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) acc[m][ni] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        // an opaque zero per tile: without it the 72 tile-invariant fragment addresses are hoisted out of the tile
+        // loop into registers the weights need (spills)
+        int zero;
+        asm volatile("v_mov_b32 %0, 0" : "=v"(zero));
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int toff = (t / 3) * kD64HaloW + (t % 3) + zero;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) {
+                    const int hr = hbase[ni] + toff;
+                    const bf16x8_t b = *(const bf16x8_t*)(lds + hr * 128 + (((kk * 4 + fg) ^ (hr & 7)) << 4));
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) acc[m][ni] = mfma16<F16>(wf[t][kk][m], b, acc[m][ni]);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);                  // keep the scheduler from hoisting later taps' reads (spills)
+        }
+
+        // ---- epilogue: lane holds channels wc*32 + fg*8 .. +7 of pixel (wp*4 + ni, frow)
+        const int n = tile / tiles_per_patch;
+        const int rem = tile - n * tiles_per_patch;
+        const int ty = rem / tiles_x, tx = rem - ty * tiles_x;
+        prev_full = (ty * 8 + 8 <= p.H) && (tx * 16 + 16 <= p.W);
+        const int c0 = wc * 32 + fg * 8;
+        float sc[8], sh[8];
+        *(float4*)&sc[0] = *(const float4*)(cst + c0);
+        *(float4*)&sc[4] = *(const float4*)(cst + c0 + 4);
+        *(float4*)&sh[0] = *(const float4*)(cst + 64 + c0);
+        *(float4*)&sh[4] = *(const float4*)(cst + 64 + c0 + 4);
+        const int ox = tx * 16 + frow;
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+            const int oy = ty * 8 + wp * 4 + ni;
+            float y[8];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                y[q] = acc[0][ni][q] * sc[q] + sh[q];
+                y[4 + q] = acc[1][ni][q] * sc[4 + q] + sh[4 + q];
+            }
+            if (p.relu) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) y[q] = fmaxf(y[q], 0.f);
+            }
+            uint4 r;
+            r.x = pack2<F16>(y[0], y[1]); r.y = pack2<F16>(y[2], y[3]);
+            r.z = pack2<F16>(y[4], y[5]); r.w = pack2<F16>(y[6], y[7]);
+            if (oy < p.H && ox < p.W)
+                *(uint4*)((uint16_t*)p.out + (((size_t)n * p.H + oy) * p.W + ox) * 64 + c0) = r;
+        }
+    }
+}
+
+hipError_t launch_direct64(const Direct64Params& p, int precision, int num_cus, hipStream_t s)
+{
+    const int n_tiles = p.n * ((p.H + 7) / 8) * ((p.W + 15) / 16);
+    const int grid = n_tiles < 2 * num_cus ? n_tiles : 2 * num_cus;
+    if (precision == kF16) hipLaunchKernelGGL(conv3x3_c64_direct<true>, dim3(grid), dim3(256), kD64LdsBytes, s, p);
+    else hipLaunchKernelGGL(conv3x3_c64_direct<false>, dim3(grid), dim3(256), kD64LdsBytes, s, p);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
 // element helpers for the HBM-bound kernels (E = uint16_t bf16 bits | float)
 // ------------------------------------------------------------------------------------------------
 template <typename E> __device__ inline E to_elem(float v);
