@@ -199,10 +199,10 @@ def main():
         # HBM-side traffic of that launch from the committed rocprofv3 PMC passes of this same command
         # (tools/pmc_run.sh; counters need their own runs, see profiles/): bytes per launch
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01t_pmc_summary.json")))["ops"].get(dom["name"])
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01u_pmc_summary.json")))["ops"].get(dom["name"])
             if pmc and abs(dom["patches"] / dom["launches"] - 70) < 1e-6:
                 roofline["traffic"] = round(pmc["fetch_bytes"] + pmc["write_bytes"])
-                roofline["traffic_source"] = "profiles/r01t_pmc_summary.json (FETCH_SIZE x2 + WRITE_SIZE per launch, L2 hit %.0f %%)" % pmc["l2_hit_pct"]
+                roofline["traffic_source"] = "profiles/r01u_pmc_summary.json (FETCH_SIZE x2 + WRITE_SIZE per launch, L2 hit %.0f %%)" % pmc["l2_hit_pct"]
         except Exception:
             pass
         for o in prof:
