@@ -54,6 +54,10 @@ int sbbseg_synchronize(sbbseg_ctx* c);
  * All work stays ordered on the handle's stream (fork/join events); results do not depend on it.
  * Call before sbbseg_finalize to skip the second set of buffers (lanes = 1), or any time to switch. */
 int sbbseg_set_lanes(sbbseg_ctx* c, int lanes);
+/* Layout of the HOST label outputs of sbbseg_segment_page / _scaled / _otsu / _whole: 1 (default) = one
+ * uint8 plane [H][W]; 3 = the reference's own return layout, uint8 [H][W][3] with three identical channels
+ * (main.py:366, 380) -- replicated on the device, the host buffer must hold 3 x H x W bytes. */
+int sbbseg_set_label_channels(sbbseg_ctx* c, int channels);
 
 /* ---- plan building: the host-side planner (planner.py) lowers the Keras model_config that the
  * reference would have handed to keras.models.load_model (main.py:221) into these calls, in

@@ -18,7 +18,7 @@ INPUT_C8, INPUT_PAIRS = 0, 1
 
 EXPORTS = [
     "sbbseg_last_error", "sbbseg_abi_version", "sbbseg_device_count", "sbbseg_create", "sbbseg_destroy",
-    "sbbseg_set_stream", "sbbseg_set_lanes", "sbbseg_synchronize", "sbbseg_set_input", "sbbseg_input_form", "sbbseg_add_tensor",
+    "sbbseg_set_stream", "sbbseg_set_lanes", "sbbseg_set_label_channels", "sbbseg_synchronize", "sbbseg_set_input", "sbbseg_input_form", "sbbseg_add_tensor",
     "sbbseg_add_conv", "sbbseg_add_maxpool", "sbbseg_add_tail", "sbbseg_add_head", "sbbseg_finalize", "sbbseg_model_info",
     "sbbseg_num_ops", "sbbseg_op_info", "sbbseg_device_bytes", "sbbseg_predict", "sbbseg_segment_page",
     "sbbseg_segment_page_dev", "sbbseg_segment_page_scaled", "sbbseg_segment_page_otsu", "sbbseg_otsu_dev",
@@ -66,6 +66,7 @@ def load_library(path: Optional[str] = None):
         "sbbseg_set_stream": [vp, vp],
         "sbbseg_synchronize": [vp],
         "sbbseg_set_lanes": [vp, i32],
+        "sbbseg_set_label_channels": [vp, i32],
         "sbbseg_set_input": [vp, i32, i32, i32],
         "sbbseg_input_form": [vp, i32, i32, C.POINTER(C.c_int)],
         "sbbseg_add_tensor": [vp, i32, i32, i32, C.POINTER(C.c_int)],
@@ -234,6 +235,14 @@ class Context:
         """1 = one stream; 2 (default) = chunks of >= 16 tiles run as two concurrent halves (see sbbseg.h)."""
         check(self.lib.sbbseg_set_lanes(self.h, int(lanes)), "sbbseg_set_lanes")
 
+    def _label_out(self, h: int, w: int, channels: int) -> np.ndarray:
+        """Output array for a host label map: one plane, or the reference's 3 identical channels (replicated on the
+        device: numpy needs ~12 ms to do that for a 3500x2500 page, more than the whole forward pass)."""
+        if channels not in (1, 3):
+            raise ValueError("channels must be 1 or 3")
+        check(self.lib.sbbseg_set_label_channels(self.h, channels), "sbbseg_set_label_channels")
+        return np.empty((h, w) if channels == 1 else (h, w, 3), np.uint8)
+
     # -- execution -----------------------------------------------------------------------------
     def predict(self, x: np.ndarray) -> np.ndarray:
         H, W, classes, _ = self.model_info()
@@ -244,29 +253,29 @@ class Context:
         check(self.lib.sbbseg_predict(self.h, _ptr(x), x.shape[0], _ptr(out)), "sbbseg_predict")
         return out
 
-    def segment_page(self, page: np.ndarray) -> np.ndarray:
+    def segment_page(self, page: np.ndarray, channels: int = 1) -> np.ndarray:
         page = np.ascontiguousarray(page, np.uint8)
         if page.ndim != 3 or page.shape[2] != 3:
             raise ValueError(f"page must be uint8 [H,W,3], got {page.shape}")
-        out = np.empty(page.shape[:2], np.uint8)
+        out = self._label_out(page.shape[0], page.shape[1], channels)
         check(self.lib.sbbseg_segment_page(self.h, _ptr(page), page.shape[0], page.shape[1], _ptr(out)), "sbbseg_segment_page")
         return out
 
-    def segment_page_scaled(self, page: np.ndarray, out_h: int, out_w: int) -> np.ndarray:
+    def segment_page_scaled(self, page: np.ndarray, out_h: int, out_w: int, channels: int = 1) -> np.ndarray:
         page = np.ascontiguousarray(page, np.uint8)
-        out = np.empty((out_h, out_w), np.uint8)
+        out = self._label_out(out_h, out_w, channels)
         check(self.lib.sbbseg_segment_page_scaled(self.h, _ptr(page), page.shape[0], page.shape[1], out_h, out_w, _ptr(out)),
               "sbbseg_segment_page_scaled")
         return out
 
-    def segment_page_otsu(self, page: np.ndarray, out_h: int = 0, out_w: int = 0):
+    def segment_page_otsu(self, page: np.ndarray, out_h: int = 0, out_w: int = 0, channels: int = 1):
         """extract_text_regions (main.py:439-447) in one call: (optional nearest rescale to out_h x out_w) +
         otsu_copy + do_prediction(patches=True).  Returns (labels uint8 [out_h, out_w], Otsu threshold)."""
         page = np.ascontiguousarray(page, np.uint8)
         if page.ndim != 3 or page.shape[2] != 3:
             raise ValueError(f"page must be uint8 [H,W,3], got {page.shape}")
         out_h, out_w = (out_h or page.shape[0]), (out_w or page.shape[1])
-        out = np.empty((out_h, out_w), np.uint8)
+        out = self._label_out(out_h, out_w, channels)
         thr = C.c_int(0)
         check(self.lib.sbbseg_segment_page_otsu(self.h, _ptr(page), page.shape[0], page.shape[1], out_h, out_w, _ptr(out),
                                                 C.byref(thr)), "sbbseg_segment_page_otsu")
@@ -279,9 +288,9 @@ class Context:
         check(self.lib.sbbseg_segment_tile_range_bin_dev(self.h, C.c_void_p(d_page), Hp, Wp, first, n, C.c_void_p(d_threshold),
                                                          C.c_void_p(d_tile_labels)), "sbbseg_segment_tile_range_bin_dev")
 
-    def segment_whole(self, page: np.ndarray, out_h: int, out_w: int) -> np.ndarray:
+    def segment_whole(self, page: np.ndarray, out_h: int, out_w: int, channels: int = 1) -> np.ndarray:
         page = np.ascontiguousarray(page, np.uint8)
-        out = np.empty((out_h, out_w), np.uint8)
+        out = self._label_out(out_h, out_w, channels)
         check(self.lib.sbbseg_segment_whole(self.h, _ptr(page), page.shape[0], page.shape[1], out_h, out_w, _ptr(out)),
               "sbbseg_segment_whole")
         return out

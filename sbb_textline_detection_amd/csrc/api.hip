@@ -131,6 +131,8 @@ struct sbbseg_ctx {
     float* d_xin = nullptr;            // predict(): staged float input, lazily allocated
     uint8_t* d_page = nullptr; size_t page_cap = 0;
     uint8_t* d_page_labels = nullptr; size_t page_labels_cap = 0;
+    uint8_t* d_page_labels3 = nullptr; size_t page_labels3_cap = 0;   // 3-channel copy for label_channels == 3
+    int label_channels = 1;
     uint8_t* d_tile_labels = nullptr; size_t tile_labels_cap = 0;
     int *d_own_x = nullptr, *d_own_y = nullptr; size_t own_cap = 0;
     int own_Hp = -1, own_Wp = -1, own_nyf = 0;
@@ -382,6 +384,19 @@ struct LaneScope {
     }
 };
 
+// device label plane [pix] -> host buffer, as one plane or as the reference's three identical channels
+int labels_to_host(sbbseg_ctx* c, void* host, size_t pix)
+{
+    if (c->label_channels == 3) {
+        if (ensure(c, (void**)&c->d_page_labels3, &c->page_labels3_cap, (pix + 3) / 4 * 12)) return 1;
+        HIPCHK(launch_replicate3(c->d_page_labels, c->d_page_labels3, pix, c->stream));
+        HIPCHK(hipMemcpyAsync(host, c->d_page_labels3, pix * 3, hipMemcpyDeviceToHost, c->stream));
+    } else {
+        HIPCHK(hipMemcpyAsync(host, c->d_page_labels, pix, hipMemcpyDeviceToHost, c->stream));
+    }
+    return 0;
+}
+
 int check_ready(sbbseg_ctx* c)
 {
     REQUIRE(c != nullptr, "null handle");
@@ -460,7 +475,7 @@ int sbbseg_destroy(sbbseg_ctx* c)
         hipFree(op.tail.d_head_scale); hipFree(op.tail.d_head_shift);
     }
     hipFree(c->d_lut); hipFree(c->d_hist); hipFree(c->d_tile_xy); hipFree(c->d_batch_labels); hipFree(c->d_probs); hipFree(c->d_xin);
-    hipFree(c->d_page); hipFree(c->d_page_labels); hipFree(c->d_tile_labels);
+    hipFree(c->d_page); hipFree(c->d_page_labels); hipFree(c->d_page_labels3); hipFree(c->d_tile_labels);
     hipFree(c->d_own_x); hipFree(c->d_own_y); hipFree(c->d_map);
     for (auto& pe : c->pending) { hipEventDestroy(pe.a); hipEventDestroy(pe.b); }
     for (auto e : c->free_events) hipEventDestroy(e);
@@ -486,6 +501,13 @@ int sbbseg_set_lanes(sbbseg_ctx* c, int lanes)
     REQUIRE(c && (lanes == 1 || lanes == 2), "lanes must be 1 or 2");
     REQUIRE(!(c->finalized && lanes == 2 && c->lane1_batch == 0), "the second lane was not allocated at finalize (lanes was 1 or max_batch < 16)");
     c->lanes = lanes;
+    return 0;
+}
+
+int sbbseg_set_label_channels(sbbseg_ctx* c, int channels)
+{
+    REQUIRE(c && (channels == 1 || channels == 3), "label channels must be 1 or 3");
+    c->label_channels = channels;
     return 0;
 }
 
@@ -1151,10 +1173,10 @@ int sbbseg_segment_page(sbbseg_ctx* c, const uint8_t* page_hwc, int Hp, int Wp, 
     REQUIRE(Hp >= c->in_H && Wp >= c->in_W, "page %dx%d is smaller than the model input %dx%d (unsupported by the reference too, main.py:278-281)", Hp, Wp, c->in_H, c->in_W);
     const size_t pix = (size_t)Hp * Wp;
     if (ensure(c, (void**)&c->d_page, &c->page_cap, pix * 3)) return 1;
-    if (ensure(c, (void**)&c->d_page_labels, &c->page_labels_cap, pix)) return 1;
+    if (ensure(c, (void**)&c->d_page_labels, &c->page_labels_cap, pix + 4)) return 1;
     HIPCHK(hipMemcpyAsync(c->d_page, page_hwc, pix * 3, hipMemcpyHostToDevice, c->stream));
     if (sbbseg_segment_page_dev(c, c->d_page, Hp, Wp, c->d_page_labels)) return 1;
-    HIPCHK(hipMemcpyAsync(labels_hw, c->d_page_labels, pix, hipMemcpyDeviceToHost, c->stream));
+    if (labels_to_host(c, labels_hw, pix)) return 1;
     HIPCHK(hipStreamSynchronize(c->stream));
     return 0;
 }
@@ -1166,7 +1188,7 @@ int sbbseg_segment_page_scaled(sbbseg_ctx* c, const uint8_t* page_hwc, int Hs, i
     REQUIRE(Hp >= c->in_H && Wp >= c->in_W, "scaled page %dx%d is smaller than the model input %dx%d", Hp, Wp, c->in_H, c->in_W);
     const size_t spix = (size_t)Hs * Ws, pix = (size_t)Hp * Wp;
     if (ensure(c, (void**)&c->d_page, &c->page_cap, spix * 3)) return 1;
-    if (ensure(c, (void**)&c->d_page_labels, &c->page_labels_cap, pix)) return 1;
+    if (ensure(c, (void**)&c->d_page_labels, &c->page_labels_cap, pix + 4)) return 1;
     std::vector<int> my, mx;
     nearest_map(Hs, Hp, my);               // scaled row -> stored row   (main.py:214 -> 112-113)
     nearest_map(Ws, Wp, mx);
@@ -1181,7 +1203,7 @@ int sbbseg_segment_page_scaled(sbbseg_ctx* c, const uint8_t* page_hwc, int Hs, i
     if (ensure(c, (void**)&c->d_tile_labels, &c->tile_labels_cap, (size_t)nx * ny * c->in_H * c->in_W)) return 1;
     if (tile_range_impl(c, c->d_page, Hs, Ws, d_my, d_mx, Hp, Wp, 0, nx * ny, c->d_tile_labels)) return 1;
     if (sbbseg_stitch_dev(c, c->d_tile_labels, Hp, Wp, c->d_page_labels)) return 1;
-    HIPCHK(hipMemcpyAsync(labels_hw, c->d_page_labels, pix, hipMemcpyDeviceToHost, c->stream));
+    if (labels_to_host(c, labels_hw, pix)) return 1;
     HIPCHK(hipStreamSynchronize(c->stream));
     return 0;
 }
@@ -1211,7 +1233,7 @@ int sbbseg_segment_page_otsu(sbbseg_ctx* c, const uint8_t* page_hwc, int Hs, int
     const size_t spix = (size_t)Hs * Ws, pix = (size_t)Hp * Wp;
     const bool scaled = Hs != Hp || Ws != Wp;
     if (ensure(c, (void**)&c->d_page, &c->page_cap, spix * 3)) return 1;
-    if (ensure(c, (void**)&c->d_page_labels, &c->page_labels_cap, pix)) return 1;
+    if (ensure(c, (void**)&c->d_page_labels, &c->page_labels_cap, pix + 4)) return 1;
     int *d_my = nullptr, *d_mx = nullptr;
     if (scaled) {
         std::vector<int> my, mx;
@@ -1231,7 +1253,7 @@ int sbbseg_segment_page_otsu(sbbseg_ctx* c, const uint8_t* page_hwc, int Hs, int
     if (ensure(c, (void**)&c->d_tile_labels, &c->tile_labels_cap, (size_t)nx * ny * c->in_H * c->in_W)) return 1;
     if (tile_range_impl(c, c->d_page, Hs, Ws, d_my, d_mx, Hp, Wp, 0, nx * ny, c->d_tile_labels, d_thr)) return 1;
     if (sbbseg_stitch_dev(c, c->d_tile_labels, Hp, Wp, c->d_page_labels)) return 1;
-    HIPCHK(hipMemcpyAsync(labels_hw, c->d_page_labels, pix, hipMemcpyDeviceToHost, c->stream));
+    if (labels_to_host(c, labels_hw, pix)) return 1;
     int thr = 0;
     HIPCHK(hipMemcpyAsync(&thr, d_thr, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -1245,7 +1267,7 @@ int sbbseg_segment_whole(sbbseg_ctx* c, const uint8_t* page_hwc, int Hp, int Wp,
     REQUIRE(page_hwc && labels_out && Hp > 0 && Wp > 0 && out_h > 0 && out_w > 0, "bad arguments");
     const size_t pix = (size_t)Hp * Wp, opix = (size_t)out_h * out_w;
     if (ensure(c, (void**)&c->d_page, &c->page_cap, pix * 3)) return 1;
-    if (ensure(c, (void**)&c->d_page_labels, &c->page_labels_cap, opix)) return 1;
+    if (ensure(c, (void**)&c->d_page_labels, &c->page_labels_cap, opix + 4)) return 1;
     std::vector<int> my, mx, oy, ox;
     nearest_map(Hp, c->in_H, my);          // model row  -> page row   (main.py:371)
     nearest_map(Wp, c->in_W, mx);
@@ -1267,7 +1289,7 @@ int sbbseg_segment_whole(sbbseg_ctx* c, const uint8_t* page_hwc, int Hp, int Wp,
     HIPCHK(launch_ingest_u8(ip, c->precision, c->stream));
     if (run_plan(c, 1, c->d_batch_labels, nullptr)) return 1;
     HIPCHK(launch_resize_labels(c->d_batch_labels, c->in_H, c->in_W, d_oy, d_ox, out_h, out_w, c->d_page_labels, c->stream));
-    HIPCHK(hipMemcpyAsync(labels_out, c->d_page_labels, opix, hipMemcpyDeviceToHost, c->stream));
+    if (labels_to_host(c, labels_out, opix)) return 1;
     HIPCHK(hipStreamSynchronize(c->stream));
     return 0;
 }

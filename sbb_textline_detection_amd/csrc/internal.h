@@ -179,6 +179,7 @@ hipError_t launch_stitch(const uint8_t* tile_labels, int H, int W, const int* ow
                          int nyf, int Hp, int Wp, uint8_t* out, hipStream_t s);
 hipError_t launch_resize_labels(const uint8_t* labels, int H, int W, const int* map_y, const int* map_x,
                                 int out_h, int out_w, uint8_t* out, hipStream_t s);
+hipError_t launch_replicate3(const uint8_t* src, uint8_t* dst, size_t n, hipStream_t s);
 hipError_t launch_to_f32(const void* src, float* dst, size_t n, int precision, hipStream_t s);
 
 int conv_row_channel(int row, int cout);   // packed weight row -> output channel (16-bit modes)

@@ -1760,6 +1760,27 @@ __global__ __launch_bounds__(256) void to_f32_kernel(const E* src, float* dst, s
     if (i < n) dst[i] = from_elem<E>(src[i]);
 }
 
+// u8 label plane -> the reference's return layout: three identical channels (main.py:366, 380)
+__global__ __launch_bounds__(256) void replicate3_kernel(const uint8_t* src, uint8_t* dst, size_t n4)
+{
+    // 4 labels -> 12 bytes per thread
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const uint32_t v = ((const uint32_t*)src)[i];
+    const uint32_t a = v & 0xff, b = (v >> 8) & 0xff, c = (v >> 16) & 0xff, d = v >> 24;
+    uint32_t* o = (uint32_t*)dst + i * 3;
+    o[0] = a | (a << 8) | (a << 16) | (b << 24);
+    o[1] = b | (b << 8) | (c << 16) | (c << 24);
+    o[2] = c | (d << 8) | (d << 16) | (d << 24);
+}
+
+hipError_t launch_replicate3(const uint8_t* src, uint8_t* dst, size_t n, hipStream_t s)
+{
+    const size_t n4 = (n + 3) / 4;                   // buffers are padded to a multiple of 4 labels by the caller
+    hipLaunchKernelGGL(replicate3_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, src, dst, n4);
+    return hipGetLastError();
+}
+
 hipError_t launch_to_f32(const void* src, float* dst, size_t n, int precision, hipStream_t s)
 {
     const unsigned grid = (unsigned)((n + 255) / 256);

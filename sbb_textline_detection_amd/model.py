@@ -61,13 +61,14 @@ class SegModel:
         return self.ctx.predict(np.asarray(x))
 
     # -- fused fast paths of seam 1 -----------------------------------------------------------
-    def segment_page(self, page_u8: np.ndarray) -> np.ndarray:
-        """uint8 [Hp,Wp,3] -> uint8 [Hp,Wp] label map == do_prediction(True, ...)[:, :, 0]."""
-        return self.ctx.segment_page(page_u8)
+    def segment_page(self, page_u8: np.ndarray, channels: int = 1) -> np.ndarray:
+        """uint8 [Hp,Wp,3] -> uint8 [Hp,Wp] label map == do_prediction(True, ...)[:, :, 0]
+        (channels=3: uint8 [Hp,Wp,3], the reference's return layout, replicated on the device)."""
+        return self.ctx.segment_page(page_u8, channels)
 
-    def segment_whole(self, page_u8: np.ndarray, out_h: int, out_w: int) -> np.ndarray:
+    def segment_whole(self, page_u8: np.ndarray, out_h: int, out_w: int, channels: int = 1) -> np.ndarray:
         """uint8 [Hp,Wp,3] -> uint8 [out_h,out_w] == do_prediction(False, ...)[:, :, 0]."""
-        return self.ctx.segment_whole(page_u8, out_h, out_w)
+        return self.ctx.segment_whole(page_u8, out_h, out_w, channels)
 
     @property
     def ctx(self) -> _capi.Context:

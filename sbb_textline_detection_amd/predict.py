@@ -56,8 +56,7 @@ def do_prediction(patches, img, model, full_image_shape=None, batch_size=None):
     fused = isinstance(model, SegModel) and _is_u8_image(img)
     if patches:
         if fused:
-            lab = model.segment_page(img)
-            return np.repeat(lab[:, :, np.newaxis], 3, axis=2)
+            return model.segment_page(img, channels=3)                   # main.py:366 layout, built on the device
         x = np.asarray(img) / float(255.0)                               # main.py:239
         img_h, img_w = x.shape[0], x.shape[1]
         margin = int(0.1 * W)                                            # main.py:233 (width for both axes)
@@ -79,8 +78,7 @@ def do_prediction(patches, img, model, full_image_shape=None, batch_size=None):
     # patches == False: main.py:368-380
     shp = tuple(full_image_shape) if full_image_shape is not None else tuple(np.asarray(img).shape)
     if fused:
-        lab = model.segment_whole(img, int(shp[0]), int(shp[1]))
-        return np.repeat(lab[:, :, np.newaxis], 3, axis=2)
+        return model.segment_whole(img, int(shp[0]), int(shp[1]), channels=3)
     x = resize_nearest(np.asarray(img) / float(255.0), H, W)
     probs = model.predict(x.reshape(1, x.shape[0], x.shape[1], x.shape[2]))
     seg = np.argmax(probs, axis=3)[0]

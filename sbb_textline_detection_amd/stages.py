@@ -107,10 +107,11 @@ class InferenceStages:
         try:
             if isinstance(model, SegModel):
                 if img_u8 is None:
-                    lab, self.otsu_threshold = model.ctx.segment_page_otsu(self.image_stored, self.img_hight_int, self.img_width_int)
+                    lab, self.otsu_threshold = model.ctx.segment_page_otsu(self.image_stored, self.img_hight_int, self.img_width_int,
+                                                                           channels=3)
                 else:
-                    lab, self.otsu_threshold = model.ctx.segment_page_otsu(np.ascontiguousarray(img_u8, np.uint8))
-                return np.repeat(lab[:, :, None], 3, axis=2)               # main.py:366 layout: 3 equal channels
+                    lab, self.otsu_threshold = model.ctx.segment_page_otsu(np.ascontiguousarray(img_u8, np.uint8), channels=3)
+                return lab                                                 # main.py:366 layout: 3 equal channels
             img = otsu_copy(self._scaled_page() if img_u8 is None else img_u8).astype(np.uint8)   # main.py:443-444
             return do_prediction(True, img, model)                         # main.py:447
         finally:

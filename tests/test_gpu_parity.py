@@ -391,3 +391,21 @@ def test_two_lanes_equal_one_lane():
         model.ctx.set_stream(-1)
     assert np.array_equal(got, ref[0])
     model.release()
+
+
+def test_three_channel_host_output(stitch_model):
+    """label_channels = 3: the reference's return layout (uint8 [H,W,3], equal channels) comes off the device."""
+    m = stitch_model
+    for shape in ((500, 610), (449, 451)):                      # odd pixel counts: the replicate kernel works on 4-label words
+        page = synthetic_page(shape[0], shape[1], seed=3)
+        one = m.segment_page(page)
+        three = m.segment_page(page, channels=3)
+        assert three.shape == shape + (3,) and three.dtype == np.uint8
+        for ch in range(3):
+            assert np.array_equal(three[:, :, ch], one)
+        w1 = m.segment_whole(page, 333, 257)
+        w3 = m.segment_whole(page, 333, 257, channels=3)
+        assert np.array_equal(w3, np.repeat(w1[:, :, None], 3, axis=2))
+        assert np.array_equal(m.segment_page(page), one)        # and back to one plane
+    out = predict.do_prediction(True, page, m)
+    assert out.shape == page.shape and np.array_equal(out[:, :, 1], one)
