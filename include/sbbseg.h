@@ -175,6 +175,11 @@ int sbbseg_segment_tile_range_bin_dev(sbbseg_ctx* c, const void* d_page_hwc, int
  * argmax, nearest-resize labels to out_h x out_w (cv2.INTER_NEAREST index rule). */
 int sbbseg_segment_whole(sbbseg_ctx* c, const uint8_t* page_hwc, int Hp, int Wp,
                          int out_h, int out_w, uint8_t* labels_out);
+/* Same for the border stage's actual input: the page do_prediction receives there is the stored image
+ * [Hp][Wp] nearest-upscaled to Hs x Ws by get_image_and_scales (main.py:196-214, 387-392).  The two
+ * nearest-neighbour index maps are composed, the upscaled page is never built. */
+int sbbseg_segment_whole_scaled(sbbseg_ctx* c, const uint8_t* page_hwc, int Hp, int Wp, int Hs, int Ws,
+                                int out_h, int out_w, uint8_t* labels_out);
 
 /* ---- building blocks (multi-GPU sharding, tests).  tile_xy: host int32 [n][2] = (x0, y0) origins.
  * d_tile_labels: device uint8 [n][H][W]. */

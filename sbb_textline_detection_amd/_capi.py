@@ -22,7 +22,7 @@ EXPORTS = [
     "sbbseg_add_conv", "sbbseg_add_maxpool", "sbbseg_add_tail", "sbbseg_add_head", "sbbseg_finalize", "sbbseg_model_info",
     "sbbseg_num_ops", "sbbseg_op_info", "sbbseg_device_bytes", "sbbseg_predict", "sbbseg_segment_page",
     "sbbseg_segment_page_dev", "sbbseg_segment_page_scaled", "sbbseg_segment_page_otsu", "sbbseg_otsu_dev",
-    "sbbseg_segment_tile_range_bin_dev", "sbbseg_segment_whole", "sbbseg_tile_grid", "sbbseg_segment_tiles_dev",
+    "sbbseg_segment_tile_range_bin_dev", "sbbseg_segment_whole", "sbbseg_segment_whole_scaled", "sbbseg_tile_grid", "sbbseg_segment_tiles_dev",
     "sbbseg_segment_tile_range_dev", "sbbseg_stitch_dev", "sbbseg_debug_ingest", "sbbseg_debug_read_tensor",
     "sbbseg_debug_set_conv_variant",
     "sbbseg_profile_enable", "sbbseg_profile_reset", "sbbseg_profile_get",
@@ -87,6 +87,7 @@ def load_library(path: Optional[str] = None):
         "sbbseg_otsu_dev": [vp, vp, i32, i32, vp],
         "sbbseg_segment_tile_range_bin_dev": [vp, vp, i32, i32, i32, i32, vp, vp],
         "sbbseg_segment_whole": [vp, vp, i32, i32, i32, i32, vp],
+        "sbbseg_segment_whole_scaled": [vp, vp, i32, i32, i32, i32, i32, i32, vp],
         "sbbseg_tile_grid": [i32, i32, i32, i32, vp, i32, C.POINTER(C.c_int), C.POINTER(C.c_int)],
         "sbbseg_segment_tiles_dev": [vp, vp, i32, i32, vp, i32, vp],
         "sbbseg_segment_tile_range_dev": [vp, vp, i32, i32, i32, i32, vp],
@@ -293,6 +294,14 @@ class Context:
         out = self._label_out(out_h, out_w, channels)
         check(self.lib.sbbseg_segment_whole(self.h, _ptr(page), page.shape[0], page.shape[1], out_h, out_w, _ptr(out)),
               "sbbseg_segment_whole")
+        return out
+
+    def segment_whole_scaled(self, page: np.ndarray, scaled_h: int, scaled_w: int, out_h: int, out_w: int, channels: int = 1) -> np.ndarray:
+        """Whole-image branch on the stored page as if it had first been nearest-upscaled to scaled_h x scaled_w."""
+        page = np.ascontiguousarray(page, np.uint8)
+        out = self._label_out(out_h, out_w, channels)
+        check(self.lib.sbbseg_segment_whole_scaled(self.h, _ptr(page), page.shape[0], page.shape[1], scaled_h, scaled_w, out_h, out_w,
+                                                   _ptr(out)), "sbbseg_segment_whole_scaled")
         return out
 
     def segment_page_dev(self, d_page: int, Hp: int, Wp: int, d_labels: int):

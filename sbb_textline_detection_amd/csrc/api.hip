@@ -1263,14 +1263,27 @@ int sbbseg_segment_page_otsu(sbbseg_ctx* c, const uint8_t* page_hwc, int Hs, int
 
 int sbbseg_segment_whole(sbbseg_ctx* c, const uint8_t* page_hwc, int Hp, int Wp, int out_h, int out_w, uint8_t* labels_out)
 {
+    return sbbseg_segment_whole_scaled(c, page_hwc, Hp, Wp, Hp, Wp, out_h, out_w, labels_out);
+}
+
+int sbbseg_segment_whole_scaled(sbbseg_ctx* c, const uint8_t* page_hwc, int Hp, int Wp, int Hs, int Ws, int out_h, int out_w,
+                                uint8_t* labels_out)
+{
     if (check_ready(c)) return 1;
-    REQUIRE(page_hwc && labels_out && Hp > 0 && Wp > 0 && out_h > 0 && out_w > 0, "bad arguments");
+    REQUIRE(page_hwc && labels_out && Hp > 0 && Wp > 0 && Hs > 0 && Ws > 0 && out_h > 0 && out_w > 0, "bad arguments");
     const size_t pix = (size_t)Hp * Wp, opix = (size_t)out_h * out_w;
     if (ensure(c, (void**)&c->d_page, &c->page_cap, pix * 3)) return 1;
     if (ensure(c, (void**)&c->d_page_labels, &c->page_labels_cap, opix + 4)) return 1;
     std::vector<int> my, mx, oy, ox;
-    nearest_map(Hp, c->in_H, my);          // model row  -> page row   (main.py:371)
-    nearest_map(Wp, c->in_W, mx);
+    nearest_map(Hs, c->in_H, my);          // model row  -> row of the page do_prediction was handed (main.py:371)
+    nearest_map(Ws, c->in_W, mx);
+    if (Hs != Hp || Ws != Wp) {            // that page is itself the nearest-upscaled stored image (main.py:214): compose
+        std::vector<int> sy, sx;
+        nearest_map(Hp, Hs, sy);           // scaled row -> stored row
+        nearest_map(Wp, Ws, sx);
+        for (auto& v : my) v = sy[v];
+        for (auto& v : mx) v = sx[v];
+    }
     nearest_map(c->in_H, out_h, oy);       // output row -> model row  (main.py:378)
     nearest_map(c->in_W, out_w, ox);
     const size_t need = sizeof(int) * (size_t)(c->in_H + c->in_W + out_h + out_w);

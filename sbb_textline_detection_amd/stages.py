@@ -12,7 +12,6 @@ page box falls back to the full image exactly like the reference's own `except` 
 """
 from __future__ import annotations
 
-import gc
 from typing import Optional, Tuple
 
 import numpy as np
@@ -94,11 +93,15 @@ class InferenceStages:
         """Border model on the whole page (main.py:384-392): uint8 [H,W,3] at the *scaled* size."""
         model, session = start_new_session_and_model(self.model_page_dir, **self.kw)
         try:
+            if isinstance(model, SegModel):
+                # stored page -> (virtual) upscaled page -> model size: the two nearest maps are composed on the
+                # library side, the 4200x3000 page is never built on the host
+                return model.ctx.segment_whole_scaled(self.image_stored, self.img_hight_int, self.img_width_int,
+                                                      self.img_hight_int, self.img_width_int, channels=3)
             img = self._scaled_page()
             return do_prediction(False, img, model, full_image_shape=img.shape)
         finally:
             session.close()
-            gc.collect()
 
     def extract_text_regions(self, img_u8: Optional[np.ndarray] = None) -> np.ndarray:
         """main.py:439-454.  On a SegModel the whole wrapper is one library call: histogram, Otsu threshold,
@@ -115,8 +118,7 @@ class InferenceStages:
             img = otsu_copy(self._scaled_page() if img_u8 is None else img_u8).astype(np.uint8)   # main.py:443-444
             return do_prediction(True, img, model)                         # main.py:447
         finally:
-            session.close()
-            gc.collect()
+            session.close()            # (the reference's gc.collect() after every stage frees TF graphs; nothing to free here)
 
     def textline_contours(self, img_u8: Optional[np.ndarray] = None) -> np.ndarray:
         """main.py:490-503.  With img_u8=None the stored page is segmented through the fused rescale
@@ -128,8 +130,7 @@ class InferenceStages:
             img = (self._scaled_page() if img_u8 is None else img_u8).astype(np.uint8)
             return do_prediction(True, img, model)[:, :, 0]
         finally:
-            session.close()
-            gc.collect()
+            session.close()            # (the reference's gc.collect() after every stage frees TF graphs; nothing to free here)
 
     def run(self, image_u8: np.ndarray):
         """border -> (full-page box) -> layout -> textline; returns the three label maps."""

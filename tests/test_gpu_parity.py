@@ -409,3 +409,15 @@ def test_three_channel_host_output(stitch_model):
         assert np.array_equal(m.segment_page(page), one)        # and back to one plane
     out = predict.do_prediction(True, page, m)
     assert out.shape == page.shape and np.array_equal(out[:, :, 1], one)
+
+
+def test_whole_image_branch_through_composed_rescale(stitch_model):
+    """sbbseg_segment_whole_scaled(stored page) == sbbseg_segment_whole(nearest-upscaled page): the border stage
+    (main.py:384-392) without building the upscaled page."""
+    from sbb_textline_detection_amd.predict import resize_nearest
+    m = stitch_model
+    page = synthetic_page(611, 503, seed=8)
+    hs, ws = 1234, 1017
+    a = m.ctx.segment_whole_scaled(page, hs, ws, hs, ws)
+    b = m.segment_whole(np.ascontiguousarray(resize_nearest(page, hs, ws)), hs, ws)
+    assert a.shape == (hs, ws) and np.array_equal(a, b)
