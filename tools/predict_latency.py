@@ -22,12 +22,12 @@ t0 = time.perf_counter()
 for _ in range(10): p = m.predict(x8)
 dt = (time.perf_counter() - t0) / 10
 print("predict(n=8): %.2f ms per call = %.0f patches/s" % (dt * 1e3, 8 / dt))
-# the reference-style Python loop over the page through seam 2 (predict per tile), host tiling
-from oracle import tiling
+# the reference-style Python loop over the page through seam 2: one predict per tile, tiling on the host
+# (a float page is not eligible for the fused path, so do_prediction takes its host loop; batch_size=1 = main.py:287)
 t0 = time.perf_counter()
-out = tiling.do_prediction(True, page, m)
+out = predict.do_prediction(True, page.astype(np.float64), m, batch_size=1)
 dt = time.perf_counter() - t0
-print("reference-style loop (oracle tiling + SegModel.predict per tile): %.2f s per page = %.0f patches/s" % (dt, 70 / dt))
+print("reference-style loop (host tiling + SegModel.predict per tile): %.2f s per page = %.0f patches/s" % (dt, 70 / dt))
 t0 = time.perf_counter()
 out2 = predict.do_prediction(True, page, m)
 dt = time.perf_counter() - t0
