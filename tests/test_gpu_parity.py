@@ -421,3 +421,17 @@ def test_whole_image_branch_through_composed_rescale(stitch_model):
     a = m.ctx.segment_whole_scaled(page, hs, ws, hs, ws)
     b = m.segment_whole(np.ascontiguousarray(resize_nearest(page, hs, ws)), hs, ws)
     assert a.shape == (hs, ws) and np.array_equal(a, b)
+
+
+def test_repeatability_under_load(stitch_model):
+    """Race screen for the hand-placed waits (counted vmcnt with stores in flight, LDS-DMA staging, two lanes):
+    the same page segmented 12 times back to back must give bit-identical maps (a stage read before it landed
+    shows up as run-to-run differences long before it shows up as a parity failure)."""
+    cfg, w, g, model = make_model(2, 448, 448, seed=0, precision="f16", max_batch=24)
+    page = synthetic_page(1400, 1200, seed=11)                  # 4 x 4 = 16 tiles -> two lanes of 8
+    first = model.segment_page(page)
+    for _ in range(11):
+        assert np.array_equal(model.segment_page(page), first)
+    model.ctx.set_lanes(1)
+    assert np.array_equal(model.segment_page(page), first)
+    model.release()
