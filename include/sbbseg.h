@@ -203,7 +203,8 @@ int sbbseg_debug_read_tensor(sbbseg_ctx* c, int tensor_id, int n, float* out, si
  * bit 2 = one block per tile instead of persistent blocks; bit 3 = no XCD-grouped tile walk;
  * bit 4 = half-K-step stages in a 4-deep ring; bit 5 = XCD-grouped tile walk on single-class layers too;
  * bit 6 = drain the epilogue stores before the next barrier; bit 7 = half-line (64-byte) epilogue stores; bits 8-15 = with bit 5: K limit (units of
- * 64) up to which every block walks a contiguous run of tiles (0 = keep the current limit) */
+ * 64) up to which every block walks a contiguous run of tiles (0 = keep the current limit);
+ * bit 16 = 8-phase schedule on the 256x256 tile (half-tile restaging, staggered wave groups) */
 int sbbseg_debug_set_conv_variant(sbbseg_ctx* c, int variant);
 
 /* ---- per-op timing with HIP events on the handle's stream (bench.py roofline) */

@@ -140,6 +140,7 @@ struct sbbseg_ctx {
     // profiling
     bool profiling = false;
     int conv_variant = 0;
+    bool ph8 = false;            // 8-phase schedule on the 256x256 tile (opt-in, conv variant bit 16)
     int contig_max_k = 0;        // short-K layers up to this K walk their tiles in per-block contiguous runs (tile map 2)
     int fused_heads = 0;
     int num_cus = 256;
@@ -277,7 +278,7 @@ int run_plan(sbbseg_ctx* c, int n, uint8_t* d_labels, float* d_probs)
             p.ktab = co.d_ktab; p.kstep = co.d_kstep; p.half_stages = (c->conv_variant & 16) ? 1 : 0;
             p.variant = c->conv_variant & 3; p.persist_blocks = (c->conv_variant & 4) ? 0 : c->num_cus;
             p.M = n * co.Ho * co.Wo;
-            p.variant_flags = ((c->conv_variant & 64) ? 1 : 0) | ((c->conv_variant & 128) ? 2 : 0);
+            p.variant_flags = ((c->conv_variant & 64) ? 1 : 0) | ((c->conv_variant & 128) ? 2 : 0) | (c->ph8 ? 4 : 0);
             // XCD-grouped walk for single-class layers: measured neutral-to-slower (it removes the n_ct-fold
             // re-fetch of the pixel operand, but those layers are not bound by fetch bytes) -> opt-in, bit 5
             p.tile_map = ((c->conv_variant & 32) && !(c->conv_variant & 8) && (c->conv_variant & 4) == 0 && co.d.cout > conv_tile_bc(co.d.cout) && p.M >= 256 * 128 &&
@@ -1356,9 +1357,10 @@ int sbbseg_debug_read_tensor(sbbseg_ctx* c, int tensor_id, int n, float* out, si
 
 int sbbseg_debug_set_conv_variant(sbbseg_ctx* c, int variant)
 {
-    REQUIRE(c && variant >= 0 && variant <= 0xffff, "variant: bits 0-1 = 0 auto | 1 4-wave/2-stage | 2 8-wave/3-stage; bit 2 = one block per tile (non-persistent); bit 3 = no XCD-grouped tile walk; bit 4 = half-K-step stages; bit 5 = XCD-grouped walk on single-class layers; bit 6 = drain epilogue stores; bit 7 = half-line epilogue stores; bits 8-15 = contiguous-run K limit / 64");
+    REQUIRE(c && variant >= 0 && variant <= 0x1ffff, "variant: bits 0-1 = 0 auto | 1 4-wave/2-stage | 2 8-wave/3-stage; bit 2 = one block per tile (non-persistent); bit 3 = no XCD-grouped tile walk; bit 4 = half-K-step stages; bit 5 = XCD-grouped walk on single-class layers; bit 6 = drain epilogue stores; bit 7 = half-line epilogue stores; bits 8-15 = contiguous-run K limit / 64; bit 16 = 8-phase schedule on the 256x256 tile");
     c->conv_variant = variant & 0xff;
-    if (variant >> 8) c->contig_max_k = (variant >> 8) * 64;
+    c->ph8 = (variant >> 16) & 1;
+    if ((variant >> 8) & 0xff) c->contig_max_k = ((variant >> 8) & 0xff) * 64;
     return 0;
 }
 

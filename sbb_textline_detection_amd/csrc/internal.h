@@ -44,7 +44,7 @@ struct ConvParams {
     const KStepRec* kstep;    // [total_ksteps]
     int variant;              // 0 = auto tile choice, 1 = force 4-wave/2-stage, 2 = force 8-wave/3-stage
     int half_stages;          // A/B: half-K-step LDS stages in a 4-deep ring
-    int variant_flags;        // A/B switches: bit 0 = drain the epilogue stores before the next barrier, bit 1 = half-line epilogue stores (old behaviour)
+    int variant_flags;        // A/B switches: bit 0 = drain the epilogue stores before the next barrier, bit 1 = half-line epilogue stores (old behaviour), bit 2 = 8-phase schedule on the 256x256 tile
     int tile_map;             // 0 = channel tile per XCD (big weights), 1 = pixel tiles grouped per XCD (small weights)
     int persist_blocks;       // CUs of the device (persistent grid = resident blocks); 0 = one block per tile
     const KTabEntry* ktab;    // [total_ksteps * 8]

@@ -138,7 +138,7 @@ template <int N> __device__ inline void wait_vmcnt()
 // their time filling and draining a 1-4 step pipeline.
 // K-step descriptors come through the scalar cache (uniform address in the constant address space
 // -> s_load, lgkmcnt): no VGPR-destination VMEM load sits in the steady-state loop.
-template <int BP, int BC, int WP, int WC, int NS, bool F16, int GS = 8>
+template <int BP, int BC, int WP, int WC, int NS, bool F16, int GS = 8, bool PH8 = false>
 __global__ __launch_bounds__(64 * WP * WC, (conv_blocks_per_cu(BP, BC, WP, WC, NS, GS) * (WP * WC) / 4))
 void conv_igemm_mfma(const ConvParams p)
 {
@@ -579,6 +579,189 @@ void conv_igemm_mfma(const ConvParams p)
     };
     constexpr int kEpiStores = (T::kMI / 2) * T::kNI;             // store instructions per wave per output tensor
 
+    if constexpr (PH8) {
+        // ============================================================================================
+        // 8-phase schedule (256 x 256 tile, 8 waves as 2 x 4, two K-steps = 8 phases per turn of the ring).
+        // A K-step is staged as FOUR half-tiles of 16 KB -- W0/W1 = the two 32-channel halves of every
+        // wave column, P0/P1 = the two 64-pixel halves of every wave row -- and a half-tile is restaged
+        // (with the data of K-step k+2) as soon as both wave groups have taken their fragments from it,
+        // not when the whole stage is spent: 5-6 phases of lead time instead of 4 in the same 128 KB.
+        // Each phase = [fragment reads + one half-tile issued + counted vmcnt] barrier [16 MFMAs] barrier;
+        // waves 4-7 run one barrier behind waves 0-3, so one group's memory half overlaps the other's
+        // matrix half on every SIMD.
+        //   phase of K-step k :   1            2            3            4
+        //   fragments read    :   W0 P0        W1           P1           -
+        //   quadrant (W,P)    :   (0,0)        (1,0)        (1,1)        (0,1)
+        //   half-tile issued  :   W1(k+1)      P1(k+1)      W0(k+2)      P0(k+2)
+        // ============================================================================================
+        static_assert(BP == 256 && BC == 256 && WP == 2 && WC == 4 && NS == 2 && GS == 8, "8-phase schedule is built for the 256x256 tile");
+        if (my_tiles == 0) return;
+        const int total_k = my_tiles * nt;                       // K-steps this block walks
+        constexpr int kHalf = 16384;
+        // ---- load side
+        int q_oy[4], q_ox[4], q_n[4];                            // P rows of this thread: [h*2 + i]
+        uint32_t q_w[4];                                         // W rows: [g*2 + i]
+        auto setup8 = [&](int tile) __attribute__((always_inline)) {
+            int ctile, cls, ptile;
+            decode(tile, ctile, cls, ptile);
+            if (p.n_cls > 1) {
+                wbase = (const char*)p.w_cls[cls];
+                kstep_tab = (const __attribute__((address_space(4))) int*)(uintptr_t)p.kstep_cls[cls];
+                ktab = p.ktab_cls[cls];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int rho = ((j & 1) * 8 + wave) * 8 + lrow;            // row inside the half-tile
+                const int m = ptile * BP + (rho >> 6) * 128 + (j >> 1) * 64 + (rho & 63);
+                if (m < p.M) {
+                    const int n = m / HoWo;
+                    const int rem = m - n * HoWo;
+                    const int oy = rem / p.Wo;
+                    q_oy[j] = oy; q_ox[j] = rem - oy * p.Wo; q_n[j] = n;
+                } else {
+                    q_oy[j] = -(1 << 20); q_ox[j] = 0; q_n[j] = 0;
+                }
+                const int crow = (rho >> 5) * 64 + (j >> 1) * 32 + (rho & 31);
+                q_w[j] = (uint32_t)((ctile * BC + min(crow, BC - 1)) * p.Ktot + gsrc * 8) * 2u;
+            }
+        };
+        int i_t = 0, i_q = 0, i_k = 0;                           // issue side: K-step in tile, tile, K-step overall
+        int r8_yx = 0, r8_coff = 0;
+        auto load_rec = [&]() __attribute__((always_inline)) {
+            r8_yx = kstep_tab[i_t * 4 + 0]; r8_coff = kstep_tab[i_t * 4 + 1];
+        };
+        // one half-tile of K-step i_k: part 0 = W0, 1 = P0, 2 = W1, 3 = P1 (issued in this order)
+        auto issue_part = [&](int part, bool checked = true) __attribute__((always_inline)) {
+            if (checked && i_k >= total_k) return;
+            char* half = smem + (i_k & 1) * (4 * kHalf) + ((part & 1) ? 2 * kHalf : 0) + (part >> 1) * kHalf;
+            if (!(part & 1)) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+                    __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(wbase + q_w[(part >> 1) * 2 + i] + (uint32_t)(i_t * (kBK * 2))),
+                                                     (LDS_AS void*)(half + (i * 8 + wave) * 1024), 16, 0, 0);
+            } else {
+                const bool s1 = i_t >= ks0;
+                const char* base = s1 ? sd1.base : sd0.base;
+                const int rowbytes = s1 ? sd1.PW * sd1.pix_bytes : sd0.PW * sd0.pix_bytes;
+                const int pixb = s1 ? sd1.pix_bytes : sd0.pix_bytes;
+                const uint32_t img = s1 ? img1 : img0;
+                const int sh = s1 ? sd1.shift : sd0.shift;
+                const int ssy = s1 ? sd1.sy_shift : sd0.sy_shift, ssx = s1 ? sd1.sx_shift : sd0.sx_shift;
+                const unsigned lim_y = s1 ? sd1.lim_y : sd0.lim_y, lim_x = s1 ? sd1.lim_x : sd0.lim_x;
+                const int dy = (int)(short)(r8_yx & 0xffff), dx = r8_yx >> 16;
+                const int coff = r8_coff + gsrc * 16 + kZeroHeaderBytes;
+                // (irregular K-steps -- 8-channel sources -- never reach this schedule: ph8_ok())
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int j = (part >> 1) * 2 + i;
+                    const int uy = (q_oy[j] << ssy) + dy, ux = (q_ox[j] << ssx) + dx;
+                    const bool ok = ((unsigned)uy < lim_y) & ((unsigned)ux < lim_x);
+                    const int yy = uy >> sh, xx = ux >> sh;
+                    uint32_t off = (uint32_t)q_n[j] * img + __umul24(yy, rowbytes) + __umul24(xx, pixb) + (uint32_t)coff;
+                    off = ok ? off : 0u;
+                    __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(base + off), (LDS_AS void*)(half + (i * 8 + wave) * 1024), 16, 0, 0);
+                }
+            }
+            if (part == 3) {                                     // K-step complete: advance
+                ++i_k;
+                if (++i_t == nt) {
+                    i_t = 0;
+                    ++i_q;
+                    if (!checked || i_q < my_tiles) setup8(tile_at(i_q));
+                }
+                if (!checked || i_k < total_k) load_rec();
+            }
+        };
+        // ---- read side
+        const int fsw0 = (((0 + fg) ^ (frow & 7)) << 4), fsw1 = (((4 + fg) ^ (frow & 7)) << 4);
+        const int a_row = (wc * 32 + frow) * 128, b_row = (wp * 64 + frow) * 128;
+        bf16x8_t aw[2][2][2], bp[4][2];                          // [g][m2][kk], [n4][kk]
+        auto read_w = [&](const char* buf, int g) __attribute__((always_inline)) {
+#pragma unroll
+            for (int m2 = 0; m2 < 2; ++m2) {
+                aw[g][m2][0] = *(const bf16x8_t*)(buf + g * kHalf + a_row + m2 * 2048 + fsw0);
+                aw[g][m2][1] = *(const bf16x8_t*)(buf + g * kHalf + a_row + m2 * 2048 + fsw1);
+            }
+        };
+        auto read_p = [&](const char* buf, int h) __attribute__((always_inline)) {
+#pragma unroll
+            for (int n4 = 0; n4 < 4; ++n4) {
+                bp[n4][0] = *(const bf16x8_t*)(buf + (2 + h) * kHalf + b_row + n4 * 2048 + fsw0);
+                bp[n4][1] = *(const bf16x8_t*)(buf + (2 + h) * kHalf + b_row + n4 * 2048 + fsw1);
+            }
+        };
+        auto quad = [&](int g, int h) __attribute__((always_inline)) {
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int m2 = 0; m2 < 2; ++m2)
+#pragma unroll
+                    for (int n4 = 0; n4 < 4; ++n4)
+                        acc[g * 2 + m2][h * 4 + n4] = mfma16<F16>(aw[g][m2][kk], bp[n4][kk], acc[g * 2 + m2][h * 4 + n4]);
+            __builtin_amdgcn_s_setprio(0);
+        };
+        // after this phase's issue: everything but the 4 youngest half-tiles (8 loads) has landed; once the
+        // stream has ended the count no longer says anything -> drain
+        auto phase_wait = [&](bool checked = true) __attribute__((always_inline)) {
+            if (!checked || i_k < total_k) wait_vmcnt<8>();
+            else wait_vmcnt<0>();
+        };
+
+        // ---- prologue: K-step 0 complete and W0, P0 of K-step 1 issued; K-step 0's first halves landed
+        setup8(tile_at(0));
+        load_rec();
+        issue_part(0); issue_part(1); issue_part(2); issue_part(3);
+        issue_part(0); issue_part(1);
+        phase_wait();
+        __builtin_amdgcn_s_barrier();
+        if (wave >= 4) __builtin_amdgcn_s_barrier();             // second group runs one barrier behind
+
+        int c_t8 = 0, c_q8 = 0;
+        // one K-step = four phases; `checked` = the stream may end inside this K-step (last two K-steps only):
+        // the steady-state body carries no end-of-stream branches -- the memory half of a phase has to be short
+        auto kstep8 = [&](int k, bool checked) __attribute__((always_inline)) {
+            const char* buf = smem + (k & 1) * (4 * kHalf);
+            // phase 1
+            read_w(buf, 0); read_p(buf, 0);
+            issue_part(2, checked);
+            phase_wait(checked);
+            __builtin_amdgcn_s_barrier();
+            quad(0, 0);
+            __builtin_amdgcn_s_barrier();
+            // phase 2
+            read_w(buf, 1);
+            issue_part(3, checked);
+            phase_wait(checked);
+            __builtin_amdgcn_s_barrier();
+            quad(1, 0);
+            __builtin_amdgcn_s_barrier();
+            // phase 3
+            read_p(buf, 1);
+            issue_part(0, checked);
+            phase_wait(checked);
+            __builtin_amdgcn_s_barrier();
+            quad(1, 1);
+            __builtin_amdgcn_s_barrier();
+            // phase 4
+            issue_part(1, checked);
+            phase_wait(checked);
+            __builtin_amdgcn_s_barrier();
+            quad(0, 1);
+            if (++c_t8 == nt) {                                  // tile finished
+                epilogue(tile_at(c_q8));
+                c_t8 = 0;
+                ++c_q8;
+            }
+            __builtin_amdgcn_s_barrier();
+        };
+        int k8 = 0;
+        for (; k8 + 2 < total_k; ++k8) kstep8(k8, false);
+        for (; k8 < total_k; ++k8) kstep8(k8, true);
+        if (wave < 4) __builtin_amdgcn_s_barrier();              // balance the second group's extra barrier
+        return;
+    }
+
     // ---- prologue: D stages in flight, stage 0 landed
     if (total == 0) return;
     setup_rows(tile_at(0));
@@ -728,7 +911,7 @@ int conv_row_channel(int row, int cout)
     return base + (mi >> 1) * 32 + (rho >> 2) * 8 + (mi & 1) * 4 + (rho & 3);
 }
 
-template <int BP, int BC, int WP, int WC, int NS, bool F16, int GS = 8>
+template <int BP, int BC, int WP, int WC, int NS, bool F16, int GS = 8, bool PH8 = false>
 static hipError_t launch_conv_t(const ConvParams& p, hipStream_t s)
 {
     using T = ConvTile<BP, BC, WP, WC, NS, GS>;
@@ -737,7 +920,7 @@ static hipError_t launch_conv_t(const ConvParams& p, hipStream_t s)
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
     if (!attr_done[dev & 63]) {
-        e = hipFuncSetAttribute((const void*)conv_igemm_mfma<BP, BC, WP, WC, NS, F16, GS>,
+        e = hipFuncSetAttribute((const void*)conv_igemm_mfma<BP, BC, WP, WC, NS, F16, GS, PH8>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, T::kLdsBytes);
         if (e != hipSuccess) return e;
         attr_done[dev & 63] = true;
@@ -750,13 +933,22 @@ static hipError_t launch_conv_t(const ConvParams& p, hipStream_t s)
     const int resident = p.persist_blocks > 0 ? p.persist_blocks * T::kBlocksPerCU : n_tiles;
     int grid = n_tiles < resident ? n_tiles : resident;
     if (p.tile_map >= 1) grid = (grid + 7) & ~7;          // the XCD-grouped walk needs a multiple of 8 blocks
-    hipLaunchKernelGGL((conv_igemm_mfma<BP, BC, WP, WC, NS, F16, GS>), dim3(grid), dim3(T::kThreads), T::kLdsBytes, s, p);
+    hipLaunchKernelGGL((conv_igemm_mfma<BP, BC, WP, WC, NS, F16, GS, PH8>), dim3(grid), dim3(T::kThreads), T::kLdsBytes, s, p);
     return hipGetLastError();
 }
 
 // Tile choice.  Measured on MI355X (profiles/r01_conv_variants.md): with two 4-wave blocks per CU the
 // 2-stage tiles already hide the staging latency (dec1-3 at 925-980 TFLOP/s); the 8-wave / 3-stage /
 // counted-vmcnt tiles (1 block per CU) are 5-25 % slower on every layer, so they are opt-in only.
+// the 8-phase schedule of the 256x256 tile: regular K-steps only (>= 64-channel sources), at least 2 K-steps
+static bool ph8_ok(const ConvParams& p)
+{
+    if (!(p.variant_flags & 4) || p.total_ksteps < 2 || p.half_stages) return false;      // opt-in: conv variant bit 16
+    for (int i = 0; i < p.n_src; ++i)
+        if (p.src[i].pix_bytes < 128) return false;
+    return true;
+}
+
 template <bool F16>
 static hipError_t launch_conv_16(const ConvParams& p, hipStream_t s)
 {
@@ -772,7 +964,7 @@ static hipError_t launch_conv_16(const ConvParams& p, hipStream_t s)
         if (bc == 64) return launch_conv_t<256, 64, 4, 1, 4, F16, 4>(p, s);
     }
     if (variant == 3) {   // force: 8 waves, wave tile 128 px x 64 ch (64x64 for cout 64), 2 LDS stages, 1 block per CU
-        if (bc == 128 && p.cout % 256 == 0) return launch_conv_t<256, 256, 2, 4, 2, F16>(p, s);
+        if (bc == 128 && p.cout % 256 == 0) return ph8_ok(p) ? launch_conv_t<256, 256, 2, 4, 2, F16, 8, true>(p, s) : launch_conv_t<256, 256, 2, 4, 2, F16>(p, s);
         if (bc == 128) return launch_conv_t<512, 128, 4, 2, 2, F16>(p, s);
         if (bc == 64) return launch_conv_t<512, 64, 8, 1, 2, F16>(p, s);
     }
@@ -782,7 +974,7 @@ static hipError_t launch_conv_16(const ConvParams& p, hipStream_t s)
         // give every CU a block; short-K / residual (HBM-bound) layers and small grids stay on 128x128
         const long t256 = (long)p.n_cls * ((p.M + 255) / 256) * (p.cout / 256);
         const long t512 = (long)p.n_cls * ((p.M + 511) / 512) * ((p.cout + 127) / 128);
-        if (p.cout % 256 == 0 && p.Ktot >= 512 && t256 >= 200) return launch_conv_t<256, 256, 2, 4, 2, F16>(p, s);
+        if (p.cout % 256 == 0 && p.Ktot >= 512 && t256 >= 200) return ph8_ok(p) ? launch_conv_t<256, 256, 2, 4, 2, F16, 8, true>(p, s) : launch_conv_t<256, 256, 2, 4, 2, F16>(p, s);
         if (p.Ktot >= 1024 && t512 >= 200) return launch_conv_t<512, 128, 4, 2, 2, F16>(p, s);
     }
     if (bc == 128) return big ? launch_conv_t<256, 128, 4, 2, 3, F16>(p, s) : launch_conv_t<128, 128, 2, 2, 2, F16>(p, s);

@@ -80,7 +80,7 @@ def test_conv_tile_families_agree():
     cfg, w, g, model = make_model(2, 224, 224, seed=3, precision="f16", max_batch=6)
     x = (patches_from_page(224, 224, 5, seed=2) / 255.0).astype(np.float32)
     outs = []
-    for variant in (1, 2, 3, 5, 6, 8, 16, 32, 0x220, 64, 128, 0):       # bit 2 = one block per tile instead of persistent blocks; bit 3 = no XCD grouping; 3 = big 8-wave tiles; 16 = half-K-step stages in a 4-deep ring
+    for variant in (1, 2, 3, 5, 6, 8, 16, 32, 0x220, 64, 128, 0x10000, 0x10003, 0):       # bit 2 = one block per tile instead of persistent blocks; bit 3 = no XCD grouping; 3 = big 8-wave tiles; 16 = half-K-step stages in a 4-deep ring
         model.ctx.set_conv_variant(variant)
         outs.append(model.predict(x))
     assert all(np.array_equal(outs[0], o) for o in outs[1:])
