@@ -663,9 +663,11 @@ int sbbseg_add_conv(sbbseg_ctx* c, const sbbseg_conv_desc* d, const float* w_src
     co.Ktot = co.total_ksteps * kBK;
     REQUIRE((size_t)co.cout_pad * co.Ktot * c->elem < (size_t)3 << 30, "weight matrix too large");
 
-    // pack weights [cout_pad][Ktot]
+    // pack weights [cout_pad][Ktot]: one source pointer per K element (null = K padding), then row by row in
+    // blocks of 64 K elements -- writes are contiguous, the 64 source lines of a block stay in cache across
+    // neighbouring output channels (the column-by-column form of this loop took 0.6 s of a model's load time)
     const size_t wn = (size_t)co.cout_pad * co.Ktot;
-    std::vector<float> wf(wn, 0.f);
+    std::vector<const float*> ksrc((size_t)co.Ktot, nullptr);
     for (size_t g = 0; g < kref.size(); ++g) {
         const KRef& r = kref[g];
         if (r.s < 0) continue;
@@ -673,21 +675,30 @@ int sbbseg_add_conv(sbbseg_ctx* c, const sbbseg_conv_desc* d, const float* w_src
         const float* wsrc_base = r.s == 0 ? w_src0 : w_src1;
         for (int q = 0; q < 8; ++q) {
             const int ch = r.c0 + q;
-            if (ch >= cs.channels) continue;
-            const float* wsrc = wsrc_base + ((size_t)(r.ky * cs.kw + r.kx) * cs.channels + ch) * d->cout;
-            const size_t k = g * 8 + q;
-            for (int row = 0; row < co.cout_pad; ++row) {
-                const int o = c->precision != kF32 ? conv_row_channel(row, d->cout) : row;
-                if (o < d->cout) wf[(size_t)row * co.Ktot + k] = wsrc[o];
-            }
+            if (ch < cs.channels) ksrc[g * 8 + q] = wsrc_base + ((size_t)(r.ky * cs.kw + r.kx) * cs.channels + ch) * d->cout;
         }
     }
+    std::vector<int> row_ch(co.cout_pad);
+    for (int row = 0; row < co.cout_pad; ++row) row_ch[row] = c->precision != kF32 ? conv_row_channel(row, d->cout) : row;
+    auto pack = [&](auto* dst, auto conv) {
+        for (int kb = 0; kb < co.Ktot; kb += kBK) {
+            const float* const* ks = &ksrc[kb];
+            for (int row = 0; row < co.cout_pad; ++row) {
+                const int o = row_ch[row];
+                auto* out = dst + (size_t)row * co.Ktot + kb;
+                if (o >= d->cout) { for (int k = 0; k < kBK; ++k) out[k] = conv(0.f); continue; }
+                for (int k = 0; k < kBK; ++k) out[k] = conv(ks[k] ? ks[k][o] : 0.f);
+            }
+        }
+    };
     if (c->precision != kF32) {
         std::vector<uint16_t> wb(wn);
-        if (c->precision == kF16) for (size_t i = 0; i < wn; ++i) wb[i] = f32_to_f16_rne(wf[i]);
-        else for (size_t i = 0; i < wn; ++i) wb[i] = f32_to_bf16_rne(wf[i]);
+        if (c->precision == kF16) pack(wb.data(), [](float v) { return f32_to_f16_rne(v); });
+        else pack(wb.data(), [](float v) { return f32_to_bf16_rne(v); });
         if (upload(c, (uint16_t**)&co.d_w, wb.data(), wn)) return 1;
     } else {
+        std::vector<float> wf(wn);
+        pack(wf.data(), [](float v) { return v; });
         if (upload(c, (float**)&co.d_w, wf.data(), wn)) return 1;
     }
     if (upload(c, &co.d_ktab, ktab.data(), ktab.size())) return 1;
