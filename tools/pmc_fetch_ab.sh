@@ -16,7 +16,7 @@ for v in vs:
     rows = defaultdict(dict); kn = {}
     for r in csv.DictReader(open("gpurun_out/fab_%s/pmc_counter_collection.csv" % v)):
         d = int(r["Dispatch_Id"]); rows[d][r["Counter_Name"]] = float(r["Counter_Value"]); kn[d] = r["Kernel_Name"]
-    ids = [d for d in sorted(kn) if any(s in kn[d] for s in ("conv_igemm", "maxpool", "head_kernel", "dec_tail", "stem_conv"))][-len(names):]
+    ids = [d for d in sorted(kn) if any(s in kn[d] for s in ("conv_igemm", "maxpool", "head_kernel", "dec_tail", "stem_conv", "conv3x3_c64_direct"))][-len(names):]
     cols.append([rows[d].get("FETCH_SIZE", 0) * 2 / 1024 for d in ids])
 print("%-46s" % "op (fetch MB, x2-corrected)", *["v%-14s" % v for v in vs])
 for i, n in enumerate(names):

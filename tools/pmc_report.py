@@ -27,7 +27,7 @@ fe, meta_f = load("fetch")
 wr, meta_w = load("write")
 # plan kernels only (conv / maxpool / head), in dispatch order; one chunk = 61 ops
 def plan_ids(meta):
-    return [d for d in sorted(meta) if any(s in meta[d][0] for s in ("conv_igemm", "maxpool", "head_kernel", "dec_tail", "stem_conv"))]
+    return [d for d in sorted(meta) if any(s in meta[d][0] for s in ("conv_igemm", "maxpool", "head_kernel", "dec_tail", "stem_conv", "conv3x3_c64_direct"))]
 ids, idf, idw = plan_ids(meta), plan_ids(meta_f), plan_ids(meta_w)
 names = None
 if ops_json:
@@ -41,9 +41,11 @@ for k, (d, df, dw) in enumerate(zip(ids, idf, idw)):
     us = meta[d][4] / 1e3
     wc = c.get("SQ_WAVE_CYCLES", 1) or 1
     busy = c.get("SQ_BUSY_CYCLES", 1) or 1
-    # SQ_VALU_MFMA_BUSY_CYCLES counts cycles summed over SIMDs? normalise by GRBM-like busy cycles * 4 SIMD * 256 CU
+    # SQ_VALU_MFMA_BUSY_CYCLES counts matrix-pipe busy cycles (16 per 16x16x32 MFMA).  In this rocprofv3 build the SQ
+    # totals cover one XCD's worth of SIMDs (1/8 of the chip): checked against the issued-FLOP rate of the decoder
+    # launches (1 000 TFLOP/s of 2 500 = 40 %; raw ratio 5.1 %).  Normalise by GPU-active cycles x 32 CUs x 4 SIMDs.
     gui = fe[df].get("GRBM_GUI_ACTIVE", 0) or 1
-    mfma = c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / (gui * 256 * 4) * 100
+    mfma = c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / (gui * 32 * 4) * 100
     fetch = fe[df].get("FETCH_SIZE", 0) * 1024 * 2 / 1e6        # gfx950: FETCH_SIZE reads half (MI355X_MICROARCH.md)
     write = wr[dw].get("WRITE_SIZE", 0) * 1024 / 1e6
     hit = wr[dw].get("TCC_HIT_sum", 0); miss = wr[dw].get("TCC_MISS_sum", 0)
