@@ -202,6 +202,8 @@ def main():
             pmc = json.load(open(os.path.join(ROOT, "profiles", "r01u_pmc_summary.json")))["ops"].get(dom["name"])
             if pmc and abs(dom["patches"] / dom["launches"] - 70) < 1e-6:
                 roofline["traffic"] = round(pmc["fetch_bytes"] + pmc["write_bytes"])
+                if "mfma_busy_pct" in pmc:
+                    roofline["mfma_pipe_busy_pct_pmc"] = pmc["mfma_busy_pct"]   # issued work (13/18 of the algorithmic FLOPs)
                 roofline["traffic_source"] = "profiles/r01u_pmc_summary.json (FETCH_SIZE x2 + WRITE_SIZE per launch, L2 hit %.0f %%)" % pmc["l2_hit_pct"]
         except Exception:
             pass
