@@ -435,3 +435,20 @@ def test_repeatability_under_load(stitch_model):
     model.ctx.set_lanes(1)
     assert np.array_equal(model.segment_page(page), first)
     model.release()
+
+
+def test_random_page_sizes_fused_equals_reference_loop():
+    """Randomised geometry sweep: for page sizes the fixtures do not cover, the fused device path (tile gather,
+    batched forward, argmax, stitch kernel, two lanes) must equal the oracle's restatement of the reference
+    loop driven with the SAME model through seam 2 (model.predict per tile + host argmax + host paste) --
+    bit for bit, because both sides run the same kernels on the same tiles."""
+    cfg, w, g, model = make_model(4, 224, 224, seed=9, precision="f16", max_batch=20)
+    rng = np.random.RandomState(1234)
+    sizes = [(224, 224), (224 + 1, 224 * 3), (int(rng.randint(230, 900)), int(rng.randint(230, 900))),
+             (int(rng.randint(230, 900)), int(rng.randint(230, 900))), (180 * 3, 180 * 4), (180 * 3 + 1, 180 * 4 - 1)]
+    for hp, wp in sizes:
+        page = synthetic_page(hp, wp, seed=hp * 7 + wp)
+        fused = predict.do_prediction(True, page, model)
+        loop = tiling.do_prediction(True, page, model)            # oracle tiling code, HIP model behind model.predict
+        assert fused.shape == (hp, wp, 3) and np.array_equal(fused, loop), (hp, wp)
+    model.release()
