@@ -458,32 +458,32 @@ int sbbseg_create(int device, int precision, sbbseg_ctx** out)
 int sbbseg_destroy(sbbseg_ctx* c)
 {
     if (!c) return 0;
-    hipSetDevice(c->device);
-    if (c->stream) hipStreamSynchronize(c->stream);
-    if (c->lane_stream) hipStreamSynchronize(c->lane_stream);
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->lane_stream) (void)hipStreamSynchronize(c->lane_stream);
     for (auto& t : c->tensors) {
-        hipFree(t.lane_buf[0]);
-        hipFree(t.lane_buf[1]);
+        (void)hipFree(t.lane_buf[0]);
+        (void)hipFree(t.lane_buf[1]);
     }
     for (auto& op : c->ops) {
-        hipFree(op.conv.d_ktab); hipFree(op.conv.d_kstep); hipFree(op.conv.d_w); hipFree(op.conv.d_scale); hipFree(op.conv.d_shift);
-        hipFree(op.conv.d_rscale); hipFree(op.conv.d_rshift);
-        hipFree(op.conv.d_head_w); hipFree(op.conv.d_head_scale); hipFree(op.conv.d_head_shift); hipFree(op.conv.d_stem_wfrag); hipFree(op.conv.d_d64_wfrag);
-        for (int q = 1; q < 4; ++q) { hipFree(op.conv.d_w_cls[q]); hipFree(op.conv.d_kstep_cls[q]); hipFree(op.conv.d_ktab_cls[q]); }
-        hipFree(op.head.d_w); hipFree(op.head.d_scale); hipFree(op.head.d_shift);
-        hipFree(op.pool.d_pre_scale); hipFree(op.pool.d_pre_shift);
-        hipFree(op.tail.d_wfrag); hipFree(op.tail.d_scale); hipFree(op.tail.d_shift); hipFree(op.tail.d_head_w);
-        hipFree(op.tail.d_head_scale); hipFree(op.tail.d_head_shift);
+        (void)hipFree(op.conv.d_ktab); (void)hipFree(op.conv.d_kstep); (void)hipFree(op.conv.d_w); (void)hipFree(op.conv.d_scale); (void)hipFree(op.conv.d_shift);
+        (void)hipFree(op.conv.d_rscale); (void)hipFree(op.conv.d_rshift);
+        (void)hipFree(op.conv.d_head_w); (void)hipFree(op.conv.d_head_scale); (void)hipFree(op.conv.d_head_shift); (void)hipFree(op.conv.d_stem_wfrag); (void)hipFree(op.conv.d_d64_wfrag);
+        for (int q = 1; q < 4; ++q) { (void)hipFree(op.conv.d_w_cls[q]); (void)hipFree(op.conv.d_kstep_cls[q]); (void)hipFree(op.conv.d_ktab_cls[q]); }
+        (void)hipFree(op.head.d_w); (void)hipFree(op.head.d_scale); (void)hipFree(op.head.d_shift);
+        (void)hipFree(op.pool.d_pre_scale); (void)hipFree(op.pool.d_pre_shift);
+        (void)hipFree(op.tail.d_wfrag); (void)hipFree(op.tail.d_scale); (void)hipFree(op.tail.d_shift); (void)hipFree(op.tail.d_head_w);
+        (void)hipFree(op.tail.d_head_scale); (void)hipFree(op.tail.d_head_shift);
     }
-    hipFree(c->d_lut); hipFree(c->d_hist); hipFree(c->d_tile_xy); hipFree(c->d_batch_labels); hipFree(c->d_probs); hipFree(c->d_xin);
-    hipFree(c->d_page); hipFree(c->d_page_labels); hipFree(c->d_page_labels3); hipFree(c->d_tile_labels);
-    hipFree(c->d_own_x); hipFree(c->d_own_y); hipFree(c->d_map);
-    for (auto& pe : c->pending) { hipEventDestroy(pe.a); hipEventDestroy(pe.b); }
-    for (auto e : c->free_events) hipEventDestroy(e);
-    if (c->own_stream) hipStreamDestroy(c->own_stream);
-    if (c->lane_stream) hipStreamDestroy(c->lane_stream);
-    if (c->ev_fork) hipEventDestroy(c->ev_fork);
-    if (c->ev_join) hipEventDestroy(c->ev_join);
+    (void)hipFree(c->d_lut); (void)hipFree(c->d_hist); (void)hipFree(c->d_tile_xy); (void)hipFree(c->d_batch_labels); (void)hipFree(c->d_probs); (void)hipFree(c->d_xin);
+    (void)hipFree(c->d_page); (void)hipFree(c->d_page_labels); (void)hipFree(c->d_page_labels3); (void)hipFree(c->d_tile_labels);
+    (void)hipFree(c->d_own_x); (void)hipFree(c->d_own_y); (void)hipFree(c->d_map);
+    for (auto& pe : c->pending) { (void)hipEventDestroy(pe.a); (void)hipEventDestroy(pe.b); }
+    for (auto e : c->free_events) (void)hipEventDestroy(e);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    if (c->lane_stream) (void)hipStreamDestroy(c->lane_stream);
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     delete c;
     return 0;
 }
@@ -821,7 +821,7 @@ int sbbseg_add_conv(sbbseg_ctx* c, const sbbseg_conv_desc* d, const float* w_src
             const int q = pc.n_cls++;
             pc.d_w_cls[q] = co.d_w; pc.d_kstep_cls[q] = co.d_kstep; pc.d_ktab_cls[q] = co.d_ktab;
             pc.ooy_cls[q] = d->out_off_y; pc.oox_cls[q] = d->out_off_x;
-            hipFree(co.d_scale); hipFree(co.d_shift); hipFree(co.d_head_w); hipFree(co.d_head_scale); hipFree(co.d_head_shift);
+            (void)hipFree(co.d_scale); (void)hipFree(co.d_shift); (void)hipFree(co.d_head_w); (void)hipFree(co.d_head_scale); (void)hipFree(co.d_head_shift);
             prev.flops += op.flops;
             prev.min_bytes += op.min_bytes;
             const size_t pos = prev.name.find("_par");
@@ -1344,7 +1344,7 @@ int sbbseg_debug_ingest(sbbseg_ctx* c, const uint8_t* page_hwc, int Hp, int Wp, 
     hipError_t e = launch_to_f32(t.data(), d_tmp, n, c->precision, c->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(out, d_tmp, n * sizeof(float), hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    hipFree(d_tmp);
+    (void)hipFree(d_tmp);
     HIPCHK(e);
     return 0;
 }
@@ -1361,7 +1361,7 @@ int sbbseg_debug_read_tensor(sbbseg_ctx* c, int tensor_id, int n, float* out, si
     hipError_t e = launch_to_f32(t.data(), d_tmp, cnt, c->precision, c->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(out, d_tmp, cnt * sizeof(float), hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    hipFree(d_tmp);
+    (void)hipFree(d_tmp);
     HIPCHK(e);
     return 0;
 }
