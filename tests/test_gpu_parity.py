@@ -452,3 +452,25 @@ def test_random_page_sizes_fused_equals_reference_loop():
         loop = tiling.do_prediction(True, page, model)            # oracle tiling code, HIP model behind model.predict
         assert fused.shape == (hp, wp, 3) and np.array_equal(fused, loop), (hp, wp)
     model.release()
+
+
+@pytest.mark.parametrize("precision", ["f32", "f16"])
+def test_committed_forward_fixture(precision):
+    """tests/golden/forward_golden_64.npz (seeded 64x64 net; inputs + fp32 probabilities committed with its
+    generator) through the C ABI: fp32 check mode within TOL_SOFTMAX['f32'], fp16 within its band."""
+    import os
+    from sbb_textline_detection_amd.model import SegModel
+    from sbb_textline_detection_amd.weights import synthetic_model
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", "forward_golden_64.npz"))
+    cfg, w = synthetic_model(int(d["classes"]), 64, 64, seed=int(d["seed"]))
+    m = SegModel(cfg, w, device=0, max_batch=2, precision=precision)
+    p = m.predict(d["x"])
+    assert p.shape == d["probs"].shape and p.dtype == np.float32
+    err = float(np.abs(p - d["probs"]).max())
+    print(f"[golden 64x64, {precision}] max|dsoftmax| = {err:.2e}")
+    assert err < TOL_SOFTMAX[precision]
+    if precision == "f32":
+        srt = np.sort(d["probs"], axis=-1)
+        decided = (srt[..., -1] - srt[..., -2]) > 1e-3
+        assert np.array_equal(p.argmax(-1)[decided], d["probs"].argmax(-1)[decided])
+    m.release()
