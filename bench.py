@@ -166,7 +166,7 @@ def main():
         torch.cuda.synchronize()
         prof = ctx.profile()
         ctx.profile_enable(False)
-        convs = [o for o in prof if o["name"].startswith("conv") and o["launches"] > 0]
+        convs = [o for o in prof if "conv" in o["name"] and o["launches"] > 0]       # incl. stem_conv*, direct_conv*, tail_conv*
         tot_ms = sum(o["total_ms"] for o in prof)
         conv_ms = sum(o["total_ms"] for o in convs)
         conv_flops = sum(o["flops"] * o["patches"] for o in convs)
@@ -174,7 +174,7 @@ def main():
         # parity classes of a decoder conv run as one grouped launch)
         dom = max(convs, key=lambda o: o["total_ms"] / o["launches"])
         ach = dom["flops"] * dom["patches"] / (dom["total_ms"] * 1e-3) / 1e12
-        k3 = [o for o in convs if o["name"].startswith(("conv3x3", "conv2x2"))]          # the 3x3 conv stages
+        k3 = [o for o in convs if any(t in o["name"] for t in ("conv3x3", "conv2x2"))]          # the 3x3 conv stages
         k3_ms = sum(o["total_ms"] for o in k3)
         k3_flops = sum(o["flops"] * o["patches"] for o in k3)
         roofline = {
@@ -186,7 +186,7 @@ def main():
             "flops_per_launch": dom["flops"] * dom["patches"] / dom["launches"],
             "launch_mode": "per-launch HIP events in a profiling pass right after the timed region: one 70-tile launch per op on "
                            "one lane (exclusive GPU).  The timed region runs the same kernels as two concurrent 35-tile halves "
-                           "(lanes=2, +5 % throughput), where per-launch durations overlap and are not separable",
+                           "(lanes=2), where per-launch durations overlap and are not separable",
             "flops_note": "algorithmic FLOPs (reference formulation: 2*MACs of the 3x3 conv over the upsampled+"
                           "concatenated input); the parity-split kernels issue 13/18 of them as MFMA work",
             "conv3x3_stages": {"achieved": round(k3_flops / (k3_ms * 1e-3) / 1e12, 2),
