@@ -35,7 +35,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--precision", default=os.environ.get("SBBSEG_PRECISION", "f16"), choices=["f16", "bf16"])
+    ap.add_argument("--precision", default=os.environ.get("SBBSEG_PRECISION", "f16"), choices=["f16", "bf16", "f16x3"])
     ap.add_argument("--max-batch", type=int, default=int(os.environ.get("SBBSEG_MAX_BATCH", "0")),
                     help="tiles per chunk (0 = one page per chunk: 70 for the 3500x2500 page, 108 for the 4000x3000 pages of batch64)")
     ap.add_argument("--conv-variant", type=int, default=int(os.environ.get("SBBSEG_CONV_VARIANT", "0")),

@@ -31,11 +31,18 @@ extern "C" {
 typedef struct sbbseg_ctx sbbseg_ctx;
 
 /* arithmetic mode of a handle */
-#define SBBSEG_PREC_BF16 0   /* bf16 operands, fp32 MFMA accumulate, fp32 epilogue (product path) */
+#define SBBSEG_PREC_BF16 0   /* bf16 operands, fp32 MFMA accumulate, fp32 epilogue.  Fast, coarse: 8-bit significands
+                                through ~60 layers move near-tie labels (kept for A/B only) */
 #define SBBSEG_PREC_F32  1   /* fp32 everything, plain FMA kernels: slow, used to separate plumbing
                                 errors from 16-bit rounding in the parity tests */
 #define SBBSEG_PREC_F16  2   /* fp16 operands (11-bit significand, saturating stores), same MFMA rate as
-                                bf16, fp32 accumulate/epilogue: 8x finer rounding, range +-65504 */
+                                bf16, fp32 accumulate/epilogue: 8x finer rounding, range +-65504.  The FAST mode:
+                                labels can differ from an fp32 run where the top-2 softmax margin is small */
+#define SBBSEG_PREC_F16X3 3  /* error-compensated fp16 ("split") mode, the LABEL-EXACT mode and the default of the
+                                Python seams: every activation and weight is carried as hi + lo fp16 halves (~22
+                                significant bits), each product is three MFMAs (hi*hi + hi*lo + lo*hi) accumulated
+                                in fp32.  Same MFMA kernels, ~1/3 of the fp16 mode's arithmetic rate; label maps
+                                equal an fp32 evaluation except at exact ties (main.py:290 "argmax bit-exact") */
 
 /* ---- lifecycle: replaces start_new_session_and_model / session.close (main.py:216-223, 428) */
 const char* sbbseg_last_error(void);

@@ -100,9 +100,11 @@ def _softmax(x):
     return (e / e.sum(axis=-1, keepdims=True)).astype(np.float32)
 
 
-def forward(graph, weights: Dict[str, np.ndarray], x: np.ndarray, taps=None) -> np.ndarray:
+def forward(graph, weights: Dict[str, np.ndarray], x: np.ndarray, taps=None, conv_hook=None) -> np.ndarray:
     """Run the graph on x [N,H,W,3] (any float dtype; cast to f32 like Keras' predict feed).
-    ``taps``: optional dict filled with {layer name: output} for the names it already contains."""
+    ``taps``: optional dict filled with {layer name: output} for the names it already contains.
+    ``conv_hook(node, x, w) -> (x, w)``: lets the error-budget test (tests/test_error_budget.py) perturb the
+    operands of chosen Conv2D layers (e.g. round them to fp16) -- never used for parity references."""
     x = np.ascontiguousarray(x, np.float32)
     vals: Dict[str, np.ndarray] = {}
     remaining = {}
@@ -119,7 +121,10 @@ def forward(graph, weights: Dict[str, np.ndarray], x: np.ndarray, taps=None) -> 
             y = np.pad(a[0], ((0, 0), (t, b), (l, r), (0, 0)))
         elif n.op == "conv":
             bias = weights.get(f"{n.name}/bias:0") if n.attrs["use_bias"] else None
-            y = conv2d(a[0], weights[f"{n.name}/kernel:0"], bias, n.attrs["strides"], n.attrs["padding"])
+            xin, wk = a[0], weights[f"{n.name}/kernel:0"]
+            if conv_hook is not None:
+                xin, wk = conv_hook(n, xin, wk)
+            y = conv2d(xin, wk, bias, n.attrs["strides"], n.attrs["padding"])
             if n.attrs.get("activation", "linear") == "relu":
                 y = np.maximum(y, 0)
         elif n.op == "bn":

@@ -13,7 +13,8 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libsbbseg.so")
 
-PREC_BF16, PREC_F32, PREC_F16 = 0, 1, 2
+PREC_BF16, PREC_F32, PREC_F16, PREC_F16X3 = 0, 1, 2, 3
+PRECISIONS = {"bf16": PREC_BF16, "f32": PREC_F32, "f16": PREC_F16, "f16x3": PREC_F16X3}
 INPUT_C8, INPUT_PAIRS = 0, 1
 
 EXPORTS = [

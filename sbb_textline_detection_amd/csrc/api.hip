@@ -71,6 +71,7 @@ struct ConvOp {
     KStepRec* d_kstep_cls[4] = {nullptr, nullptr, nullptr, nullptr};
     KTabEntry* d_ktab_cls[4] = {nullptr, nullptr, nullptr, nullptr};
     int ooy_cls[4] = {0, 0, 0, 0}, oox_cls[4] = {0, 0, 0, 0};
+    float wmul_cls[4] = {1.f, 1.f, 1.f, 1.f};   // split mode: 2^-s of the class's power-of-two weight pre-scale
     uint16_t* d_stem_wfrag = nullptr;     // non-null: the op is the network stem and runs stem_conv_pairs
     uint16_t* d_d64_wfrag = nullptr;      // non-null: 3x3 s1 64->64 conv, runs conv3x3_c64_direct
 };
@@ -107,7 +108,8 @@ struct PendingEvent { int op; hipEvent_t a, b; int patches; };
 struct sbbseg_ctx {
     int device = 0;
     int precision = kBF16;
-    int elem = 2;
+    int elem = 2;                 // bytes per stored half-element (weights, one activation plane)
+    int planes = 1;               // 16-bit planes per activation element: 2 in the split mode (hi, lo), else 1
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     // second lane: its own activation buffers and stream; a chunk of tiles is split over the two lanes so
@@ -269,7 +271,8 @@ int run_plan(sbbseg_ctx* c, int n, uint8_t* d_labels, float* d_probs)
                 SrcDesc& sd = p.src[s];
                 sd.base = t.buf;
                 sd.PH = t.H; sd.PW = t.W;
-                sd.pix_bytes = t.C * c->elem;
+                sd.pix_bytes = t.C * c->elem * c->planes;
+                sd.lo_off = c->planes == 2 ? t.C * c->elem : 64;
                 sd.shift = co.d.src[s].up_shift;
                 sd.lim_y = t.H << sd.shift; sd.lim_x = t.W << sd.shift;
                 sd.ksteps = co.ksteps[s];
@@ -297,7 +300,7 @@ int run_plan(sbbseg_ctx* c, int n, uint8_t* d_labels, float* d_probs)
             }
             for (int q = 0; q < 4; ++q) {
                 p.w_cls[q] = co.d_w_cls[q]; p.kstep_cls[q] = co.d_kstep_cls[q]; p.ktab_cls[q] = co.d_ktab_cls[q];
-                p.ooy_cls[q] = co.ooy_cls[q]; p.oox_cls[q] = co.oox_cls[q];
+                p.ooy_cls[q] = co.ooy_cls[q]; p.oox_cls[q] = co.oox_cls[q]; p.wmul_cls[q] = co.wmul_cls[q];
             }
             p.head_classes = co.d.head_classes; p.head_w = co.d_head_w; p.head_scale = co.d_head_scale;
             p.head_shift = co.d_head_shift; p.labels = d_labels; p.probs = d_probs;
@@ -424,7 +427,8 @@ int sbbseg_device_count(int* count)
 int sbbseg_create(int device, int precision, sbbseg_ctx** out)
 {
     REQUIRE(out, "null out");
-    REQUIRE(precision == SBBSEG_PREC_BF16 || precision == SBBSEG_PREC_F32 || precision == SBBSEG_PREC_F16, "bad precision %d", precision);
+    REQUIRE(precision == SBBSEG_PREC_BF16 || precision == SBBSEG_PREC_F32 || precision == SBBSEG_PREC_F16 || precision == SBBSEG_PREC_F16X3,
+            "bad precision %d", precision);
     int ndev = 0;
     HIPCHK(hipGetDeviceCount(&ndev));
     REQUIRE(device >= 0 && device < ndev, "device %d out of range (have %d)", device, ndev);
@@ -437,6 +441,7 @@ int sbbseg_create(int device, int precision, sbbseg_ctx** out)
     c->device = device;
     c->precision = precision;
     c->elem = precision == SBBSEG_PREC_F32 ? 4 : 2;
+    c->planes = is_split(precision) ? 2 : 1;
     c->num_cus = prop.multiProcessorCount;
     hipError_t e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
     if (e != hipSuccess) {
@@ -629,32 +634,36 @@ int sbbseg_add_conv(sbbseg_ctx* c, const sbbseg_conv_desc* d, const float* w_src
     // of the same pixel rows hit in L2 (measured with tap-outer order: dec1 fetched 2.5 GB per
     // launch for 70 MB of input).  Each source's segment is padded to whole K-steps (64) with
     // out-of-bounds ("zero") granules.  Tap offsets carry the source's padding and placement offset.
-    std::vector<KTabEntry> ktab;
+    // Split mode (kF16X3): a K-step is 32 channels (4 granules) of one tap; its slots 0-3 are those granules' "hi"
+    // halves, slots 4-7 the "lo" halves of the same channels (lo plane of the stored pixel, lo half of the weight).
+    const bool split = is_split(c->precision);
+    const int gps = split ? 4 : kGranulesPerStep;            // channel granules per K-step
+    std::vector<KTabEntry> lin;                              // granule list in contraction order (hi halves in split mode)
     struct KRef { int s, ky, kx, c0; };
-    std::vector<KRef> kref;
+    std::vector<KRef> lref;
     double geo_macs = 0;
     for (int s = 0; s < d->n_src; ++s) {
         const sbbseg_conv_src& cs = d->src[s];
         const int g8 = (cs.channels + 7) / 8;
         int granules = 0;
-        for (int cg = 0; cg < g8; cg += kGranulesPerStep)
+        for (int cg = 0; cg < g8; cg += gps)
             for (int ky = 0; ky < cs.kh; ++ky)
                 for (int kx = 0; kx < cs.kw; ++kx)
-                    for (int g = cg; g < g8 && g < cg + kGranulesPerStep; ++g) {
+                    for (int g = cg; g < g8 && g < cg + gps; ++g) {
                         KTabEntry e;
                         e.dy = (int16_t)(ky - cs.pad_top - cs.off_y);
                         e.dx = (int16_t)(kx - cs.pad_left - cs.off_x);
                         e.coff = g * 8 * c->elem;
-                        ktab.push_back(e);
-                        kref.push_back({s, ky, kx, g * 8});
+                        lin.push_back(e);
+                        lref.push_back({s, ky, kx, g * 8});
                         ++granules;
                     }
-        const int ks = (granules + kGranulesPerStep - 1) / kGranulesPerStep;
-        for (int g = granules; g < ks * kGranulesPerStep; ++g) {
+        const int ks = (granules + gps - 1) / gps;
+        for (int g = granules; g < ks * gps; ++g) {
             KTabEntry e;
             e.dy = 16000; e.dx = 0; e.coff = 0;
-            ktab.push_back(e);
-            kref.push_back({-1, 0, 0, 0});
+            lin.push_back(e);
+            lref.push_back({-1, 0, 0, 0});
         }
         co.ksteps[s] = ks;
         co.total_ksteps += ks;
@@ -662,12 +671,28 @@ int sbbseg_add_conv(sbbseg_ctx* c, const sbbseg_conv_desc* d, const float* w_src
     }
     co.Ktot = co.total_ksteps * kBK;
     REQUIRE((size_t)co.cout_pad * co.Ktot * c->elem < (size_t)3 << 30, "weight matrix too large");
+    // slot table: 8 entries per K-step (what the kernels index); kpart = 0 plain / hi half, 1 lo half
+    std::vector<KTabEntry> ktab((size_t)co.total_ksteps * kGranulesPerStep);
+    std::vector<KRef> kref(ktab.size());
+    std::vector<int> kpart(ktab.size(), 0);
+    for (int t = 0; t < co.total_ksteps; ++t)
+        for (int g = 0; g < kGranulesPerStep; ++g) {
+            const size_t li = (size_t)t * gps + (split ? (g & 3) : g), ki = (size_t)t * kGranulesPerStep + g;
+            ktab[ki] = lin[li];
+            kref[ki] = lref[li];
+            if (split && g >= 4) {
+                kpart[ki] = 1;
+                if (lref[li].s >= 0) ktab[ki].coff += c->tensors[d->src[lref[li].s].tensor].C * c->elem;      // the pixel's lo plane
+            }
+        }
 
     // pack weights [cout_pad][Ktot]: one source pointer per K element (null = K padding), then row by row in
     // blocks of 64 K elements -- writes are contiguous, the 64 source lines of a block stay in cache across
     // neighbouring output channels (the column-by-column form of this loop took 0.6 s of a model's load time)
     const size_t wn = (size_t)co.cout_pad * co.Ktot;
     std::vector<const float*> ksrc((size_t)co.Ktot, nullptr);
+    std::vector<uint8_t> klo((size_t)co.Ktot, 0);
+    float wmax = 0.f;
     for (size_t g = 0; g < kref.size(); ++g) {
         const KRef& r = kref[g];
         if (r.s < 0) continue;
@@ -675,30 +700,62 @@ int sbbseg_add_conv(sbbseg_ctx* c, const sbbseg_conv_desc* d, const float* w_src
         const float* wsrc_base = r.s == 0 ? w_src0 : w_src1;
         for (int q = 0; q < 8; ++q) {
             const int ch = r.c0 + q;
-            if (ch < cs.channels) ksrc[g * 8 + q] = wsrc_base + ((size_t)(r.ky * cs.kw + r.kx) * cs.channels + ch) * d->cout;
+            if (ch < cs.channels) {
+                ksrc[g * 8 + q] = wsrc_base + ((size_t)(r.ky * cs.kw + r.kx) * cs.channels + ch) * d->cout;
+                klo[g * 8 + q] = (uint8_t)kpart[g];
+            }
         }
+    }
+    // split mode: one power-of-two pre-scale per conv brings the largest |w| into [256, 512), so that the lo halves of
+    // all weights within 2^12 of it are normal fp16 numbers; the epilogue multiplies `scale` by 2^-s (exact)
+    float wpre = 1.f;
+    if (split) {
+        for (int s2 = 0; s2 < d->n_src; ++s2) {
+            const sbbseg_conv_src& cs = d->src[s2];
+            const float* wp = s2 == 0 ? w_src0 : w_src1;
+            const size_t cnt = (size_t)cs.kh * cs.kw * cs.channels * d->cout;
+            for (size_t i = 0; i < cnt; ++i) wmax = std::fmax(wmax, std::fabs(wp[i]));
+        }
+        REQUIRE(std::isfinite(wmax), "%s: non-finite weights", "conv");
+        if (wmax > 0.f) {
+            int ex = 0;
+            (void)std::frexp(wmax, &ex);                     // wmax = m * 2^ex, m in [0.5, 1)
+            int sexp = 9 - ex;                               // wmax * 2^sexp in [256, 512)
+            sexp = sexp > 60 ? 60 : (sexp < -60 ? -60 : sexp);
+            wpre = std::ldexp(1.f, sexp);
+        }
+        co.wmul_cls[0] = 1.f / wpre;
     }
     std::vector<int> row_ch(co.cout_pad);
     for (int row = 0; row < co.cout_pad; ++row) row_ch[row] = c->precision != kF32 ? conv_row_channel(row, d->cout) : row;
     auto pack = [&](auto* dst, auto conv) {
         for (int kb = 0; kb < co.Ktot; kb += kBK) {
             const float* const* ks = &ksrc[kb];
+            const uint8_t* kl = &klo[kb];
             for (int row = 0; row < co.cout_pad; ++row) {
                 const int o = row_ch[row];
                 auto* out = dst + (size_t)row * co.Ktot + kb;
-                if (o >= d->cout) { for (int k = 0; k < kBK; ++k) out[k] = conv(0.f); continue; }
-                for (int k = 0; k < kBK; ++k) out[k] = conv(ks[k] ? ks[k][o] : 0.f);
+                if (o >= d->cout) { for (int k = 0; k < kBK; ++k) out[k] = conv(0.f, 0); continue; }
+                for (int k = 0; k < kBK; ++k) out[k] = conv(ks[k] ? ks[k][o] : 0.f, (int)kl[k]);
             }
         }
     };
     if (c->precision != kF32) {
         std::vector<uint16_t> wb(wn);
-        if (c->precision == kF16) pack(wb.data(), [](float v) { return f32_to_f16_rne(v); });
-        else pack(wb.data(), [](float v) { return f32_to_bf16_rne(v); });
+        if (split)
+            pack(wb.data(), [wpre](float v, int part) {
+                const float sv = v * wpre;                   // exact (power of two)
+                const uint16_t hb = f32_to_f16_rne(sv);
+                if (!part) return hb;
+                const _Float16 h = __builtin_bit_cast(_Float16, hb);
+                return f32_to_f16_rne(sv - (float)h);
+            });
+        else if (c->precision == kF16) pack(wb.data(), [](float v, int) { return f32_to_f16_rne(v); });
+        else pack(wb.data(), [](float v, int) { return f32_to_bf16_rne(v); });
         if (upload(c, (uint16_t**)&co.d_w, wb.data(), wn)) return 1;
     } else {
         std::vector<float> wf(wn);
-        pack(wf.data(), [](float v) { return v; });
+        pack(wf.data(), [](float v, int) { return v; });
         if (upload(c, (float**)&co.d_w, wf.data(), wn)) return 1;
     }
     if (upload(c, &co.d_ktab, ktab.data(), ktab.size())) return 1;
@@ -707,8 +764,18 @@ int sbbseg_add_conv(sbbseg_ctx* c, const sbbseg_conv_desc* d, const float* w_src
         const KTabEntry* e = &ktab[(size_t)t * kGranulesPerStep];
         KStepRec r;
         r.dy = e[0].dy; r.dx = e[0].dx; r.coff = e[0].coff; r.irregular = 0; r.pad_ = 0;
-        for (int g = 1; g < kGranulesPerStep; ++g)
-            if (e[g].dy != e[0].dy || e[g].dx != e[0].dx || e[g].coff != e[0].coff + 16 * g) r.irregular = 1;
+        for (int g = 1; g < kGranulesPerStep; ++g) {
+            // regular: one tap, channel-consecutive granules; in split mode slots 4-7 are slots 0-3 moved to the lo plane
+            // (same distance for every step of a source: SrcDesc::lo_off)
+            int want = e[0].coff + 16 * g;
+            if (split) {
+                const KRef& r0 = kref[(size_t)t * kGranulesPerStep];
+                const int lo_off = r0.s >= 0 ? c->tensors[d->src[r0.s].tensor].C * c->elem : 0;
+                want = e[0].coff + 16 * (g & 3) + (g >> 2) * lo_off;
+                if (r0.s < 0 || kref[(size_t)t * kGranulesPerStep + g].s != r0.s) r.irregular = 1;
+            }
+            if (e[g].dy != e[0].dy || e[g].dx != e[0].dx || e[g].coff != want) r.irregular = 1;
+        }
         if (c->precision == kF32) r.irregular = 1;     // the fp32 check kernel only walks the granule table
         ksteps[t] = r;
     }
@@ -743,9 +810,9 @@ int sbbseg_add_conv(sbbseg_ctx* c, const sbbseg_conv_desc* d, const float* w_src
     double bytes = 0;
     for (int s = 0; s < d->n_src; ++s) {
         const Tensor& t = c->tensors[d->src[s].tensor];
-        bytes += (double)t.H * t.W * ((d->src[s].channels + 7) / 8 * 8) * c->elem / (d->out_stride_y * d->out_stride_x);
+        bytes += (double)t.H * t.W * ((d->src[s].channels + 7) / 8 * 8) * c->elem * c->planes / (d->out_stride_y * d->out_stride_x);
     }
-    const double ob = (double)d->out_h * d->out_w * d->cout * c->elem;
+    const double ob = (double)d->out_h * d->out_w * d->cout * c->elem * c->planes;
     bytes += (d->out_tensor >= 0 ? ob : 0) + (d->raw_out_tensor >= 0 ? ob : 0) + (d->residual_tensor >= 0 ? ob : 0);
     op.min_bytes = bytes;
     co.d_w_cls[0] = co.d_w; co.d_kstep_cls[0] = co.d_kstep; co.d_ktab_cls[0] = co.d_ktab;
@@ -756,7 +823,8 @@ int sbbseg_add_conv(sbbseg_ctx* c, const sbbseg_conv_desc* d, const float* w_src
         const sbbseg_conv_src& cs = d->src[0];
         const Tensor& st = c->tensors[cs.tensor];
         const char* env = getenv("SBBSEG_STEM_KERNEL");
-        if (c->precision != kF32 && !(env && env[0] == '0') && d->n_src == 1 && st.is_input_form && st.form == SBBSEG_INPUT_PAIRS &&
+        const bool plain16 = c->precision == kF16 || c->precision == kBF16;     // the dedicated kernels read the one-plane layout
+        if (plain16 && !(env && env[0] == '0') && d->n_src == 1 && st.is_input_form && st.form == SBBSEG_INPUT_PAIRS &&
             cs.channels == 8 && cs.kh == 7 && cs.kw == 4 && cs.stride_y == 2 && cs.stride_x == 1 && cs.pad_top == 0 && cs.pad_left == 0 &&
             cs.up_shift == 0 && cs.off_y == 0 && cs.off_x == 0 && d->cout == 64 && d->out_h % 16 == 0 && d->out_w % 16 == 0 &&
             st.H >= 2 * d->out_h + 5 && st.W >= d->out_w + 3 &&
@@ -778,7 +846,7 @@ int sbbseg_add_conv(sbbseg_ctx* c, const sbbseg_conv_desc* d, const float* w_src
         }
         // 3x3 / stride 1 / pad 1, 64 -> 64 channels: direct conv on an LDS halo tile, weights in registers
         const char* env2 = getenv("SBBSEG_DIRECT64_KERNEL");
-        if (c->precision != kF32 && !(env2 && env2[0] == '0') && d->n_src == 1 && !st.is_input_form && st.C == 64 && cs.channels == 64 &&
+        if (plain16 && !(env2 && env2[0] == '0') && d->n_src == 1 && !st.is_input_form && st.C == 64 && cs.channels == 64 &&
             cs.kh == 3 && cs.kw == 3 && cs.stride_y == 1 && cs.stride_x == 1 && cs.pad_top == 1 && cs.pad_left == 1 && cs.up_shift == 0 &&
             cs.off_y == 0 && cs.off_x == 0 && d->cout == 64 && d->out_h == st.H && d->out_w == st.W && d->residual_tensor < 0 &&
             d->raw_out_tensor < 0 && d->head_classes == 0 && d->out_tensor >= 0 && d->out_stride_y == 1 && d->out_stride_x == 1 &&
@@ -820,7 +888,7 @@ int sbbseg_add_conv(sbbseg_ctx* c, const sbbseg_conv_desc* d, const float* w_src
         if (same) {
             const int q = pc.n_cls++;
             pc.d_w_cls[q] = co.d_w; pc.d_kstep_cls[q] = co.d_kstep; pc.d_ktab_cls[q] = co.d_ktab;
-            pc.ooy_cls[q] = d->out_off_y; pc.oox_cls[q] = d->out_off_x;
+            pc.ooy_cls[q] = d->out_off_y; pc.oox_cls[q] = d->out_off_x; pc.wmul_cls[q] = co.wmul_cls[0];
             (void)hipFree(co.d_scale); (void)hipFree(co.d_shift); (void)hipFree(co.d_head_w); (void)hipFree(co.d_head_scale); (void)hipFree(co.d_head_shift);
             prev.flops += op.flops;
             prev.min_bytes += op.min_bytes;
@@ -856,7 +924,7 @@ int sbbseg_add_maxpool(sbbseg_ctx* c, int src_tensor, int dst_tensor, int k, int
     snprintf(nm, sizeof(nm), "maxpool%dx%d_s%d_c%d_%dx%d", k, k, stride, s.C, Ho, Wo);
     op.name = nm;
     op.flops = 0;
-    op.min_bytes = ((double)s.H * s.W + (double)Ho * Wo) * s.C * c->elem;
+    op.min_bytes = ((double)s.H * s.W + (double)Ho * Wo) * s.C * c->elem * c->planes;
     c->ops.push_back(op);
     return 0;
 }
@@ -867,7 +935,7 @@ int sbbseg_add_tail(sbbseg_ctx* c, int src0_tensor, int img_c8_tensor, const flo
 {
     REQUIRE(c && !c->finalized && w_src0 && w_img && scale && shift && head_w && head_scale && head_shift, "bad arguments");
     HIPCHK(hipSetDevice(c->device));
-    REQUIRE(c->precision != kF32, "the fused tail is a 16-bit-mode kernel");
+    REQUIRE(c->precision == kF16 || c->precision == kBF16, "the fused tail is a plain 16-bit-mode kernel");
     const int ntens = (int)c->tensors.size();
     REQUIRE(src0_tensor >= 0 && src0_tensor < ntens && img_c8_tensor >= 0 && img_c8_tensor < ntens, "tail tensors undefined");
     const Tensor& s0 = c->tensors[src0_tensor];
@@ -941,7 +1009,7 @@ int sbbseg_add_head(sbbseg_ctx* c, int src_tensor, int cin, int classes, const f
     snprintf(nm, sizeof(nm), "head1x1_c%dto%d_softmax_argmax", cin, classes);
     op.name = nm;
     op.flops = 2.0 * s.H * s.W * cin * classes;
-    op.min_bytes = (double)s.H * s.W * (cin * c->elem + 1);
+    op.min_bytes = (double)s.H * s.W * (cin * c->elem * c->planes + 1);
     c->classes = classes;
     c->ops.push_back(op);
     return 0;
@@ -955,7 +1023,7 @@ int sbbseg_finalize(sbbseg_ctx* c, int max_batch)
     REQUIRE(c->classes > 0 && !c->ops.empty(), "plan must contain a head (head op or a conv with a fused head)");
     c->max_batch = max_batch;
     for (auto& t : c->tensors) {
-        const size_t bytes = kZeroHeaderBytes + t.elems_per_patch * max_batch * c->elem + 256;
+        const size_t bytes = kZeroHeaderBytes + t.elems_per_patch * max_batch * c->elem * c->planes + 256;
         REQUIRE(bytes < ((size_t)1 << 32), "tensor %dx%dx%d x batch %d exceeds the 4 GiB gather window", t.H, t.W, t.C, max_batch);
         if (dmalloc(c, (void**)&t.lane_buf[0], bytes)) return 1;
         t.buf = t.lane_buf[0];
@@ -965,7 +1033,7 @@ int sbbseg_finalize(sbbseg_ctx* c, int max_batch)
     c->lane1_batch = (c->lanes == 2 && max_batch >= 2 * kMinLaneTiles) ? (max_batch + 1) / 2 : 0;
     if (c->lane1_batch)
         for (auto& t : c->tensors) {
-            const size_t bytes = kZeroHeaderBytes + t.elems_per_patch * c->lane1_batch * c->elem + 256;
+            const size_t bytes = kZeroHeaderBytes + t.elems_per_patch * c->lane1_batch * c->elem * c->planes + 256;
             if (dmalloc(c, (void**)&t.lane_buf[1], bytes)) return 1;
             HIPCHK(hipMemset(t.lane_buf[1], 0, t.is_input_form ? bytes : (size_t)kZeroHeaderBytes));
         }
@@ -1341,7 +1409,8 @@ int sbbseg_debug_ingest(sbbseg_ctx* c, const uint8_t* page_hwc, int Hp, int Wp, 
     HIPCHK(launch_ingest_u8(ip, c->precision, c->stream));
     float* d_tmp = nullptr;
     HIPCHK(hipMalloc((void**)&d_tmp, n * sizeof(float)));
-    hipError_t e = launch_to_f32(t.data(), d_tmp, n, c->precision, c->stream);
+    hipError_t e = c->planes == 2 ? launch_split_to_f32(t.data(), d_tmp, n / t.C, t.C, c->stream)
+                                  : launch_to_f32(t.data(), d_tmp, n, c->precision, c->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(out, d_tmp, n * sizeof(float), hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     (void)hipFree(d_tmp);
@@ -1358,7 +1427,8 @@ int sbbseg_debug_read_tensor(sbbseg_ctx* c, int tensor_id, int n, float* out, si
     REQUIRE(out_floats >= cnt, "output buffer too small (%zu < %zu)", out_floats, cnt);
     float* d_tmp = nullptr;
     HIPCHK(hipMalloc((void**)&d_tmp, cnt * sizeof(float)));
-    hipError_t e = launch_to_f32(t.data(), d_tmp, cnt, c->precision, c->stream);
+    hipError_t e = c->planes == 2 ? launch_split_to_f32(t.data(), d_tmp, cnt / t.C, t.C, c->stream)
+                                  : launch_to_f32(t.data(), d_tmp, cnt, c->precision, c->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(out, d_tmp, cnt * sizeof(float), hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     (void)hipFree(d_tmp);

@@ -21,6 +21,9 @@ struct SrcDesc {
     int ksteps;           // K-steps contributed by this source
     int sy_shift, sx_shift; // log2 of this source's input step per output step (stride 1|2); the
                           // source's padding and placement offset are folded into the tap table
+    int lo_off;           // byte distance from slot 0-3's granules to slot 4-7's inside a K-step: 64 (the next four
+                          // 8-channel granules) in the plain modes; channels * 2 in the split mode (the "lo" plane
+                          // of the same 32 channels, see kF16X3)
 };
 
 // one entry per 16-byte granule of the contraction axis
@@ -74,6 +77,7 @@ struct ConvParams {
     const KTabEntry* ktab_cls[4];
     int ooy_cls[4], oox_cls[4];
     // fused head (cout == 32 tiles only): 1x1 conv + BN + softmax + argmax on the fp32 epilogue values
+    float wmul_cls[4];        // per-class multiplier of `scale` (split mode: 2^-s of the power-of-two weight pre-scale; else 1)
     int head_classes;         // 0 = none
     const float* head_w;      // [cout][classes]
     const float* head_scale;  // [classes]
@@ -158,7 +162,13 @@ struct IngestParams {
     const int* bin_thr;       // device int: binarise channel 0 at this (Otsu) threshold into all 3 channels, or null
 };
 
-enum Precision { kBF16 = 0, kF32 = 1, kF16 = 2 };
+// kF16X3: error-compensated fp16 ("split") mode.  Every activation and weight v is carried as two fp16 numbers
+// hi = fp16(v), lo = fp16(v - hi) (about 22 significant bits together); a product is three MFMAs
+// (hi*hi + hi*lo + lo*hi, fp32 accumulate), the dropped lo*lo term is ~2^-22 relative.  Activations are stored
+// per pixel as [C hi][C lo] (4 bytes per element), weights per 32-channel K-step as [32 hi][32 lo] after a
+// power-of-two pre-scale that keeps their lo parts out of the fp16 subnormal range.
+enum Precision { kBF16 = 0, kF32 = 1, kF16 = 2, kF16X3 = 3 };
+inline bool is_split(int precision) { return precision == kF16X3; }
 
 // launchers implemented in kernels.hip ---------------------------------------------------------
 hipError_t launch_conv(const ConvParams& p, int precision, hipStream_t s);
@@ -181,6 +191,7 @@ hipError_t launch_resize_labels(const uint8_t* labels, int H, int W, const int* 
                                 int out_h, int out_w, uint8_t* out, hipStream_t s);
 hipError_t launch_replicate3(const uint8_t* src, uint8_t* dst, size_t n, hipStream_t s);
 hipError_t launch_to_f32(const void* src, float* dst, size_t n, int precision, hipStream_t s);
+hipError_t launch_split_to_f32(const void* src, float* dst, size_t npix, int C, hipStream_t s);   // [pix][C hi][C lo] -> [pix][C]
 
 int conv_row_channel(int row, int cout);   // packed weight row -> output channel (16-bit modes)
 int conv_tile_bc(int cout);   // channel-tile width the bf16 conv kernel uses for `cout` (weights are padded to it)

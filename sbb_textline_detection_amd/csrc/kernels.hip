@@ -70,6 +70,29 @@ template <bool F16> __device__ inline f32x4_t mfma16(bf16x8_t a, bf16x8_t b, f32
         return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
 
+// ---- split mode (kF16X3) element helpers: v = hi + lo, hi = fp16(v) (saturating), lo = fp16(v - hi)
+__device__ inline void split_f32(float v, _Float16& hi, _Float16& lo)
+{
+    v = fminf(fmaxf(v, -65504.f), 65504.f);
+    hi = (_Float16)v;
+    lo = (_Float16)(v - (float)hi);               // exact difference (Sterbenz-like: |v - hi| <= ulp(hi)/2), then one rounding
+}
+// 8 consecutive channels of one pixel: hi halves at dst, lo halves `plane` elements behind
+__device__ inline void store_split8(uint16_t* dst, int plane, const float (&y)[8])
+{
+    f16x8_t h, l;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { _Float16 a, b; split_f32(y[q], a, b); h[q] = a; l[q] = b; }
+    *(f16x8_t*)dst = h;
+    *(f16x8_t*)(dst + plane) = l;
+}
+__device__ inline void add_split8(const uint16_t* src, int plane, float (&y)[8])
+{
+    const f16x8_t h = *(const f16x8_t*)src, l = *(const f16x8_t*)(src + plane);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) y[q] += (float)h[q] + (float)l[q];      // hi + lo is exact in fp32
+}
+
 // ------------------------------------------------------------------------------------------------
 // conv_igemm_mfma  (16-bit operands: bf16 or fp16, fp32 accumulate)
 // ------------------------------------------------------------------------------------------------
@@ -138,10 +161,15 @@ template <int N> __device__ inline void wait_vmcnt()
 // their time filling and draining a 1-4 step pipeline.
 // K-step descriptors come through the scalar cache (uniform address in the constant address space
 // -> s_load, lgkmcnt): no VGPR-destination VMEM load sits in the steady-state loop.
-template <int BP, int BC, int WP, int WC, int NS, bool F16, int GS = 8, bool PH8 = false>
+// X3 = the split mode (internal.h, kF16X3): a K-step is 32 channels of one tap staged as slots 0-3 = "hi" halves,
+// slots 4-7 = "lo" halves (same LDS image, same staging code: only the source offset of slots 4-7 differs, SrcDesc::lo_off);
+// three MFMAs per product; outputs are split again in the epilogue and stored as [C hi][C lo] per pixel.
+template <int BP, int BC, int WP, int WC, int NS, bool F16, int GS = 8, bool PH8 = false, bool X3 = false>
 __global__ __launch_bounds__(64 * WP * WC, (conv_blocks_per_cu(BP, BC, WP, WC, NS, GS) * (WP * WC) / 4))
 void conv_igemm_mfma(const ConvParams p)
 {
+    static_assert(!X3 || (F16 && GS == 8 && !PH8), "split mode: fp16 halves, whole-K-step stages, plain loop");
+    constexpr int PL = X3 ? 2 : 1;                       // 16-bit planes per stored activation element
     using T = ConvTile<BP, BC, WP, WC, NS, GS>;
     constexpr int RPI = T::kRowsPerInstr, RB = T::kRowBytes, SPK = T::kStagesPerKStep;
     constexpr int NW = T::kWaves;
@@ -268,7 +296,8 @@ void conv_igemm_mfma(const ConvParams p)
         const unsigned lim_y = s1 ? sd1.lim_y : sd0.lim_y, lim_x = s1 ? sd1.lim_x : sd0.lim_x;
         const int gfull = l_h * GS + gsrc;                     // granule inside the 64-element K-step
         int dy = (int)(short)(rec_yx & 0xffff), dx = rec_yx >> 16;
-        int coff = rec_coff + gfull * 16 + kZeroHeaderBytes;
+        // slots 4-7 sit lo_off bytes behind slots 0-3: 64 in the plain modes (= gfull * 16), the lo plane in split mode
+        int coff = rec_coff + (X3 ? (gfull & 3) * 16 + (gfull >> 2) * (s1 ? sd1.lo_off : sd0.lo_off) : gfull * 16) + kZeroHeaderBytes;
         if (rec_irr) {                                         // granules of this step differ in tap
             const KTabEntry e = ktab[t * kGranulesPerStep + gfull];
             dy = e.dy; dx = e.dx; coff = e.coff + kZeroHeaderBytes;
@@ -337,7 +366,7 @@ void conv_igemm_mfma(const ConvParams p)
 
     // residual tile of the tile being finished: requested BEFORE its last K-step's MFMAs so the HBM
     // round trip hides under them
-    constexpr bool kPrefetchRes = (T::kMI / 2) * T::kNI <= 8;      // big wave tiles cannot spare the registers
+    constexpr bool kPrefetchRes = !X3 && (T::kMI / 2) * T::kNI <= 8;      // big wave tiles (and the split mode's hi+lo pairs) cannot spare the registers
     uint4 res[kPrefetchRes ? T::kMI / 2 : 1][kPrefetchRes ? T::kNI : 1];
     auto prefetch_residual = [&](int tile) __attribute__((always_inline)) {
         int ctile, cls, ptile;
@@ -360,7 +389,7 @@ void conv_igemm_mfma(const ConvParams p)
     // epilogue constants of the tile being finished, requested like the residual BEFORE the next
     // stage's loads are issued: vmcnt retires in order, so a load issued in the epilogue itself would
     // only return after the whole next stage has landed -- one extra round trip per tile on short-K layers
-    constexpr bool kPrefetchConst = kPrefetchRes;
+    constexpr bool kPrefetchConst = (T::kMI / 2) * T::kNI <= 8;
     float csc[kPrefetchConst ? T::kMI / 2 : 1][8], csh[kPrefetchConst ? T::kMI / 2 : 1][8];
     auto prefetch_consts = [&](int tile) __attribute__((always_inline)) {
         int ctile, cls, ptile;
@@ -374,6 +403,11 @@ void conv_igemm_mfma(const ConvParams p)
                     *(float4*)&csc[s2][4] = *(const float4*)(p.scale + c0 + 4);
                     *(float4*)&csh[s2][0] = *(const float4*)(p.shift + c0);
                     *(float4*)&csh[s2][4] = *(const float4*)(p.shift + c0 + 4);
+                    if constexpr (X3) {                          // undo the class's power-of-two weight pre-scale (exact)
+                        const float wm = p.wmul_cls[cls];
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) csc[s2][q] *= wm;
+                    }
                 }
             }
         }
@@ -397,7 +431,7 @@ void conv_igemm_mfma(const ConvParams p)
             const int m = ptile * BP + wp * T::kWPX + ni * 16 + frow;
             opix[ni] = m < p.M ? out_pixel(m, cls) : -1;
         }
-        if constexpr (T::kMI % 4 == 0) {
+        if constexpr (T::kMI % 4 == 0 && !X3) {
             // Full interior tile: whole-line stores.  A lane holds 8 channels of pixel `frow` from row-block
             // pair s2 (A) and from pair s2+1 (B); lanes frow and frow^8 swap "B of the low pixel" against
             // "A of the high pixel" (one DPP row rotate), after which each store instruction writes 8
@@ -485,12 +519,20 @@ void conv_igemm_mfma(const ConvParams p)
                     *(float4*)&sc[4] = *(const float4*)(p.scale + c0 + 4);
                     *(float4*)&sh[0] = *(const float4*)(p.shift + c0);
                     *(float4*)&sh[4] = *(const float4*)(p.shift + c0 + 4);
+                    if constexpr (X3) {
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) sc[q] *= p.wmul_cls[cls];
+                    }
                 }
                 if (p.raw_out) {
                     *(float4*)&rsc[0] = *(const float4*)(p.raw_scale + c0);
                     *(float4*)&rsc[4] = *(const float4*)(p.raw_scale + c0 + 4);
                     *(float4*)&rsh[0] = *(const float4*)(p.raw_shift + c0);
                     *(float4*)&rsh[4] = *(const float4*)(p.raw_shift + c0 + 4);
+                    if constexpr (X3) {
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) rsc[q] *= p.wmul_cls[cls];
+                    }
                 }
 #pragma unroll
                 for (int ni = 0; ni < T::kNI; ++ni) {
@@ -499,24 +541,32 @@ void conv_igemm_mfma(const ConvParams p)
                     for (int q = 0; q < 4; ++q) { v[q] = acc[2 * s2][ni][q]; v[4 + q] = acc[2 * s2 + 1][ni][q]; }
 #pragma unroll
                     for (int q = 0; q < 8; ++q) y[q] = v[q] * sc[q] + sh[q];
-                    const size_t o = (size_t)(opix[ni] < 0 ? 0 : opix[ni]) * p.cout + c0;
+                    // element offset of the pixel's channel group; the split mode stores [C hi][C lo] per pixel
+                    const size_t o = (size_t)(opix[ni] < 0 ? 0 : opix[ni]) * (p.cout * PL) + c0;
                     if (opix[ni] >= 0) {
                         if (p.raw_out) {
-                            uint4 r;
-                            r.x = pack2<F16>(v[0] * rsc[0] + rsh[0], v[1] * rsc[1] + rsh[1]);
-                            r.y = pack2<F16>(v[2] * rsc[2] + rsh[2], v[3] * rsc[3] + rsh[3]);
-                            r.z = pack2<F16>(v[4] * rsc[4] + rsh[4], v[5] * rsc[5] + rsh[5]);
-                            r.w = pack2<F16>(v[6] * rsc[6] + rsh[6], v[7] * rsc[7] + rsh[7]);
-                            *(uint4*)((uint16_t*)p.raw_out + o) = r;
+                            float rv[8];
+#pragma unroll
+                            for (int q = 0; q < 8; ++q) rv[q] = v[q] * rsc[q] + rsh[q];
+                            if constexpr (X3) store_split8((uint16_t*)p.raw_out + o, p.cout, rv);
+                            else {
+                                uint4 r;
+                                r.x = pack2<F16>(rv[0], rv[1]); r.y = pack2<F16>(rv[2], rv[3]);
+                                r.z = pack2<F16>(rv[4], rv[5]); r.w = pack2<F16>(rv[6], rv[7]);
+                                *(uint4*)((uint16_t*)p.raw_out + o) = r;
+                            }
                         }
                         if (p.residual) {
-                            uint4 rr;
-                            if constexpr (kPrefetchRes) rr = res[s2][ni];
-                            else rr = *(const uint4*)((const uint16_t*)p.residual + o);
-                            y[0] += unpack_lo<F16>(rr.x); y[1] += unpack_hi<F16>(rr.x);
-                            y[2] += unpack_lo<F16>(rr.y); y[3] += unpack_hi<F16>(rr.y);
-                            y[4] += unpack_lo<F16>(rr.z); y[5] += unpack_hi<F16>(rr.z);
-                            y[6] += unpack_lo<F16>(rr.w); y[7] += unpack_hi<F16>(rr.w);
+                            if constexpr (X3) add_split8((const uint16_t*)p.residual + o, p.cout, y);
+                            else {
+                                uint4 rr;
+                                if constexpr (kPrefetchRes) rr = res[s2][ni];
+                                else rr = *(const uint4*)((const uint16_t*)p.residual + o);
+                                y[0] += unpack_lo<F16>(rr.x); y[1] += unpack_hi<F16>(rr.x);
+                                y[2] += unpack_lo<F16>(rr.y); y[3] += unpack_hi<F16>(rr.y);
+                                y[4] += unpack_lo<F16>(rr.z); y[5] += unpack_hi<F16>(rr.z);
+                                y[6] += unpack_lo<F16>(rr.w); y[7] += unpack_hi<F16>(rr.w);
+                            }
                         }
                     }
                     if (p.relu) {
@@ -524,10 +574,13 @@ void conv_igemm_mfma(const ConvParams p)
                         for (int q = 0; q < 8; ++q) y[q] = fmaxf(y[q], 0.f);
                     }
                     if (p.out && opix[ni] >= 0) {
-                        uint4 r;
-                        r.x = pack2<F16>(y[0], y[1]); r.y = pack2<F16>(y[2], y[3]);
-                        r.z = pack2<F16>(y[4], y[5]); r.w = pack2<F16>(y[6], y[7]);
-                        *(uint4*)((uint16_t*)p.out + o) = r;
+                        if constexpr (X3) store_split8((uint16_t*)p.out + o, p.cout, y);
+                        else {
+                            uint4 r;
+                            r.x = pack2<F16>(y[0], y[1]); r.y = pack2<F16>(y[2], y[3]);
+                            r.z = pack2<F16>(y[4], y[5]); r.w = pack2<F16>(y[6], y[7]);
+                            *(uint4*)((uint16_t*)p.out + o) = r;
+                        }
                     }
                     if constexpr (BC == 32) {
                         // fused head: the 32 channels of a pixel sit in the 4 lanes {frow + 16*fg}; each
@@ -781,7 +834,34 @@ void conv_igemm_mfma(const ConvParams p)
         }
         if (issued < total) issue(nxt);
         const char* sb = smem + cur * T::kStageBytes;
-        {
+        if constexpr (X3) {
+            // split mode: slots 0-3 hold the hi halves of the stage's 32 channels, slots 4-7 the lo halves (rd_k0 / rd_k1
+            // address exactly these).  value = hi + lo on both operands: w*x ~= wl*xh + wh*xl + wh*xh, small terms first.
+            // Three sweeps over the wave tile keep MFMAs on the same accumulator 16 instructions apart.
+            bf16x8_t ah[T::kMI], al[T::kMI], bh[T::kNI], bl[T::kNI];
+#pragma unroll
+            for (int mi = 0; mi < T::kMI; ++mi) {
+                ah[mi] = *(const bf16x8_t*)(sb + w_rd + mi * 16 * RB + rd_k0);
+                al[mi] = *(const bf16x8_t*)(sb + w_rd + mi * 16 * RB + rd_k1);
+            }
+#pragma unroll
+            for (int q = 0; q < T::kNI; ++q) {
+                bh[q] = *(const bf16x8_t*)(sb + p_rd + q * 16 * RB + rd_k0);
+                bl[q] = *(const bf16x8_t*)(sb + p_rd + q * 16 * RB + rd_k1);
+            }
+#pragma unroll
+            for (int mi = 0; mi < T::kMI; ++mi)
+#pragma unroll
+                for (int q = 0; q < T::kNI; ++q) acc[mi][q] = mfma16<true>(al[mi], bh[q], acc[mi][q]);
+#pragma unroll
+            for (int mi = 0; mi < T::kMI; ++mi)
+#pragma unroll
+                for (int q = 0; q < T::kNI; ++q) acc[mi][q] = mfma16<true>(ah[mi], bl[q], acc[mi][q]);
+#pragma unroll
+            for (int mi = 0; mi < T::kMI; ++mi)
+#pragma unroll
+                for (int q = 0; q < T::kNI; ++q) acc[mi][q] = mfma16<true>(ah[mi], bh[q], acc[mi][q]);
+        } else {
             // The K-step's MFMAs run in phases of (k-half kk, group of <= 4 pixel blocks); the LDS
             // fragments of phase i+1 are requested BEFORE the MFMAs of phase i (register double
             // buffer).  hipcc on its own emits "all ds_reads, lgkmcnt(0), all MFMAs" per k-half, which
@@ -832,8 +912,8 @@ void conv_igemm_mfma(const ConvParams p)
             const bool ring_full = D < 2 || s + D < total;          // D-1 younger stages really are in flight
             if (tile_done) {
                 if (counted && ring_full && !(p.variant_flags & 1)) {
-                    if (p.raw_out) wait_vmcnt<kAhead + 2 * kEpiStores>();
-                    else wait_vmcnt<kAhead + kEpiStores>();
+                    if (p.raw_out) wait_vmcnt<kAhead + 2 * PL * kEpiStores>();      // (split mode: a hi and a lo store per group)
+                    else wait_vmcnt<kAhead + PL * kEpiStores>();
                 } else wait_vmcnt<0>();
             } else if (D >= 2 && ring_full) wait_vmcnt<kAhead>();
             else wait_vmcnt<0>();
@@ -911,7 +991,7 @@ int conv_row_channel(int row, int cout)
     return base + (mi >> 1) * 32 + (rho >> 2) * 8 + (mi & 1) * 4 + (rho & 3);
 }
 
-template <int BP, int BC, int WP, int WC, int NS, bool F16, int GS = 8, bool PH8 = false>
+template <int BP, int BC, int WP, int WC, int NS, bool F16, int GS = 8, bool PH8 = false, bool X3 = false>
 static hipError_t launch_conv_t(const ConvParams& p, hipStream_t s)
 {
     using T = ConvTile<BP, BC, WP, WC, NS, GS>;
@@ -920,7 +1000,7 @@ static hipError_t launch_conv_t(const ConvParams& p, hipStream_t s)
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
     if (!attr_done[dev & 63]) {
-        e = hipFuncSetAttribute((const void*)conv_igemm_mfma<BP, BC, WP, WC, NS, F16, GS, PH8>,
+        e = hipFuncSetAttribute((const void*)conv_igemm_mfma<BP, BC, WP, WC, NS, F16, GS, PH8, X3>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, T::kLdsBytes);
         if (e != hipSuccess) return e;
         attr_done[dev & 63] = true;
@@ -933,7 +1013,7 @@ static hipError_t launch_conv_t(const ConvParams& p, hipStream_t s)
     const int resident = p.persist_blocks > 0 ? p.persist_blocks * T::kBlocksPerCU : n_tiles;
     int grid = n_tiles < resident ? n_tiles : resident;
     if (p.tile_map >= 1) grid = (grid + 7) & ~7;          // the XCD-grouped walk needs a multiple of 8 blocks
-    hipLaunchKernelGGL((conv_igemm_mfma<BP, BC, WP, WC, NS, F16, GS, PH8>), dim3(grid), dim3(T::kThreads), T::kLdsBytes, s, p);
+    hipLaunchKernelGGL((conv_igemm_mfma<BP, BC, WP, WC, NS, F16, GS, PH8, X3>), dim3(grid), dim3(T::kThreads), T::kLdsBytes, s, p);
     return hipGetLastError();
 }
 
@@ -982,8 +1062,19 @@ static hipError_t launch_conv_16(const ConvParams& p, hipStream_t s)
     return big ? launch_conv_t<256, 32, 8, 1, 3, F16>(p, s) : launch_conv_t<256, 32, 4, 1, 2, F16>(p, s);
 }
 
+// split mode: the 4-wave tiles at 2 blocks per CU (3 MFMAs per product for the same LDS bytes: the matrix pipe, not the
+// staging path, is what fills first here)
+static hipError_t launch_conv_x3(const ConvParams& p, hipStream_t s)
+{
+    const int bc = conv_tile_bc(p.cout);
+    if (bc == 128) return launch_conv_t<128, 128, 2, 2, 2, true, 8, false, true>(p, s);
+    if (bc == 64) return launch_conv_t<256, 64, 4, 1, 2, true, 8, false, true>(p, s);
+    return launch_conv_t<256, 32, 4, 1, 2, true, 8, false, true>(p, s);
+}
+
 hipError_t launch_conv(const ConvParams& p, int precision, hipStream_t s)
 {
+    if (precision == kF16X3) return launch_conv_x3(p, s);
     if (precision == kF32) {
         const long total = (long)p.M * (p.cout / 4);
         hipLaunchKernelGGL(conv_naive_f32, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, p);
@@ -1555,11 +1646,39 @@ template <> __device__ inline float from_elem<_Float16>(_Float16 v) { return (fl
 template <typename E> struct alignas(16) Vec8 { E v[8]; };
 template <typename E> struct alignas(sizeof(E) * 4) Vec4 { E v[4]; };
 
+// split-mode writer of one network-input pixel into both input forms (see ingest_u8_kernel)
+template <typename E>
+__device__ inline void write_split_input(const float (&f)[3], void* c8, void* pairs, long idx, int t, int y, int x,
+                                         int H, int pad, int pairs_w)
+{
+    _Float16 hi[3], lo[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) split_f32(f[i], hi[i], lo[i]);
+    const _Float16 z = (_Float16)0.f;
+    Vec8<_Float16> oh, ol;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { oh.v[i] = i < 3 ? hi[i] : z; ol.v[i] = i < 3 ? lo[i] : z; }
+    ((Vec8<_Float16>*)c8)[2 * idx] = oh;
+    ((Vec8<_Float16>*)c8)[2 * idx + 1] = ol;
+    if (pairs) {
+        const int PH = H + 2 * pad;
+        const int xp = x + pad;
+        _Float16* dst = (_Float16*)pairs + (((size_t)t * PH + (y + pad)) * pairs_w + (xp >> 1)) * 16 + (xp & 1) * 4;
+        Vec4<_Float16> qh, ql;
+        qh.v[0] = hi[0]; qh.v[1] = hi[1]; qh.v[2] = hi[2]; qh.v[3] = z;
+        ql.v[0] = lo[0]; ql.v[1] = lo[1]; ql.v[2] = lo[2]; ql.v[3] = z;
+        *(Vec4<_Float16>*)dst = qh;
+        *(Vec4<_Float16>*)(dst + 8) = ql;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // ingest: u8 page -> normalised network input in both forms (main.py:239 `img / 255.0`, 285 slice)
 // one thread per (tile, y, x)
 // ------------------------------------------------------------------------------------------------
-template <typename E>
+// SPLIT (kF16X3): every stored element is an fp16 (hi, lo) pair -- C8 pixel = [8 hi][8 lo] (32 bytes), PAIRS
+// granule = [2 px x 4 hi][2 px x 4 lo] (32 bytes); f32(v / 255.0) is carried to ~22 bits
+template <typename E, bool SPLIT = false>
 __global__ __launch_bounds__(256) void ingest_u8_kernel(const IngestParams p)
 {
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
@@ -1591,6 +1710,13 @@ __global__ __launch_bounds__(256) void ingest_u8_kernel(const IngestParams p)
         v0 = to_elem<E>(p.lut[px[0]]); v1 = to_elem<E>(p.lut[px[1]]); v2 = to_elem<E>(p.lut[px[2]]);
     }
     const E z = to_elem<E>(0.f);
+    if constexpr (SPLIT) {
+        float f[3];
+        if (p.bin_thr) f[0] = f[1] = f[2] = (int)px[0] > *p.bin_thr ? 1.f : 0.f;
+        else { f[0] = p.lut[px[0]]; f[1] = p.lut[px[1]]; f[2] = p.lut[px[2]]; }
+        write_split_input<E>(f, p.c8, p.pairs, idx, t, y, x, p.H, p.pad, p.pairs_w);
+        return;
+    }
     Vec8<E> o;
     o.v[0] = v0; o.v[1] = v1; o.v[2] = v2;
 #pragma unroll
@@ -1605,7 +1731,7 @@ __global__ __launch_bounds__(256) void ingest_u8_kernel(const IngestParams p)
     }
 }
 
-template <typename E>
+template <typename E, bool SPLIT = false>
 __global__ __launch_bounds__(256) void ingest_f32_kernel(const float* x, int n, int H, int W, void* c8,
                                                          void* pairs, int pad, int pairs_w)
 {
@@ -1616,6 +1742,11 @@ __global__ __launch_bounds__(256) void ingest_f32_kernel(const float* x, int n, 
     const int rem = (int)(idx - t * per);
     const int y = rem / W, xx = rem - y * W;
     const float* px = x + idx * 3;
+    if constexpr (SPLIT) {
+        const float f[3] = {px[0], px[1], px[2]};
+        write_split_input<E>(f, c8, pairs, idx, t, y, xx, H, pad, pairs_w);
+        return;
+    }
     const E v0 = to_elem<E>(px[0]), v1 = to_elem<E>(px[1]), v2 = to_elem<E>(px[2]);
     const E z = to_elem<E>(0.f);
     Vec8<E> o;
@@ -1715,6 +1846,7 @@ hipError_t launch_ingest_u8(const IngestParams& p, int precision, hipStream_t s)
     const long total = (long)p.H * p.W * p.n_tiles;
     const unsigned grid = (unsigned)((total + 255) / 256);
     if (precision == kF32) hipLaunchKernelGGL(ingest_u8_kernel<float>, dim3(grid), dim3(256), 0, s, p);
+    else if (precision == kF16X3) hipLaunchKernelGGL((ingest_u8_kernel<_Float16, true>), dim3(grid), dim3(256), 0, s, p);
     else if (precision == kF16) hipLaunchKernelGGL(ingest_u8_kernel<_Float16>, dim3(grid), dim3(256), 0, s, p);
     else hipLaunchKernelGGL(ingest_u8_kernel<uint16_t>, dim3(grid), dim3(256), 0, s, p);
     return hipGetLastError();
@@ -1727,6 +1859,8 @@ hipError_t launch_ingest_f32(const float* x, int n, int H, int W, void* c8, void
     const unsigned grid = (unsigned)((total + 255) / 256);
     if (precision == kF32)
         hipLaunchKernelGGL(ingest_f32_kernel<float>, dim3(grid), dim3(256), 0, s, x, n, H, W, c8, pairs, pad, pairs_w);
+    else if (precision == kF16X3)
+        hipLaunchKernelGGL((ingest_f32_kernel<_Float16, true>), dim3(grid), dim3(256), 0, s, x, n, H, W, c8, pairs, pad, pairs_w);
     else if (precision == kF16)
         hipLaunchKernelGGL(ingest_f32_kernel<_Float16>, dim3(grid), dim3(256), 0, s, x, n, H, W, c8, pairs, pad, pairs_w);
     else
@@ -1739,7 +1873,8 @@ hipError_t launch_ingest_f32(const float* x, int n, int H, int W, void* c8, void
 // ------------------------------------------------------------------------------------------------
 // optional per-channel affine + ReLU applied to every input element before the max: lets the stem
 // write only its pre-BN tensor (the f1 skip) and the pool apply bn_conv1 + relu on the fly
-template <typename E>
+// SPLIT (kF16X3): pixels are [C hi][C lo]; values are re-assembled in fp32 (exact), the maximum is split again
+template <typename E, bool SPLIT = false>
 __global__ __launch_bounds__(256) void maxpool_kernel(const E* src, E* dst, int n, int H, int W, int C,
                                                       int k, int stride, int Ho, int Wo,
                                                       const float* pre_scale, const float* pre_shift, int pre_relu)
@@ -1773,20 +1908,26 @@ __global__ __launch_bounds__(256) void maxpool_kernel(const E* src, E* dst, int 
         for (int o = 0; o < OX; ++o) m[o][i] = -3.0e38f;
     }
     const int ncol = (nout - 1) * stride + k;                   // input columns of the strip
+    const int CS = SPLIT ? 2 * C : C;                           // elements per stored pixel
     if (k == 3 && stride == 2 && nout == OX) {
         // the ResNet stem pool, full strip: all 27 loads are independent -> issue them back to back
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky) {
-            const E* row = src + (((size_t)b * H + oy * 2 + ky) * W + ox0 * 2) * C + g * 8;
-            Vec8<E> v[9];
+            const E* row = src + (((size_t)b * H + oy * 2 + ky) * W + ox0 * 2) * CS + g * 8;
+            Vec8<E> v[9], vl[SPLIT ? 9 : 1];
 #pragma unroll
-            for (int c = 0; c < 9; ++c) v[c] = *(const Vec8<E>*)(row + (size_t)c * C);
+            for (int c = 0; c < 9; ++c) {
+                v[c] = *(const Vec8<E>*)(row + (size_t)c * CS);
+                if constexpr (SPLIT) vl[c] = *(const Vec8<E>*)(row + (size_t)c * CS + C);
+            }
 #pragma unroll
             for (int c = 0; c < 9; ++c) {
                 float x[8];
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
-                    x[i] = from_elem<E>(v[c].v[i]) * ps[i] + pb[i];
+                    float xv = from_elem<E>(v[c].v[i]);
+                    if constexpr (SPLIT) xv += from_elem<E>(vl[c].v[i]);
+                    x[i] = xv * ps[i] + pb[i];
                     if (pre_relu) x[i] = fmaxf(x[i], 0.f);
                 }
 #pragma unroll
@@ -1800,13 +1941,15 @@ __global__ __launch_bounds__(256) void maxpool_kernel(const E* src, E* dst, int 
         }
     } else
     for (int ky = 0; ky < k; ++ky) {
-        const E* row = src + (((size_t)b * H + oy * stride + ky) * W + ox0 * stride) * C + g * 8;
+        const E* row = src + (((size_t)b * H + oy * stride + ky) * W + ox0 * stride) * CS + g * 8;
         for (int c = 0; c < ncol; ++c) {
-            const Vec8<E> v = *(const Vec8<E>*)(row + (size_t)c * C);
+            const Vec8<E> v = *(const Vec8<E>*)(row + (size_t)c * CS);
             float x[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                x[i] = from_elem<E>(v.v[i]) * ps[i] + pb[i];
+                float xv = from_elem<E>(v.v[i]);
+                if constexpr (SPLIT) xv += from_elem<E>((*(const Vec8<E>*)(row + (size_t)c * CS + C)).v[i]);
+                x[i] = xv * ps[i] + pb[i];
                 if (pre_relu) x[i] = fmaxf(x[i], 0.f);
             }
 #pragma unroll
@@ -1822,10 +1965,14 @@ __global__ __launch_bounds__(256) void maxpool_kernel(const E* src, E* dst, int 
 #pragma unroll
     for (int o = 0; o < OX; ++o) {
         if (o < nout) {
-            Vec8<E> r;
+            E* dp = dst + (((size_t)b * Ho + oy) * Wo + ox0 + o) * CS + g * 8;
+            if constexpr (SPLIT) store_split8((uint16_t*)dp, C, m[o]);
+            else {
+                Vec8<E> r;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) r.v[i] = to_elem<E>(m[o][i]);
-            *(Vec8<E>*)(dst + (((size_t)b * Ho + oy) * Wo + ox0 + o) * C + g * 8) = r;
+                for (int i = 0; i < 8; ++i) r.v[i] = to_elem<E>(m[o][i]);
+                *(Vec8<E>*)dp = r;
+            }
         }
     }
 }
@@ -1838,6 +1985,8 @@ hipError_t launch_maxpool(const void* src, void* dst, int n, int H, int W, int C
     const unsigned grid = (unsigned)((total + 255) / 256);
     if (precision == kF32)
         hipLaunchKernelGGL(maxpool_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)src, (float*)dst, n, H, W, C, k, stride, Ho, Wo, pre_scale, pre_shift, pre_relu);
+    else if (precision == kF16X3)
+        hipLaunchKernelGGL((maxpool_kernel<_Float16, true>), dim3(grid), dim3(256), 0, s, (const _Float16*)src, (_Float16*)dst, n, H, W, C, k, stride, Ho, Wo, pre_scale, pre_shift, pre_relu);
     else if (precision == kF16)
         hipLaunchKernelGGL(maxpool_kernel<_Float16>, dim3(grid), dim3(256), 0, s, (const _Float16*)src, (_Float16*)dst, n, H, W, C, k, stride, Ho, Wo, pre_scale, pre_shift, pre_relu);
     else
@@ -1849,7 +1998,7 @@ hipError_t launch_maxpool(const void* src, void* dst, int n, int H, int W, int C
 // head: 1x1 conv + BN + softmax + argmax (main.py:290: np.argmax over the softmax output, first
 // maximum wins).  One thread per pixel; weights broadcast from LDS.
 // ------------------------------------------------------------------------------------------------
-template <typename E>
+template <typename E, bool SPLIT = false>
 __global__ __launch_bounds__(256) void head_kernel(const HeadParams p)
 {
     __shared__ float sw[64 * 8];
@@ -1862,12 +2011,15 @@ __global__ __launch_bounds__(256) void head_kernel(const HeadParams p)
     float logit[8];
 #pragma unroll
     for (int c = 0; c < 8; ++c) logit[c] = 0.f;
-    const E* src = (const E*)p.src + (size_t)m * p.cin;
+    const E* src = (const E*)p.src + (size_t)m * p.cin * (SPLIT ? 2 : 1);
     for (int g = 0; g < p.cin / 8; ++g) {
         const Vec8<E> v = *(const Vec8<E>*)(src + g * 8);
+        Vec8<E> vl;
+        if constexpr (SPLIT) vl = *(const Vec8<E>*)(src + p.cin + g * 8);
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            const float xv = from_elem<E>(v.v[i]);
+            float xv = from_elem<E>(v.v[i]);
+            if constexpr (SPLIT) xv += from_elem<E>(vl.v[i]);
             const float* wr = sw + (g * 8 + i) * p.classes;
 #pragma unroll
             for (int c = 0; c < 8; ++c)
@@ -1898,6 +2050,7 @@ hipError_t launch_head(const HeadParams& p, int precision, hipStream_t s)
 {
     const unsigned grid = (unsigned)((p.M + 255) / 256);
     if (precision == kF32) hipLaunchKernelGGL(head_kernel<float>, dim3(grid), dim3(256), 0, s, p);
+    else if (precision == kF16X3) hipLaunchKernelGGL((head_kernel<_Float16, true>), dim3(grid), dim3(256), 0, s, p);
     else if (precision == kF16) hipLaunchKernelGGL(head_kernel<_Float16>, dim3(grid), dim3(256), 0, s, p);
     else hipLaunchKernelGGL(head_kernel<uint16_t>, dim3(grid), dim3(256), 0, s, p);
     return hipGetLastError();
@@ -1950,6 +2103,22 @@ __global__ __launch_bounds__(256) void to_f32_kernel(const E* src, float* dst, s
 {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i < n) dst[i] = from_elem<E>(src[i]);
+}
+
+__global__ __launch_bounds__(256) void split_to_f32_kernel(const _Float16* src, float* dst, size_t n, int C)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;         // i = pixel * C + channel
+    if (i >= n) return;
+    const size_t pix = i / C;
+    const int ch = (int)(i - pix * C);
+    dst[i] = (float)src[pix * 2 * C + ch] + (float)src[pix * 2 * C + C + ch];
+}
+
+hipError_t launch_split_to_f32(const void* src, float* dst, size_t npix, int C, hipStream_t s)
+{
+    const size_t n = npix * C;
+    hipLaunchKernelGGL(split_to_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const _Float16*)src, dst, n, C);
+    return hipGetLastError();
 }
 
 // u8 label plane -> the reference's return layout: three identical channels (main.py:366, 380)

@@ -30,21 +30,36 @@ def default_max_batch() -> int:
     return int(os.environ.get("SBBSEG_MAX_BATCH", "32"))
 
 
+def default_precision() -> str:
+    """Arithmetic mode of a model loaded without an explicit ``precision=``.
+
+    ``"f16x3"`` (default) -- the label-exact mode: split-fp16 operands, three MFMAs per product; label maps equal an
+    fp32 evaluation of the network except at exact ties (what ``main.py:290`` ``np.argmax`` of the Keras/TF output gives).
+    ``"f16"`` -- the fast mode (~3x the throughput): plain fp16 operands; labels may differ where the top-2 softmax margin
+    is below ~0.15.  Opt in per call (``precision="f16"``) or process-wide (``SBBSEG_PRECISION=f16``).
+    ``"bf16"`` (A/B only) and ``"f32"`` (plain-FMA check mode, slow) exist for tests."""
+    return os.environ.get("SBBSEG_PRECISION", "f16x3")
+
+
 class SegModel:
     """A segmentation net resident on one MI355X, duck-typed like the Keras model the reference uses."""
 
     def __init__(self, model_config, weights, device: int = 0, max_batch: Optional[int] = None,
-                 precision: str = "f16"):
+                 precision: Optional[str] = None):
+        precision = precision or default_precision()
+        if precision not in _capi.PRECISIONS:
+            raise ValueError(f"precision must be one of {sorted(_capi.PRECISIONS)}, got {precision!r}")
         self.graph: Graph = parse_model_config(model_config)
         self.plan: Plan = build_plan(self.graph, weights, parity_split=os.environ.get("SBBSEG_PARITY_SPLIT", "1") != "0",
                                      fuse_head=precision != "f32" and os.environ.get("SBBSEG_FUSE_HEAD", "1") != "0",
-                                     fuse_tail=os.environ.get("SBBSEG_FUSE_TAIL", "1") != "0",
+                                     # the dedicated tail kernel reads the one-plane 16-bit layout (f16 / bf16 only)
+                                     fuse_tail=precision in ("f16", "bf16") and os.environ.get("SBBSEG_FUSE_TAIL", "1") != "0",
                                      merge_shortcut=os.environ.get("SBBSEG_MERGE_SHORTCUT", "1") != "0")
         self.layers = self.graph.nodes                     # main.py:227-229 reads layers[-1].output_shape
         self.device = device
         self.precision = precision
         self.max_batch = int(max_batch or default_max_batch())
-        prec = {"bf16": _capi.PREC_BF16, "f32": _capi.PREC_F32, "f16": _capi.PREC_F16}[precision]
+        prec = _capi.PRECISIONS[precision]
         self._ctx: Optional[_capi.Context] = _capi.Context(device, prec)
         try:
             self._ctx.set_lanes(int(os.environ.get("SBBSEG_LANES", "2")))   # before finalize: 1 skips the second buffer set
@@ -112,8 +127,10 @@ def resolve_model_path(path: str) -> str:
 
 
 def load_model(path: str, compile: bool = False, device: int = 0, max_batch: Optional[int] = None,
-               precision: str = "f16") -> SegModel:
-    """``keras.models.load_model(path, compile=False)`` replacement (main.py:221)."""
+               precision: Optional[str] = None) -> SegModel:
+    """``keras.models.load_model(path, compile=False)`` replacement (main.py:221).  ``precision``: see
+    :func:`default_precision` (label-exact ``"f16x3"`` unless the caller opts into the fast ``"f16"``)."""
+    precision = precision or default_precision()
     real = resolve_model_path(path)
     use_cache = os.environ.get("SBBSEG_MODEL_CACHE", "1") != "0"
     key = (os.path.realpath(real), os.path.getmtime(real), device, precision, int(max_batch or default_max_batch()))

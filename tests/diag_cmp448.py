@@ -11,7 +11,7 @@ from oracle import keras_forward as kf  # noqa: E402
 
 x = (patches_from_page(448, 448, 2, seed=9) / 255.0).astype(np.float32)
 ref = None
-for prec in ("f32", "bf16", "f16"):
+for prec in ("f32", "f16x3", "bf16", "f16"):
     cfg, w, g, model = make_model(2, 448, 448, seed=2, precision=prec, max_batch=4)
     if ref is None:
         t = time.time(); ref = kf.forward(g, w, x)

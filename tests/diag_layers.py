@@ -13,7 +13,7 @@ from oracle import keras_forward as kf  # noqa: E402
 
 def main():
     hw = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (64, 96)
-    for precision in ("f32", "bf16", "f16"):
+    for precision in (sys.argv[3].split(",") if len(sys.argv) > 3 else ("f32", "f16x3", "bf16", "f16")):
         cfg, w, g, model = make_model(2, hw[0], hw[1], seed=2, precision=precision, max_batch=4, calib_hw=64)
         x = (patches_from_page(hw[0], hw[1], 3, seed=4) / 255.0).astype(np.float32)
         taps = {name: None for name in model.plan.layer_tensor}

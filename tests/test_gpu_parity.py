@@ -10,7 +10,8 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-from gpu_common import TOL_LAYER_REL, TOL_SOFTMAX, compare_probs, make_model, patches_from_page  # noqa: E402
+from gpu_common import (EXACT_MARGIN, TOL_LAYER_REL, TOL_SOFTMAX, compare_probs, exact_label_check, make_model,  # noqa: E402
+                        patches_from_page)
 from oracle import keras_forward as kf  # noqa: E402
 from oracle import tiling  # noqa: E402
 from sbb_textline_detection_amd import _capi, predict  # noqa: E402
@@ -27,7 +28,7 @@ def torch_cuda():
 
 
 # ------------------------------------------------------------------------------------------ ingest
-@pytest.mark.parametrize("precision", ["f16", "bf16", "f32"])
+@pytest.mark.parametrize("precision", ["f16", "bf16", "f32", "f16x3"])
 def test_ingest_forms(precision):
     cfg, w, g, model = make_model(2, 64, 96, precision=precision, calib_hw=64)
     page = noise_page(200, 300, 1)
@@ -37,17 +38,21 @@ def test_ingest_forms(precision):
     import torch
     for k, (x0, y0) in enumerate(xy):
         ref = (page[y0:y0 + 64, x0:x0 + 96] / 255.0).astype(np.float32)       # main.py:239, 285
-        if precision != "f32":
+        if precision in ("f16", "bf16"):
             ref = torch.from_numpy(ref).to(torch.bfloat16 if precision == "bf16" else torch.float16).to(torch.float32).numpy()
-        assert np.array_equal(c8[k, :, :, :3], ref) and not c8[k, :, :, 3:].any()
         padded = np.zeros((70, 102, 4), np.float32)
         padded[3:67, 3:99, :3] = ref
+        if precision == "f16x3":          # hi + lo halves carry f32(v/255) to ~22 bits (read back as their fp32 sum)
+            assert np.allclose(c8[k, :, :, :3], ref, rtol=2.0 ** -21, atol=0) and not c8[k, :, :, 3:].any()
+            assert np.allclose(pairs[k], padded.reshape(70, 51, 8), rtol=2.0 ** -21, atol=0)
+            continue
+        assert np.array_equal(c8[k, :, :, :3], ref) and not c8[k, :, :, 3:].any()
         assert np.array_equal(pairs[k], padded.reshape(70, 51, 8))
     model.release()
 
 
 # --------------------------------------------------------------------------------- forward, by layer
-@pytest.mark.parametrize("precision", ["f32", "f16", "bf16"])
+@pytest.mark.parametrize("precision", ["f32", "f16x3", "f16", "bf16"])
 def test_every_fused_layer_matches_oracle(precision):
     cfg, w, g, model = make_model(2, 64, 96, seed=2, precision=precision, max_batch=4, calib_hw=64)
     # (calibrating BN on 64x64 crops leaves stage 5 with 8 samples per channel: activations reach
@@ -70,7 +75,7 @@ def test_every_fused_layer_matches_oracle(precision):
         assert rel < rel_tol, f"{name}: rel err {rel:.4g} ({precision})"
     d, mism, bad = compare_probs(ref, got, TOL_SOFTMAX[precision])
     print(f"[layers {precision}] worst layer {worst}, max|dsoftmax| {d:.4f}, label mismatches {mism}")
-    if precision == "f32":
+    if precision in ("f32", "f16x3"):
         assert d < TOL_SOFTMAX[precision] and bad == 0, (d, mism, bad, worst)
     model.release()
 
@@ -100,6 +105,24 @@ def test_predict_448_matches_oracle(classes, precision):
     print(f"[448 C={classes} {precision}] max|dsoftmax|={d:.4f} label mismatches={mism}/{ref[...,0].size} outside tolerance band={bad}")
     assert d < TOL_SOFTMAX[precision] and bad == 0
     assert mism / ref[..., 0].size < (0.04 if precision == "f16" else 0.15)
+    model.release()
+
+
+@pytest.mark.parametrize("classes,decisive,seed", [(2, False, 2), (4, False, 4), (2, True, 7)])
+def test_predict_448_label_exact(classes, decisive, seed):
+    """The label-exact mode (split fp16, SBBSEG_PREC_F16X3 -- the default of the Python seams) on the 448x448 nets:
+    max|d softmax| <= 2e-3 against the fp32 oracle and labels identical wherever the oracle's top-2 margin
+    exceeds 1e-3 (north_star: "argmax label map bit-exact", main.py:290)."""
+    cfg, w, g, model = make_model(classes, 448, 448, seed=seed, precision="f16x3", max_batch=4, decisive=decisive)
+    x = (patches_from_page(448, 448, 2, seed=9 if not decisive else 5) / 255.0).astype(np.float32)
+    ref = kf.forward(g, w, x)
+    got = model.predict(x)
+    assert got.shape == ref.shape and got.dtype == np.float32
+    d = float(np.abs(ref - got).max())
+    mism, bad = exact_label_check(ref, got)
+    print(f"[448 C={classes} decisive={decisive} f16x3] max|dsoftmax|={d:.2e} label mismatches={mism}/{ref[...,0].size} "
+          f"with oracle margin > {EXACT_MARGIN}: {bad}")
+    assert d <= TOL_SOFTMAX["f16x3"] and bad == 0
     model.release()
 
 
