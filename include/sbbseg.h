@@ -191,6 +191,10 @@ int sbbseg_segment_whole_scaled(sbbseg_ctx* c, const uint8_t* page_hwc, int Hp, 
 /* ---- building blocks (multi-GPU sharding, tests).  tile_xy: host int32 [n][2] = (x0, y0) origins.
  * d_tile_labels: device uint8 [n][H][W]. */
 int sbbseg_tile_grid(int Hp, int Wp, int H, int W, int32_t* tile_xy, int capacity, int* nxf, int* nyf);
+/* The index rule every nearest-neighbour rescale of this library uses (page upscale of get_image_and_scales, main.py:214;
+ * both resizes of the whole-image branch, main.py:371, 378): map[i] = source index of destination index i for
+ * cv2.resize(..., interpolation=cv2.INTER_NEAREST) = min(floor(i * (1 / (dst_len / src_len))), src_len - 1).  Host only. */
+int sbbseg_nearest_map(int src_len, int dst_len, int32_t* map);
 int sbbseg_segment_tiles_dev(sbbseg_ctx* c, const void* d_page_hwc, int Hp, int Wp,
                              const int32_t* tile_xy, int n_tiles, void* d_tile_labels);
 /* same, for the contiguous range [first_tile, first_tile+n_tiles) of the page's own tile grid in the
@@ -213,6 +217,10 @@ int sbbseg_debug_read_tensor(sbbseg_ctx* c, int tensor_id, int n, float* out, si
  * 64) up to which every block walks a contiguous run of tiles (0 = keep the current limit);
  * bit 16 = 8-phase schedule on the 256x256 tile (half-tile restaging, staggered wave groups) */
 int sbbseg_debug_set_conv_variant(sbbseg_ctx* c, int variant);
+/* Test hook for the no-abort guarantee: the nth_check-th next internal host-allocation checkpoint throws
+ * std::bad_alloc, which every entry point turns into a non-zero status + sbbseg_last_error() instead of
+ * terminating the process (main.py:2061-2157 relies on ordinary exceptions).  0 disarms.  Process-global. */
+int sbbseg_debug_inject_alloc_failure(int nth_check);
 
 /* ---- per-op timing with HIP events on the handle's stream (bench.py roofline) */
 int sbbseg_profile_enable(sbbseg_ctx* c, int enable);

@@ -23,9 +23,9 @@ EXPORTS = [
     "sbbseg_add_conv", "sbbseg_add_maxpool", "sbbseg_add_tail", "sbbseg_add_head", "sbbseg_finalize", "sbbseg_model_info",
     "sbbseg_num_ops", "sbbseg_op_info", "sbbseg_device_bytes", "sbbseg_predict", "sbbseg_segment_page",
     "sbbseg_segment_page_dev", "sbbseg_segment_page_scaled", "sbbseg_segment_page_otsu", "sbbseg_otsu_dev",
-    "sbbseg_segment_tile_range_bin_dev", "sbbseg_segment_whole", "sbbseg_segment_whole_scaled", "sbbseg_tile_grid", "sbbseg_segment_tiles_dev",
+    "sbbseg_segment_tile_range_bin_dev", "sbbseg_segment_whole", "sbbseg_segment_whole_scaled", "sbbseg_tile_grid", "sbbseg_nearest_map", "sbbseg_segment_tiles_dev",
     "sbbseg_segment_tile_range_dev", "sbbseg_stitch_dev", "sbbseg_debug_ingest", "sbbseg_debug_read_tensor",
-    "sbbseg_debug_set_conv_variant",
+    "sbbseg_debug_set_conv_variant", "sbbseg_debug_inject_alloc_failure",
     "sbbseg_profile_enable", "sbbseg_profile_reset", "sbbseg_profile_get",
 ]
 
@@ -90,12 +90,14 @@ def load_library(path: Optional[str] = None):
         "sbbseg_segment_whole": [vp, vp, i32, i32, i32, i32, vp],
         "sbbseg_segment_whole_scaled": [vp, vp, i32, i32, i32, i32, i32, i32, vp],
         "sbbseg_tile_grid": [i32, i32, i32, i32, vp, i32, C.POINTER(C.c_int), C.POINTER(C.c_int)],
+        "sbbseg_nearest_map": [i32, i32, vp],
         "sbbseg_segment_tiles_dev": [vp, vp, i32, i32, vp, i32, vp],
         "sbbseg_segment_tile_range_dev": [vp, vp, i32, i32, i32, i32, vp],
         "sbbseg_stitch_dev": [vp, vp, i32, i32, vp],
         "sbbseg_debug_ingest": [vp, vp, i32, i32, vp, i32, i32, vp, C.c_size_t],
         "sbbseg_debug_read_tensor": [vp, i32, i32, vp, C.c_size_t],
         "sbbseg_debug_set_conv_variant": [vp, i32],
+        "sbbseg_debug_inject_alloc_failure": [i32],
         "sbbseg_profile_enable": [vp, i32],
         "sbbseg_profile_reset": [vp],
         "sbbseg_profile_get": [vp, i32, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_int64)],
@@ -362,3 +364,10 @@ def tile_grid(Hp: int, Wp: int, H: int, W: int):
     xy = np.empty((nx.value * ny.value, 2), np.int32)
     check(lib.sbbseg_tile_grid(Hp, Wp, H, W, _ptr(xy), xy.shape[0], None, None), "sbbseg_tile_grid")
     return xy, nx.value, ny.value
+
+
+def nearest_map(src_len: int, dst_len: int) -> np.ndarray:
+    """int32 [dst_len]: the library's cv2.INTER_NEAREST index rule (sbbseg_nearest_map)."""
+    out = np.empty(dst_len, np.int32)
+    check(load_library().sbbseg_nearest_map(int(src_len), int(dst_len), _ptr(out)), "sbbseg_nearest_map")
+    return out

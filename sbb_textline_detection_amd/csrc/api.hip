@@ -9,6 +9,8 @@
 #include <string.h>
 
 #include <cmath>
+#include <new>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
@@ -44,6 +46,23 @@ int fail(const char* fmt, ...)
         if (!(cond)) return fail(__VA_ARGS__); \
     } while (0)
 
+// Every extern "C" body runs inside API_BEGIN / API_END: a C++ exception (std::bad_alloc from a std::vector, ...)
+// becomes a non-zero status + sbbseg_last_error() instead of terminating the caller's process -- the reference's
+// callers rely on ordinary Python exceptions (main.py:2061-2157).
+#define API_BEGIN try {
+#define API_END                                                                                     \
+    }                                                                                               \
+    catch (const std::bad_alloc&) { return fail("out of host memory (std::bad_alloc)"); }           \
+    catch (const std::exception& e_) { return fail("internal error: %s", e_.what()); }              \
+    catch (...) { return fail("unknown internal error"); }
+
+// test hook (sbbseg_debug_inject_alloc_failure): the n-th next alloc_check() throws std::bad_alloc
+int g_alloc_fail_countdown = 0;
+inline void alloc_check()
+{
+    if (g_alloc_fail_countdown > 0 && --g_alloc_fail_countdown == 0) throw std::bad_alloc();
+}
+
 struct Tensor {
     int H = 0, W = 0, C = 0;
     size_t elems_per_patch = 0;
@@ -72,6 +91,8 @@ struct ConvOp {
     KTabEntry* d_ktab_cls[4] = {nullptr, nullptr, nullptr, nullptr};
     int ooy_cls[4] = {0, 0, 0, 0}, oox_cls[4] = {0, 0, 0, 0};
     float wmul_cls[4] = {1.f, 1.f, 1.f, 1.f};   // split mode: 2^-s of the class's power-of-two weight pre-scale
+    std::vector<float> h_epi;             // host copy of scale | shift | head_w | head_scale | head_shift: parity siblings are
+                                          // only merged into one launch when these are identical (they share class 0's)
     uint16_t* d_stem_wfrag = nullptr;     // non-null: the op is the network stem and runs stem_conv_pairs
     uint16_t* d_d64_wfrag = nullptr;      // non-null: 3x3 s1 64->64 conv, runs conv3x3_c64_direct
 };
@@ -419,13 +440,16 @@ int sbbseg_abi_version(void) { return SBBSEG_ABI_VERSION; }
 
 int sbbseg_device_count(int* count)
 {
+    API_BEGIN
     REQUIRE(count, "null count");
     HIPCHK(hipGetDeviceCount(count));
     return 0;
+    API_END
 }
 
 int sbbseg_create(int device, int precision, sbbseg_ctx** out)
 {
+    API_BEGIN
     REQUIRE(out, "null out");
     REQUIRE(precision == SBBSEG_PREC_BF16 || precision == SBBSEG_PREC_F32 || precision == SBBSEG_PREC_F16 || precision == SBBSEG_PREC_F16X3,
             "bad precision %d", precision);
@@ -458,10 +482,12 @@ int sbbseg_create(int device, int precision, sbbseg_ctx** out)
     }
     *out = c;
     return 0;
+    API_END
 }
 
 int sbbseg_destroy(sbbseg_ctx* c)
 {
+    API_BEGIN
     if (!c) return 0;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
@@ -491,51 +517,63 @@ int sbbseg_destroy(sbbseg_ctx* c)
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     delete c;
     return 0;
+    API_END
 }
 
 int sbbseg_set_stream(sbbseg_ctx* c, void* hip_stream)
 {
+    API_BEGIN
     REQUIRE(c, "null handle");
     if (resolve_pending(c)) return 1;
     // NULL is a real stream (the legacy default stream torch uses unless told otherwise)
     c->stream = hip_stream == SBBSEG_OWN_STREAM ? c->own_stream : (hipStream_t)hip_stream;
     return 0;
+    API_END
 }
 
 int sbbseg_set_lanes(sbbseg_ctx* c, int lanes)
 {
+    API_BEGIN
     REQUIRE(c && (lanes == 1 || lanes == 2), "lanes must be 1 or 2");
     REQUIRE(!(c->finalized && lanes == 2 && c->lane1_batch == 0), "the second lane was not allocated at finalize (lanes was 1 or max_batch < 16)");
     c->lanes = lanes;
     return 0;
+    API_END
 }
 
 int sbbseg_set_label_channels(sbbseg_ctx* c, int channels)
 {
+    API_BEGIN
     REQUIRE(c && (channels == 1 || channels == 3), "label channels must be 1 or 3");
     c->label_channels = channels;
     return 0;
+    API_END
 }
 
 int sbbseg_synchronize(sbbseg_ctx* c)
 {
+    API_BEGIN
     REQUIRE(c, "null handle");
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipStreamSynchronize(c->stream));
     return 0;
+    API_END
 }
 
 // ---------------------------------------------------------------------------------- plan building
 int sbbseg_set_input(sbbseg_ctx* c, int H, int W, int channels)
 {
+    API_BEGIN
     REQUIRE(c && !c->finalized, "bad handle / already finalized");
     REQUIRE(H > 0 && W > 0 && channels == 3, "input must be HxWx3 (got %dx%dx%d)", H, W, channels);
     c->in_H = H; c->in_W = W; c->in_C = channels;
     return 0;
+    API_END
 }
 
 int sbbseg_input_form(sbbseg_ctx* c, int form, int pad, int* tensor_id)
 {
+    API_BEGIN
     REQUIRE(c && !c->finalized && tensor_id, "bad handle / already finalized");
     REQUIRE(c->in_H > 0, "sbbseg_set_input first");
     REQUIRE(form == SBBSEG_INPUT_C8 || form == SBBSEG_INPUT_PAIRS, "unknown input form %d", form);
@@ -558,10 +596,12 @@ int sbbseg_input_form(sbbseg_ctx* c, int form, int pad, int* tensor_id)
     c->form_tensor[form] = (int)c->tensors.size() - 1;
     *tensor_id = c->form_tensor[form];
     return 0;
+    API_END
 }
 
 int sbbseg_add_tensor(sbbseg_ctx* c, int H, int W, int C, int* tensor_id)
 {
+    API_BEGIN
     REQUIRE(c && !c->finalized && tensor_id, "bad handle / already finalized");
     REQUIRE(H > 0 && W > 0 && C > 0 && C % 8 == 0, "tensor %dx%dx%d: channels must be a positive multiple of 8", H, W, C);
     Tensor t;
@@ -570,12 +610,14 @@ int sbbseg_add_tensor(sbbseg_ctx* c, int H, int W, int C, int* tensor_id)
     c->tensors.push_back(t);
     *tensor_id = (int)c->tensors.size() - 1;
     return 0;
+    API_END
 }
 
 int sbbseg_add_conv(sbbseg_ctx* c, const sbbseg_conv_desc* d, const float* w_src0, const float* w_src1,
                     const float* scale, const float* shift, const float* raw_scale, const float* raw_shift,
                     const float* head_w, const float* head_scale, const float* head_shift)
 {
+    API_BEGIN
     REQUIRE(c && !c->finalized && d && w_src0 && scale && shift, "bad arguments");
     HIPCHK(hipSetDevice(c->device));
     REQUIRE(d->n_src == 1 || d->n_src == 2, "n_src must be 1 or 2");
@@ -619,7 +661,6 @@ int sbbseg_add_conv(sbbseg_ctx* c, const sbbseg_conv_desc* d, const float* w_src
     }
     REQUIRE((d->out_h - 1) * d->out_stride_y + d->out_off_y < TH && (d->out_w - 1) * d->out_stride_x + d->out_off_x < TW,
             "output placement leaves the %dx%d tensor", TH, TW);
-    REQUIRE(d->residual_tensor < 0 || (d->out_stride_y == 1 && d->out_stride_x == 1) || true, "unused");
 
     Op op;
     op.type = kConv;
@@ -636,6 +677,7 @@ int sbbseg_add_conv(sbbseg_ctx* c, const sbbseg_conv_desc* d, const float* w_src
     // out-of-bounds ("zero") granules.  Tap offsets carry the source's padding and placement offset.
     // Split mode (kF16X3): a K-step is 32 channels (4 granules) of one tap; its slots 0-3 are those granules' "hi"
     // halves, slots 4-7 the "lo" halves of the same channels (lo plane of the stored pixel, lo half of the weight).
+    alloc_check();
     const bool split = is_split(c->precision);
     const int gps = split ? 4 : kGranulesPerStep;            // channel granules per K-step
     std::vector<KTabEntry> lin;                              // granule list in contraction order (hi halves in split mode)
@@ -790,6 +832,13 @@ int sbbseg_add_conv(sbbseg_ctx* c, const sbbseg_conv_desc* d, const float* w_src
         memcpy(pad_b.data(), raw_shift, sizeof(float) * d->cout);
         if (upload(c, &co.d_rscale, pad_s.data(), pad_s.size()) || upload(c, &co.d_rshift, pad_b.data(), pad_b.size())) return 1;
     }
+    co.h_epi.assign(scale, scale + d->cout);
+    co.h_epi.insert(co.h_epi.end(), shift, shift + d->cout);
+    if (d->head_classes > 0) {
+        co.h_epi.insert(co.h_epi.end(), head_w, head_w + (size_t)d->cout * d->head_classes);
+        co.h_epi.insert(co.h_epi.end(), head_scale, head_scale + d->head_classes);
+        co.h_epi.insert(co.h_epi.end(), head_shift, head_shift + d->head_classes);
+    }
     if (d->head_classes > 0) {
         if (upload(c, &co.d_head_w, head_w, (size_t)d->cout * d->head_classes) ||
             upload(c, &co.d_head_scale, head_scale, d->head_classes) || upload(c, &co.d_head_shift, head_shift, d->head_classes))
@@ -879,7 +928,8 @@ int sbbseg_add_conv(sbbseg_ctx* c, const sbbseg_conv_desc* d, const float* w_src
                     d->raw_out_tensor < 0 && pc.d.out_h == d->out_h && pc.d.out_w == d->out_w &&
                     pc.d.out_stride_y == d->out_stride_y && pc.d.out_stride_x == d->out_stride_x &&
                     (d->out_stride_y > 1 || d->out_stride_x > 1) && pc.d.head_classes == d->head_classes &&
-                    pc.total_ksteps == co.total_ksteps && pc.ksteps[0] == co.ksteps[0];
+                    pc.total_ksteps == co.total_ksteps && pc.ksteps[0] == co.ksteps[0] &&
+                    pc.h_epi == co.h_epi;       // the merged launch applies class 0's BN / head constants to every class
         for (int s = 0; same && s < d->n_src; ++s) {
             const sbbseg_conv_src &x = pc.d.src[s], &y = d->src[s];
             same = x.tensor == y.tensor && x.channels == y.channels && x.kh == y.kh && x.kw == y.kw && x.stride_y == y.stride_y &&
@@ -890,6 +940,8 @@ int sbbseg_add_conv(sbbseg_ctx* c, const sbbseg_conv_desc* d, const float* w_src
             pc.d_w_cls[q] = co.d_w; pc.d_kstep_cls[q] = co.d_kstep; pc.d_ktab_cls[q] = co.d_ktab;
             pc.ooy_cls[q] = d->out_off_y; pc.oox_cls[q] = d->out_off_x; pc.wmul_cls[q] = co.wmul_cls[0];
             (void)hipFree(co.d_scale); (void)hipFree(co.d_shift); (void)hipFree(co.d_head_w); (void)hipFree(co.d_head_scale); (void)hipFree(co.d_head_shift);
+            c->device_bytes -= 2 * sizeof(float) * co.cout_pad;
+            if (d->head_classes > 0) c->device_bytes -= sizeof(float) * ((size_t)d->cout * d->head_classes + 2 * d->head_classes);
             prev.flops += op.flops;
             prev.min_bytes += op.min_bytes;
             const size_t pos = prev.name.find("_par");
@@ -899,11 +951,13 @@ int sbbseg_add_conv(sbbseg_ctx* c, const sbbseg_conv_desc* d, const float* w_src
     }
     c->ops.push_back(op);
     return 0;
+    API_END
 }
 
 int sbbseg_add_maxpool(sbbseg_ctx* c, int src_tensor, int dst_tensor, int k, int stride, const float* pre_scale,
                        const float* pre_shift, int pre_relu)
 {
+    API_BEGIN
     REQUIRE(c && !c->finalized, "bad handle / already finalized");
     const int ntens = (int)c->tensors.size();
     REQUIRE(src_tensor >= 0 && src_tensor < ntens && dst_tensor >= 0 && dst_tensor < ntens, "maxpool tensors undefined");
@@ -927,12 +981,14 @@ int sbbseg_add_maxpool(sbbseg_ctx* c, int src_tensor, int dst_tensor, int k, int
     op.min_bytes = ((double)s.H * s.W + (double)Ho * Wo) * s.C * c->elem * c->planes;
     c->ops.push_back(op);
     return 0;
+    API_END
 }
 
 int sbbseg_add_tail(sbbseg_ctx* c, int src0_tensor, int img_c8_tensor, const float* w_src0, const float* w_img,
                     const float* scale, const float* shift, int classes, const float* head_w, const float* head_scale,
                     const float* head_shift, double algorithmic_macs)
 {
+    API_BEGIN
     REQUIRE(c && !c->finalized && w_src0 && w_img && scale && shift && head_w && head_scale && head_shift, "bad arguments");
     HIPCHK(hipSetDevice(c->device));
     REQUIRE(c->precision == kF16 || c->precision == kBF16, "the fused tail is a plain 16-bit-mode kernel");
@@ -986,11 +1042,13 @@ int sbbseg_add_tail(sbbseg_ctx* c, int src0_tensor, int img_c8_tensor, const flo
     c->classes = classes;
     c->ops.push_back(op);
     return 0;
+    API_END
 }
 
 int sbbseg_add_head(sbbseg_ctx* c, int src_tensor, int cin, int classes, const float* w, const float* scale,
                     const float* shift)
 {
+    API_BEGIN
     REQUIRE(c && !c->finalized && w && scale && shift, "bad arguments");
     HIPCHK(hipSetDevice(c->device));
     REQUIRE(src_tensor >= 0 && src_tensor < (int)c->tensors.size(), "head source undefined");
@@ -1013,10 +1071,12 @@ int sbbseg_add_head(sbbseg_ctx* c, int src_tensor, int cin, int classes, const f
     c->classes = classes;
     c->ops.push_back(op);
     return 0;
+    API_END
 }
 
 int sbbseg_finalize(sbbseg_ctx* c, int max_batch)
 {
+    API_BEGIN
     REQUIRE(c && !c->finalized, "bad handle / already finalized");
     HIPCHK(hipSetDevice(c->device));
     REQUIRE(max_batch >= 1, "max_batch must be >= 1");
@@ -1046,45 +1106,55 @@ int sbbseg_finalize(sbbseg_ctx* c, int max_batch)
     HIPCHK(hipDeviceSynchronize());
     c->finalized = true;
     return 0;
+    API_END
 }
 
 // ----------------------------------------------------------------------------------------- queries
 int sbbseg_model_info(sbbseg_ctx* c, int* H, int* W, int* classes, int* max_batch)
 {
+    API_BEGIN
     REQUIRE(c, "null handle");
     if (H) *H = c->in_H;
     if (W) *W = c->in_W;
     if (classes) *classes = c->classes;
     if (max_batch) *max_batch = c->max_batch;
     return 0;
+    API_END
 }
 
 int sbbseg_num_ops(sbbseg_ctx* c, int* n)
 {
+    API_BEGIN
     REQUIRE(c && n, "bad arguments");
     *n = (int)c->ops.size();
     return 0;
+    API_END
 }
 
 int sbbseg_op_info(sbbseg_ctx* c, int op, char* name, int name_len, double* flops_per_patch, double* min_bytes_per_patch)
 {
+    API_BEGIN
     REQUIRE(c && op >= 0 && op < (int)c->ops.size(), "op index out of range");
     if (name && name_len > 0) snprintf(name, name_len, "%s", c->ops[op].name.c_str());
     if (flops_per_patch) *flops_per_patch = c->ops[op].flops;
     if (min_bytes_per_patch) *min_bytes_per_patch = c->ops[op].min_bytes;
     return 0;
+    API_END
 }
 
 int sbbseg_device_bytes(sbbseg_ctx* c, size_t* bytes)
 {
+    API_BEGIN
     REQUIRE(c && bytes, "bad arguments");
     *bytes = c->device_bytes;
     return 0;
+    API_END
 }
 
 // -------------------------------------------------------------------------------------- seam 2
 int sbbseg_predict(sbbseg_ctx* c, const float* x_nhwc, int n, float* probs_nhwc)
 {
+    API_BEGIN
     if (check_ready(c)) return 1;
     REQUIRE(x_nhwc && probs_nhwc && n >= 0, "bad arguments");
     const size_t per_in = (size_t)c->in_H * c->in_W * 3, per_out = (size_t)c->in_H * c->in_W * c->classes;
@@ -1101,11 +1171,14 @@ int sbbseg_predict(sbbseg_ctx* c, const float* x_nhwc, int n, float* probs_nhwc)
         HIPCHK(hipStreamSynchronize(c->stream));
     }
     return 0;
+    API_END
 }
 
 // -------------------------------------------------------------------------------------- seam 1
 int sbbseg_tile_grid(int Hp, int Wp, int H, int W, int32_t* tile_xy, int capacity, int* nxf, int* nyf)
 {
+    API_BEGIN
+    alloc_check();
     std::vector<int> ox, oy;
     const int margin = margin_of(W);
     const int nx = axis_tiles(Wp, W, margin, ox), ny = axis_tiles(Hp, H, margin, oy);
@@ -1121,11 +1194,25 @@ int sbbseg_tile_grid(int Hp, int Wp, int H, int W, int32_t* tile_xy, int capacit
             }
     }
     return 0;
+    API_END
+}
+
+int sbbseg_nearest_map(int src_len, int dst_len, int32_t* map)
+{
+    API_BEGIN
+    REQUIRE(src_len > 0 && dst_len > 0 && map, "bad arguments");
+    alloc_check();
+    std::vector<int> m;
+    nearest_map(src_len, dst_len, m);
+    for (int i = 0; i < dst_len; ++i) map[i] = m[i];
+    return 0;
+    API_END
 }
 
 int sbbseg_segment_tiles_dev(sbbseg_ctx* c, const void* d_page_hwc, int Hp, int Wp, const int32_t* tile_xy, int n_tiles,
                              void* d_tile_labels)
 {
+    API_BEGIN
     if (check_ready(c)) return 1;
     REQUIRE(d_page_hwc && tile_xy && d_tile_labels && n_tiles >= 0, "bad arguments");
     for (int t = 0; t < n_tiles; ++t)
@@ -1146,6 +1233,7 @@ int sbbseg_segment_tiles_dev(sbbseg_ctx* c, const void* d_page_hwc, int Hp, int 
         if (run_plan(c, nb, (uint8_t*)d_tile_labels + done * per, nullptr)) return 1;
     }
     return 0;
+    API_END
 }
 
 static int tile_range_impl(sbbseg_ctx* c, const void* d_page_hwc, int src_Hp, int src_Wp, const int* d_map_y, const int* d_map_x,
@@ -1198,13 +1286,16 @@ static int tile_range_impl(sbbseg_ctx* c, const void* d_page_hwc, int src_Hp, in
 int sbbseg_segment_tile_range_dev(sbbseg_ctx* c, const void* d_page_hwc, int Hp, int Wp, int first_tile, int n_tiles,
                                   void* d_tile_labels)
 {
+    API_BEGIN
     if (check_ready(c)) return 1;
     return tile_range_impl(c, d_page_hwc, Hp, Wp, nullptr, nullptr, Hp, Wp, first_tile, n_tiles, d_tile_labels);
+    API_END
 }
 
 static int prepare_owner(sbbseg_ctx* c, int Hp, int Wp)
 {
     if (c->own_Hp == Hp && c->own_Wp == Wp) return 0;
+    alloc_check();
     std::vector<int> ox, oy, own_x, own_y;
     const int margin = margin_of(c->in_W);
     const int nx = axis_tiles(Wp, c->in_W, margin, ox), ny = axis_tiles(Hp, c->in_H, margin, oy);
@@ -1228,26 +1319,31 @@ static int prepare_owner(sbbseg_ctx* c, int Hp, int Wp)
 
 int sbbseg_stitch_dev(sbbseg_ctx* c, const void* d_tile_labels, int Hp, int Wp, void* d_labels_hw)
 {
+    API_BEGIN
     if (check_ready(c)) return 1;
     REQUIRE(d_tile_labels && d_labels_hw, "bad arguments");
     if (prepare_owner(c, Hp, Wp)) return 1;
     HIPCHK(launch_stitch((const uint8_t*)d_tile_labels, c->in_H, c->in_W, c->d_own_x, c->d_own_y, c->own_nyf, Hp, Wp,
                          (uint8_t*)d_labels_hw, c->stream));
     return 0;
+    API_END
 }
 
 int sbbseg_segment_page_dev(sbbseg_ctx* c, const void* d_page_hwc, int Hp, int Wp, void* d_labels_hw)
 {
+    API_BEGIN
     if (check_ready(c)) return 1;
     int nx = 0, ny = 0;
     if (sbbseg_tile_grid(Hp, Wp, c->in_H, c->in_W, nullptr, 0, &nx, &ny)) return 1;
     if (ensure(c, (void**)&c->d_tile_labels, &c->tile_labels_cap, (size_t)nx * ny * c->in_H * c->in_W)) return 1;
     if (sbbseg_segment_tile_range_dev(c, d_page_hwc, Hp, Wp, 0, nx * ny, c->d_tile_labels)) return 1;
     return sbbseg_stitch_dev(c, c->d_tile_labels, Hp, Wp, d_labels_hw);
+    API_END
 }
 
 int sbbseg_segment_page(sbbseg_ctx* c, const uint8_t* page_hwc, int Hp, int Wp, uint8_t* labels_hw)
 {
+    API_BEGIN
     if (check_ready(c)) return 1;
     REQUIRE(page_hwc && labels_hw, "bad arguments");
     REQUIRE(Hp >= c->in_H && Wp >= c->in_W, "page %dx%d is smaller than the model input %dx%d (unsupported by the reference too, main.py:278-281)", Hp, Wp, c->in_H, c->in_W);
@@ -1259,10 +1355,12 @@ int sbbseg_segment_page(sbbseg_ctx* c, const uint8_t* page_hwc, int Hp, int Wp, 
     if (labels_to_host(c, labels_hw, pix)) return 1;
     HIPCHK(hipStreamSynchronize(c->stream));
     return 0;
+    API_END
 }
 
 int sbbseg_segment_page_scaled(sbbseg_ctx* c, const uint8_t* page_hwc, int Hs, int Ws, int Hp, int Wp, uint8_t* labels_hw)
 {
+    API_BEGIN
     if (check_ready(c)) return 1;
     REQUIRE(page_hwc && labels_hw && Hs > 0 && Ws > 0, "bad arguments");
     REQUIRE(Hp >= c->in_H && Wp >= c->in_W, "scaled page %dx%d is smaller than the model input %dx%d", Hp, Wp, c->in_H, c->in_W);
@@ -1286,27 +1384,33 @@ int sbbseg_segment_page_scaled(sbbseg_ctx* c, const uint8_t* page_hwc, int Hs, i
     if (labels_to_host(c, labels_hw, pix)) return 1;
     HIPCHK(hipStreamSynchronize(c->stream));
     return 0;
+    API_END
 }
 
 int sbbseg_otsu_dev(sbbseg_ctx* c, const void* d_page_hwc, int Hp, int Wp, int* d_threshold)
 {
+    API_BEGIN
     if (check_ready(c)) return 1;
     REQUIRE(d_page_hwc && d_threshold && Hp > 0 && Wp > 0, "bad arguments");
     HIPCHK(launch_otsu((const uint8_t*)d_page_hwc, Wp, Hp, Wp, nullptr, nullptr, c->d_hist, d_threshold, c->num_cus, c->stream));
     return 0;
+    API_END
 }
 
 int sbbseg_segment_tile_range_bin_dev(sbbseg_ctx* c, const void* d_page_hwc, int Hp, int Wp, int first_tile, int n_tiles,
                                       const int* d_threshold, void* d_tile_labels)
 {
+    API_BEGIN
     if (check_ready(c)) return 1;
     REQUIRE(d_threshold, "bad arguments");
     return tile_range_impl(c, d_page_hwc, Hp, Wp, nullptr, nullptr, Hp, Wp, first_tile, n_tiles, d_tile_labels, d_threshold);
+    API_END
 }
 
 int sbbseg_segment_page_otsu(sbbseg_ctx* c, const uint8_t* page_hwc, int Hs, int Ws, int Hp, int Wp, uint8_t* labels_hw,
                              int* threshold)
 {
+    API_BEGIN
     if (check_ready(c)) return 1;
     REQUIRE(page_hwc && labels_hw && Hs > 0 && Ws > 0, "bad arguments");
     REQUIRE(Hp >= c->in_H && Wp >= c->in_W, "page %dx%d is smaller than the model input %dx%d", Hp, Wp, c->in_H, c->in_W);
@@ -1339,16 +1443,20 @@ int sbbseg_segment_page_otsu(sbbseg_ctx* c, const uint8_t* page_hwc, int Hs, int
     HIPCHK(hipStreamSynchronize(c->stream));
     if (threshold) *threshold = thr;
     return 0;
+    API_END
 }
 
 int sbbseg_segment_whole(sbbseg_ctx* c, const uint8_t* page_hwc, int Hp, int Wp, int out_h, int out_w, uint8_t* labels_out)
 {
+    API_BEGIN
     return sbbseg_segment_whole_scaled(c, page_hwc, Hp, Wp, Hp, Wp, out_h, out_w, labels_out);
+    API_END
 }
 
 int sbbseg_segment_whole_scaled(sbbseg_ctx* c, const uint8_t* page_hwc, int Hp, int Wp, int Hs, int Ws, int out_h, int out_w,
                                 uint8_t* labels_out)
 {
+    API_BEGIN
     if (check_ready(c)) return 1;
     REQUIRE(page_hwc && labels_out && Hp > 0 && Wp > 0 && Hs > 0 && Ws > 0 && out_h > 0 && out_w > 0, "bad arguments");
     const size_t pix = (size_t)Hp * Wp, opix = (size_t)out_h * out_w;
@@ -1385,12 +1493,14 @@ int sbbseg_segment_whole_scaled(sbbseg_ctx* c, const uint8_t* page_hwc, int Hp, 
     if (labels_to_host(c, labels_out, opix)) return 1;
     HIPCHK(hipStreamSynchronize(c->stream));
     return 0;
+    API_END
 }
 
 // ----------------------------------------------------------------------------------------- debug
 int sbbseg_debug_ingest(sbbseg_ctx* c, const uint8_t* page_hwc, int Hp, int Wp, const int32_t* tile_xy, int n_tiles,
                         int form, float* out, size_t out_floats)
 {
+    API_BEGIN
     if (check_ready(c)) return 1;
     REQUIRE(page_hwc && tile_xy && out && n_tiles >= 1 && n_tiles <= c->max_batch, "bad arguments (n_tiles <= max_batch)");
     REQUIRE(form == SBBSEG_INPUT_C8 || form == SBBSEG_INPUT_PAIRS, "unknown form");
@@ -1416,10 +1526,12 @@ int sbbseg_debug_ingest(sbbseg_ctx* c, const uint8_t* page_hwc, int Hp, int Wp, 
     (void)hipFree(d_tmp);
     HIPCHK(e);
     return 0;
+    API_END
 }
 
 int sbbseg_debug_read_tensor(sbbseg_ctx* c, int tensor_id, int n, float* out, size_t out_floats)
 {
+    API_BEGIN
     if (check_ready(c)) return 1;
     REQUIRE(tensor_id >= 0 && tensor_id < (int)c->tensors.size() && out && n >= 1 && n <= c->max_batch, "bad arguments");
     const Tensor& t = c->tensors[tensor_id];
@@ -1434,42 +1546,60 @@ int sbbseg_debug_read_tensor(sbbseg_ctx* c, int tensor_id, int n, float* out, si
     (void)hipFree(d_tmp);
     HIPCHK(e);
     return 0;
+    API_END
+}
+
+int sbbseg_debug_inject_alloc_failure(int nth_check)
+{
+    API_BEGIN
+    REQUIRE(nth_check >= 0, "nth_check must be >= 0 (0 disarms)");
+    g_alloc_fail_countdown = nth_check;
+    return 0;
+    API_END
 }
 
 int sbbseg_debug_set_conv_variant(sbbseg_ctx* c, int variant)
 {
+    API_BEGIN
     REQUIRE(c && variant >= 0 && variant <= 0x1ffff, "variant: bits 0-1 = 0 auto | 1 4-wave/2-stage | 2 8-wave/3-stage; bit 2 = one block per tile (non-persistent); bit 3 = no XCD-grouped tile walk; bit 4 = half-K-step stages; bit 5 = XCD-grouped walk on single-class layers; bit 6 = drain epilogue stores; bit 7 = half-line epilogue stores; bits 8-15 = contiguous-run K limit / 64; bit 16 = 8-phase schedule on the 256x256 tile");
     c->conv_variant = variant & 0xff;
     c->ph8 = (variant >> 16) & 1;
     if ((variant >> 8) & 0xff) c->contig_max_k = ((variant >> 8) & 0xff) * 64;
     return 0;
+    API_END
 }
 
 // ------------------------------------------------------------------------------------- profiling
 int sbbseg_profile_enable(sbbseg_ctx* c, int enable)
 {
+    API_BEGIN
     REQUIRE(c, "null handle");
     if (resolve_pending(c)) return 1;
     c->profiling = enable != 0;
     return 0;
+    API_END
 }
 
 int sbbseg_profile_reset(sbbseg_ctx* c)
 {
+    API_BEGIN
     REQUIRE(c, "null handle");
     if (resolve_pending(c)) return 1;
     for (auto& op : c->ops) { op.prof_ms = 0; op.prof_launches = 0; op.prof_patches = 0; }
     return 0;
+    API_END
 }
 
 int sbbseg_profile_get(sbbseg_ctx* c, int op, double* total_ms, int64_t* launches, int64_t* patches)
 {
+    API_BEGIN
     REQUIRE(c && op >= 0 && op < (int)c->ops.size(), "op index out of range");
     if (resolve_pending(c)) return 1;
     if (total_ms) *total_ms = c->ops[op].prof_ms;
     if (launches) *launches = c->ops[op].prof_launches;
     if (patches) *patches = c->ops[op].prof_patches;
     return 0;
+    API_END
 }
 
 }  // extern "C"

@@ -42,3 +42,37 @@ def test_tile_grid_equals_reference(lib, case):
 def test_small_page_is_an_error_not_a_crash(lib):
     with pytest.raises(RuntimeError, match="smaller than the model"):
         _capi.tile_grid(300, 500, 448, 448)
+
+
+def test_cpp_exception_becomes_status_not_abort(lib):
+    """No-abort guarantee (sbbseg.h conventions; the reference's callers rely on ordinary exceptions,
+    main.py:2061-2157): a std::bad_alloc thrown inside the library -- injected at its next host-allocation
+    checkpoint -- comes back as a non-zero status with a message; the process and the library stay usable."""
+    assert lib.sbbseg_debug_inject_alloc_failure(1) == 0
+    with pytest.raises(RuntimeError, match="out of host memory"):
+        _capi.tile_grid(1000, 900, 448, 448)
+    xy, nx, ny = _capi.tile_grid(1000, 900, 448, 448)          # the hook disarmed itself; the call works again
+    assert (nx, ny) == (3, 3) and xy.shape == (9, 2)
+    assert lib.sbbseg_debug_inject_alloc_failure(-1) != 0       # bad argument: status, not a crash
+    assert lib.sbbseg_debug_inject_alloc_failure(0) == 0
+
+
+def test_nearest_map_rule(lib):
+    """The library's INTER_NEAREST index rule (page rescale fused into the tile gather) against
+    hand-computed cases (odd ratios, up and down) and against the oracle's restatement on the sizes the
+    reference's own 2800-rule / x1.2-rule produce (main.py:201-207, fixtures from the imported reference)."""
+    from oracle import tiling
+    hand = {(3, 7): [0, 0, 0, 1, 1, 2, 2], (5, 3): [0, 1, 3], (4, 6): [0, 0, 1, 2, 2, 3], (2, 5): [0, 0, 0, 1, 1],
+            (7, 2): [0, 3], (1, 4): [0, 0, 0, 0]}
+    for (src, dst), want in hand.items():
+        assert _capi.nearest_map(src, dst).tolist() == want, (src, dst)
+    scales = json.load(open(os.path.join(ROOT, "tests", "golden", "tiling_golden.json")))["scale_cases"]
+    pairs = [(c["h"], c["img_hight_int"]) for c in scales] + [(c["w"], c["img_width_int"]) for c in scales]
+    pairs += [(448, 3500), (3500, 448), (4200, 448), (448, 2800), (611, 1234), (1017, 503)]
+    for src, dst in pairs:
+        ref = tiling.resize_nearest(np.arange(src).reshape(src, 1), dst, 1)[:, 0]
+        got = _capi.nearest_map(src, dst)
+        assert np.array_equal(got, ref), (src, dst)
+        assert got[0] == 0 and got.max() <= src - 1 and np.all(np.diff(got) >= 0)
+    with pytest.raises(RuntimeError):
+        _capi.nearest_map(0, 5)

@@ -10,8 +10,8 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-from gpu_common import (EXACT_MARGIN, TOL_LAYER_REL, TOL_SOFTMAX, compare_probs, exact_label_check, make_model,  # noqa: E402
-                        patches_from_page)
+from gpu_common import (EXACT_MARGIN, TOL_LABEL_FRAC_F16, TOL_LAYER_REL, TOL_SOFTMAX, compare_probs, exact_label_check,  # noqa: E402
+                        make_model, patches_from_page)
 from oracle import keras_forward as kf  # noqa: E402
 from oracle import tiling  # noqa: E402
 from sbb_textline_detection_amd import _capi, predict  # noqa: E402
@@ -73,7 +73,7 @@ def test_every_fused_layer_matches_oracle(precision):
         if rel > worst[1]:
             worst = (name, rel)
         assert rel < rel_tol, f"{name}: rel err {rel:.4g} ({precision})"
-    d, mism, bad = compare_probs(ref, got, TOL_SOFTMAX[precision])
+    d, mism, bad = compare_probs(ref, got, TOL_SOFTMAX.get(precision, 1.0))
     print(f"[layers {precision}] worst layer {worst}, max|dsoftmax| {d:.4f}, label mismatches {mism}")
     if precision in ("f32", "f16x3"):
         assert d < TOL_SOFTMAX[precision] and bad == 0, (d, mism, bad, worst)
@@ -93,8 +93,9 @@ def test_conv_tile_families_agree():
 
 
 # ------------------------------------------------------------------------------- seam 2 at full size
-@pytest.mark.parametrize("classes,precision", [(2, "f16"), (4, "f16"), (2, "bf16")])
+@pytest.mark.parametrize("classes,precision", [(2, "f16"), (4, "f16")])
 def test_predict_448_matches_oracle(classes, precision):
+    """The FAST fp16 mode (opt-in; the label-exact default is checked by test_predict_448_label_exact)."""
     cfg, w, g, model = make_model(classes, 448, 448, seed=classes, precision=precision, max_batch=4)
     x = (patches_from_page(448, 448, 2, seed=9) / 255.0).astype(np.float32)
     ref = kf.forward(g, w, x)
@@ -104,7 +105,7 @@ def test_predict_448_matches_oracle(classes, precision):
     d, mism, bad = compare_probs(ref, got, TOL_SOFTMAX[precision])
     print(f"[448 C={classes} {precision}] max|dsoftmax|={d:.4f} label mismatches={mism}/{ref[...,0].size} outside tolerance band={bad}")
     assert d < TOL_SOFTMAX[precision] and bad == 0
-    assert mism / ref[..., 0].size < (0.04 if precision == "f16" else 0.15)
+    assert mism / ref[..., 0].size < TOL_LABEL_FRAC_F16
     model.release()
 
 
@@ -152,7 +153,7 @@ def test_segment_page_matches_oracle_loop():
     assert np.array_equal(got[:, :, 0], got[:, :, 1]) and np.array_equal(got[:, :, 0], got[:, :, 2])
     mism = (got[:, :, 0] != ref[:, :, 0]).mean()
     print(f"[page 500x610, 224 model] label mismatch fraction vs oracle loop: {mism:.5f}")
-    assert mism < 0.04
+    assert mism < TOL_LABEL_FRAC_F16
     # the f32 check handle must agree with the oracle almost everywhere (only summation order differs)
     cfg2, w2, g2, m32 = make_model(2, 224, 224, seed=5, precision="f32", max_batch=5)
     got32 = predict.do_prediction(True, page, m32)
@@ -198,9 +199,10 @@ def test_device_stitch_reproduces_reference_fixture(case, torch_cuda, stitch_mod
 @pytest.fixture(scope="module")
 def stitch_model():
     from sbb_textline_detection_amd.model import SegModel
-    from sbb_textline_detection_amd.weights import synthetic_model
-    cfg, w = synthetic_model(2, 448, 448, seed=0)
-    m = SegModel(cfg, w, device=0, max_batch=8)
+    from tools.synth_model import calibrated_model
+    cfg, w = calibrated_model(2, 448, 448, seed=0)      # BN statistics calibrated: a non-trivial label map
+    m = SegModel(cfg, w, device=0, max_batch=8)          # default precision = the label-exact f16x3 mode
+    m.test_cfg, m.test_weights = cfg, w
     yield m
     m.release()
 
@@ -217,8 +219,8 @@ def test_full_page_properties_3500x2500(torch_cuda, stitch_model):
     b = model.segment_page(page)
     assert a.shape == (3500, 2500) and np.array_equal(a, b)
     from sbb_textline_detection_amd.model import SegModel
-    from sbb_textline_detection_amd.weights import synthetic_model
-    cfg, w = synthetic_model(2, 448, 448, seed=0)
+    cfg, w = model.test_cfg, model.test_weights
+    assert 0.02 < float(a.mean()) < 0.98, "calibrated net: both labels occur"
     m3 = SegModel(cfg, w, device=0, max_batch=3)
     assert np.array_equal(m3.segment_page(page), a)
     # sharded tile ranges, stitched, equal the one-call result
@@ -231,6 +233,23 @@ def test_full_page_properties_3500x2500(torch_cuda, stitch_model):
     m3.ctx.synchronize()
     assert np.array_equal(d_out.cpu().numpy(), a)
     m3.release()
+    # oracle agreement on a sample of the 70 tiles (the oracle needs ~1 s per tile on the GPU box's host cores):
+    # the page map inside a tile's owned region == argmax of the oracle's softmax for that tile, label-exact
+    # (stitch_model runs the seams' default mode, f16x3)
+    tiles, nxf, nyf = tiling.tile_grid(3500, 2500, 448, 448)
+    assert len(tiles) == 70
+    g = model.graph
+    for k in (0, 23, 38, 52, 69):                                    # corners, an interior tile, clamped last row/column
+        t = tiles[k]
+        x = (page[t["y0"]:t["y0"] + 448, t["x0"]:t["x0"] + 448][None] / 255.0).astype(np.float32)
+        ref = kf.forward(g, w, x)
+        got_tile = a[t["y0"] + t["ylo"]:t["y0"] + t["yhi"], t["x0"] + t["xlo"]:t["x0"] + t["xhi"]]
+        own = tiling.owner_map(3500, 2500, 448, 448)[t["y0"] + t["ylo"]:t["y0"] + t["yhi"], t["x0"] + t["xlo"]:t["x0"] + t["xhi"]] == k
+        r = ref[0, t["ylo"]:t["yhi"], t["xlo"]:t["xhi"]]
+        srt = np.sort(r, axis=-1)
+        decided = (srt[..., -1] - srt[..., -2]) > EXACT_MARGIN
+        bad = (got_tile != r.argmax(-1)) & own & decided
+        assert not bad.any(), f"tile {k}: {int(bad.sum())} labels differ from the oracle outside its near-ties"
 
 
 def test_sharded_entry_points_single_rank(torch_cuda, stitch_model):
@@ -497,3 +516,73 @@ def test_committed_forward_fixture(precision):
         decided = (srt[..., -1] - srt[..., -2]) > 1e-3
         assert np.array_equal(p.argmax(-1)[decided], d["probs"].argmax(-1)[decided])
     m.release()
+
+
+def test_config4_pages_4000x3000_sharded_single_rank(torch_cuda, stitch_model):
+    """BASELINE config[3] at one GPU: pages of 4000x3000 (108 tiles each) through distributed.segment_pages_sharded ==
+    the one-call fused path per page, and the label-exact mode agrees with the oracle on sampled tiles."""
+    from sbb_textline_detection_amd import distributed as D
+    pages = [synthetic_page(4000, 3000, seed=100), synthetic_page(4000, 3000, seed=101)]
+    be = D.DeviceBackend(stitch_model)
+    got = D.segment_pages_sharded(be, pages).cpu().numpy()
+    stitch_model.ctx.synchronize()
+    stitch_model.ctx.set_stream(-1)
+    assert got.shape == (2, 4000, 3000)
+    w = stitch_model.test_weights
+    tiles, nxf, nyf = tiling.tile_grid(4000, 3000, 448, 448)
+    assert len(tiles) == 108
+    own = tiling.owner_map(4000, 3000, 448, 448)
+    for p, page in enumerate(pages):
+        assert np.array_equal(got[p], stitch_model.segment_page(page))
+        for k in (5 + 40 * p, 107 - 30 * p):
+            t = tiles[k]
+            x = (page[t["y0"]:t["y0"] + 448, t["x0"]:t["x0"] + 448][None] / 255.0).astype(np.float32)
+            ref = kf.forward(stitch_model.graph, w, x)[0]
+            sl = (slice(t["y0"] + t["ylo"], t["y0"] + t["yhi"]), slice(t["x0"] + t["xlo"], t["x0"] + t["xhi"]))
+            r = ref[t["ylo"]:t["yhi"], t["xlo"]:t["xhi"]]
+            srt = np.sort(r, axis=-1)
+            bad = (got[p][sl] != r.argmax(-1)) & (own[sl] == k) & ((srt[..., -1] - srt[..., -2]) > EXACT_MARGIN)
+            assert not bad.any(), (p, k, int(bad.sum()))
+
+
+def test_scaled_page_equals_oracle_resize(stitch_model):
+    """SURVEY 8f-2 (get_image_and_scales fused into the gather): segment_page_scaled(stored page) == segment_page of the
+    page resized by the ORACLE's resize_nearest (not the product's), at sizes the reference's own rules produce
+    (main.py:201-207: the < 2500 -> 2800 rule and the x1.2 rule) and at an odd ratio."""
+    from sbb_textline_detection_amd.stages import scaled_size
+    m = stitch_model
+    for (h, w, hs, ws) in ((700, 560, 2800, 2240), (2600, 500, 3120, 600), (611, 503, 1234, 1017)):
+        if (hs, ws) != (1234, 1017):
+            assert scaled_size(h, w) == (hs, ws)
+        page = synthetic_page(h, w, seed=h)
+        a = m.ctx.segment_page_scaled(page, hs, ws)
+        b = m.segment_page(np.ascontiguousarray(tiling.resize_nearest(page, hs, ws)))
+        assert a.shape == (hs, ws) and np.array_equal(a, b), (h, w, hs, ws)
+
+
+def test_whole_image_branch_fused_equals_reference_structure(stitch_model):
+    """patches=False (main.py:368-380): the fused device path (resize gather -> forward -> argmax -> resize back) must equal,
+    bit for bit, the oracle's restatement of the branch -- itself pinned to the imported reference by the whole_cases
+    fixtures -- driven with the SAME HIP model through seam 2 (model.predict): same net, same kernels, so any
+    difference is a structural one (which size is resized to which, main.py:378's self.image.shape)."""
+    m = stitch_model
+    for (h, w, fh, fw) in ((700, 520, 840, 624), (611, 503, 2800, 2305), (448, 448, 448, 448), (1234, 777, 333, 257)):
+        page = synthetic_page(h, w, seed=h + w)
+        fused = predict.do_prediction(False, page, m, full_image_shape=(fh, fw, 3))
+        loop = tiling.do_prediction(False, page, m, full_image_shape=(fh, fw, 3))
+        assert fused.shape == (fh, fw, 3) and fused.dtype == np.uint8 and np.array_equal(fused, loop), (h, w, fh, fw)
+
+
+def test_model_load_survives_injected_bad_alloc():
+    """A std::bad_alloc inside the plan upload (sbbseg_add_conv) is a RuntimeError, not a dead process; the next load works."""
+    lib = _capi.load_library()
+    cfg, w, g, model = make_model(2, 64, 64, seed=1, precision="f16", max_batch=2, calib_hw=64)
+    model.release()
+    from sbb_textline_detection_amd.model import SegModel
+    assert lib.sbbseg_debug_inject_alloc_failure(7) == 0
+    with pytest.raises(RuntimeError, match="out of host memory"):
+        SegModel(cfg, w, device=0, max_batch=2, precision="f16")
+    assert lib.sbbseg_debug_inject_alloc_failure(0) == 0
+    m2 = SegModel(cfg, w, device=0, max_batch=2, precision="f16")
+    assert m2.predict(np.zeros((1, 64, 64, 3), np.float32)).shape == (1, 64, 64, 2)
+    m2.release()

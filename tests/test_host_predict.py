@@ -60,3 +60,16 @@ def test_sbbw_roundtrip(tmp_path):
     assert resolve_model_path(str(tmp_path / "model_textline_new.h5")) == p
     with pytest.raises(FileNotFoundError):
         resolve_model_path(str(tmp_path / "missing.h5"))
+
+
+def test_host_whole_image_branch_matches_reference():
+    """predict.do_prediction(patches=False) against the fixtures of the imported reference (stub cv2.resize)."""
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "tiling_golden.json")))["whole_cases"]
+    for case in gold:
+        if case["page_h"] * case["page_w"] > 1300 * 1300:
+            continue
+        page = tiling.coord_page(case["page_h"], case["page_w"])
+        fm = tiling.FakeModel(case["model_h"], case["model_w"], case["classes"])
+        res = predict.do_prediction(False, page, fm, full_image_shape=(case["full_h"], case["full_w"], 3))
+        assert res.dtype == np.uint8 and list(res.shape) == case["out_shape"]
+        assert zlib.crc32(np.ascontiguousarray(res).tobytes()) & 0xFFFFFFFF == case["out_crc32"]

@@ -55,3 +55,32 @@ def test_resize_nearest_rule():
     assert up.shape == (10, 14) and np.array_equal(up[::2, ::2], a)
     dn = tiling.resize_nearest(a, 2, 3)
     assert np.array_equal(dn, a[[0, 2]][:, [0, 2, 4]])
+
+
+# ---- whole-image branch (patches=False, main.py:368-380) and the page rescale (main.py:196-214): fixtures from the
+# IMPORTED reference run with a stub cv2.resize (the restated index rule) -- they pin what is resized to which size in
+# which order (incl. the `self.image.shape` quirk of main.py:378); the cv2 index rule itself stays [EXT]
+@pytest.mark.parametrize("case", GOLD["whole_cases"], ids=lambda c: f"{c['page_h']}x{c['page_w']}_to_{c['full_h']}x{c['full_w']}")
+def test_whole_image_branch_matches_reference_output(case):
+    page = tiling.coord_page(case["page_h"], case["page_w"])
+    fm = tiling.FakeModel(case["model_h"], case["model_w"], case["classes"])
+    res = tiling.do_prediction(False, page, fm, full_image_shape=(case["full_h"], case["full_w"], 3))
+    assert str(res.dtype) == case["out_dtype"] and list(res.shape) == case["out_shape"]
+    assert fm.in_dtype == case["predict_in_dtype"] and list(fm.in_shape) == case["predict_in_shape"]
+    assert int(res.astype(np.int64).sum()) == case["out_sum"]
+    assert zlib.crc32(np.ascontiguousarray(res).tobytes()) & 0xFFFFFFFF == case["out_crc32"]
+
+
+def test_resize_nearest_hand_computed_cases():
+    """cv2.INTER_NEAREST index rule [EXT: OpenCV resizeNN, src = min(floor(dst * (1/(dst_len/src_len))), src_len-1)],
+    worked by hand for odd ratios (not centre-aligned: index 0 always maps to 0, the last output may not reach the last input)."""
+    hand = {(3, 7): [0, 0, 0, 1, 1, 2, 2],          # 1/(7/3) = 0.428571...: 0 .43 .86 1.29 1.71 2.14 2.57
+            (5, 3): [0, 1, 3],                      # 1/(3/5) = 1.6667: 0 1.67 3.33
+            (4, 6): [0, 0, 1, 2, 2, 3],             # 0.6667: 0 .67 1.33 2 2.67 3.33
+            (2, 5): [0, 0, 0, 1, 1],                # 0.4: 0 .4 .8 1.2 1.6
+            (7, 2): [0, 3],                         # 3.5: 0 3.5
+            (1, 4): [0, 0, 0, 0]}
+    for (src, dst), want in hand.items():
+        a = np.arange(src).reshape(src, 1)
+        assert tiling.resize_nearest(a, dst, 1)[:, 0].tolist() == want, (src, dst)
+        assert tiling.resize_nearest(a.T, 1, dst)[0].tolist() == want, (src, dst)

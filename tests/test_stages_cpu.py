@@ -37,3 +37,17 @@ def test_otsu_matches_bruteforce_and_quirk():
     assert np.array_equal(out[:, :, 0], out[:, :, 1]) and np.array_equal(out[:, :, 0], out[:, :, 2])   # main.py:191-193
     t = stages.otsu_threshold_u8(page[:, :, 0])
     assert np.array_equal(out[:, :, 0] > 0, page[:, :, 0] > t)
+
+
+def test_scaled_size_equals_imported_reference():
+    """stages.scaled_size against fixtures produced by the imported reference's get_image_and_scales (main.py:196-214;
+    tests/golden/make_tiling_golden.py): the < 2500 -> 2800 rule, the x1.2 rule, and their int() truncations."""
+    import json
+    import os
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "tiling_golden.json")))["scale_cases"]
+    assert len(gold) >= 8
+    for c in gold:
+        assert stages.scaled_size(c["h"], c["w"]) == (c["img_hight_int"], c["img_width_int"]), c
+        st = stages.InferenceStages("a", "b", "c")
+        st.get_image_and_scales(np.zeros((c["h"], c["w"], 3), np.uint8))
+        assert (st.scale_y, st.scale_x) == (c["scale_y"], c["scale_x"])
