@@ -220,9 +220,9 @@ def main():
         pick = np.linspace(0, len(xy) - 1, args.cpu_patches).astype(int)
         patches = np.stack([page[y0:y0 + MODEL_HW, x0:x0 + MODEL_HW] for (x0, y0) in xy[pick]])
         x = (patches / 255.0).astype(np.float32)
-        kf.forward(model.graph, weights, x[:1])                       # warm (page-in, thread pool)
+        kf.forward_config(cfg, weights, x[:1])                        # warm (page-in, thread pool)
         t1 = time.perf_counter()
-        ref = kf.forward(model.graph, weights, x)
+        ref = kf.forward_config(cfg, weights, x)
         cpu_dt = time.perf_counter() - t1
         got = model.predict(x)
         srt = np.sort(ref, axis=-1)

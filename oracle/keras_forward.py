@@ -11,7 +11,9 @@ not installable offline).  Layer semantics restated from their documentation [EX
   ``Concatenate`` (channels), ``Add``, ``Activation`` relu/softmax, ``Lambda`` = one_side_pad crop.
 
 The graph is walked layer by layer, unfused, every tensor fp32 -- deliberately a different
-program shape from the fused HIP plan it checks.  PARITY UNPINNED vs real Keras/TF (no golden
+program shape from the fused HIP plan it checks.  ``forward`` accepts the layer list of either reader (the
+oracle's own ``keras_config.read_model_config`` or the product's ``keras_graph.parse_model_config``: same
+vocabulary); ``OracleModel`` and :func:`forward_config` use the oracle's own.  PARITY UNPINNED vs real Keras/TF (no golden
 vectors exist in the reference); cross-checked against torch-CPU in
 ``tests/test_oracle_forward.py``.
 
@@ -158,12 +160,18 @@ def forward(graph, weights: Dict[str, np.ndarray], x: np.ndarray, taps=None, con
     return vals[graph.output_name]
 
 
+def forward_config(model_config, weights: Dict[str, np.ndarray], x: np.ndarray, **kw) -> np.ndarray:
+    """forward() on a Keras model_config read by the oracle's own reader (independent of the product's parser)."""
+    from .keras_config import read_model_config
+    return forward(read_model_config(model_config), weights, x, **kw)
+
+
 class OracleModel:
     """Duck-typed stand-in for the Keras model (main.py:227-229, 287-288) on the CPU oracle."""
 
     def __init__(self, model_config, weights):
-        from sbb_textline_detection_amd.keras_graph import parse_model_config
-        self.graph = parse_model_config(model_config)
+        from .keras_config import read_model_config          # the oracle's own reader, NOT the product's parser
+        self.graph = read_model_config(model_config)
         self.weights = weights
         self.layers = self.graph.nodes
 

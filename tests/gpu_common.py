@@ -2,7 +2,7 @@
 import numpy as np
 
 from oracle import keras_forward as kf
-from sbb_textline_detection_amd.keras_graph import parse_model_config
+from oracle.keras_config import read_model_config
 from sbb_textline_detection_amd.model import SegModel
 from sbb_textline_detection_amd.synthetic import synthetic_page
 from tools.synth_model import calibrated_model
@@ -28,7 +28,7 @@ EXACT_MARGIN = 1e-3
 
 def make_model(classes, h, w, seed=0, precision="f16", max_batch=8, calib_hw=None, decisive=False):
     cfg, weights = calibrated_model(classes, h, w, seed=seed, calib_hw=calib_hw or min(160, max(h, w)), decisive=decisive)
-    graph = parse_model_config(cfg)
+    graph = read_model_config(cfg)          # the ORACLE's own reader of the model_config (not the product's parser)
     model = SegModel(cfg, weights, device=0, max_batch=max_batch, precision=precision)
     return cfg, weights, graph, model
 

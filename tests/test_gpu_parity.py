@@ -238,7 +238,8 @@ def test_full_page_properties_3500x2500(torch_cuda, stitch_model):
     # (stitch_model runs the seams' default mode, f16x3)
     tiles, nxf, nyf = tiling.tile_grid(3500, 2500, 448, 448)
     assert len(tiles) == 70
-    g = model.graph
+    from oracle.keras_config import read_model_config
+    g = read_model_config(cfg)
     for k in (0, 23, 38, 52, 69):                                    # corners, an interior tile, clamped last row/column
         t = tiles[k]
         x = (page[t["y0"]:t["y0"] + 448, t["x0"]:t["x0"] + 448][None] / 255.0).astype(np.float32)
@@ -537,7 +538,7 @@ def test_config4_pages_4000x3000_sharded_single_rank(torch_cuda, stitch_model):
         for k in (5 + 40 * p, 107 - 30 * p):
             t = tiles[k]
             x = (page[t["y0"]:t["y0"] + 448, t["x0"]:t["x0"] + 448][None] / 255.0).astype(np.float32)
-            ref = kf.forward(stitch_model.graph, w, x)[0]
+            ref = kf.forward_config(stitch_model.test_cfg, w, x)[0]
             sl = (slice(t["y0"] + t["ylo"], t["y0"] + t["yhi"]), slice(t["x0"] + t["xlo"], t["x0"] + t["xhi"]))
             r = ref[t["ylo"]:t["yhi"], t["xlo"]:t["xhi"]]
             srt = np.sort(r, axis=-1)
@@ -586,3 +587,32 @@ def test_model_load_survives_injected_bad_alloc():
     m2 = SegModel(cfg, w, device=0, max_batch=2, precision="f16")
     assert m2.predict(np.zeros((1, 64, 64, 3), np.float32)).shape == (1, 64, 64, 2)
     m2.release()
+
+
+@pytest.mark.parametrize("precision", ["f16x3", "f32", "f16"])
+def test_handwritten_keras23_fixture_through_c_abi(precision):
+    """tests/golden/keras23_model_config.json (hand-written Keras-2.3 functional Model: marshalled Lambda, three ZeroPadding2D
+    tuple forms, stride-2 1x1 projection, 3 classes) loaded by the product's parser/planner and run through the C ABI, against
+    the oracle reading the same JSON with its OWN reader (oracle/keras_config.py)."""
+    from sbb_textline_detection_amd.keras_graph import parse_model_config
+    from sbb_textline_detection_amd.model import SegModel
+    from sbb_textline_detection_amd.weights import synthetic_weights
+    cfg = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "keras23_model_config.json")))
+    w = synthetic_weights(parse_model_config(cfg), seed=5)
+    rng = np.random.RandomState(2)
+    for name in list(w):
+        if name.endswith("moving_variance:0"):
+            w[name] = rng.uniform(0.5, 2.0, w[name].shape).astype(np.float32)
+    x = rng.rand(3, 32, 48, 3).astype(np.float32)
+    ref = kf.forward_config(cfg, w, x)
+    m = SegModel(cfg, w, device=0, max_batch=3, precision=precision)
+    got = m.predict(x)
+    d = float(np.abs(got - ref).max())
+    print(f"[keras23 fixture {precision}] max|dsoftmax| = {d:.2e}")
+    assert got.shape == (3, 32, 48, 3)
+    if precision in ("f16x3", "f32"):
+        mism, bad = exact_label_check(ref, got)
+        assert d < TOL_SOFTMAX[precision] and bad == 0
+    else:
+        assert d < 0.05
+    m.release()

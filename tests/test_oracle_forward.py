@@ -7,6 +7,7 @@ import pytest
 import torch
 
 from oracle import keras_forward as kf
+from oracle.keras_config import read_model_config
 from sbb_textline_detection_amd.keras_graph import parse_model_config, resnet50_unet_config
 from sbb_textline_detection_amd.weights import synthetic_model
 from tools.synth_model import calibrated_model, forward_torch
@@ -17,7 +18,7 @@ GOLD = os.path.join(os.path.dirname(__file__), "golden", "forward_golden_64.npz"
 def test_forward_golden_regression():
     d = np.load(GOLD)
     cfg, w = synthetic_model(int(d["classes"]), 64, 64, seed=int(d["seed"]))
-    p = kf.forward(parse_model_config(cfg), w, d["x"])
+    p = kf.forward(read_model_config(cfg), w, d["x"])
     assert p.shape == d["probs"].shape and p.dtype == np.float32
     assert np.abs(p - d["probs"]).max() < 1e-5
     assert np.array_equal(p.argmax(-1), d["probs"].argmax(-1))
@@ -28,7 +29,7 @@ def test_oracle_vs_torch_cpu(classes, hw):
     cfg, w = calibrated_model(classes, hw[0], hw[1], seed=3, calib_hw=64)
     g = parse_model_config(cfg)
     x = (np.random.RandomState(5).randint(0, 256, (2, hw[0], hw[1], 3)) / 255.0).astype(np.float32)
-    p = kf.forward(g, w, x)
+    p = kf.forward(read_model_config(cfg), w, x)          # oracle: its own reader + C conv; torch: the product's parser + torch ops
     q32 = forward_torch(g, w, x, torch.float32)
     q64 = forward_torch(g, w, x, torch.float64)
     assert np.abs(p - q64).max() < 1e-3 and np.abs(p - q32).max() < 1e-3

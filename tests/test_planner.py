@@ -4,6 +4,7 @@ import numpy as np
 import pytest
 
 from oracle import keras_forward as kf
+from oracle.keras_config import read_model_config
 from plan_interp import run_plan
 from sbb_textline_detection_amd.keras_graph import parse_model_config, resnet50_unet_config
 from sbb_textline_detection_amd.planner import PlanError, build_plan
@@ -20,7 +21,7 @@ def test_plan_equals_oracle(classes, hw, parity, fuse):
     plan = build_plan(g, w, parity_split=parity, fuse_head=fuse, fuse_tail=(classes == 2))
     page = synthetic_page(300, 400, 5)
     x = np.stack([page[10:10 + hw[0], 20:20 + hw[1]], page[100:100 + hw[0], 200:200 + hw[1]]]).astype(np.float32) / 255
-    ref = kf.forward(g, w, x)
+    ref = kf.forward(read_model_config(cfg), w, x)
     lab, pr, _ = run_plan(plan, x)
     assert np.abs(ref - pr).max() < 5e-4
     srt = np.sort(ref, axis=-1)
