@@ -89,6 +89,16 @@ def read_model_config(model_config) -> LayerGraph:
                         "activation": c.get("activation", "linear")}, (_window_out(h, k[0], s[0], c["padding"]),
                                                                        _window_out(w, k[1], s[1], c["padding"]), f)
 
+    def conv_transpose(c, i):
+        k, s = _two(c["kernel_size"]), _two(c["strides"])
+        if c.get("output_padding") is not None or _two(c.get("dilation_rate", 1)) != (1, 1) or c["padding"] not in ("same", "valid"):
+            raise ValueError("Conv2DTranspose with output_padding / dilation")
+        h, w, _ = shape_of[i[0]]
+        f = int(c["filters"])
+        grow = (0, 0) if c["padding"] == "same" else (max(k[0] - s[0], 0), max(k[1] - s[1], 0))
+        return "convT", {"kernel": k, "strides": s, "padding": c["padding"], "filters": f, "use_bias": bool(c.get("use_bias", True)),
+                         "activation": c.get("activation", "linear")}, (h * s[0] + grow[0], w * s[1] + grow[1], f)
+
     def bn(c, i):
         ax = c.get("axis", -1)
         ax = ax[0] if isinstance(ax, (list, tuple)) else ax
@@ -147,7 +157,7 @@ def read_model_config(model_config) -> LayerGraph:
     def identity(c, i):
         return "act", {"kind": "linear"}, shape_of[i[0]]
 
-    readers = {"Conv2D": conv, "BatchNormalization": bn, "ZeroPadding2D": zeropad, "Activation": act, "MaxPooling2D": maxpool,
+    readers = {"Conv2D": conv, "Conv2DTranspose": conv_transpose, "BatchNormalization": bn, "ZeroPadding2D": zeropad, "Activation": act, "MaxPooling2D": maxpool,
                "UpSampling2D": upsample, "Concatenate": concat, "Add": add, "Lambda": lam, "Dropout": identity,
                "SpatialDropout2D": identity}
     for entry in top["layers"]:

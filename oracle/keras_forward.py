@@ -84,6 +84,30 @@ def conv2d(x: np.ndarray, w: np.ndarray, bias: Optional[np.ndarray], strides, pa
     return y
 
 
+def conv2d_transpose(x: np.ndarray, w: np.ndarray, bias: Optional[np.ndarray], strides, padding: str) -> np.ndarray:
+    """Keras ``Conv2DTranspose`` [EXT]: x [N,H,W,Cin] f32, w [KH,KW,Cout,Cin] (Keras' transposed-conv kernel layout).
+    TF ``conv2d_transpose`` = the gradient of ``conv2d`` w.r.t. its input: every input pixel scatters its
+    KH x KW x Cout patch at stride s; 'same' crops the result to H*s x W*s starting max(K-s,0)//2 in (the SAME padding
+    of the forward conv it is the gradient of), 'valid' keeps all (H-1)*s + K rows (H*s when K < s).  Plain numpy."""
+    x = np.ascontiguousarray(x, np.float32)
+    N, H, W, Cin = x.shape
+    KH, KW, Cout, Cin2 = w.shape
+    assert Cin == Cin2
+    sy, sx = strides
+    if padding == "same":
+        OH, OW, pt, pl = H * sy, W * sx, max(KH - sy, 0) // 2, max(KW - sx, 0) // 2
+    else:
+        OH, OW, pt, pl = H * sy + max(KH - sy, 0), W * sx + max(KW - sx, 0), 0, 0
+    full = np.zeros((N, max((H - 1) * sy + KH, pt + OH), max((W - 1) * sx + KW, pl + OW), Cout), np.float32)
+    for ky in range(KH):
+        for kx in range(KW):
+            full[:, ky:ky + (H - 1) * sy + 1:sy, kx:kx + (W - 1) * sx + 1:sx, :] += x @ np.ascontiguousarray(w[ky, kx].T, np.float32)
+    y = full[:, pt:pt + OH, pl:pl + OW, :]
+    if bias is not None:
+        y = y + np.asarray(bias, np.float32)
+    return np.ascontiguousarray(y, np.float32)
+
+
 def _maxpool(x, pool, strides):
     ph, pw = pool
     sy, sx = strides
@@ -127,6 +151,11 @@ def forward(graph, weights: Dict[str, np.ndarray], x: np.ndarray, taps=None, con
             if conv_hook is not None:
                 xin, wk = conv_hook(n, xin, wk)
             y = conv2d(xin, wk, bias, n.attrs["strides"], n.attrs["padding"])
+            if n.attrs.get("activation", "linear") == "relu":
+                y = np.maximum(y, 0)
+        elif n.op == "convT":
+            bias = weights.get(f"{n.name}/bias:0") if n.attrs["use_bias"] else None
+            y = conv2d_transpose(a[0], weights[f"{n.name}/kernel:0"], bias, n.attrs["strides"], n.attrs["padding"])
             if n.attrs.get("activation", "linear") == "relu":
                 y = np.maximum(y, 0)
         elif n.op == "bn":

@@ -123,6 +123,12 @@ class _Builder:
             "bias_regularizer": None, "activity_regularizer": None, "kernel_constraint": None,
             "bias_constraint": None}, [x])
 
+    def conv_transpose(self, x, filters, k, strides=2, padding="same", name=None):
+        return self._add("Conv2DTranspose", name or self._auto("conv2d_transpose"), {
+            "filters": filters, "kernel_size": [k, k], "strides": [strides, strides], "padding": padding,
+            "output_padding": None, "data_format": "channels_last", "dilation_rate": [1, 1], "activation": "linear",
+            "use_bias": True}, [x])
+
     def bn(self, x, name=None):
         return self._add("BatchNormalization", name or self._auto("batch_normalization"), {
             "axis": 3, "momentum": 0.99, "epsilon": BN_EPS_DEFAULT, "center": True, "scale": True,
@@ -236,6 +242,30 @@ def resnet50_unet_config(n_classes: int, input_height: int = 448, input_width: i
             "keras_version": "2.3.1", "backend": "tensorflow"}
 
 
+def transpose_unet_config(n_classes: int, input_height: int = 64, input_width: int = 64, k: int = 2,
+                          padding: str = "same", base: int = 16) -> dict:
+    """A small U-Net whose decoder upsamples with ``Conv2DTranspose`` (k x k, stride 2) instead of ``UpSampling2D`` --
+    the decoder form BASELINE.json's north_star names ("transposed-conv upsamples"; SURVEY.md 0.5: support both).
+    Two 3x3 stride-2 encoder convs, two transposed convs back up, skip concats, 32-channel last conv, 1x1 head."""
+    assert input_height % 4 == 0 and input_width % 4 == 0
+    b = _Builder()
+    img = b.input(input_height, input_width, 3)
+    e1 = b.act(b.bn(b.conv(img, base, 3, padding="same")), "relu")                       # H
+    e2 = b.act(b.bn(b.conv(e1, 2 * base, 3, strides=2, padding="same")), "relu")         # H/2
+    e3 = b.act(b.bn(b.conv(e2, 4 * base, 3, strides=2, padding="same")), "relu")         # H/4
+    assert padding == "same" or k == 2, "valid padding with k > stride grows the output (no matching skip size)"
+    u = b.act(b.bn(b.conv_transpose(e3, 2 * base, k, 2, padding)), "relu")               # H/2
+    o = b.concat([u, e2])
+    o = b.act(b.bn(b.conv(o, 2 * base, 3, padding="same")), "relu")
+    u = b.act(b.bn(b.conv_transpose(o, base, k, 2, "same")), "relu")                     # H
+    o = b.concat([u, e1])
+    o = b.act(b.bn(b.conv(o, 32, 3, padding="same")), "relu")
+    o = b.act(b.bn(b.conv(o, n_classes, 1, padding="same")), "softmax")
+    return {"class_name": "Model",
+            "config": {"name": "model_t", "layers": b.layers, "input_layers": [[img, 0, 0]], "output_layers": [[o, 0, 0]]},
+            "keras_version": "2.3.1", "backend": "tensorflow"}
+
+
 # ------------------------------------------------------------------- parser
 def _pad4(padding) -> Tuple[int, int, int, int]:
     """Keras ZeroPadding2D ``padding`` -> (top, bottom, left, right)."""
@@ -310,6 +340,8 @@ def parse_model_config(model_config) -> Graph:
         elif cls == "Conv2DTranspose":
             kh, kw = _pair(lc["kernel_size"]); sy, sx = _pair(lc["strides"])
             padding = lc["padding"]
+            if lc.get("output_padding") is not None or _pair(lc.get("dilation_rate", 1)) != (1, 1) or padding not in ("same", "valid"):
+                raise ValueError(f"layer {name}: Conv2DTranspose with output_padding / dilation / padding {padding!r} unsupported")
             oh = ish[0] * sy if padding == "same" else ish[0] * sy + max(kh - sy, 0)
             ow = ish[1] * sx if padding == "same" else ish[1] * sx + max(kw - sx, 0)
             node = Node(name, "convT", ins, {

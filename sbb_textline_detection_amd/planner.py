@@ -178,6 +178,7 @@ class _Pending:
         self.emitted_raw = -1
         self.stage = "conv"          # conv -> bn -> (add) -> relu
         self.multi = None            # merged convs: explicit per-source Segs (geometry + weights)
+        self.convT = None            # Conv2DTranspose: (kh, kw, pad_top, pad_left) of the transposed conv, stride 2
         self.name = node.name
 
 
@@ -248,6 +249,41 @@ def build_plan(graph: Graph, weights: Dict[str, np.ndarray], parity_split: bool 
                       out=p.emitted_out, relu=p.relu, residual=p.residual, raw_out=p.emitted_raw,
                       raw_scale=p.raw_scale.astype(np.float32) if p.raw_needed else None,
                       raw_shift=p.raw_shift.astype(np.float32) if p.raw_needed else None)
+        if p.convT is not None:
+            # Conv2DTranspose, stride 2:  out[2i + ky - pt][2j + kx - pl] += x[i][j] . w[ky][kx]   (gradient-of-conv form).
+            # Output row y = 2a + py collects the taps ky with (py + pt - ky) even, from input row a + d, d = (py + pt - ky) / 2:
+            # each output-parity class is an ordinary stride-1 conv over the SOURCE resolution with a sub-kernel of the taps
+            # that land on it (k = 2: four 1x1 convs; k = 3: 2x2 / 2x1 / 1x2 / 1x1) -- same MACs as the reference's scatter form.
+            kh, kw, pt, pl = p.convT
+            ih, iw = p.in_hw
+            macs_t = float(ih * iw * kh * kw * sum(g.channels for g in srcs) * p.cout)
+            n_cls = 0
+            for py in (0, 1):
+                dys = sorted({(py + pt - ky) // 2 for ky in range(kh) if (py + pt - ky) % 2 == 0})
+                for px in (0, 1):
+                    dxs = sorted({(px + pl - kx) // 2 for kx in range(kw) if (px + pl - kx) % 2 == 0})
+                    ch, cw = (oh - py + 1) // 2, (ow - px + 1) // 2
+                    if ch <= 0 or cw <= 0:
+                        continue
+                    if not dys or not dxs:
+                        raise PlanError(f"{p.name}: Conv2DTranspose parity class ({py},{px}) receives no taps (kernel smaller than stride)")
+                    kh2, kw2 = dys[-1] - dys[0] + 1, dxs[-1] - dxs[0] + 1
+                    psrcs = []
+                    for g in srcs:
+                        w2 = np.zeros((kh2, kw2, g.channels, p.cout), np.float32)
+                        for ty in range(kh2):
+                            ky = py + pt - 2 * (dys[0] + ty)
+                            for tx in range(kw2):
+                                kx = px + pl - 2 * (dxs[0] + tx)
+                                if 0 <= ky < kh and 0 <= kx < kw:
+                                    w2[ty, tx] = g.w[ky, kx]
+                        psrcs.append(Seg(g.tensor, g.channels, 0, g.off_y, g.off_x, kh2, kw2, 1, 1, -dys[0], -dxs[0], w2))
+                    plan.steps.append(ConvStep(f"{p.node.name}:t{py}{px}", psrcs, out_h=ch, out_w=cw, out_stride=(2, 2),
+                                               out_off=(py, px), algorithmic_macs=0.0, **common))
+                    n_cls += 1
+            for st in plan.steps[-n_cls:]:
+                st.algorithmic_macs = macs_t / n_cls
+            return
         macs = float(oh * ow * p.cout * p.logical_macs_per_out)
         origin = dict(srcs=srcs, geom=(p.kh, p.kw, p.sy, p.sx, p.pt, p.pl), out_hw=(oh, ow), macs=macs, name=p.node.name)
         splittable = (parity_split and p.multi is None and srcs[0].shift == 1 and (p.kh, p.kw, p.sy, p.sx, p.pt, p.pl) == (3, 3, 1, 1, 1, 1)
@@ -417,7 +453,8 @@ def build_plan(graph: Graph, weights: Dict[str, np.ndarray], parity_split: bool 
             if not cand:
                 raise PlanError(f"{n.name}: Add needs one input that is a conv(+BN) with a single consumer")
             pa, pb = va.pending, vb.pending
-            if (merge_shortcut and len(cand) == 2 and pa.multi is None and pb.multi is None and len(pa.srcs) == 1
+            if (merge_shortcut and len(cand) == 2 and pa.multi is None and pb.multi is None and pa.convT is None and pb.convT is None
+                    and len(pa.srcs) == 1
                     and len(pb.srcs) == 1 and not pa.raw_needed and not pb.raw_needed and pa.cout == pb.cout
                     and pa.out_hw == pb.out_hw and not pa.srcs[0].shift and not pb.srcs[0].shift
                     and pa.srcs[0].tensor >= 0 and pb.srcs[0].tensor >= 0):
@@ -531,8 +568,27 @@ def build_plan(graph: Graph, weights: Dict[str, np.ndarray], parity_split: bool 
             views[n.name] = _View(oh, ow, [Seg(dst, c)])
             plan.layer_tensor[n.name] = dst
         elif n.op == "convT":
-            raise PlanError(f"{n.name}: Conv2DTranspose decoders are not used by the sbb models "
-                            "(UpSampling2D is); not lowered yet")
+            # Keras Conv2DTranspose (kernel [kh][kw][out][in]); lowered to output-parity classes in emit()
+            src = gatherable(n.inputs[0])
+            kh, kw = n.attrs["kernel"]
+            sy, sx = n.attrs["strides"]
+            oh, ow, cout = n.out_shape
+            if (sy, sx) != (2, 2) or kh < 2 or kw < 2:
+                raise PlanError(f"{n.name}: only stride-2 Conv2DTranspose with kernel >= 2 is lowered")
+            if any(s.shift or s.tensor < 0 for s in src.segs) or len(src.segs) > 2:
+                raise PlanError(f"{n.name}: Conv2DTranspose source must be one or two stored tensors")
+            if n.attrs.get("activation", "linear") not in ("linear", "relu"):
+                raise PlanError(f"{n.name}: inline activation {n.attrs['activation']} unsupported")
+            # TF: the transposed conv is the gradient of a SAME/VALID conv with this kernel and stride
+            pt = max(kh - sy, 0) // 2 if n.attrs["padding"] == "same" else 0
+            pl = max(kw - sx, 0) // 2 if n.attrs["padding"] == "same" else 0
+            wt = np.ascontiguousarray(np.transpose(weights[f"{n.name}/kernel:0"].astype(np.float32), (0, 1, 3, 2)))   # -> [kh][kw][in][out]
+            bias = weights[f"{n.name}/bias:0"] if n.attrs["use_bias"] else None
+            p = _Pending(n, src.segs, kh, kw, 1, 1, 0, 0, cout, wt, bias, (oh, ow), 0)
+            p.convT, p.in_hw = (kh, kw, pt, pl), (src.H, src.W)
+            if n.attrs.get("activation", "linear") == "relu":
+                p.relu, p.stage = True, "relu"
+            views[n.name] = _View(oh, ow, pending=p)
         else:
             raise PlanError(f"{n.name}: op {n.op} not lowered")
 

@@ -616,3 +616,25 @@ def test_handwritten_keras23_fixture_through_c_abi(precision):
     else:
         assert d < 0.05
     m.release()
+
+
+@pytest.mark.parametrize("k,precision", [(2, "f16x3"), (3, "f16x3"), (2, "f16"), (3, "f32")])
+def test_conv2d_transpose_decoder_through_c_abi(k, precision):
+    """A U-Net whose decoder upsamples with Conv2DTranspose (k x k, stride 2) -- lowered to output-parity class convs --
+    through the C ABI against the oracle's scatter-form Conv2DTranspose."""
+    from sbb_textline_detection_amd.keras_graph import parse_model_config, transpose_unet_config
+    from sbb_textline_detection_amd.model import SegModel
+    from sbb_textline_detection_amd.weights import synthetic_weights
+    cfg = transpose_unet_config(3, 64, 96, k=k)
+    w = synthetic_weights(parse_model_config(cfg), seed=4)
+    x = (patches_from_page(64, 96, 3, seed=6) / 255.0).astype(np.float32)
+    ref = kf.forward_config(cfg, w, x)
+    m = SegModel(cfg, w, device=0, max_batch=3, precision=precision)
+    got = m.predict(x)
+    d = float(np.abs(got - ref).max())
+    print(f"[convT k={k} {precision}] max|dsoftmax| = {d:.2e}")
+    if precision in ("f16x3", "f32"):
+        assert d < TOL_SOFTMAX[precision] and exact_label_check(ref, got)[1] == 0
+    else:
+        assert d < 0.05
+    m.release()

@@ -51,6 +51,19 @@ def forward_torch(graph, weights, x_nhwc, dtype=torch.float32, calibrate_bn=Fals
                 th = max((-(-H // sy) - 1) * sy + kh - H, 0); tw = max((-(-W // sx) - 1) * sx + kw - W, 0)
                 xin = F.pad(xin, (tw // 2, tw - tw // 2, th // 2, th - th // 2))
             y = F.conv2d(xin, w, bias, stride=n.attrs["strides"])
+        elif n.op == "convT":
+            # Keras kernel [kh][kw][out][in] -> torch conv_transpose2d weight [in][out][kh][kw]
+            w = t(weights[f"{n.name}/kernel:0"]).permute(3, 2, 0, 1).contiguous()
+            bias = t(weights[f"{n.name}/bias:0"]) if n.attrs["use_bias"] else None
+            kh, kw = n.attrs["kernel"]; sy, sx = n.attrs["strides"]
+            full = F.conv_transpose2d(a[0], w, bias, stride=(sy, sx))                 # (H-1)*s + k rows: the 'valid' result for k >= s
+            H, W = a[0].shape[2:]
+            if n.attrs["padding"] == "same":
+                pt, pl = max(kh - sy, 0) // 2, max(kw - sx, 0) // 2
+                full = F.pad(full, (0, max(pl + W * sx - full.shape[3], 0), 0, max(pt + H * sy - full.shape[2], 0)))
+                y = full[:, :, pt:pt + H * sy, pl:pl + W * sx]
+            else:
+                y = F.pad(full, (0, max(W * sx - full.shape[3], 0), 0, max(H * sy - full.shape[2], 0)))
         elif n.op == "bn":
             if calibrate_bn:
                 m = a[0].mean(dim=(0, 2, 3)); v = a[0].var(dim=(0, 2, 3), unbiased=False)
