@@ -1,21 +1,31 @@
 #!/usr/bin/env python3
 """bench.py -- segmented patches/sec (448x448x3) on MI355X for the do_prediction hot path.
 
-A *step* is one pass of the fused hot path over one synthetic page resident in HBM:
+A *step* is one pass of the fused hot path over one batch of synthetic pages resident in HBM:
 u8 page -> LUT normalise + tiling -> ResNet-50-U-Net forward (HIP, MFMA) -> softmax/argmax ->
-margin-crop stitch -> u8 label map in HBM.  Workload (BASELINE.json configs[1]): one 3500x2500 page,
-textline model (2 classes), margin 0.1 -> 70 tiles of 448x448 per step and per GPU.
+margin-crop stitch -> u8 label map in HBM, page after page.
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): every rank segments its own page
-(weak scaling) and the per-rank label maps are exchanged with one RCCL all-gather per step
-(the "stitch" exchange north_star names).  value = tiles of all ranks / max-over-ranks time.
+N = 1 (default): BASELINE.json configs[1] -- 3500x2500 pages, textline model (2 classes), margin 0.1 -> 70 tiles
+of 448x448 per page; a step is `--pages-per-step` (16) such pages back to back, so that the timed region lasts
+seconds, not a fraction of one (the clocks settle).  value = tiles / time, the median of `--repeats` (3) timed
+regions of exactly K steps each (all repeats are reported).
 
-Prints ONE JSON line on rank 0.  Extra objects: `roofline` (dominant conv kernel, HIP-event timed
-per launch on the library's stream) and `cpu_baseline` (oracle port on the host cores, rank 0, N=1).
+N > 1 (launched by torch.distributed.run, one rank per GPU): BASELINE.json configs[3] -- 64 pages of 4000x3000
+(108 tiles each) sharded as whole pages over the ranks, one RCCL all-gather of the u8 masks per step (the
+"stitch" exchange north_star names); strong scaling.  `--workload page` keeps the weak-scaling page workload.
+
+Two arithmetic modes are measured in the same run (N = 1): the one `--precision` names is `value`; the other one
+is reported under `modes`.  "f16" = the fast mode (plain fp16 operands), "f16x3" = the label-exact split mode
+(the default of the Python seams).  Each carries its live label agreement with the fp32 oracle.
+
+Prints ONE JSON line on rank 0.  Extra objects: `roofline` (dominant conv launch, HIP-event timed per launch on
+the library's stream) and `cpu_baseline` (torch-CPU fp32 proxy of the Keras/TF CPU path on the host cores;
+the oracle port is kept beside it), rank 0, N = 1.
 """
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -27,7 +37,10 @@ import numpy as np  # noqa: E402
 
 MFMA_PEAK_TFLOPS = 2500.0      # dense bf16/f16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md
 PAGE_H, PAGE_W = 3500, 2500    # BASELINE.json configs[1]
+if os.environ.get("SBBSEG_BENCH_PAGE"):      # experiment knob (A/B of chunk sizes): "HxW" of the page workload's pages
+    PAGE_H, PAGE_W = (int(v) for v in os.environ["SBBSEG_BENCH_PAGE"].lower().split("x"))
 MODEL_HW, CLASSES = 448, 2
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r02_pmc_summary.json")
 
 
 def main():
@@ -35,19 +48,20 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--precision", default=os.environ.get("SBBSEG_PRECISION", "f16"), choices=["f16", "bf16", "f16x3"])
+    ap.add_argument("--repeats", type=int, default=3, help="timed regions of exactly --steps steps each; value = their median")
+    ap.add_argument("--precision", default=os.environ.get("SBBSEG_BENCH_PRECISION", "f16"), choices=["f16", "bf16", "f16x3"])
     ap.add_argument("--max-batch", type=int, default=int(os.environ.get("SBBSEG_MAX_BATCH", "0")),
                     help="tiles per chunk (0 = one page per chunk: 70 for the 3500x2500 page, 108 for the 4000x3000 pages of batch64)")
     ap.add_argument("--conv-variant", type=int, default=int(os.environ.get("SBBSEG_CONV_VARIANT", "0")),
-                    help="0 auto, 1 force 4-wave/2-stage conv tiles, 2 force 8-wave/3-stage (A/B only)")
-    ap.add_argument("--workload", default="page", choices=["page", "pipeline3", "batch64"],
-                    help="page = BASELINE configs[1] (default, the metric's config); pipeline3 = configs[2] (border whole-image "
-                         "+ layout + textline on one page); batch64 = configs[3] (64 pages of 4000x3000 sharded over the ranks)")
+                    help="A/B knob of the conv kernel (see sbbseg.h sbbseg_debug_set_conv_variant)")
+    ap.add_argument("--workload", default="auto", choices=["auto", "page", "pipeline3", "batch64"],
+                    help="auto = page at 1 GPU (BASELINE configs[1], the metric's config), batch64 at N > 1 (configs[3]: 64 pages of "
+                         "4000x3000 sharded over the ranks, strong scaling); pipeline3 = configs[2] (border + layout + textline)")
+    ap.add_argument("--pages-per-step", type=int, default=16, help="page workload: pages segmented back to back per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-second-mode", action="store_true")
     ap.add_argument("--cpu-patches", type=int, default=8)
     args = ap.parse_args()
-    if args.max_batch <= 0:
-        args.max_batch = 108 if args.workload == "batch64" else 70
 
     import torch
     import torch.distributed as dist
@@ -59,64 +73,53 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
         raise SystemExit(f"WORLD_SIZE={world} but --gpus {args.gpus}")
+    workload = args.workload if args.workload != "auto" else ("page" if world == 1 else "batch64")
+    if args.max_batch <= 0:
+        args.max_batch = 108 if workload == "batch64" else 70
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
+    from sbb_textline_detection_amd import _capi
     from sbb_textline_detection_amd.model import SegModel
     from sbb_textline_detection_amd.synthetic import synthetic_page
     from tools.synth_model import calibrated_model
 
     cfg, weights = calibrated_model(CLASSES, MODEL_HW, MODEL_HW, seed=0)
-    model = SegModel(cfg, weights, device=local_rank, max_batch=args.max_batch, precision=args.precision)
-    ctx = model.ctx
-    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
-    ctx.set_conv_variant(args.conv_variant)
+    stream = torch.cuda.current_stream().cuda_stream
 
-    page = synthetic_page(PAGE_H, PAGE_W, seed=rank)
-    d_page = torch.from_numpy(page).cuda()
-    d_labels = torch.empty((PAGE_H, PAGE_W), dtype=torch.uint8, device="cuda")
-    d_all = torch.empty((world, PAGE_H, PAGE_W), dtype=torch.uint8, device="cuda") if world > 1 else None
-    from sbb_textline_detection_amd import _capi
+    def make_model(precision, classes_cfg=None, max_batch=None):
+        c, w = classes_cfg or (cfg, weights)
+        m = SegModel(c, w, device=local_rank, max_batch=max_batch or args.max_batch, precision=precision)
+        m.ctx.set_stream(stream)
+        m.ctx.set_conv_variant(args.conv_variant)
+        return m
+
+    model = make_model(args.precision)
     tiles_per_page = _capi.tile_grid(PAGE_H, PAGE_W, MODEL_HW, MODEL_HW)[0].shape[0]
+    page0 = synthetic_page(PAGE_H, PAGE_W, seed=rank)
 
-    scaling = "weak"
-    workload_desc = (f"one {PAGE_H}x{PAGE_W} page per GPU per step, textline model (ResNet-50-U-Net, {CLASSES} classes, "
-                     f"seeded synthetic weights), margin 0.1 -> {tiles_per_page} tiles of 448x448")
-    tiles_per_step = tiles_per_page * world
+    # ---- workloads: build(model) -> (step(), tiles per step, description, scaling, gather() or None, bytes gathered)
+    def build_page(m):
+        P = max(1, args.pages_per_step)
+        pages = [torch.from_numpy(page0 if k == 0 else synthetic_page(PAGE_H, PAGE_W, seed=rank * 1000 + k)).cuda() for k in range(P)]
+        labels = torch.empty((P, PAGE_H, PAGE_W), dtype=torch.uint8, device="cuda")
+        d_all = torch.empty((world, P, PAGE_H, PAGE_W), dtype=torch.uint8, device="cuda") if world > 1 else None
 
-    def step():
-        ctx.segment_page_dev(d_page.data_ptr(), PAGE_H, PAGE_W, d_labels.data_ptr())
-        if world > 1:
-            dist.all_gather_into_tensor(d_all.view(-1), d_labels.view(-1))
+        def gather():
+            dist.all_gather_into_tensor(d_all.view(-1), labels.view(-1))
 
-    if args.workload == "pipeline3":
-        # configs[2]: the three stage models on one page (model load excluded, models stay resident)
-        cfg_b, w_b = calibrated_model(2, MODEL_HW, MODEL_HW, seed=11)
-        cfg_l, w_l = calibrated_model(4, MODEL_HW, MODEL_HW, seed=12)
-        m_border = SegModel(cfg_b, w_b, device=local_rank, max_batch=1, precision=args.precision)
-        m_layout = SegModel(cfg_l, w_l, device=local_rank, max_batch=args.max_batch, precision=args.precision)
-        for m in (m_border, m_layout):
-            m.ctx.set_stream(torch.cuda.current_stream().cuda_stream)
-        d_thr = torch.zeros(1, dtype=torch.int32, device="cuda")
-        d_tiles2 = torch.empty((tiles_per_page, MODEL_HW, MODEL_HW), dtype=torch.uint8, device="cuda")
-        d_lab2 = torch.empty((PAGE_H, PAGE_W), dtype=torch.uint8, device="cuda")
-        tiles_per_step = (1 + 2 * tiles_per_page) * world
-        workload_desc = (f"three-model pipeline on one {PAGE_H}x{PAGE_W} page per GPU: border (whole image, 1 forward) + layout "
-                         f"(device Otsu + binarising gather, 4 classes, {tiles_per_page} tiles) + textline ({tiles_per_page} tiles); models resident")
+        def step():
+            for k in range(P):
+                m.ctx.segment_page_dev(pages[k].data_ptr(), PAGE_H, PAGE_W, labels[k].data_ptr())
+            if world > 1:
+                gather()
+        desc = (f"{P} pages of {PAGE_H}x{PAGE_W} per GPU per step (BASELINE configs[1]: one such page = {tiles_per_page} tiles of 448x448, "
+                f"margin 0.1), textline model (ResNet-50-U-Net, {CLASSES} classes, seeded synthetic weights)")
+        return step, tiles_per_page * P * world, desc, "weak", (gather if world > 1 else None), P * PAGE_H * PAGE_W * world
 
-        def step():  # noqa: F811
-            m_border.segment_whole(page, PAGE_H, PAGE_W)                       # host page in / host mask out (1 forward)
-            # layout stage = otsu_copy + do_prediction (main.py:443-447): histogram, threshold and the
-            # binarising gather all run on the device inside the timed step
-            m_layout.ctx.otsu_dev(d_page.data_ptr(), PAGE_H, PAGE_W, d_thr.data_ptr())
-            m_layout.ctx.segment_tile_range_bin_dev(d_page.data_ptr(), PAGE_H, PAGE_W, 0, tiles_per_page, d_thr.data_ptr(),
-                                                    d_tiles2.data_ptr())
-            m_layout.ctx.stitch_dev(d_tiles2.data_ptr(), PAGE_H, PAGE_W, d_lab2.data_ptr())
-            ctx.segment_page_dev(d_page.data_ptr(), PAGE_H, PAGE_W, d_labels.data_ptr())
-    elif args.workload == "batch64":
-        # configs[3]: 64 pages of 4000x3000, whole pages per rank, one all-gather of the masks per step
+    def build_batch64(m):
         BH, BW, NPAGES = 4000, 3000, 64
         from sbb_textline_detection_amd.distributed import shard_block
         first, count, block = shard_block(NPAGES, rank, world)
@@ -124,118 +127,244 @@ def main():
         d_mine = torch.empty((block, BH, BW), dtype=torch.uint8, device="cuda")
         d_everything = torch.empty((world * block, BH, BW), dtype=torch.uint8, device="cuda") if world > 1 else None
         tpp = _capi.tile_grid(BH, BW, MODEL_HW, MODEL_HW)[0].shape[0]
-        tiles_per_step = tpp * NPAGES
-        scaling = "strong"
-        workload_desc = (f"{NPAGES} pages of {BH}x{BW} ({tpp} tiles each) sharded as whole pages over the ranks, textline model, "
-                         f"one RCCL all-gather of the u8 masks per step")
 
-        def step():  # noqa: F811
+        def gather():
+            dist.all_gather_into_tensor(d_everything.view(-1), d_mine.view(-1))
+
+        def step():
             for k in range(count):
-                ctx.segment_page_dev(pages[k].data_ptr(), BH, BW, d_mine[k].data_ptr())
+                m.ctx.segment_page_dev(pages[k].data_ptr(), BH, BW, d_mine[k].data_ptr())
             if world > 1:
-                dist.all_gather_into_tensor(d_everything.view(-1), d_mine.view(-1))
+                gather()
+        desc = (f"BASELINE configs[3]: {NPAGES} pages of {BH}x{BW} ({tpp} tiles each) sharded as whole pages over the ranks, textline model, "
+                f"one RCCL all-gather of the u8 masks per step")
+        return step, tpp * NPAGES, desc, "strong", (gather if world > 1 else None), world * block * BH * BW
+
+    def build_pipeline3(m):
+        cfg_b, w_b = calibrated_model(2, MODEL_HW, MODEL_HW, seed=11)
+        cfg_l, w_l = calibrated_model(4, MODEL_HW, MODEL_HW, seed=12)
+        m_border = make_model(m.precision, (cfg_b, w_b), max_batch=1)
+        m_layout = make_model(m.precision, (cfg_l, w_l))
+        d_page = torch.from_numpy(page0).cuda()
+        d_labels = torch.empty((PAGE_H, PAGE_W), dtype=torch.uint8, device="cuda")
+        d_thr = torch.zeros(1, dtype=torch.int32, device="cuda")
+        d_tiles2 = torch.empty((tiles_per_page, MODEL_HW, MODEL_HW), dtype=torch.uint8, device="cuda")
+        d_lab2 = torch.empty((PAGE_H, PAGE_W), dtype=torch.uint8, device="cuda")
+
+        def step():
+            m_border.segment_whole(page0, PAGE_H, PAGE_W)                       # host page in / host mask out (1 forward)
+            # layout stage = otsu_copy + do_prediction (main.py:443-447): histogram, threshold and the
+            # binarising gather all run on the device inside the timed step
+            m_layout.ctx.otsu_dev(d_page.data_ptr(), PAGE_H, PAGE_W, d_thr.data_ptr())
+            m_layout.ctx.segment_tile_range_bin_dev(d_page.data_ptr(), PAGE_H, PAGE_W, 0, tiles_per_page, d_thr.data_ptr(), d_tiles2.data_ptr())
+            m_layout.ctx.stitch_dev(d_tiles2.data_ptr(), PAGE_H, PAGE_W, d_lab2.data_ptr())
+            m.ctx.segment_page_dev(d_page.data_ptr(), PAGE_H, PAGE_W, d_labels.data_ptr())
+        desc = (f"BASELINE configs[2]: three-model pipeline on one {PAGE_H}x{PAGE_W} page per GPU: border (whole image, 1 forward) + layout "
+                f"(device Otsu + binarising gather, 4 classes, {tiles_per_page} tiles) + textline ({tiles_per_page} tiles); models resident")
+        return step, (1 + 2 * tiles_per_page) * world, desc, "weak", None, 0
+
+    builders = {"page": build_page, "batch64": build_batch64, "pipeline3": build_pipeline3}
 
     def fence():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    total_tiles = tiles_per_step * args.steps
-    value = total_tiles / dt
+    def timed(step, steps, warmup, repeats):
+        for _ in range(warmup):
+            step()
+        out = []
+        for _ in range(repeats):
+            fence()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                step()
+            fence()
+            dt = time.perf_counter() - t0
+            if world > 1:
+                t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                dt = float(t.item())
+            out.append(dt)
+        return out
+
+    step, tiles_per_step, workload_desc, scaling, gather, gathered_bytes = builders[workload](model)
+    dts = timed(step, args.steps, args.warmup, max(1, args.repeats))
+    dt = statistics.median(dts)
+    value = tiles_per_step * args.steps / dt
+    rates = [tiles_per_step * args.steps / t for t in dts]
+
+    exchange = None
+    if gather is not None:                                          # the exchange alone: all-gather GB/s over xGMI
+        for _ in range(2):
+            gather()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(10):
+            gather()
+        fence()
+        gdt = (time.perf_counter() - t0) / 10
+        exchange = {"collective": "all_gather_into_tensor (RCCL) of the u8 page masks", "bytes_gathered_per_rank": gathered_bytes,
+                    "ms": round(gdt * 1e3, 3), "algbw_GBps": round(gathered_bytes / gdt / 1e9, 1),
+                    "busbw_GBps": round(gathered_bytes * (world - 1) / world / gdt / 1e9, 1),
+                    "share_of_step": round(gdt / (dt / args.steps), 4)}
 
     # ---- roofline of the dominant kernel: per-launch HIP events on the library's stream ----------
-    roofline = None
-    per_op = []
-    if rank == 0:
-        ctx.profile_enable(True)
-        ctx.profile_reset()
-        for _ in range(max(2, min(args.steps, 5))):
-            ctx.segment_page_dev(d_page.data_ptr(), PAGE_H, PAGE_W, d_labels.data_ptr())
+    def roofline_of(m):
+        d_page = torch.from_numpy(page0).cuda()
+        d_labels = torch.empty((PAGE_H, PAGE_W), dtype=torch.uint8, device="cuda")
+        c = m.ctx
+        c.profile_enable(True)
+        c.profile_reset()
+        for _ in range(5):
+            c.segment_page_dev(d_page.data_ptr(), PAGE_H, PAGE_W, d_labels.data_ptr())
         torch.cuda.synchronize()
-        prof = ctx.profile()
-        ctx.profile_enable(False)
+        prof = c.profile()
+        c.profile_enable(False)
         convs = [o for o in prof if "conv" in o["name"] and o["launches"] > 0]       # incl. stem_conv*, direct_conv*, tail_conv*
         tot_ms = sum(o["total_ms"] for o in prof)
-        conv_ms = sum(o["total_ms"] for o in convs)
-        conv_flops = sum(o["flops"] * o["patches"] for o in convs)
+
+        def rate(ops, key="flops"):
+            ms = sum(o["total_ms"] for o in ops)
+            return sum(o[key] * o["patches"] for o in ops) / (ms * 1e-3) / 1e12 if ms else 0.0
         # dominant kernel launch = the conv launch with the largest average duration (the four output-
         # parity classes of a decoder conv run as one grouped launch)
         dom = max(convs, key=lambda o: o["total_ms"] / o["launches"])
-        ach = dom["flops"] * dom["patches"] / (dom["total_ms"] * 1e-3) / 1e12
         k3 = [o for o in convs if any(t in o["name"] for t in ("conv3x3", "conv2x2"))]          # the 3x3 conv stages
-        k3_ms = sum(o["total_ms"] for o in k3)
-        k3_flops = sum(o["flops"] * o["patches"] for o in k3)
-        roofline = {
+        ach, iss = rate([dom]), rate([dom], "issued_flops")
+        r = {
             "bound": "mfma", "kernel": "conv_igemm_mfma:" + dom["name"],
             "achieved": round(ach, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": None,
+            "frac": round(ach / MFMA_PEAK_TFLOPS, 4),
+            "achieved_issued": round(iss, 2), "frac_issued": round(iss / MFMA_PEAK_TFLOPS, 4),
+            "traffic": None,
             "avg_launch_ms": round(dom["total_ms"] / dom["launches"], 4),
             "patches_per_launch": dom["patches"] / dom["launches"],
             "flops_per_launch": dom["flops"] * dom["patches"] / dom["launches"],
+            "issued_flops_per_launch": dom["issued_flops"] * dom["patches"] / dom["launches"],
             "launch_mode": "per-launch HIP events in a profiling pass right after the timed region: one 70-tile launch per op on "
                            "one lane (exclusive GPU).  The timed region runs the same kernels as two concurrent 35-tile halves "
                            "(lanes=2), where per-launch durations overlap and are not separable",
-            "flops_note": "algorithmic FLOPs (reference formulation: 2*MACs of the 3x3 conv over the upsampled+"
-                          "concatenated input); the parity-split kernels issue 13/18 of them as MFMA work",
-            "conv3x3_stages": {"achieved": round(k3_flops / (k3_ms * 1e-3) / 1e12, 2),
-                               "frac": round(k3_flops / (k3_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4),
-                               "share_of_gpu_time": round(k3_ms / tot_ms, 4)},
-            "all_convs": {"achieved": round(conv_flops / (conv_ms * 1e-3) / 1e12, 2),
-                          "frac": round(conv_flops / (conv_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4),
-                          "share_of_gpu_time": round(conv_ms / tot_ms, 4)},
+            "flops_note": "achieved/frac = ALGORITHMIC FLOPs (reference formulation: 2*MACs of the 3x3 conv over the upsampled+"
+                          "concatenated input); achieved_issued/frac_issued = the MFMA work the kernel really issues (parity-split "
+                          "decoder convs pre-sum coincident taps: 13/18 of the algorithmic MACs; the split mode issues 3 MFMAs per product)",
+            "conv3x3_stages": {"achieved": round(rate(k3), 2), "frac": round(rate(k3) / MFMA_PEAK_TFLOPS, 4),
+                               "frac_issued": round(rate(k3, "issued_flops") / MFMA_PEAK_TFLOPS, 4),
+                               "share_of_gpu_time": round(sum(o["total_ms"] for o in k3) / tot_ms, 4)},
+            "all_convs": {"achieved": round(rate(convs), 2), "frac": round(rate(convs) / MFMA_PEAK_TFLOPS, 4),
+                          "frac_issued": round(rate(convs, "issued_flops") / MFMA_PEAK_TFLOPS, 4),
+                          "share_of_gpu_time": round(sum(o["total_ms"] for o in convs) / tot_ms, 4)},
         }
         # HBM-side traffic of that launch from the committed rocprofv3 PMC passes of this same command
         # (tools/pmc_run.sh; counters need their own runs, see profiles/): bytes per launch
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01u_pmc_summary.json")))["ops"].get(dom["name"])
-            if pmc and abs(dom["patches"] / dom["launches"] - 70) < 1e-6:
-                roofline["traffic"] = round(pmc["fetch_bytes"] + pmc["write_bytes"])
-                if "mfma_busy_pct" in pmc:
-                    roofline["mfma_pipe_busy_pct_pmc"] = pmc["mfma_busy_pct"]   # issued work (13/18 of the algorithmic FLOPs)
-                roofline["traffic_source"] = "profiles/r01u_pmc_summary.json (FETCH_SIZE x2 + WRITE_SIZE per launch, L2 hit %.0f %%)" % pmc["l2_hit_pct"]
+            pmc = json.load(open(PMC_SUMMARY))
+            ent = pmc["ops"].get(dom["name"]) if pmc.get("precision", "f16") == m.precision else None
+            if ent and abs(dom["patches"] / dom["launches"] - 70) < 1e-6:
+                r["traffic"] = round(ent["fetch_bytes"] + ent["write_bytes"])
+                if "mfma_busy_pct" in ent:
+                    r["mfma_pipe_busy_pct_pmc"] = ent["mfma_busy_pct"]
+                r["traffic_source"] = "%s (FETCH_SIZE x2 + WRITE_SIZE per launch, L2 hit %.0f %%)" % (os.path.relpath(PMC_SUMMARY, ROOT), ent["l2_hit_pct"])
         except Exception:
             pass
-        for o in prof:
-            if o["launches"]:
-                per_op.append({"name": o["name"], "ms_per_launch": round(o["total_ms"] / o["launches"], 4),
-                               "tflops": round(o["flops"] * o["patches"] / (o["total_ms"] * 1e-3) / 1e12, 1) if o["total_ms"] else 0})
+        per_op = [{"name": o["name"], "ms_per_launch": round(o["total_ms"] / o["launches"], 4),
+                   "tflops": round(o["flops"] * o["patches"] / (o["total_ms"] * 1e-3) / 1e12, 1) if o["total_ms"] else 0,
+                   "tflops_issued": round(o["issued_flops"] * o["patches"] / (o["total_ms"] * 1e-3) / 1e12, 1) if o["total_ms"] else 0}
+                  for o in prof if o["launches"]]
+        return r, per_op
 
-    # ---- CPU baseline (oracle port) on a bounded sample; also the live label-map check -----------
-    cpu_baseline, label_match = None, None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        from oracle import keras_forward as kf
+    roofline, per_op = (roofline_of(model) if rank == 0 else (None, []))
+
+    # ---- the other arithmetic mode + live label agreement of both modes with the fp32 oracle ------
+    modes, label_match, cpu_baseline, cpu_port = None, None, None, None
+    if rank == 0 and world == 1:
         xy = _capi.tile_grid(PAGE_H, PAGE_W, MODEL_HW, MODEL_HW)[0]
         pick = np.linspace(0, len(xy) - 1, args.cpu_patches).astype(int)
-        patches = np.stack([page[y0:y0 + MODEL_HW, x0:x0 + MODEL_HW] for (x0, y0) in xy[pick]])
+        patches = np.stack([page0[y0:y0 + MODEL_HW, x0:x0 + MODEL_HW] for (x0, y0) in xy[pick]])
         x = (patches / 255.0).astype(np.float32)
-        kf.forward_config(cfg, weights, x[:1])                        # warm (page-in, thread pool)
-        t1 = time.perf_counter()
-        ref = kf.forward_config(cfg, weights, x)
-        cpu_dt = time.perf_counter() - t1
-        got = model.predict(x)
-        srt = np.sort(ref, axis=-1)
-        margin = srt[..., -1] - srt[..., -2]
-        mism = ref.argmax(-1) != got.argmax(-1)
-        label_match = {"vs": "oracle (fp32 CPU port)", "patches": int(len(pick)),
-                       "max_abs_softmax_diff": round(float(np.abs(ref - got).max()), 5),
-                       "label_mismatch_frac": round(float(mism.mean()), 6),
-                       "max_oracle_margin_among_mismatches": round(float(margin[mism].max()) if mism.any() else 0.0, 5)}
-        cpu_baseline = {"value": round(len(pick) / cpu_dt, 3), "unit": "patches/s", "cores": kf.num_threads(),
-                        "kind": "port",
-                        "sample": f"{len(pick)} of the page's {len(xy)} 448x448 tiles through oracle/keras_forward "
-                                  f"(fp32 C conv + numpy, OpenMP); host has {os.cpu_count()} logical CPUs"}
+        ref = None
+        if not args.no_cpu_baseline:
+            from oracle import keras_forward as kf
+            kf.forward_config(cfg, weights, x[:1])                        # warm (page-in, thread pool)
+            t1 = time.perf_counter()
+            ref = kf.forward_config(cfg, weights, x)
+            port_dt = time.perf_counter() - t1
+            cpu_port = {"value": round(len(pick) / port_dt, 3), "unit": "patches/s", "cores": kf.num_threads(), "kind": "port",
+                        "sample": f"{len(pick)} of the page's {len(xy)} 448x448 tiles through oracle/keras_forward (fp32 C conv + numpy, OpenMP)"}
+            # torch-CPU fp32 proxy of the Keras/TF CPU path: same graph, F.conv2d / batch_norm / interpolate,
+            # batch 1 (mirrors main.py:287-288: one patch per predict call) and batch 8, all host cores
+            try:
+                from sbb_textline_detection_amd.keras_graph import parse_model_config
+                from tools.synth_model import forward_torch
+                g = parse_model_config(cfg)
+                import torch.nn.functional as F
+                ncpu = os.cpu_count() or 1
+                # torch's intra-op pool at one thread per LOGICAL cpu was measured 10x slower than the OpenMP port on the 2-socket
+                # box (0.017 patches/s at 256 threads): probe one decoder-sized conv per candidate count and keep the fastest
+                xa, wa = torch.randn(1, 512, 112, 112), torch.randn(128, 512, 3, 3)
+                best, probe = None, {}
+                with torch.no_grad():
+                    for nt_ in sorted({t for t in (16, 32, 64, ncpu // 2, ncpu) if 1 <= t <= ncpu}):
+                        torch.set_num_threads(nt_)
+                        F.conv2d(xa, wa, padding=1)
+                        t1 = time.perf_counter()
+                        F.conv2d(xa, wa, padding=1)
+                        probe[nt_] = time.perf_counter() - t1
+                        if best is None or probe[nt_] < probe[best]:
+                            best = nt_
+                    nthreads = best
+                    torch.set_num_threads(nthreads)
+                    t1 = time.perf_counter()
+                    forward_torch(g, weights, x[:1], torch.float32)      # warm (also the batch-1 estimate if the box is slow)
+                    warm = time.perf_counter() - t1
+                    nb1 = 2 if warm < 8 else 1
+                    t1 = time.perf_counter()
+                    for k in range(nb1):
+                        forward_torch(g, weights, x[k:k + 1], torch.float32)
+                    b1 = nb1 / (time.perf_counter() - t1)
+                    nb8 = len(x) if warm < 4 else min(len(x), 2)
+                    t1 = time.perf_counter()
+                    q = forward_torch(g, weights, x[:nb8], torch.float32)
+                    b8 = nb8 / (time.perf_counter() - t1)
+                cpu_baseline = {"value": round(max(b1, b8), 3), "unit": "patches/s", "cores": nthreads, "kind": "proxy",
+                                "batch1_patches_per_s": round(b1, 3), f"batch{nb8}_patches_per_s": round(b8, 3),
+                                "thread_probe_s": {str(k): round(v, 3) for k, v in probe.items()},
+                                "sample": f"torch-CPU fp32 forward of the same ResNet-50-U-Net graph (a PROXY for the reference's Keras/TF-1.15 CPU "
+                                          f"path, which cannot run here): {nb1} patches at batch 1 (main.py:287-288) + {nb8} at batch {nb8}, "
+                                          f"torch.set_num_threads({nthreads}) = the fastest of the probed counts on {ncpu} logical CPUs; "
+                                          f"max|dsoftmax| vs the oracle port {float(np.abs(q - ref[:nb8]).max()):.1e}",
+                                "oracle_port": cpu_port}
+            except Exception as e:                                        # torch CPU ops unavailable: keep the port
+                cpu_baseline = dict(cpu_port, note=f"torch-CPU proxy failed: {e}")
+
+        def match(m):
+            if ref is None:
+                return None
+            got = m.predict(x)
+            srt = np.sort(ref, axis=-1)
+            margin = srt[..., -1] - srt[..., -2]
+            mism = ref.argmax(-1) != got.argmax(-1)
+            return {"vs": "oracle (fp32 CPU port)", "patches": int(len(pick)),
+                    "max_abs_softmax_diff": float(f"{np.abs(ref - got).max():.3g}"),
+                    "label_mismatch_frac": float(f"{mism.mean():.3g}"),
+                    "max_oracle_margin_among_mismatches": float(f"{(margin[mism].max() if mism.any() else 0.0):.3g}")}
+        label_match = match(model)
+        modes = {args.precision: {"patches_per_s": round(value, 2), "label_match": label_match,
+                                  "roofline_frac": roofline["frac"], "roofline_frac_issued": roofline["frac_issued"]}}
+        other = {"f16": "f16x3", "f16x3": "f16"}.get(args.precision)
+        if other and not args.no_second_mode and workload == "page":
+            m2 = make_model(other)
+            step2, tps2, _, _, _, _ = build_page(m2)
+            n2 = max(3, args.steps // 4)
+            dts2 = timed(step2, n2, 1, 1)
+            r2, _ = roofline_of(m2)
+            modes[other] = {"patches_per_s": round(tps2 * n2 / dts2[0], 2), "label_match": match(m2),
+                            "roofline_kernel": r2["kernel"], "roofline_frac": r2["frac"], "roofline_frac_issued": r2["frac_issued"],
+                            "steps": n2}
+            m2.release()
+        for k, v in modes.items():
+            v["what"] = ("label-exact split-fp16 mode (hi+lo operands, 3 MFMAs per product; default of the Python seams)" if k == "f16x3"
+                         else "fast mode: plain fp16 operands, fp32 accumulate")
 
     if rank == 0:
         out = {
@@ -243,14 +372,16 @@ def main():
             "value": round(value, 2), "unit": "patches/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": scaling,
             "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
-            "config": {"workload": workload_desc, "workload_id": args.workload,
+            "config": {"workload": workload_desc, "workload_id": workload,
                        "tiles_per_step": tiles_per_step, "max_batch": args.max_batch,
                        "lanes": int(os.environ.get("SBBSEG_LANES", "2")),
                        "exchange": "all_gather of u8 label maps over RCCL" if world > 1 else "none (1 GPU)",
                        "flops_per_patch": 2 * model.plan.macs_per_patch()},
+            "repeats": {"patches_per_s": [round(r, 2) for r in rates], "min": round(min(rates), 2), "median": round(value, 2),
+                        "max": round(max(rates), 2), "timed_region_s": [round(t, 3) for t in dts]},
             "patches_per_s_per_gpu": round(value / world, 2),
             "achieved_tflops_end_to_end": round(value / world * 2 * model.plan.macs_per_patch() / 1e12, 1),
-            "roofline": roofline, "cpu_baseline": cpu_baseline, "label_match": label_match,
+            "roofline": roofline, "cpu_baseline": cpu_baseline, "label_match": label_match, "modes": modes, "exchange": exchange,
         }
         print(json.dumps(out))
         if os.environ.get("SBBSEG_BENCH_OPS"):

@@ -146,6 +146,10 @@ int sbbseg_model_info(sbbseg_ctx* c, int* H, int* W, int* classes, int* max_batc
 int sbbseg_num_ops(sbbseg_ctx* c, int* n);
 int sbbseg_op_info(sbbseg_ctx* c, int op, char* name, int name_len, double* flops_per_patch,
                    double* min_bytes_per_patch);
+/* MFMA FLOPs op `op` really issues per patch (contraction axis padded to whole K-steps, parity-split decoder convs
+ * with pre-summed taps, three MFMAs per product in the split mode): the numerator of bench.py's `frac_issued`;
+ * sbbseg_op_info's flops are the ALGORITHMIC ones (reference formulation). */
+int sbbseg_op_issued_flops(sbbseg_ctx* c, int op, double* issued_flops_per_patch);
 int sbbseg_device_bytes(sbbseg_ctx* c, size_t* bytes);
 
 /* ---- seam 2: model.predict (main.py:287-288, 373-374).

@@ -21,7 +21,7 @@ EXPORTS = [
     "sbbseg_last_error", "sbbseg_abi_version", "sbbseg_device_count", "sbbseg_create", "sbbseg_destroy",
     "sbbseg_set_stream", "sbbseg_set_lanes", "sbbseg_set_label_channels", "sbbseg_synchronize", "sbbseg_set_input", "sbbseg_input_form", "sbbseg_add_tensor",
     "sbbseg_add_conv", "sbbseg_add_maxpool", "sbbseg_add_tail", "sbbseg_add_head", "sbbseg_finalize", "sbbseg_model_info",
-    "sbbseg_num_ops", "sbbseg_op_info", "sbbseg_device_bytes", "sbbseg_predict", "sbbseg_segment_page",
+    "sbbseg_num_ops", "sbbseg_op_info", "sbbseg_op_issued_flops", "sbbseg_device_bytes", "sbbseg_predict", "sbbseg_segment_page",
     "sbbseg_segment_page_dev", "sbbseg_segment_page_scaled", "sbbseg_segment_page_otsu", "sbbseg_otsu_dev",
     "sbbseg_segment_tile_range_bin_dev", "sbbseg_segment_whole", "sbbseg_segment_whole_scaled", "sbbseg_tile_grid", "sbbseg_nearest_map", "sbbseg_segment_tiles_dev",
     "sbbseg_segment_tile_range_dev", "sbbseg_stitch_dev", "sbbseg_debug_ingest", "sbbseg_debug_read_tensor",
@@ -79,6 +79,7 @@ def load_library(path: Optional[str] = None):
         "sbbseg_model_info": [vp] + [C.POINTER(C.c_int)] * 4,
         "sbbseg_num_ops": [vp, C.POINTER(C.c_int)],
         "sbbseg_op_info": [vp, i32, C.c_char_p, i32, C.POINTER(C.c_double), C.POINTER(C.c_double)],
+        "sbbseg_op_issued_flops": [vp, i32, C.POINTER(C.c_double)],
         "sbbseg_device_bytes": [vp, C.POINTER(C.c_size_t)],
         "sbbseg_predict": [vp, vp, i32, vp],
         "sbbseg_segment_page": [vp, vp, i32, i32, vp],
@@ -220,7 +221,9 @@ class Context:
             buf = C.create_string_buffer(128)
             fl, by = C.c_double(), C.c_double()
             check(self.lib.sbbseg_op_info(self.h, i, buf, 128, C.byref(fl), C.byref(by)))
-            out.append({"name": buf.value.decode(), "flops": fl.value, "min_bytes": by.value})
+            iss = C.c_double()
+            check(self.lib.sbbseg_op_issued_flops(self.h, i, C.byref(iss)))
+            out.append({"index": i, "name": buf.value.decode(), "flops": fl.value, "issued_flops": iss.value, "min_bytes": by.value})
         return out
 
     def device_bytes(self) -> int:

@@ -114,6 +114,7 @@ struct Op {
     OpType type;
     std::string name;
     double flops = 0, min_bytes = 0;
+    double issued_flops = 0;      // MFMA work the kernel really issues per patch (K padding, pre-summed taps, 3x in split mode)
     ConvOp conv;
     PoolOp pool;
     HeadOp head;
@@ -856,6 +857,7 @@ int sbbseg_add_conv(sbbseg_ctx* c, const sbbseg_conv_desc* d, const float* w_src
     op.name = nm;
     const double macs = d->algorithmic_macs > 0 ? d->algorithmic_macs : (double)d->out_h * d->out_w * d->cout * geo_macs;
     op.flops = 2.0 * macs;
+    op.issued_flops = 2.0 * d->out_h * d->out_w * d->cout * (double)co.total_ksteps * (split ? 32 * 3 : kBK);
     double bytes = 0;
     for (int s = 0; s < d->n_src; ++s) {
         const Tensor& t = c->tensors[d->src[s].tensor];
@@ -943,6 +945,7 @@ int sbbseg_add_conv(sbbseg_ctx* c, const sbbseg_conv_desc* d, const float* w_src
             c->device_bytes -= 2 * sizeof(float) * co.cout_pad;
             if (d->head_classes > 0) c->device_bytes -= sizeof(float) * ((size_t)d->cout * d->head_classes + 2 * d->head_classes);
             prev.flops += op.flops;
+            prev.issued_flops += op.issued_flops;
             prev.min_bytes += op.min_bytes;
             const size_t pos = prev.name.find("_par");
             if (pos != std::string::npos) prev.name = prev.name.substr(0, pos) + "_par4" + (d->head_classes > 0 ? "_head" : "");
@@ -1038,6 +1041,7 @@ int sbbseg_add_tail(sbbseg_ctx* c, int src0_tensor, int img_c8_tensor, const flo
     snprintf(nm, sizeof(nm), "tail_conv3x3_c67to32_up_cat_head%d_%dx%d", classes, c->in_H, c->in_W);
     op.name = nm;
     op.flops = 2.0 * (algorithmic_macs > 0 ? algorithmic_macs : (double)c->in_H * c->in_W * CO * (9.0 * 67 + classes));
+    op.issued_flops = 2.0 * c->in_H * c->in_W * CO * (double)(kTailKSteps * kBK);
     op.min_bytes = (double)s0.H * s0.W * 64 * c->elem + (double)c->in_H * c->in_W * (8 * c->elem + 1);
     c->classes = classes;
     c->ops.push_back(op);
@@ -1067,6 +1071,7 @@ int sbbseg_add_head(sbbseg_ctx* c, int src_tensor, int cin, int classes, const f
     snprintf(nm, sizeof(nm), "head1x1_c%dto%d_softmax_argmax", cin, classes);
     op.name = nm;
     op.flops = 2.0 * s.H * s.W * cin * classes;
+    op.issued_flops = 0;           // plain FMA kernel, no MFMA
     op.min_bytes = (double)s.H * s.W * (cin * c->elem * c->planes + 1);
     c->classes = classes;
     c->ops.push_back(op);
@@ -1138,6 +1143,15 @@ int sbbseg_op_info(sbbseg_ctx* c, int op, char* name, int name_len, double* flop
     if (name && name_len > 0) snprintf(name, name_len, "%s", c->ops[op].name.c_str());
     if (flops_per_patch) *flops_per_patch = c->ops[op].flops;
     if (min_bytes_per_patch) *min_bytes_per_patch = c->ops[op].min_bytes;
+    return 0;
+    API_END
+}
+
+int sbbseg_op_issued_flops(sbbseg_ctx* c, int op, double* issued_flops_per_patch)
+{
+    API_BEGIN
+    REQUIRE(c && op >= 0 && op < (int)c->ops.size() && issued_flops_per_patch, "op index out of range");
+    *issued_flops_per_patch = c->ops[op].issued_flops;
     return 0;
     API_END
 }
