@@ -75,7 +75,9 @@ def main():
         raise SystemExit(f"WORLD_SIZE={world} but --gpus {args.gpus}")
     workload = args.workload if args.workload != "auto" else ("page" if world == 1 else "batch64")
     if args.max_batch <= 0:
-        args.max_batch = 108 if workload == "batch64" else 70
+        # tiles per chunk: two pages' worth (2 x 70 / 2 x 108), pooled across pages by sbbseg_segment_pages_dev and run as two
+        # concurrent halves -- one page's 70 tiles leave the persistent conv grids a ragged last round (profiles/r02_experiments.md)
+        args.max_batch = 216 if workload == "batch64" else (140 if workload == "page" else 70)
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -110,9 +112,10 @@ def main():
         def gather():
             dist.all_gather_into_tensor(d_all.view(-1), labels.view(-1))
 
+        page_ptrs, label_ptrs = [p_.data_ptr() for p_ in pages], [labels[k].data_ptr() for k in range(P)]
+
         def step():
-            for k in range(P):
-                m.ctx.segment_page_dev(pages[k].data_ptr(), PAGE_H, PAGE_W, labels[k].data_ptr())
+            m.ctx.segment_pages_dev(page_ptrs, PAGE_H, PAGE_W, label_ptrs)      # tiles pooled across pages, chunks of max_batch
             if world > 1:
                 gather()
         desc = (f"{P} pages of {PAGE_H}x{PAGE_W} per GPU per step (BASELINE configs[1]: one such page = {tiles_per_page} tiles of 448x448, "
@@ -131,9 +134,11 @@ def main():
         def gather():
             dist.all_gather_into_tensor(d_everything.view(-1), d_mine.view(-1))
 
+        page_ptrs, label_ptrs = [p_.data_ptr() for p_ in pages], [d_mine[k].data_ptr() for k in range(count)]
+
         def step():
-            for k in range(count):
-                m.ctx.segment_page_dev(pages[k].data_ptr(), BH, BW, d_mine[k].data_ptr())
+            if count:
+                m.ctx.segment_pages_dev(page_ptrs, BH, BW, label_ptrs)
             if world > 1:
                 gather()
         desc = (f"BASELINE configs[3]: {NPAGES} pages of {BH}x{BW} ({tpp} tiles each) sharded as whole pages over the ranks, textline model, "
@@ -216,8 +221,11 @@ def main():
         c = m.ctx
         c.profile_enable(True)
         c.profile_reset()
+        # (profiling runs every chunk whole on one lane: launches of min(max_batch, tiles) tiles -- two pages pooled by default)
+        d_page2 = torch.from_numpy(synthetic_page(PAGE_H, PAGE_W, seed=4242)).cuda()
+        d_labels2 = torch.empty((PAGE_H, PAGE_W), dtype=torch.uint8, device="cuda")
         for _ in range(5):
-            c.segment_page_dev(d_page.data_ptr(), PAGE_H, PAGE_W, d_labels.data_ptr())
+            c.segment_pages_dev([d_page.data_ptr(), d_page2.data_ptr()], PAGE_H, PAGE_W, [d_labels.data_ptr(), d_labels2.data_ptr()])
         torch.cuda.synchronize()
         prof = c.profile()
         c.profile_enable(False)
@@ -242,8 +250,8 @@ def main():
             "patches_per_launch": dom["patches"] / dom["launches"],
             "flops_per_launch": dom["flops"] * dom["patches"] / dom["launches"],
             "issued_flops_per_launch": dom["issued_flops"] * dom["patches"] / dom["launches"],
-            "launch_mode": "per-launch HIP events in a profiling pass right after the timed region: one 70-tile launch per op on "
-                           "one lane (exclusive GPU).  The timed region runs the same kernels as two concurrent 35-tile halves "
+            "launch_mode": "per-launch HIP events in a profiling pass right after the timed region: one launch of a whole chunk per op on "
+                           "one lane (exclusive GPU).  The timed region runs the same kernels as two concurrent half-chunks "
                            "(lanes=2), where per-launch durations overlap and are not separable",
             "flops_note": "achieved/frac = ALGORITHMIC FLOPs (reference formulation: 2*MACs of the 3x3 conv over the upsampled+"
                           "concatenated input); achieved_issued/frac_issued = the MFMA work the kernel really issues (parity-split "
@@ -260,7 +268,7 @@ def main():
         try:
             pmc = json.load(open(PMC_SUMMARY))
             ent = pmc["ops"].get(dom["name"]) if pmc.get("precision", "f16") == m.precision else None
-            if ent and abs(dom["patches"] / dom["launches"] - 70) < 1e-6:
+            if ent and abs(dom["patches"] / dom["launches"] - pmc.get("patches_per_launch", 70)) < 1e-6:
                 r["traffic"] = round(ent["fetch_bytes"] + ent["write_bytes"])
                 if "mfma_busy_pct" in ent:
                     r["mfma_pipe_busy_pct_pmc"] = ent["mfma_busy_pct"]

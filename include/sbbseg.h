@@ -160,6 +160,11 @@ int sbbseg_predict(sbbseg_ctx* c, const float* x_nhwc, int n, float* probs_nhwc)
  * forward, argmax, margin-crop + last-writer-wins stitch.  page: uint8 [Hp][Wp][3];
  * labels: uint8 [Hp][Wp] (the reference returns this plane replicated x3). */
 int sbbseg_segment_page(sbbseg_ctx* c, const uint8_t* page_hwc, int Hp, int Wp, uint8_t* labels_hw);
+/* Many equally sized pages in one call (the reference walks them one by one: ocrd_cli.py:51 -> main.py:2056 per page): their
+ * tiles are pooled into chunks of up to max_batch tiles, so launches stay large when a page has few tiles (a 3500x2500 page has
+ * 70; the persistent conv grids want a few hundred).  d_pages_hwc / d_labels_hw: HOST arrays of n_pages DEVICE pointers
+ * (uint8 [Hp][Wp][3] in, uint8 [Hp][Wp] out).  Result per page == sbbseg_segment_page_dev. */
+int sbbseg_segment_pages_dev(sbbseg_ctx* c, int n_pages, const void* const* d_pages_hwc, int Hp, int Wp, void* const* d_labels_hw);
 int sbbseg_segment_page_dev(sbbseg_ctx* c, const void* d_page_hwc, int Hp, int Wp, void* d_labels_hw);
 
 /* Same, with the page rescale of get_image_and_scales (main.py:196-214: cv2.resize INTER_NEAREST to Hp x Wp)

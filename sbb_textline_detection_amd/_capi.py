@@ -22,7 +22,7 @@ EXPORTS = [
     "sbbseg_set_stream", "sbbseg_set_lanes", "sbbseg_set_label_channels", "sbbseg_synchronize", "sbbseg_set_input", "sbbseg_input_form", "sbbseg_add_tensor",
     "sbbseg_add_conv", "sbbseg_add_maxpool", "sbbseg_add_tail", "sbbseg_add_head", "sbbseg_finalize", "sbbseg_model_info",
     "sbbseg_num_ops", "sbbseg_op_info", "sbbseg_op_issued_flops", "sbbseg_device_bytes", "sbbseg_predict", "sbbseg_segment_page",
-    "sbbseg_segment_page_dev", "sbbseg_segment_page_scaled", "sbbseg_segment_page_otsu", "sbbseg_otsu_dev",
+    "sbbseg_segment_page_dev", "sbbseg_segment_pages_dev", "sbbseg_segment_page_scaled", "sbbseg_segment_page_otsu", "sbbseg_otsu_dev",
     "sbbseg_segment_tile_range_bin_dev", "sbbseg_segment_whole", "sbbseg_segment_whole_scaled", "sbbseg_tile_grid", "sbbseg_nearest_map", "sbbseg_segment_tiles_dev",
     "sbbseg_segment_tile_range_dev", "sbbseg_stitch_dev", "sbbseg_debug_ingest", "sbbseg_debug_read_tensor",
     "sbbseg_debug_set_conv_variant", "sbbseg_debug_inject_alloc_failure",
@@ -84,6 +84,7 @@ def load_library(path: Optional[str] = None):
         "sbbseg_predict": [vp, vp, i32, vp],
         "sbbseg_segment_page": [vp, vp, i32, i32, vp],
         "sbbseg_segment_page_dev": [vp, vp, i32, i32, vp],
+        "sbbseg_segment_pages_dev": [vp, i32, vp, i32, i32, vp],
         "sbbseg_segment_page_scaled": [vp, vp, i32, i32, i32, i32, vp],
         "sbbseg_segment_page_otsu": [vp, vp, i32, i32, i32, i32, vp, C.POINTER(C.c_int)],
         "sbbseg_otsu_dev": [vp, vp, i32, i32, vp],
@@ -312,6 +313,15 @@ class Context:
 
     def segment_page_dev(self, d_page: int, Hp: int, Wp: int, d_labels: int):
         check(self.lib.sbbseg_segment_page_dev(self.h, C.c_void_p(d_page), Hp, Wp, C.c_void_p(d_labels)), "sbbseg_segment_page_dev")
+
+    def segment_pages_dev(self, d_pages, Hp: int, Wp: int, d_labels):
+        """Equally sized pages (device pointers) -> their label maps (device pointers), tiles pooled across pages."""
+        n = len(d_pages)
+        if n != len(d_labels) or n == 0:
+            raise ValueError("need as many label buffers as pages (at least one)")
+        pa = (C.c_void_p * n)(*[C.c_void_p(int(v)) for v in d_pages])
+        la = (C.c_void_p * n)(*[C.c_void_p(int(v)) for v in d_labels])
+        check(self.lib.sbbseg_segment_pages_dev(self.h, n, pa, Hp, Wp, la), "sbbseg_segment_pages_dev")
 
     def segment_tile_range_dev(self, d_page: int, Hp: int, Wp: int, first: int, n: int, d_tile_labels: int):
         check(self.lib.sbbseg_segment_tile_range_dev(self.h, C.c_void_p(d_page), Hp, Wp, first, n, C.c_void_p(d_tile_labels)),

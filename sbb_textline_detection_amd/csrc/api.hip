@@ -1250,30 +1250,48 @@ int sbbseg_segment_tiles_dev(sbbseg_ctx* c, const void* d_page_hwc, int Hp, int 
     API_END
 }
 
-static int tile_range_impl(sbbseg_ctx* c, const void* d_page_hwc, int src_Hp, int src_Wp, const int* d_map_y, const int* d_map_x,
+// Tiles [first_tile, first_tile + n_tiles) of the tile list of `n_pages` equally sized pages (page-major: tile g = page g / tpp,
+// grid index g % tpp) -> d_tile_labels[g - first_tile].  Chunks of <= max_batch tiles may span pages: big launches fill the chip's
+// persistent grids better than one page's 70 tiles (profiles/r02_experiments.md).
+static int tile_range_impl(sbbseg_ctx* c, const void* const* d_pages, int n_pages, int src_Hp, int src_Wp, const int* d_map_y, const int* d_map_x,
                            int Hp, int Wp, int first_tile, int n_tiles, void* d_tile_labels, const int* d_bin_thr = nullptr)
 {
-    REQUIRE(d_page_hwc && d_tile_labels && first_tile >= 0 && n_tiles >= 0, "bad arguments");
+    REQUIRE(d_pages && n_pages >= 1 && d_tile_labels && first_tile >= 0 && n_tiles >= 0, "bad arguments");
+    for (int k = 0; k < n_pages; ++k) REQUIRE(d_pages[k], "null page pointer (page %d)", k);
     int nx = 0, ny = 0;
     if (sbbseg_tile_grid(Hp, Wp, c->in_H, c->in_W, nullptr, 0, &nx, &ny)) return 1;
-    REQUIRE(first_tile + n_tiles <= nx * ny, "tile range [%d,%d) exceeds the %d tiles of the page", first_tile, first_tile + n_tiles, nx * ny);
+    const int tpp = nx * ny;
+    REQUIRE((long)first_tile + n_tiles <= (long)tpp * n_pages, "tile range [%d,%d) exceeds the %d tiles of the %d page(s)", first_tile,
+            first_tile + n_tiles, tpp * n_pages, n_pages);
     const int margin = margin_of(c->in_W);
     IngestParams ip;
     if (fill_ingest(c, ip)) return 1;
-    ip.page = (const uint8_t*)d_page_hwc; ip.Hp = Hp; ip.Wp = Wp; ip.src_Hp = src_Hp; ip.src_Wp = src_Wp; ip.tile_xy = nullptr;
+    ip.page = (const uint8_t*)d_pages[0]; ip.Hp = Hp; ip.Wp = Wp; ip.src_Hp = src_Hp; ip.src_Wp = src_Wp; ip.tile_xy = nullptr;
     ip.map_y = d_map_y; ip.map_x = d_map_x; ip.bin_thr = d_bin_thr;
     ip.grid_nyf = ny; ip.grid_mid_x = c->in_W - 2 * margin; ip.grid_mid_y = c->in_H - 2 * margin;
     const size_t per = (size_t)c->in_H * c->in_W;
+    const size_t act = (size_t)c->elem * c->planes;          // bytes per stored element
     auto run_chunk = [&](int lane, int first, int nb) -> int {
         LaneScope scope(c, lane);
         IngestParams lp = ip;
         if (fill_ingest(c, lp)) return 1;          // (input-form pointers of this lane)
-        lp.page = ip.page; lp.Hp = ip.Hp; lp.Wp = ip.Wp; lp.src_Hp = ip.src_Hp; lp.src_Wp = ip.src_Wp; lp.tile_xy = nullptr;
+        char* const c8_base = (char*)lp.c8;
+        char* const pairs_base = (char*)lp.pairs;
+        const size_t c8_tile = per * 8 * act, pairs_tile = lp.pairs ? (size_t)(c->in_H + 2 * lp.pad) * lp.pairs_w * 8 * act : 0;
+        lp.Hp = ip.Hp; lp.Wp = ip.Wp; lp.src_Hp = ip.src_Hp; lp.src_Wp = ip.src_Wp; lp.tile_xy = nullptr;
         lp.map_y = ip.map_y; lp.map_x = ip.map_x; lp.bin_thr = ip.bin_thr;
         lp.grid_nyf = ip.grid_nyf; lp.grid_mid_x = ip.grid_mid_x; lp.grid_mid_y = ip.grid_mid_y;
-        lp.grid_first = first_tile + first;
-        lp.n_tiles = nb;
-        HIPCHK(launch_ingest_u8(lp, c->precision, c->stream));
+        for (int done = 0; done < nb;) {            // one ingest launch per page the chunk touches
+            const int g = first_tile + first + done, pg = g / tpp, local = g - pg * tpp;
+            const int run = nb - done < tpp - local ? nb - done : tpp - local;
+            lp.page = (const uint8_t*)d_pages[pg];
+            lp.grid_first = local;
+            lp.n_tiles = run;
+            lp.c8 = c8_base + (size_t)done * c8_tile;
+            lp.pairs = pairs_base ? pairs_base + (size_t)done * pairs_tile : nullptr;
+            HIPCHK(launch_ingest_u8(lp, c->precision, c->stream));
+            done += run;
+        }
         return run_plan(c, nb, (uint8_t*)d_tile_labels + first * per, nullptr);
     };
     // chunks of equal size (108 tiles at max_batch 70 -> 54 + 54, not 70 + 38): launches shrink evenly
@@ -1302,7 +1320,7 @@ int sbbseg_segment_tile_range_dev(sbbseg_ctx* c, const void* d_page_hwc, int Hp,
 {
     API_BEGIN
     if (check_ready(c)) return 1;
-    return tile_range_impl(c, d_page_hwc, Hp, Wp, nullptr, nullptr, Hp, Wp, first_tile, n_tiles, d_tile_labels);
+    return tile_range_impl(c, &d_page_hwc, 1, Hp, Wp, nullptr, nullptr, Hp, Wp, first_tile, n_tiles, d_tile_labels);
     API_END
 }
 
@@ -1355,6 +1373,23 @@ int sbbseg_segment_page_dev(sbbseg_ctx* c, const void* d_page_hwc, int Hp, int W
     API_END
 }
 
+int sbbseg_segment_pages_dev(sbbseg_ctx* c, int n_pages, const void* const* d_pages_hwc, int Hp, int Wp, void* const* d_labels_hw)
+{
+    API_BEGIN
+    if (check_ready(c)) return 1;
+    REQUIRE(n_pages >= 1 && d_pages_hwc && d_labels_hw, "bad arguments");
+    for (int k = 0; k < n_pages; ++k) REQUIRE(d_pages_hwc[k] && d_labels_hw[k], "null page / label pointer (page %d)", k);
+    int nx = 0, ny = 0;
+    if (sbbseg_tile_grid(Hp, Wp, c->in_H, c->in_W, nullptr, 0, &nx, &ny)) return 1;
+    const size_t per = (size_t)c->in_H * c->in_W, tpp = (size_t)nx * ny;
+    if (ensure(c, (void**)&c->d_tile_labels, &c->tile_labels_cap, tpp * n_pages * per)) return 1;
+    if (tile_range_impl(c, d_pages_hwc, n_pages, Hp, Wp, nullptr, nullptr, Hp, Wp, 0, (int)(tpp * n_pages), c->d_tile_labels)) return 1;
+    for (int k = 0; k < n_pages; ++k)
+        if (sbbseg_stitch_dev(c, c->d_tile_labels + (size_t)k * tpp * per, Hp, Wp, d_labels_hw[k])) return 1;
+    return 0;
+    API_END
+}
+
 int sbbseg_segment_page(sbbseg_ctx* c, const uint8_t* page_hwc, int Hp, int Wp, uint8_t* labels_hw)
 {
     API_BEGIN
@@ -1393,7 +1428,8 @@ int sbbseg_segment_page_scaled(sbbseg_ctx* c, const uint8_t* page_hwc, int Hs, i
     int nx = 0, ny = 0;
     if (sbbseg_tile_grid(Hp, Wp, c->in_H, c->in_W, nullptr, 0, &nx, &ny)) return 1;
     if (ensure(c, (void**)&c->d_tile_labels, &c->tile_labels_cap, (size_t)nx * ny * c->in_H * c->in_W)) return 1;
-    if (tile_range_impl(c, c->d_page, Hs, Ws, d_my, d_mx, Hp, Wp, 0, nx * ny, c->d_tile_labels)) return 1;
+    const void* pg_ = c->d_page;
+    if (tile_range_impl(c, &pg_, 1, Hs, Ws, d_my, d_mx, Hp, Wp, 0, nx * ny, c->d_tile_labels)) return 1;
     if (sbbseg_stitch_dev(c, c->d_tile_labels, Hp, Wp, c->d_page_labels)) return 1;
     if (labels_to_host(c, labels_hw, pix)) return 1;
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -1417,7 +1453,7 @@ int sbbseg_segment_tile_range_bin_dev(sbbseg_ctx* c, const void* d_page_hwc, int
     API_BEGIN
     if (check_ready(c)) return 1;
     REQUIRE(d_threshold, "bad arguments");
-    return tile_range_impl(c, d_page_hwc, Hp, Wp, nullptr, nullptr, Hp, Wp, first_tile, n_tiles, d_tile_labels, d_threshold);
+    return tile_range_impl(c, &d_page_hwc, 1, Hp, Wp, nullptr, nullptr, Hp, Wp, first_tile, n_tiles, d_tile_labels, d_threshold);
     API_END
 }
 
@@ -1449,7 +1485,8 @@ int sbbseg_segment_page_otsu(sbbseg_ctx* c, const uint8_t* page_hwc, int Hs, int
     int nx = 0, ny = 0;
     if (sbbseg_tile_grid(Hp, Wp, c->in_H, c->in_W, nullptr, 0, &nx, &ny)) return 1;
     if (ensure(c, (void**)&c->d_tile_labels, &c->tile_labels_cap, (size_t)nx * ny * c->in_H * c->in_W)) return 1;
-    if (tile_range_impl(c, c->d_page, Hs, Ws, d_my, d_mx, Hp, Wp, 0, nx * ny, c->d_tile_labels, d_thr)) return 1;
+    const void* pg_ = c->d_page;
+    if (tile_range_impl(c, &pg_, 1, Hs, Ws, d_my, d_mx, Hp, Wp, 0, nx * ny, c->d_tile_labels, d_thr)) return 1;
     if (sbbseg_stitch_dev(c, c->d_tile_labels, Hp, Wp, c->d_page_labels)) return 1;
     if (labels_to_host(c, labels_hw, pix)) return 1;
     int thr = 0;

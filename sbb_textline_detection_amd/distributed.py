@@ -59,6 +59,11 @@ class DeviceBackend:
     def whole_page(self, d_page, out_page) -> None:
         self.ctx.segment_page_dev(d_page.data_ptr(), int(d_page.shape[0]), int(d_page.shape[1]), out_page.data_ptr())
 
+    def whole_pages(self, d_pages, out_pages) -> None:
+        """Equally sized pages in one library call: their tiles are pooled into max_batch-sized chunks."""
+        Hp, Wp = int(d_pages[0].shape[0]), int(d_pages[0].shape[1])
+        self.ctx.segment_pages_dev([p.data_ptr() for p in d_pages], Hp, Wp, [o.data_ptr() for o in out_pages])
+
 
 def _world(group):
     import torch.distributed as dist
@@ -96,8 +101,11 @@ def segment_pages_sharded(backend, pages: Sequence[np.ndarray], group=None):
         raise ValueError("segment_pages_sharded needs equally sized pages")
     first, count, block = shard_block(n, rank, world)
     mine = backend.empty((block, Hp, Wp))
-    for k in range(count):
-        backend.whole_page(backend.to_device(pages[first + k]), mine[k])
+    if count and hasattr(backend, "whole_pages"):
+        backend.whole_pages([backend.to_device(pages[first + k]) for k in range(count)], [mine[k] for k in range(count)])
+    else:
+        for k in range(count):
+            backend.whole_page(backend.to_device(pages[first + k]), mine[k])
     if world > 1:
         everything = backend.empty((world * block, Hp, Wp))
         dist.all_gather_into_tensor(everything.view(-1), mine.view(-1), group=group)

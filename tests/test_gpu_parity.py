@@ -638,3 +638,24 @@ def test_conv2d_transpose_decoder_through_c_abi(k, precision):
     else:
         assert d < 0.05
     m.release()
+
+
+def test_pooled_pages_equal_page_by_page(torch_cuda):
+    """sbbseg_segment_pages_dev (tiles of several pages pooled into max_batch-sized chunks, chunks spanning page borders,
+    two lanes) == sbbseg_segment_page_dev page by page, bit for bit."""
+    torch = torch_cuda
+    cfg, w, g, model = make_model(2, 224, 224, seed=3, precision="f16", max_batch=40)
+    pages = [synthetic_page(700, 610, seed=20 + k) for k in range(5)]            # 4 x 4 = 16 tiles each -> chunks of 40 span pages
+    d_pages = [torch.from_numpy(p).cuda() for p in pages]
+    d_out = [torch.zeros((700, 610), dtype=torch.uint8, device="cuda") for _ in pages]
+    model.ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    try:
+        model.ctx.segment_pages_dev([p.data_ptr() for p in d_pages], 700, 610, [o.data_ptr() for o in d_out])
+        got = [o.cpu().numpy() for o in d_out]
+    finally:
+        model.ctx.set_stream(-1)
+    for p, a in zip(pages, got):
+        assert np.array_equal(a, model.segment_page(p))
+    with pytest.raises(ValueError):
+        model.ctx.segment_pages_dev([], 700, 610, [])
+    model.release()
