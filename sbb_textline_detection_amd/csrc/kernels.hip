@@ -151,7 +151,8 @@ __device__ inline uint32_t row_ror8(uint32_t v)
 
 template <int N> __device__ inline void wait_vmcnt()
 {
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+    // (the counter field holds 0..63: a larger count cannot be expressed -> drain)
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N > 63 ? 0 : N) : "memory");
 }
 
 // Pipeline: NS LDS stages, stage s+D (D = NS-1) is issued while stage s is multiplied.  Blocks are
@@ -838,29 +839,36 @@ void conv_igemm_mfma(const ConvParams p)
             // split mode: slots 0-3 hold the hi halves of the stage's 32 channels, slots 4-7 the lo halves (rd_k0 / rd_k1
             // address exactly these).  value = hi + lo on both operands: w*x ~= wl*xh + wh*xl + wh*xh, small terms first.
             // Three sweeps over the wave tile keep MFMAs on the same accumulator 16 instructions apart.
-            bf16x8_t ah[T::kMI], al[T::kMI], bh[T::kNI], bl[T::kNI];
+            // Wide wave tiles (8 pixel blocks) take the pixel fragments in two halves: the fragments of a stage do not all fit
+            // beside 128 accumulator registers.
+            constexpr int NIH = T::kNI >= 8 ? T::kNI / 2 : T::kNI;
+            bf16x8_t ah[T::kMI], al[T::kMI];
 #pragma unroll
             for (int mi = 0; mi < T::kMI; ++mi) {
                 ah[mi] = *(const bf16x8_t*)(sb + w_rd + mi * 16 * RB + rd_k0);
                 al[mi] = *(const bf16x8_t*)(sb + w_rd + mi * 16 * RB + rd_k1);
             }
 #pragma unroll
-            for (int q = 0; q < T::kNI; ++q) {
-                bh[q] = *(const bf16x8_t*)(sb + p_rd + q * 16 * RB + rd_k0);
-                bl[q] = *(const bf16x8_t*)(sb + p_rd + q * 16 * RB + rd_k1);
+            for (int h = 0; h < T::kNI / NIH; ++h) {
+                bf16x8_t bh[NIH], bl[NIH];
+#pragma unroll
+                for (int q = 0; q < NIH; ++q) {
+                    bh[q] = *(const bf16x8_t*)(sb + p_rd + (h * NIH + q) * 16 * RB + rd_k0);
+                    bl[q] = *(const bf16x8_t*)(sb + p_rd + (h * NIH + q) * 16 * RB + rd_k1);
+                }
+#pragma unroll
+                for (int mi = 0; mi < T::kMI; ++mi)
+#pragma unroll
+                    for (int q = 0; q < NIH; ++q) acc[mi][h * NIH + q] = mfma16<true>(al[mi], bh[q], acc[mi][h * NIH + q]);
+#pragma unroll
+                for (int mi = 0; mi < T::kMI; ++mi)
+#pragma unroll
+                    for (int q = 0; q < NIH; ++q) acc[mi][h * NIH + q] = mfma16<true>(ah[mi], bl[q], acc[mi][h * NIH + q]);
+#pragma unroll
+                for (int mi = 0; mi < T::kMI; ++mi)
+#pragma unroll
+                    for (int q = 0; q < NIH; ++q) acc[mi][h * NIH + q] = mfma16<true>(ah[mi], bh[q], acc[mi][h * NIH + q]);
             }
-#pragma unroll
-            for (int mi = 0; mi < T::kMI; ++mi)
-#pragma unroll
-                for (int q = 0; q < T::kNI; ++q) acc[mi][q] = mfma16<true>(al[mi], bh[q], acc[mi][q]);
-#pragma unroll
-            for (int mi = 0; mi < T::kMI; ++mi)
-#pragma unroll
-                for (int q = 0; q < T::kNI; ++q) acc[mi][q] = mfma16<true>(ah[mi], bl[q], acc[mi][q]);
-#pragma unroll
-            for (int mi = 0; mi < T::kMI; ++mi)
-#pragma unroll
-                for (int q = 0; q < T::kNI; ++q) acc[mi][q] = mfma16<true>(ah[mi], bh[q], acc[mi][q]);
         } else {
             // The K-step's MFMAs run in phases of (k-half kk, group of <= 4 pixel blocks); the LDS
             // fragments of phase i+1 are requested BEFORE the MFMAs of phase i (register double
@@ -1067,6 +1075,12 @@ static hipError_t launch_conv_16(const ConvParams& p, hipStream_t s)
 static hipError_t launch_conv_x3(const ConvParams& p, hipStream_t s)
 {
     const int bc = conv_tile_bc(p.cout);
+    if (p.variant == 0 && bc == 128 && !p.residual) {          // the long-K decoder launches: same 8-wave tiles as the plain modes
+        const long t256 = (long)p.n_cls * ((p.M + 255) / 256) * (p.cout / 256);
+        const long t512 = (long)p.n_cls * ((p.M + 511) / 512) * ((p.cout + 127) / 128);
+        if (p.cout % 256 == 0 && p.Ktot >= 1024 && t256 >= 200) return launch_conv_t<256, 256, 2, 4, 2, true, 8, false, true>(p, s);
+        if (p.Ktot >= 2048 && t512 >= 200) return launch_conv_t<512, 128, 4, 2, 2, true, 8, false, true>(p, s);
+    }
     if (bc == 128) return launch_conv_t<128, 128, 2, 2, 2, true, 8, false, true>(p, s);
     if (bc == 64) return launch_conv_t<256, 64, 4, 1, 2, true, 8, false, true>(p, s);
     return launch_conv_t<256, 32, 4, 1, 2, true, 8, false, true>(p, s);

@@ -27,7 +27,7 @@ _CACHE: Dict[Tuple, "SegModel"] = {}
 
 
 def default_max_batch() -> int:
-    return int(os.environ.get("SBBSEG_MAX_BATCH", "32"))
+    return int(os.environ.get("SBBSEG_MAX_BATCH", "70"))       # one 3500x2500 page (70 tiles) per chunk
 
 
 def default_precision() -> str:
