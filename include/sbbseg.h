@@ -197,6 +197,27 @@ int sbbseg_segment_whole(sbbseg_ctx* c, const uint8_t* page_hwc, int Hp, int Wp,
 int sbbseg_segment_whole_scaled(sbbseg_ctx* c, const uint8_t* page_hwc, int Hp, int Wp, int Hs, int Ws,
                                 int out_h, int out_w, uint8_t* labels_out);
 
+/* ---- stage glue either side of the models, on u8 label planes [H][W]:
+ * cv2.erode / cv2.dilate with a ksize x ksize kernel of ones (the reference's self.kernel is 5x5, main.py:57), `iterations` times,
+ * OpenCV's default border (outside pixels never win): text_regions erode x 3 / dilate x 4 (main.py:2074-2075), border mask
+ * dilate x 6 (main.py:397).  Integer-exact: n iterations of a k x k flat kernel == one (n(k-1)+1)-wide clipped min / max.
+ * src may equal dst.  _dev: device pointers, enqueued on the handle's stream. */
+#define SBBSEG_MORPH_ERODE  0
+#define SBBSEG_MORPH_DILATE 1
+int sbbseg_morph_dev(sbbseg_ctx* c, const void* d_src_hw, int H, int W, int op, int ksize, int iterations, void* d_dst_hw);
+int sbbseg_morph(sbbseg_ctx* c, const uint8_t* src_hw, int H, int W, int op, int ksize, int iterations, uint8_t* dst_hw);
+/* extract_page's box (main.py:394-404): mask > 0 -> dilate 5x5 x 6 -> largest 8-connected component -> its bounding box
+ * {x, y, w, h} (cv2.boundingRect convention) and pixel count; {0,0,0,0} / 0 when the mask is empty.  [EXT, unpinned]: the
+ * reference ranks cv2.findContours contours by cv2.contourArea (polygon area of the traced border) and breaks ties by
+ * contour order; here components are ranked by PIXEL COUNT, ties by first pixel in raster order.  Both pick the same blob
+ * unless two components are nearly equal in size or the largest one is mostly holes. */
+int sbbseg_page_box_dev(sbbseg_ctx* c, const void* d_mask_hw, int H, int W, int32_t* box_xywh, int64_t* pixels);
+/* extract_page's model + glue in one call: border model on the page as upscaled to Hs x Ws (sbbseg_segment_whole_scaled),
+ * then sbbseg_page_box_dev on the label plane while it is still on the device.  mask_out: Hs x Ws labels (x3 with
+ * sbbseg_set_label_channels(3)) or NULL. */
+int sbbseg_extract_page_box(sbbseg_ctx* c, const uint8_t* page_hwc, int Hp, int Wp, int Hs, int Ws, uint8_t* mask_out,
+                            int32_t* box_xywh, int64_t* pixels);
+
 /* ---- building blocks (multi-GPU sharding, tests).  tile_xy: host int32 [n][2] = (x0, y0) origins.
  * d_tile_labels: device uint8 [n][H][W]. */
 int sbbseg_tile_grid(int Hp, int Wp, int H, int W, int32_t* tile_xy, int capacity, int* nxf, int* nyf);

@@ -69,3 +69,69 @@ def otsu_copy(img: np.ndarray) -> np.ndarray:
     out[:, :, 1] = b
     out[:, :, 2] = b
     return out
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Morphology and page box (SURVEY.md 8f-3 remainder).  Reference: self.kernel = np.ones((5, 5), np.uint8) (main.py:57);
+#   extract_page           main.py:394-404   cvtColor -> threshold(>0 -> 255) -> dilate x 6 -> findContours -> largest -> boundingRect
+#   textline_contours      main.py:2074-2075 text_regions = erode x 3, then dilate x 4
+#   crop_image_inside_box  main.py:174-176
+# cv2.erode / cv2.dilate semantics restated [EXT OpenCV morph.dispatch.cpp]: flat structuring element, anchor at its centre,
+# borderType = BORDER_CONSTANT with borderValue = morphologyDefaultBorderValue() -- +inf for erode, -inf for dilate, i.e. pixels
+# outside the image never win the min / max; `iterations` applies the filter repeatedly.  Written here LITERALLY (one 5x5 pass
+# per iteration), so the device's shortcut (one clipped (4n+1)-wide separable filter) is checked, not assumed.
+# cv2.findContours / contourArea / boundingRect are NOT restated: the largest blob is taken as the 8-connected component with
+# the most pixels (ties: first in raster order) -- see include/sbbseg.h sbbseg_page_box_dev for what that leaves [EXT, unpinned].
+def _morph_once(a: np.ndarray, k: int, is_max: bool) -> np.ndarray:
+    r = (k - 1) // 2
+    fill = 0 if is_max else 255
+    p = np.pad(a, r, constant_values=fill)
+    out = np.full_like(a, fill)
+    H, W = a.shape
+    for dy in range(k):
+        for dx in range(k):
+            v = p[dy:dy + H, dx:dx + W]
+            out = np.maximum(out, v) if is_max else np.minimum(out, v)
+    return out
+
+
+def morph(plane: np.ndarray, op: str, ksize: int = 5, iterations: int = 1) -> np.ndarray:
+    """cv2.erode (op='erode') / cv2.dilate (op='dilate') of a uint8 plane with a ksize x ksize kernel of ones."""
+    a = np.ascontiguousarray(plane, np.uint8)
+    for _ in range(iterations):
+        a = _morph_once(a, ksize, op == "dilate")
+    return a
+
+
+def region_cleanup(text_regions: np.ndarray) -> np.ndarray:
+    """main.py:2074-2075 on the layout stage's label image (any number of equal channels)."""
+    if text_regions.ndim == 3:
+        return np.stack([region_cleanup(text_regions[:, :, c]) for c in range(text_regions.shape[2])], axis=2)
+    return morph(morph(text_regions, "erode", 5, 3), "dilate", 5, 4)
+
+
+def largest_component_box(mask: np.ndarray):
+    """((x, y, w, h), pixels) of the 8-connected component of mask > 0 with the most pixels; ((0,0,0,0), 0) if none."""
+    from scipy import ndimage
+    lab, n = ndimage.label(np.asarray(mask) > 0, structure=np.ones((3, 3), int))
+    if n == 0:
+        return (0, 0, 0, 0), 0
+    counts = np.bincount(lab.reshape(-1))[1:]
+    best = int(np.argmax(counts)) + 1                    # scipy numbers components in raster order of their first pixel: ties -> first
+    ys, xs = np.nonzero(lab == best)
+    return (int(xs.min()), int(ys.min()), int(xs.max() - xs.min() + 1), int(ys.max() - ys.min() + 1)), int(counts[best - 1])
+
+
+def page_box(img_page_prediction: np.ndarray):
+    """main.py:394-404 from do_prediction(patches=False)'s uint8 [H,W,3] (or [H,W]) label image.  BGR2GRAY of three equal
+    channels returns the channel (the weights sum to one); threshold(gray, 0, 255, THRESH_BINARY) = gray > 0."""
+    gray = img_page_prediction[:, :, 0] if img_page_prediction.ndim == 3 else img_page_prediction
+    thresh = np.where(gray > 0, 255, 0).astype(np.uint8)             # main.py:394-395
+    thresh = morph(thresh, "dilate", 5, 6)                           # main.py:397
+    return largest_component_box(thresh)                             # main.py:398-404 (see [EXT] note above)
+
+
+def crop_image_inside_box(box, img):
+    """main.py:174-176."""
+    x, y, w, h = box
+    return img[y:y + h, x:x + w], [y, y + h, x, x + w]

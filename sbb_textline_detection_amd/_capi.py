@@ -26,6 +26,7 @@ EXPORTS = [
     "sbbseg_segment_tile_range_bin_dev", "sbbseg_segment_whole", "sbbseg_segment_whole_scaled", "sbbseg_tile_grid", "sbbseg_nearest_map", "sbbseg_segment_tiles_dev",
     "sbbseg_segment_tile_range_dev", "sbbseg_stitch_dev", "sbbseg_debug_ingest", "sbbseg_debug_read_tensor",
     "sbbseg_debug_set_conv_variant", "sbbseg_debug_inject_alloc_failure",
+    "sbbseg_morph_dev", "sbbseg_morph", "sbbseg_page_box_dev", "sbbseg_extract_page_box",
     "sbbseg_profile_enable", "sbbseg_profile_reset", "sbbseg_profile_get",
 ]
 
@@ -99,6 +100,10 @@ def load_library(path: Optional[str] = None):
         "sbbseg_debug_ingest": [vp, vp, i32, i32, vp, i32, i32, vp, C.c_size_t],
         "sbbseg_debug_read_tensor": [vp, i32, i32, vp, C.c_size_t],
         "sbbseg_debug_set_conv_variant": [vp, i32],
+        "sbbseg_morph_dev": [vp, vp, i32, i32, i32, i32, i32, vp],
+        "sbbseg_morph": [vp, vp, i32, i32, i32, i32, i32, vp],
+        "sbbseg_page_box_dev": [vp, vp, i32, i32, vp, C.POINTER(C.c_int64)],
+        "sbbseg_extract_page_box": [vp, vp, i32, i32, i32, i32, vp, vp, C.POINTER(C.c_int64)],
         "sbbseg_debug_inject_alloc_failure": [i32],
         "sbbseg_profile_enable": [vp, i32],
         "sbbseg_profile_reset": [vp],
@@ -348,6 +353,37 @@ class Context:
         check(self.lib.sbbseg_debug_read_tensor(self.h, self.tensor_ids[plan_tensor], n, _ptr(out), out.size),
               "sbbseg_debug_read_tensor")
         return out
+
+    # -- stage glue ---------------------------------------------------------------
+    def morph(self, plane: np.ndarray, op: int, ksize: int = 5, iterations: int = 1) -> np.ndarray:
+        """cv2.erode (op 0) / cv2.dilate (op 1) of a uint8 plane [H,W] with a ksize x ksize kernel of ones, on the device."""
+        plane = np.ascontiguousarray(plane, np.uint8)
+        if plane.ndim != 2:
+            raise ValueError("morph expects a uint8 plane [H, W]")
+        out = np.empty_like(plane)
+        check(self.lib.sbbseg_morph(self.h, _ptr(plane), plane.shape[0], plane.shape[1], int(op), int(ksize), int(iterations), _ptr(out)),
+              "sbbseg_morph")
+        return out
+
+    def morph_dev(self, d_src: int, H: int, W: int, op: int, ksize: int, iterations: int, d_dst: int):
+        check(self.lib.sbbseg_morph_dev(self.h, C.c_void_p(d_src), H, W, int(op), int(ksize), int(iterations), C.c_void_p(d_dst)), "sbbseg_morph_dev")
+
+    def page_box_dev(self, d_mask: int, H: int, W: int):
+        """((x, y, w, h), pixels) of the largest component of the dilated mask (main.py:394-404); pixels == 0: empty mask."""
+        box = np.zeros(4, np.int32)
+        px = C.c_int64(0)
+        check(self.lib.sbbseg_page_box_dev(self.h, C.c_void_p(d_mask), H, W, _ptr(box), C.byref(px)), "sbbseg_page_box_dev")
+        return tuple(int(v) for v in box), int(px.value)
+
+    def extract_page_box(self, page: np.ndarray, scaled_h: int, scaled_w: int, channels: int = 1):
+        """Border model on the page as upscaled to scaled_h x scaled_w + the page box, one call: (mask, (x, y, w, h), pixels)."""
+        page = np.ascontiguousarray(page, np.uint8)
+        mask = self._label_out(scaled_h, scaled_w, channels)
+        box = np.zeros(4, np.int32)
+        px = C.c_int64(0)
+        check(self.lib.sbbseg_extract_page_box(self.h, _ptr(page), page.shape[0], page.shape[1], scaled_h, scaled_w, _ptr(mask), _ptr(box),
+                                               C.byref(px)), "sbbseg_extract_page_box")
+        return mask, tuple(int(v) for v in box), int(px.value)
 
     def set_conv_variant(self, variant: int):
         check(self.lib.sbbseg_debug_set_conv_variant(self.h, int(variant)))

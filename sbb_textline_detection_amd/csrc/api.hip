@@ -161,6 +161,10 @@ struct sbbseg_ctx {
     int *d_own_x = nullptr, *d_own_y = nullptr; size_t own_cap = 0;
     int own_Hp = -1, own_Wp = -1, own_nyf = 0;
     int *d_map = nullptr; size_t map_cap = 0;
+    // stage glue scratch (morphology planes, union-find arrays, result words)
+    uint8_t *d_morph_a = nullptr, *d_morph_b = nullptr; size_t morph_a_cap = 0, morph_b_cap = 0;
+    int *d_cc_parent = nullptr, *d_cc_count = nullptr; size_t cc_parent_cap = 0, cc_count_cap = 0;
+    unsigned long long* d_cc_small = nullptr;      // [0] best key, [1..2] box (4 ints)
     // profiling
     bool profiling = false;
     int conv_variant = 0;
@@ -510,6 +514,7 @@ int sbbseg_destroy(sbbseg_ctx* c)
     (void)hipFree(c->d_lut); (void)hipFree(c->d_hist); (void)hipFree(c->d_tile_xy); (void)hipFree(c->d_batch_labels); (void)hipFree(c->d_probs); (void)hipFree(c->d_xin);
     (void)hipFree(c->d_page); (void)hipFree(c->d_page_labels); (void)hipFree(c->d_page_labels3); (void)hipFree(c->d_tile_labels);
     (void)hipFree(c->d_own_x); (void)hipFree(c->d_own_y); (void)hipFree(c->d_map);
+    (void)hipFree(c->d_morph_a); (void)hipFree(c->d_morph_b); (void)hipFree(c->d_cc_parent); (void)hipFree(c->d_cc_count); (void)hipFree(c->d_cc_small);
     for (auto& pe : c->pending) { (void)hipEventDestroy(pe.a); (void)hipEventDestroy(pe.b); }
     for (auto e : c->free_events) (void)hipEventDestroy(e);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -1544,6 +1549,81 @@ int sbbseg_segment_whole_scaled(sbbseg_ctx* c, const uint8_t* page_hwc, int Hp, 
     if (labels_to_host(c, labels_out, opix)) return 1;
     HIPCHK(hipStreamSynchronize(c->stream));
     return 0;
+    API_END
+}
+
+// ------------------------------------------------------------------------------ stage glue (8f-3)
+int sbbseg_morph_dev(sbbseg_ctx* c, const void* d_src_hw, int H, int W, int op, int ksize, int iterations, void* d_dst_hw)
+{
+    API_BEGIN
+    if (check_ready(c)) return 1;
+    REQUIRE(d_src_hw && d_dst_hw && H > 0 && W > 0, "bad arguments");
+    REQUIRE((op == SBBSEG_MORPH_ERODE || op == SBBSEG_MORPH_DILATE) && ksize >= 1 && (ksize & 1) && iterations >= 1, "morph: op 0|1, odd kernel, iterations >= 1");
+    const size_t pix = (size_t)H * W;
+    if (ensure(c, (void**)&c->d_morph_a, &c->morph_a_cap, pix)) return 1;
+    HIPCHK(launch_morph((const uint8_t*)d_src_hw, c->d_morph_a, (uint8_t*)d_dst_hw, H, W, (ksize - 1) / 2 * iterations, op == SBBSEG_MORPH_DILATE, 0, c->stream));
+    return 0;
+    API_END
+}
+
+int sbbseg_morph(sbbseg_ctx* c, const uint8_t* src_hw, int H, int W, int op, int ksize, int iterations, uint8_t* dst_hw)
+{
+    API_BEGIN
+    if (check_ready(c)) return 1;
+    REQUIRE(src_hw && dst_hw && H > 0 && W > 0, "bad arguments");
+    const size_t pix = (size_t)H * W;
+    if (ensure(c, (void**)&c->d_morph_b, &c->morph_b_cap, pix)) return 1;
+    HIPCHK(hipMemcpyAsync(c->d_morph_b, src_hw, pix, hipMemcpyHostToDevice, c->stream));
+    if (sbbseg_morph_dev(c, c->d_morph_b, H, W, op, ksize, iterations, c->d_morph_b)) return 1;
+    HIPCHK(hipMemcpyAsync(dst_hw, c->d_morph_b, pix, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+    API_END
+}
+
+int sbbseg_page_box_dev(sbbseg_ctx* c, const void* d_mask_hw, int H, int W, int32_t* box_xywh, int64_t* pixels)
+{
+    API_BEGIN
+    if (check_ready(c)) return 1;
+    REQUIRE(d_mask_hw && box_xywh && H > 0 && W > 0, "bad arguments");
+    REQUIRE((size_t)H * W < ((size_t)1 << 31), "mask too large for 32-bit pixel indices");
+    const size_t pix = (size_t)H * W;
+    if (ensure(c, (void**)&c->d_morph_a, &c->morph_a_cap, pix) || ensure(c, (void**)&c->d_morph_b, &c->morph_b_cap, pix)) return 1;
+    if (ensure(c, (void**)&c->d_cc_parent, &c->cc_parent_cap, pix * sizeof(int)) || ensure(c, (void**)&c->d_cc_count, &c->cc_count_cap, pix * sizeof(int))) return 1;
+    if (!c->d_cc_small && dmalloc(c, (void**)&c->d_cc_small, 4 * sizeof(unsigned long long))) return 1;
+    // main.py:394-398: gray > 0 -> 255, dilate with the 5x5 kernel of ones, 6 iterations (= one clipped 25x25 maximum)
+    HIPCHK(launch_morph((const uint8_t*)d_mask_hw, c->d_morph_a, c->d_morph_b, H, W, 12, 1, 1, c->stream));
+    int* d_box = (int*)(c->d_cc_small + 1);
+    HIPCHK(launch_largest_component(c->d_morph_b, H, W, c->d_cc_parent, c->d_cc_count, c->d_cc_small, d_box, c->stream));
+    unsigned long long best = 0;
+    int box[4] = {0, 0, 0, 0};
+    HIPCHK(hipMemcpyAsync(&best, c->d_cc_small, sizeof(best), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(box, d_box, sizeof(box), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (pixels) *pixels = (int64_t)(best >> 32);
+    if (best == 0) {                                   // empty mask: the reference's np.argmax of an empty list raises (main.py:399-401)
+        box_xywh[0] = box_xywh[1] = box_xywh[2] = box_xywh[3] = 0;
+        return 0;
+    }
+    box_xywh[0] = box[0]; box_xywh[1] = box[1]; box_xywh[2] = box[2] - box[0] + 1; box_xywh[3] = box[3] - box[1] + 1;   // cv2.boundingRect
+    return 0;
+    API_END
+}
+
+int sbbseg_extract_page_box(sbbseg_ctx* c, const uint8_t* page_hwc, int Hp, int Wp, int Hs, int Ws, uint8_t* mask_out, int32_t* box_xywh,
+                            int64_t* pixels)
+{
+    API_BEGIN
+    if (check_ready(c)) return 1;
+    REQUIRE(page_hwc && box_xywh && Hs > 0 && Ws > 0, "bad arguments");
+    // border model on the (virtually) upscaled page, result at the upscaled size (main.py:384-392) ...
+    const size_t opix = (size_t)Hs * Ws;
+    std::vector<uint8_t> scratch;
+    uint8_t* host_mask = mask_out;
+    if (!host_mask) { alloc_check(); scratch.resize(opix * (c->label_channels == 3 ? 3 : 1)); host_mask = scratch.data(); }
+    if (sbbseg_segment_whole_scaled(c, page_hwc, Hp, Wp, Hs, Ws, Hs, Ws, host_mask)) return 1;
+    // ... whose label plane is still in d_page_labels: threshold, dilate x 6, largest component, bounding box (main.py:394-404)
+    return sbbseg_page_box_dev(c, c->d_page_labels, Hs, Ws, box_xywh, pixels);
     API_END
 }
 

@@ -2112,6 +2112,174 @@ hipError_t launch_resize_labels(const uint8_t* labels, int H, int W, const int* 
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------
+// Stage glue around the border / layout models: cv2.erode / cv2.dilate with the reference's
+// 5x5 kernel of ones (main.py:57) and the largest connected component of the border mask (main.py:394-404).
+// ------------------------------------------------------------------------------------------------
+// n iterations of a k x k min (erode) / max (dilate) filter with cv2's default border (the outside never wins:
+// BORDER_CONSTANT with +inf / -inf) == ONE (n(k-1)+1)-wide filter over the window clipped to the image, separable.
+// pass 0: along x, pass 1: along y.
+__global__ __launch_bounds__(256) void morph_pass_kernel(const uint8_t* src, uint8_t* dst, int H, int W, int radius, int is_max,
+                                                         int vertical, int binarize)
+{
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)H * W) return;
+    const int y = (int)(idx / W), x = (int)(idx - (long)y * W);
+    int v = is_max ? 0 : 255;
+    if (!vertical) {
+        const int lo = max(x - radius, 0), hi = min(x + radius, W - 1);
+        const uint8_t* row = src + (size_t)y * W;
+        for (int q = lo; q <= hi; ++q) {
+            int t = row[q];
+            if (binarize) t = t > 0 ? 255 : 0;             // cv2.threshold(gray, 0, 255, THRESH_BINARY) of main.py:395
+            v = is_max ? max(v, t) : min(v, t);
+        }
+    } else {
+        const int lo = max(y - radius, 0), hi = min(y + radius, H - 1);
+        for (int q = lo; q <= hi; ++q) {
+            const int t = src[(size_t)q * W + x];
+            v = is_max ? max(v, t) : min(v, t);
+        }
+    }
+    dst[idx] = (uint8_t)v;
+}
+
+hipError_t launch_morph(const uint8_t* src, uint8_t* tmp, uint8_t* dst, int H, int W, int radius, int is_max, int binarize, hipStream_t s)
+{
+    const unsigned grid = (unsigned)(((long)H * W + 255) / 256);
+    hipLaunchKernelGGL(morph_pass_kernel, dim3(grid), dim3(256), 0, s, src, tmp, H, W, radius, is_max, 0, binarize);
+    hipLaunchKernelGGL(morph_pass_kernel, dim3(grid), dim3(256), 0, s, (const uint8_t*)tmp, dst, H, W, radius, is_max, 1, 0);
+    return hipGetLastError();
+}
+
+// 8-connected components of mask > 0 by union-find on pixel indices (roots = smallest index of a component = its first
+// pixel in raster order).  parent values only ever decrease and every value ever stored is an ancestor, so a stale read
+// (another CU's update not yet visible) costs a retry, never a wrong merge: links are made by atomicMin, whose RETURN
+// value is what decides.
+__device__ inline int cc_find(int* parent, int i)
+{
+    int p = parent[i];
+    while (p != i) {
+        const int g = parent[p];
+        if (g != p) parent[i] = g;                          // path halving (any ancestor is a valid parent)
+        i = p;
+        p = g;
+    }
+    return i;
+}
+__device__ inline void cc_union(int* parent, int a, int b)
+{
+    for (;;) {
+        a = cc_find(parent, a);
+        b = cc_find(parent, b);
+        if (a == b) return;
+        if (a > b) { const int t = a; a = b; b = t; }
+        const int old = atomicMin(&parent[b], a);           // hang the larger root under the smaller one
+        if (old == b) return;
+        b = old;                                            // b had been linked meanwhile: go on from its parent
+    }
+}
+// one thread per row: parent = first pixel of the horizontal run (keeps the union-find trees flat)
+__global__ __launch_bounds__(64) void cc_rows_kernel(const uint8_t* mask, int* parent, int* count, int H, int W)
+{
+    const int y = blockIdx.x * 64 + threadIdx.x;
+    if (y >= H) return;
+    int start = -1;
+    for (int x = 0; x < W; ++x) {
+        const long i = (long)y * W + x;
+        count[i] = 0;
+        if (mask[i]) {
+            if (start < 0) start = (int)i;
+            parent[i] = start;
+        } else {
+            start = -1;
+            parent[i] = -1;
+        }
+    }
+}
+__global__ __launch_bounds__(256) void cc_link_kernel(const uint8_t* mask, int* parent, int H, int W)
+{
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)H * W) return;
+    const int y = (int)(idx / W), x = (int)(idx - (long)y * W);
+    if (y == 0 || !mask[idx]) return;
+    const long up = idx - W;
+    // a pixel whose left neighbour is set and sees the same upper pixels through it can skip them; keep it simple: link to
+    // every set upper neighbour (redundant unions end at the first find)
+    if (mask[up]) { cc_union(parent, (int)idx, (int)up); return; }          // N set: NW / NE are joined to it through their row runs
+    if (x > 0 && mask[up - 1]) cc_union(parent, (int)idx, (int)(up - 1));
+    if (x + 1 < W && mask[up + 1]) cc_union(parent, (int)idx, (int)(up + 1));
+}
+// flatten + pixel count per root (runs of equal root inside a 64-pixel strip are added with one atomic)
+__global__ __launch_bounds__(256) void cc_count_kernel(int* parent, int* count, long n)
+{
+    const long base = ((long)blockIdx.x * 256 + threadIdx.x) * 64;
+    int cur = -1, run = 0;
+    for (int k = 0; k < 64 && base + k < n; ++k) {
+        const long i = base + k;
+        int r = -1;
+        if (parent[i] >= 0) { r = cc_find(parent, (int)i); parent[i] = r; }
+        if (r != cur) {
+            if (cur >= 0) atomicAdd(&count[cur], run);
+            cur = r;
+            run = 0;
+        }
+        ++run;
+    }
+    if (cur >= 0) atomicAdd(&count[cur], run);
+}
+// best = max over roots of (count, then smallest root index); key = count << 32 | ~root
+__global__ __launch_bounds__(256) void cc_best_kernel(const int* parent, const int* count, long n, unsigned long long* best)
+{
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    unsigned long long key = 0;
+    if (i < n && parent[i] == (int)i) key = ((unsigned long long)(unsigned)count[i] << 32) | (0xffffffffu - (unsigned)i);
+    // wave maximum, one atomic per wave
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned long long o = __shfl_xor(key, off);
+        key = o > key ? o : key;
+    }
+    if ((threadIdx.x & 63) == 0 && key) atomicMax(best, key);
+}
+__global__ __launch_bounds__(256) void cc_bbox_kernel(const int* parent, int H, int W, const unsigned long long* best, int* box)
+{
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const unsigned long long key = *best;
+    const int root = key ? (int)(0xffffffffu - (unsigned)(key & 0xffffffffu)) : -2;
+    int x0 = 1 << 30, y0 = 1 << 30, x1 = -1, y1 = -1;
+    if (i < (long)H * W && parent[i] == root) {
+        const int y = (int)(i / W), x = (int)(i - (long)y * W);
+        x0 = x1 = x; y0 = y1 = y;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        x0 = min(x0, __shfl_xor(x0, off)); y0 = min(y0, __shfl_xor(y0, off));
+        x1 = max(x1, __shfl_xor(x1, off)); y1 = max(y1, __shfl_xor(y1, off));
+    }
+    if ((threadIdx.x & 63) == 0 && x1 >= 0) {
+        atomicMin(&box[0], x0); atomicMin(&box[1], y0); atomicMax(&box[2], x1); atomicMax(&box[3], y1);
+    }
+}
+
+// d_box: int[4] = {min x, min y, max x, max y} of the largest component (untouched sentinel {2^30, 2^30, -1, -1} if none);
+// d_best: its (pixel count << 32 | ~root) key
+hipError_t launch_largest_component(const uint8_t* mask, int H, int W, int* parent, int* count, unsigned long long* d_best, int* d_box,
+                                    hipStream_t s)
+{
+    const long n = (long)H * W;
+    static const int init_box[4] = {1 << 30, 1 << 30, -1, -1};
+    hipError_t e = hipMemsetAsync(d_best, 0, sizeof(unsigned long long), s);
+    if (e != hipSuccess) return e;
+    e = hipMemcpyAsync(d_box, init_box, sizeof(init_box), hipMemcpyHostToDevice, s);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(cc_rows_kernel, dim3((unsigned)((H + 63) / 64)), dim3(64), 0, s, mask, parent, count, H, W);
+    hipLaunchKernelGGL(cc_link_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, mask, parent, H, W);
+    hipLaunchKernelGGL(cc_count_kernel, dim3((unsigned)((n + 256 * 64 - 1) / (256 * 64))), dim3(256), 0, s, parent, count, n);
+    hipLaunchKernelGGL(cc_best_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const int*)parent, (const int*)count, n, d_best);
+    hipLaunchKernelGGL(cc_bbox_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const int*)parent, H, W,
+                       (const unsigned long long*)d_best, d_box);
+    return hipGetLastError();
+}
+
 template <typename E>
 __global__ __launch_bounds__(256) void to_f32_kernel(const E* src, float* dst, size_t n)
 {

@@ -7,8 +7,10 @@ it that section 8(f) ranks next, with the reference's names and call pattern:
     extract_text_regions            main.py:439-454   Otsu'd page, layout model (4 classes), patches=True
     textline_contours               main.py:490-503   textline model, patches=True, returns channel 0
 
-The cv2 contour / morphology post-processing of extract_page (main.py:394-426) is out of scope; the
-page box falls back to the full image exactly like the reference's own `except` branch (main.py:417-419).
+    extract_page   (glue part)      main.py:394-426   border mask -> dilate x 6 -> largest blob -> box -> crop (device)
+    erode x 3 / dilate x 4          main.py:2074-2075 on the layout map (device)
+
+The rest of the cv2 contour post-processing (text-region contours, line separation, ...) is out of scope.
 """
 from __future__ import annotations
 
@@ -66,6 +68,34 @@ def otsu_copy(img: np.ndarray) -> np.ndarray:
     return np.repeat(b[:, :, None], 3, axis=2)
 
 
+def host_morph(plane: np.ndarray, is_max: bool, ksize: int, iterations: int) -> np.ndarray:
+    """Host mirror of sbbseg_morph (foreign model objects only): one clipped (n(k-1)+1)-wide separable min / max."""
+    r = (ksize - 1) // 2 * iterations
+    a = np.ascontiguousarray(plane, np.uint8)
+    fill = 0 if is_max else 255
+    f = np.maximum if is_max else np.minimum
+    for axis in (1, 0):
+        p = np.pad(a, [(r, r) if ax == axis else (0, 0) for ax in (0, 1)], constant_values=fill)
+        out = np.full_like(a, fill)
+        for d in range(2 * r + 1):
+            out = f(out, p[:, d:d + a.shape[1]] if axis == 1 else p[d:d + a.shape[0], :])
+        a = out
+    return a
+
+
+def host_page_box(mask: np.ndarray):
+    """Host mirror of sbbseg_page_box_dev (foreign model objects only)."""
+    from scipy import ndimage
+    d = host_morph(np.where(np.asarray(mask) > 0, 255, 0).astype(np.uint8), True, 5, 6)
+    lab, n = ndimage.label(d > 0, structure=np.ones((3, 3), int))
+    if n == 0:
+        return (0, 0, 0, 0), 0
+    counts = np.bincount(lab.reshape(-1))[1:]
+    best = int(np.argmax(counts)) + 1
+    ys, xs = np.nonzero(lab == best)
+    return (int(xs.min()), int(ys.min()), int(xs.max() - xs.min() + 1), int(ys.max() - ys.min() + 1)), int(counts[best - 1])
+
+
 class InferenceStages:
     """The model-running part of ``textline_detector.run()`` (main.py:2056-2107)."""
 
@@ -100,6 +130,44 @@ class InferenceStages:
                                                       self.img_hight_int, self.img_width_int, channels=3)
             img = self._scaled_page()
             return do_prediction(False, img, model, full_image_shape=img.shape)
+        finally:
+            session.close()
+
+    def extract_page(self):
+        """main.py:384-437: border model + page box + crop.  Returns (croped_page, page_coord) like the reference;
+        ``self.cont_page`` holds the box corners.  The mask never leaves the device between the model and the box.
+        Like the reference, an empty border mask is an error (np.argmax of an empty list raises there, main.py:399-401)."""
+        model, session = start_new_session_and_model(self.model_page_dir, **self.kw)
+        try:
+            if isinstance(model, SegModel):
+                self.page_mask, box, pixels = model.ctx.extract_page_box(self.image_stored, self.img_hight_int, self.img_width_int, channels=3)
+            else:
+                from .predict import resize_nearest
+                img = self._scaled_page()
+                self.page_mask = do_prediction(False, img, model, full_image_shape=img.shape)
+                box, pixels = host_page_box(self.page_mask[:, :, 0])
+            if pixels == 0:
+                raise ValueError("attempt to get argmax of an empty sequence")          # what main.py:401 raises
+            x, y, w, h = box
+            # crop_image_inside_box (main.py:174-176) on the upscaled page; built here only for the crop
+            page = self._scaled_page()
+            croped_page, page_coord = page[y:y + h, x:x + w], [y, y + h, x, x + w]
+            self.cont_page = [np.array([[page_coord[2], page_coord[0]], [page_coord[3], page_coord[0]],
+                                        [page_coord[3], page_coord[1]], [page_coord[2], page_coord[1]]])]
+            return croped_page, page_coord
+        finally:
+            session.close()
+
+    def clean_text_regions(self, text_regions: np.ndarray) -> np.ndarray:
+        """main.py:2074-2075: cv2.erode(text_regions, kernel, iterations=3) then cv2.dilate(..., iterations=4), on the device."""
+        model, session = start_new_session_and_model(self.model_region_dir, **self.kw)
+        try:
+            plane = np.ascontiguousarray(text_regions[:, :, 0] if text_regions.ndim == 3 else text_regions, np.uint8)
+            if isinstance(model, SegModel):
+                out = model.ctx.morph(model.ctx.morph(plane, 0, 5, 3), 1, 5, 4)
+            else:
+                out = host_morph(host_morph(plane, False, 5, 3), True, 5, 4)
+            return np.repeat(out[:, :, None], 3, axis=2) if text_regions.ndim == 3 else out
         finally:
             session.close()
 

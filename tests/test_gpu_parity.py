@@ -659,3 +659,58 @@ def test_pooled_pages_equal_page_by_page(torch_cuda):
     with pytest.raises(ValueError):
         model.ctx.segment_pages_dev([], 700, 610, [])
     model.release()
+
+
+def test_device_morphology_and_page_box(torch_cuda, stitch_model):
+    """SURVEY 8f-3 remainder on the device, bit-exact against oracle/stage_glue.py (which applies the 5x5 kernel literally,
+    iteration by iteration): erode x 3 / dilate x 4 of a layout map (main.py:2074-2075), dilate x 6 + largest component +
+    bounding box of a border mask (main.py:394-404), incl. speckle noise, corner-touching blobs, page edges and the empty mask."""
+    from oracle import stage_glue
+    torch = torch_cuda
+    m = stitch_model
+    rng = np.random.RandomState(11)
+    # layout-like map: classes 0..3 in blobs + noise
+    lay = np.zeros((613, 877), np.uint8)
+    lay[50:300, 60:500] = 1; lay[320:600, 100:800] = 2; lay[0:40, 700:877] = 3
+    lay[rng.rand(*lay.shape) < 0.01] = rng.randint(0, 4)
+    for op, name, it in ((0, "erode", 3), (1, "dilate", 4), (1, "dilate", 6), (0, "erode", 1)):
+        assert np.array_equal(m.ctx.morph(lay, op, 5, it), stage_glue.morph(lay, name, 5, it)), (name, it)
+    assert np.array_equal(m.ctx.morph(m.ctx.morph(lay, 0, 5, 3), 1, 5, 4), stage_glue.region_cleanup(lay))
+    masks = []
+    a = np.zeros((700, 520), np.uint8); a[40:660, 30:500] = 1; a[rng.rand(*a.shape) < 0.002] = 1; masks.append(a)     # page + specks
+    b = np.zeros((300, 300), np.uint8); b[0:100, 0:100] = 1; b[125:200, 125:290] = 1; masks.append(b)                 # two blobs, 25 px apart -> merge after dilation
+    c = np.zeros((300, 300), np.uint8); c[0:100, 0:100] = 1; c[126:200, 126:290] = 1; masks.append(c)                 # 26 px apart -> stay separate
+    d = (rng.rand(257, 391) < 0.0005).astype(np.uint8); masks.append(d)                                               # sparse specks: many small components
+    masks.append(np.zeros((64, 64), np.uint8))                                                                         # empty
+    masks.append(np.ones((50, 70), np.uint8))                                                                          # full
+    for k, mask in enumerate(masks):
+        d_mask = torch.from_numpy(mask).cuda()
+        got = m.ctx.page_box_dev(d_mask.data_ptr(), mask.shape[0], mask.shape[1])
+        assert got == stage_glue.page_box(mask), (k, got, stage_glue.page_box(mask))
+
+
+def test_extract_page_stage(tmp_path):
+    """extract_page (main.py:384-437) through the stage wrapper: border model on the upscaled page, box and crop; the box equals
+    the oracle's box of the mask the same call returns."""
+    from oracle import stage_glue
+    from sbb_textline_detection_amd import clear_session, stages
+    from sbb_textline_detection_amd.weights import save_sbbw
+    from tools.synth_model import calibrated_model
+    cfg, w = calibrated_model(2, 224, 224, seed=2)
+    for name in ("model_page_mixed_best", "model_strukturerkennung", "model_textline_new"):
+        save_sbbw(str(tmp_path / (name + ".sbbw")), cfg, w)
+    st = stages.InferenceStages(*[str(tmp_path / (n + ".h5")) for n in ("model_page_mixed_best", "model_strukturerkennung", "model_textline_new")],
+                                model_kwargs={"max_batch": 8})
+    page = synthetic_page(520, 400, seed=9)
+    st.get_image_and_scales(page)
+    try:
+        croped, coord = st.extract_page()
+    except ValueError:
+        croped, coord = None, None                     # an all-background border mask raises like the reference (main.py:401)
+    if croped is not None:
+        box, px = stage_glue.page_box(st.page_mask)
+        assert coord == [box[1], box[1] + box[3], box[0], box[0] + box[2]] and croped.shape[:2] == (box[3], box[2])
+        assert st.cont_page[0].shape == (4, 2)
+    regions = st.extract_text_regions()
+    assert np.array_equal(st.clean_text_regions(regions), stage_glue.region_cleanup(regions))
+    clear_session()

@@ -74,3 +74,47 @@ def test_otsu_copy_quirk():
     for c in range(3):                                                   # main.py:191-193
         assert np.array_equal(out[:, :, c], np.where(page[:, :, 0] > t, 255.0, 0.0))
     assert np.array_equal(out, stages.otsu_copy(page))
+
+
+# ---- morphology / page box (SURVEY 8f-3 remainder)
+def test_morph_hand_cases():
+    a = np.zeros((9, 11), np.uint8)
+    a[4, 5] = 255
+    d = stage_glue.morph(a, "dilate", 5, 1)
+    assert d.sum() == 25 * 255 and d[2:7, 3:8].min() == 255                  # one pixel -> 5x5 block
+    d2 = stage_glue.morph(a, "dilate", 5, 2)
+    assert np.count_nonzero(d2) == 9 * 9                                      # two iterations == one 9x9 (clipped: fits here)
+    assert np.array_equal(stage_glue.morph(d, "erode", 5, 1), a)              # erosion of the block gives the pixel back
+    # border: the outside never wins -> a full plane stays full under erosion, an empty one stays empty under dilation
+    assert stage_glue.morph(np.full((6, 7), 255, np.uint8), "erode", 5, 3).min() == 255
+    assert stage_glue.morph(np.zeros((6, 7), np.uint8), "dilate", 5, 6).max() == 0
+    # grey levels (the layout map holds classes 0..3): min / max, not binary logic
+    g = np.array([[3, 3, 3, 3, 3, 3, 3], [3, 1, 3, 3, 3, 2, 3]], np.uint8)
+    assert stage_glue.morph(g, "erode", 5, 1).tolist() == [[1, 1, 1, 1, 2, 2, 2]] * 2
+    # corner pixel: clipped window
+    c = np.zeros((8, 8), np.uint8); c[0, 0] = 7
+    assert np.count_nonzero(stage_glue.morph(c, "dilate", 5, 1)) == 9
+
+
+def test_host_mirrors_equal_oracle_morph_and_box():
+    rng = np.random.RandomState(5)
+    for shape in ((40, 57), (64, 64), (33, 90)):
+        m = (rng.rand(*shape) < 0.08).astype(np.uint8) * rng.randint(1, 4, shape).astype(np.uint8)
+        for op, it in (("erode", 3), ("dilate", 4), ("dilate", 6), ("erode", 1)):
+            assert np.array_equal(stages.host_morph(m, op == "dilate", 5, it), stage_glue.morph(m, op, 5, it)), (shape, op, it)
+        assert stages.host_page_box(m) == stage_glue.page_box(m)
+    assert stage_glue.page_box(np.zeros((30, 30), np.uint8)) == ((0, 0, 0, 0), 0)
+
+
+def test_page_box_by_hand():
+    m = np.zeros((100, 120), np.uint8)
+    m[30:60, 40:90] = 1                      # the page blob: 30 x 50
+    m[5:8, 5:8] = 1                          # a speck far away (more than 24 px: stays a separate component after dilation)
+    box, px = stage_glue.page_box(np.repeat(m[:, :, None], 3, axis=2))
+    assert box == (28, 18, 74, 54)           # dilated by 12 on every side: x 40-12 .. 89+12, y 30-12 .. 59+12
+    assert px == 74 * 54
+    crop, coord = stage_glue.crop_image_inside_box(box, np.zeros((100, 120, 3), np.uint8))
+    assert crop.shape == (54, 74, 3) and coord == [18, 72, 28, 102]          # main.py:174-176: [y, y+h, x, x+w]
+    # 8-connectivity: two blobs touching at a corner are ONE component
+    d = np.zeros((40, 40), np.uint8); d[0:10, 0:10] = 1; d[10:20, 10:20] = 1
+    assert stage_glue.largest_component_box(d) == ((0, 0, 20, 20), 200)
