@@ -159,7 +159,8 @@ def forward(graph, weights: Dict[str, np.ndarray], x: np.ndarray, taps=None, con
             if n.attrs.get("activation", "linear") == "relu":
                 y = np.maximum(y, 0)
         elif n.op == "bn":
-            g = weights[f"{n.name}/gamma:0"]; be = weights[f"{n.name}/beta:0"]
+            g = weights[f"{n.name}/gamma:0"] if n.attrs.get("scale", True) else np.float32(1.0)      # Keras: no gamma with scale=False,
+            be = weights[f"{n.name}/beta:0"] if n.attrs.get("center", True) else np.float32(0.0)     #        no beta with center=False
             mu = weights[f"{n.name}/moving_mean:0"]; var = weights[f"{n.name}/moving_variance:0"]
             y = (g * (a[0] - mu) / np.sqrt(var + np.float32(n.attrs["eps"])) + be).astype(np.float32)
         elif n.op == "act":

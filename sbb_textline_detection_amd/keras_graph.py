@@ -79,7 +79,10 @@ class Graph:
                     specs.append((f"{n.name}/bias:0", (n.attrs["filters"],)))
             elif n.op == "bn":
                 c = n.out_shape[2]
+                # Keras creates gamma only with scale=True and beta only with center=True (BatchNormalization.build)
                 for w in ("gamma", "beta", "moving_mean", "moving_variance"):
+                    if (w == "gamma" and not n.attrs.get("scale", True)) or (w == "beta" and not n.attrs.get("center", True)):
+                        continue
                     specs.append((f"{n.name}/{w}:0", (c,)))
         return specs
 

@@ -19,11 +19,14 @@ def _has_h5py():
 
 
 @pytest.mark.skipif(not _has_h5py(), reason="no interpreter with h5py in this image")
-def test_h5_roundtrip(tmp_path):
+@pytest.mark.parametrize("uniquify", [False, True])
+def test_h5_roundtrip(tmp_path, uniquify):
+    """uniquify: the file's weight_names do not start with the layer name ("conv1_1/kernel:0" inside group "conv1", nested
+    datasets) -- the converter resolves them per layer group and re-keys to "<layer>/<leaf>"."""
     h5 = str(tmp_path / "model_textline_new.h5")
     tool = os.path.join(ROOT, "tools", "h5_to_sbbw.py")
     env = dict(os.environ, PYTHONPATH="")
-    r = subprocess.run([PY_H5, tool, h5, "--fake-from-synthetic", "--classes", "4", "--size", "64", "--seed", "5"],
+    r = subprocess.run([PY_H5, tool, h5, "--fake-from-synthetic", "--classes", "4", "--size", "64", "--seed", "5"] + (["--uniquify"] if uniquify else []),
                        capture_output=True, text=True, env=env)
     assert r.returncode == 0, r.stderr
     r = subprocess.run([PY_H5, tool, h5], capture_output=True, text=True, env=env)

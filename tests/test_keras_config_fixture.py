@@ -95,3 +95,24 @@ def test_unrecognised_lambda_is_refused_by_both_readers(cfg):
     for reader in (read_model_config, parse_model_config):
         with pytest.raises(ValueError):
             reader(bad)
+
+
+def test_batchnorm_without_scale_or_center(cfg):
+    """BatchNormalization(scale=False) has no gamma, (center=False) no beta (Keras build()): weight_specs, the planner, the
+    oracle and the torch cross-check all honour the flags."""
+    c = copy.deepcopy(cfg)
+    for layer in c["config"]["layers"]:
+        if layer["name"] == "bn2a_branch2a":
+            layer["config"]["scale"] = False
+        if layer["name"] == "batch_normalization_2":
+            layer["config"]["center"] = False
+    g = parse_model_config(c)
+    names = [n for n, _ in g.weight_specs()]
+    assert "bn2a_branch2a/gamma:0" not in names and "bn2a_branch2a/beta:0" in names
+    assert "batch_normalization_2/beta:0" not in names and "batch_normalization_2/gamma:0" in names
+    w = synthetic_weights(g, seed=6)
+    x = np.random.RandomState(3).rand(1, 32, 48, 3).astype(np.float32)
+    p = kf.forward_config(c, w, x)
+    q = forward_torch(g, w, x, torch.float64)
+    lab, pr, _ = run_plan(build_plan(g, w), x)
+    assert np.abs(p - q).max() < 1e-4 and np.abs(pr - p).max() < 5e-4

@@ -51,21 +51,42 @@ def h5_to_sbbw(h5_path: str, out_path: str) -> None:
     with h5py.File(h5_path, "r") as f:
         cfg = json.loads(_s(f.attrs["model_config"]))
         grp = f["model_weights"] if "model_weights" in f else f
-        weights = {}
-        for lname in grp.attrs["layer_names"]:
-            g = grp[_s(lname)]
-            for wname in g.attrs["weight_names"]:
-                weights[_s(wname)] = np.asarray(g[_s(wname)], np.float32)
-    graph = kg.parse_model_config(cfg)
-    missing = [n for n, _ in graph.weight_specs() if n not in weights]
-    if missing:
-        raise SystemExit(f"{h5_path}: weights missing for {missing[:5]} ...")
+        graph = kg.parse_model_config(cfg)
+        # Keras keys a layer's group by the LAYER name, but the weight_names inside carry the variable scope, which is often
+        # uniquified ("conv1_1/kernel:0", "batch_normalization_1_1/gamma:0") and so need not start with the layer name.  Resolve
+        # per layer: by leaf name ("kernel:0") when unique, else by position in weight_names (Keras' creation order = ours),
+        # and re-key to "<layer name>/<leaf>" -- what the planner and the oracle look up.
+        expected = {}
+        for name, shape in graph.weight_specs():
+            expected.setdefault(name.split("/")[0], []).append((name.split("/", 1)[1], tuple(shape)))
+        weights, problems = {}, []
+        for layer, leaves in expected.items():
+            if layer not in grp:
+                problems.append(f"{layer}: no group in model_weights")
+                continue
+            g = grp[layer]
+            names = [_s(w) for w in g.attrs["weight_names"]]
+            for pos, (leaf, shape) in enumerate(leaves):
+                byleaf = [w for w in names if w.rsplit("/", 1)[-1] == leaf]
+                pick = byleaf[0] if len(byleaf) == 1 else (names[pos] if pos < len(names) and len(names) == len(leaves) else None)
+                if pick is None:
+                    problems.append(f"{layer}/{leaf}: not found among {names}")
+                    continue
+                arr = np.asarray(g[pick], np.float32)
+                if tuple(arr.shape) != shape:
+                    problems.append(f"{layer}/{leaf}: shape {arr.shape} != expected {shape} (from {pick})")
+                    continue
+                weights[f"{layer}/{leaf}"] = arr
+    if problems:
+        raise SystemExit(f"{h5_path}: cannot resolve weights:\n  " + "\n  ".join(problems[:12]))
     wt.save_sbbw(out_path, cfg, weights)
     print(f"wrote {out_path}: {len(graph.nodes)} layers, {sum(v.size for v in weights.values())/1e6:.2f} M parameters, "
           f"input {graph.input_shape}, output {graph.output_shape}")
 
 
-def fake_h5(out_path: str, classes: int, size: int, seed: int) -> None:
+def fake_h5(out_path: str, classes: int, size: int, seed: int, uniquify: bool = False) -> None:
+    """A Keras-2.3-layout .h5 of the seeded synthetic model.  ``uniquify``: weight_names carry a uniquified variable scope
+    ("<layer>_1/kernel:0") and nested datasets, like files written after the layer names were taken once already."""
     import h5py
     kg, wt = _load_pkg()
     cfg, weights = wt.synthetic_model(classes, size, size, seed)
@@ -82,9 +103,10 @@ def fake_h5(out_path: str, classes: int, size: int, seed: int) -> None:
         for n in graph.nodes:
             g = mw.create_group(n.name)
             names = per_layer.get(n.name, [])
-            g.attrs["weight_names"] = [w.encode() for w in names]
-            for w in names:
-                g.create_dataset(w, data=weights[w])
+            stored = [(f"{n.name}_1/{w.split('/', 1)[1]}" if uniquify else w) for w in names]
+            g.attrs["weight_names"] = [w.encode() for w in stored]
+            for w, sw in zip(names, stored):
+                g.create_dataset(sw, data=weights[w])                  # (a path with "/" creates the nested scope group, as Keras does)
 
 
 if __name__ == "__main__":
@@ -92,11 +114,12 @@ if __name__ == "__main__":
     ap.add_argument("h5")
     ap.add_argument("-o", "--out")
     ap.add_argument("--fake-from-synthetic", action="store_true")
+    ap.add_argument("--uniquify", action="store_true", help="with --fake-from-synthetic: uniquified weight scopes in weight_names")
     ap.add_argument("--classes", type=int, default=2)
     ap.add_argument("--size", type=int, default=64)
     ap.add_argument("--seed", type=int, default=0)
     a = ap.parse_args()
     if a.fake_from_synthetic:
-        fake_h5(a.h5, a.classes, a.size, a.seed)
+        fake_h5(a.h5, a.classes, a.size, a.seed, a.uniquify)
     else:
         h5_to_sbbw(a.h5, a.out or os.path.splitext(a.h5)[0] + ".sbbw")

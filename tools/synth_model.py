@@ -70,7 +70,8 @@ def forward_torch(graph, weights, x_nhwc, dtype=torch.float32, calibrate_bn=Fals
                 weights[f"{n.name}/moving_mean:0"] = m.to(torch.float32).numpy().copy()
                 weights[f"{n.name}/moving_variance:0"] = np.maximum(v.to(torch.float32).numpy(), 1e-4).copy()
             y = F.batch_norm(a[0], t(weights[f"{n.name}/moving_mean:0"]), t(weights[f"{n.name}/moving_variance:0"]),
-                             t(weights[f"{n.name}/gamma:0"]), t(weights[f"{n.name}/beta:0"]), False, 0.0, n.attrs["eps"])
+                             t(weights[f"{n.name}/gamma:0"]) if n.attrs.get("scale", True) else None,
+                             t(weights[f"{n.name}/beta:0"]) if n.attrs.get("center", True) else None, False, 0.0, n.attrs["eps"])
         elif n.op == "act":
             k = n.attrs["kind"]
             y = F.relu(a[0]) if k == "relu" else F.softmax(a[0], dim=1) if k == "softmax" else a[0]
