@@ -50,6 +50,21 @@ int sbbseg_abi_version(void);
 int sbbseg_device_count(int* count);
 int sbbseg_create(int device, int precision, sbbseg_ctx** out);
 int sbbseg_destroy(sbbseg_ctx* c);                       /* frees all device memory; NULL ok */
+/* ONE-CALL model load: what keras.models.load_model(path, compile=False) + the first predict do in the reference
+ * (main.py:216-223).  Takes the .sbbw container (magic "SBBW0001", JSON header = the Keras-2.3 model_config of the .h5 plus a
+ * tensor table, little-endian fp32 weights; written offline by tools/h5_to_sbbw.py), reads the layer graph, lowers it to the fused
+ * plan (BN folding, parity split of the decoder convs, shortcut merge, fused head / tail -- the planner of planner.py restated in
+ * C++, same algebra in the same precision) and returns a finalized handle: no Python needed on the consumer's side.
+ * flags: SBBSEG_LOAD_* switches (0 = all lowerings on).  The step-by-step plan API below stays available. */
+#define SBBSEG_LOAD_NO_PARITY_SPLIT   1
+#define SBBSEG_LOAD_NO_SHORTCUT_MERGE 2
+#define SBBSEG_LOAD_NO_FUSED_HEAD     4
+#define SBBSEG_LOAD_NO_FUSED_TAIL     8
+int sbbseg_model_load(const void* sbbw_bytes, size_t n_bytes, int device, int precision, int max_batch, int flags, sbbseg_ctx** out);
+int sbbseg_model_load_file(const char* sbbw_path, int device, int precision, int max_batch, int flags, sbbseg_ctx** out);
+/* Test hook (no GPU needed): the plan sbbseg_model_load would build, as text -- one line per tensor / step with the CRC32 of every
+ * weight plane, scale and shift vector -- so the library's planner can be compared with planner.py value for value. */
+int sbbseg_debug_plan_summary(const void* sbbw_bytes, size_t n_bytes, int precision, int flags, char* out, size_t capacity, size_t* needed);
 /* run on the caller's HIP stream (NULL = the legacy default stream, e.g. torch's current stream when
  * no stream context is active); SBBSEG_OWN_STREAM returns to the handle's private non-blocking stream */
 #define SBBSEG_OWN_STREAM ((void*)(intptr_t)-1)

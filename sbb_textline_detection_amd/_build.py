@@ -8,7 +8,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libsbbseg.so")
-SOURCES = ["kernels.hip", "api.hip"]
+SOURCES = ["kernels.hip", "api.hip", "loader.cpp"]
 HEADERS = [os.path.join(CSRC, "internal.h"), os.path.join(HERE, "..", "include", "sbbseg.h")]
 
 

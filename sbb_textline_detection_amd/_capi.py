@@ -19,6 +19,7 @@ INPUT_C8, INPUT_PAIRS = 0, 1
 
 EXPORTS = [
     "sbbseg_last_error", "sbbseg_abi_version", "sbbseg_device_count", "sbbseg_create", "sbbseg_destroy",
+    "sbbseg_model_load", "sbbseg_model_load_file", "sbbseg_debug_plan_summary",
     "sbbseg_set_stream", "sbbseg_set_lanes", "sbbseg_set_label_channels", "sbbseg_synchronize", "sbbseg_set_input", "sbbseg_input_form", "sbbseg_add_tensor",
     "sbbseg_add_conv", "sbbseg_add_maxpool", "sbbseg_add_tail", "sbbseg_add_head", "sbbseg_finalize", "sbbseg_model_info",
     "sbbseg_num_ops", "sbbseg_op_info", "sbbseg_op_issued_flops", "sbbseg_device_bytes", "sbbseg_predict", "sbbseg_segment_page",
@@ -65,6 +66,9 @@ def load_library(path: Optional[str] = None):
         "sbbseg_device_count": [C.POINTER(C.c_int)],
         "sbbseg_create": [i32, i32, C.POINTER(vp)],
         "sbbseg_destroy": [vp],
+        "sbbseg_model_load": [vp, C.c_size_t, i32, i32, i32, i32, C.POINTER(vp)],
+        "sbbseg_model_load_file": [C.c_char_p, i32, i32, i32, i32, C.POINTER(vp)],
+        "sbbseg_debug_plan_summary": [vp, C.c_size_t, i32, i32, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)],
         "sbbseg_set_stream": [vp, vp],
         "sbbseg_synchronize": [vp],
         "sbbseg_set_lanes": [vp, i32],
@@ -133,13 +137,29 @@ def _ptr(a: Optional[np.ndarray]):
 class Context:
     """Owns one sbbseg_ctx (one GPU, one plan)."""
 
-    def __init__(self, device: int = 0, precision: int = PREC_BF16):
+    def __init__(self, device: int = 0, precision: int = PREC_BF16, _handle=None):
         self.lib = load_library()
-        h = C.c_void_p()
-        check(self.lib.sbbseg_create(device, precision, C.byref(h)), "sbbseg_create")
+        if _handle is None:
+            h = C.c_void_p()
+            check(self.lib.sbbseg_create(device, precision, C.byref(h)), "sbbseg_create")
+        else:
+            h = _handle
         self.h = h
         self.device, self.precision = device, precision
         self.tensor_ids = []
+
+    @classmethod
+    def from_sbbw(cls, source, device: int, precision: int, max_batch: int, flags: int = 0) -> "Context":
+        """One-call load through the library's own graph reader + planner (sbbseg_model_load[_file]): ``source`` is a path or the
+        container's bytes.  The handle comes back finalized."""
+        lib = load_library()
+        h = C.c_void_p()
+        if isinstance(source, (bytes, bytearray, memoryview)):
+            buf = bytes(source)
+            check(lib.sbbseg_model_load(buf, len(buf), device, precision, int(max_batch), int(flags), C.byref(h)), "sbbseg_model_load")
+        else:
+            check(lib.sbbseg_model_load_file(os.fsencode(source), device, precision, int(max_batch), int(flags), C.byref(h)), "sbbseg_model_load_file")
+        return cls(device, precision, _handle=h)
 
     def close(self):
         if getattr(self, "h", None):
@@ -420,3 +440,13 @@ def nearest_map(src_len: int, dst_len: int) -> np.ndarray:
     out = np.empty(dst_len, np.int32)
     check(load_library().sbbseg_nearest_map(int(src_len), int(dst_len), _ptr(out)), "sbbseg_nearest_map")
     return out
+
+
+def native_plan_summary(sbbw_bytes: bytes, precision: int, flags: int = 0) -> str:
+    """Text summary of the plan the library's own planner builds from a .sbbw container (no GPU needed; test hook)."""
+    lib = load_library()
+    need = C.c_size_t(0)
+    check(lib.sbbseg_debug_plan_summary(sbbw_bytes, len(sbbw_bytes), precision, flags, None, 0, C.byref(need)), "sbbseg_debug_plan_summary")
+    buf = C.create_string_buffer(need.value)
+    check(lib.sbbseg_debug_plan_summary(sbbw_bytes, len(sbbw_bytes), precision, flags, buf, need.value, None), "sbbseg_debug_plan_summary")
+    return buf.value.decode()

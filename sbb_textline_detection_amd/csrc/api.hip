@@ -63,6 +63,23 @@ inline void alloc_check()
     if (g_alloc_fail_countdown > 0 && --g_alloc_fail_countdown == 0) throw std::bad_alloc();
 }
 
+}  // namespace
+
+namespace sbbseg {
+int set_error(const char* fmt, ...)                     // for the other translation units of the library (loader.cpp)
+{
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return 1;
+}
+}  // namespace sbbseg
+
+namespace {
+
 struct Tensor {
     int H = 0, W = 0, C = 0;
     size_t elems_per_patch = 0;

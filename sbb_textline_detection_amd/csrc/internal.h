@@ -199,6 +199,7 @@ hipError_t launch_split_to_f32(const void* src, float* dst, size_t npix, int C, 
 
 int conv_row_channel(int row, int cout);   // packed weight row -> output channel (16-bit modes)
 int conv_tile_bc(int cout);   // channel-tile width the bf16 conv kernel uses for `cout` (weights are padded to it)
+int set_error(const char* fmt, ...);   // fills sbbseg_last_error() (thread-local), returns 1
 uint16_t f32_to_bf16_rne(float f);
 uint16_t f32_to_f16_rne(float f);
 float bf16_to_f32(uint16_t h);

@@ -21,7 +21,7 @@ import numpy as np
 from . import _capi
 from .keras_graph import Graph, parse_model_config
 from .planner import Plan, build_plan
-from .weights import load_sbbw
+from .weights import load_sbbw, read_sbbw_config
 
 _CACHE: Dict[Tuple, "SegModel"] = {}
 
@@ -45,30 +45,53 @@ class SegModel:
     """A segmentation net resident on one MI355X, duck-typed like the Keras model the reference uses."""
 
     def __init__(self, model_config, weights, device: int = 0, max_batch: Optional[int] = None,
-                 precision: Optional[str] = None):
+                 precision: Optional[str] = None, sbbw_path: Optional[str] = None):
+        """``weights``: {Keras weight name: array} -> lowered by the Python planner (planner.py) and uploaded step by step.
+        ``sbbw_path`` (instead of weights): the library reads the container itself and lowers it with its own planner
+        (``sbbseg_model_load_file``, csrc/loader.cpp) -- one C call, same plan value for value (tests/test_native_planner.py)."""
         precision = precision or default_precision()
         if precision not in _capi.PRECISIONS:
             raise ValueError(f"precision must be one of {sorted(_capi.PRECISIONS)}, got {precision!r}")
         self.graph: Graph = parse_model_config(model_config)
-        self.plan: Plan = build_plan(self.graph, weights, parity_split=os.environ.get("SBBSEG_PARITY_SPLIT", "1") != "0",
-                                     fuse_head=precision != "f32" and os.environ.get("SBBSEG_FUSE_HEAD", "1") != "0",
-                                     # the dedicated tail kernel reads the one-plane 16-bit layout (f16 / bf16 only)
-                                     fuse_tail=precision in ("f16", "bf16") and os.environ.get("SBBSEG_FUSE_TAIL", "1") != "0",
-                                     merge_shortcut=os.environ.get("SBBSEG_MERGE_SHORTCUT", "1") != "0")
+        self._plan_args = dict(parity_split=os.environ.get("SBBSEG_PARITY_SPLIT", "1") != "0",
+                               fuse_head=precision != "f32" and os.environ.get("SBBSEG_FUSE_HEAD", "1") != "0",
+                               # the dedicated tail kernel reads the one-plane 16-bit layout (f16 / bf16 only)
+                               fuse_tail=precision in ("f16", "bf16") and os.environ.get("SBBSEG_FUSE_TAIL", "1") != "0",
+                               merge_shortcut=os.environ.get("SBBSEG_MERGE_SHORTCUT", "1") != "0")
+        self._weights = weights
+        self._plan: Optional[Plan] = None
         self.layers = self.graph.nodes                     # main.py:227-229 reads layers[-1].output_shape
         self.device = device
         self.precision = precision
         self.max_batch = int(max_batch or default_max_batch())
         prec = _capi.PRECISIONS[precision]
-        self._ctx: Optional[_capi.Context] = _capi.Context(device, prec)
-        try:
-            self._ctx.set_lanes(int(os.environ.get("SBBSEG_LANES", "2")))   # before finalize: 1 skips the second buffer set
-            self._ctx.load_plan(self.plan, self.max_batch)
-        except Exception:
-            self._ctx.close()
-            raise
+        if sbbw_path is not None:
+            a = self._plan_args
+            flags = (0 if a["parity_split"] else 1) | (0 if a["merge_shortcut"] else 2) | (0 if a["fuse_head"] or precision == "f32" else 4) | \
+                    (0 if a["fuse_tail"] or precision not in ("f16", "bf16") else 8)
+            if int(os.environ.get("SBBSEG_LANES", "2")) != 2:
+                raise ValueError("the native loader builds two-lane handles; use the Python planner path for SBBSEG_LANES=1")
+            self._ctx: Optional[_capi.Context] = _capi.Context.from_sbbw(sbbw_path, device, prec, self.max_batch, flags)
+            self._sbbw_path = sbbw_path
+        else:
+            self._ctx = _capi.Context(device, prec)
+            try:
+                self._ctx.set_lanes(int(os.environ.get("SBBSEG_LANES", "2")))   # before finalize: 1 skips the second buffer set
+                self._ctx.load_plan(self.plan, self.max_batch)
+            except Exception:
+                self._ctx.close()
+                raise
         self.input_shape = (None,) + tuple(self.graph.input_shape)
         self.output_shape = (None,) + tuple(self.graph.output_shape)
+
+    @property
+    def plan(self) -> Plan:
+        """The fused op plan as the Python planner builds it (statistics, tests); built on first use for natively loaded models."""
+        if self._plan is None:
+            if self._weights is None:
+                _, self._weights = load_sbbw(self._sbbw_path)
+            self._plan = build_plan(self.graph, self._weights, **self._plan_args)
+        return self._plan
 
     # -- seam 2 ------------------------------------------------------------------------------
     def predict(self, x, batch_size=None, verbose=0):
@@ -136,8 +159,12 @@ def load_model(path: str, compile: bool = False, device: int = 0, max_batch: Opt
     key = (os.path.realpath(real), os.path.getmtime(real), device, precision, int(max_batch or default_max_batch()))
     if use_cache and key in _CACHE and _CACHE[key]._ctx is not None:
         return _CACHE[key]
-    cfg, weights = load_sbbw(real)
-    model = SegModel(cfg, weights, device=device, max_batch=max_batch, precision=precision)
+    if os.environ.get("SBBSEG_NATIVE_LOADER", "1") != "0" and os.environ.get("SBBSEG_LANES", "2") == "2":
+        # one C call: the library reads the container and lowers the graph itself (sbbseg_model_load_file)
+        model = SegModel(read_sbbw_config(real), None, device=device, max_batch=max_batch, precision=precision, sbbw_path=real)
+    else:
+        cfg, weights = load_sbbw(real)
+        model = SegModel(cfg, weights, device=device, max_batch=max_batch, precision=precision)
     if use_cache:
         _CACHE[key] = model
     model._from_cache = use_cache

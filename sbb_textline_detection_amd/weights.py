@@ -63,6 +63,15 @@ def load_sbbw(path: str) -> Tuple[dict, Dict[str, np.ndarray]]:
     return header["model_config"], weights
 
 
+def read_sbbw_config(path: str) -> dict:
+    """Only the Keras model_config of a container (the weights stay on disk: the library reads them itself)."""
+    with open(path, "rb") as f:
+        if f.read(8) != MAGIC:
+            raise ValueError(f"{path}: not an SBBW0001 container")
+        (hlen,) = struct.unpack("<Q", f.read(8))
+        return json.loads(f.read(hlen).decode("utf-8"))["model_config"]
+
+
 def synthetic_weights(graph: Graph, seed: int = 0) -> Dict[str, np.ndarray]:
     """Seeded stand-in weights: He-normal conv kernels, small biases,
     BN gamma ~ 1 +- 0.1, beta/mean ~ +-0.1, variance ~ 1 +- 0.1.  Deterministic for a given

@@ -714,3 +714,37 @@ def test_extract_page_stage(tmp_path):
     regions = st.extract_text_regions()
     assert np.array_equal(st.clean_text_regions(regions), stage_glue.region_cleanup(regions))
     clear_session()
+
+
+@pytest.mark.parametrize("precision", ["f16", "f16x3", "f32"])
+def test_one_call_native_load_equals_python_planned_context(tmp_path, precision):
+    """sbbseg_model_load_file (the library's own graph reader + planner, csrc/loader.cpp) against a context the Python planner
+    built through the step-by-step plan API: same op list, bit-identical probabilities and label maps (main.py:216-223)."""
+    from sbb_textline_detection_amd.model import SegModel, load_model
+    from sbb_textline_detection_amd.weights import save_sbbw
+    from tools.synth_model import calibrated_model
+    cfg, w = calibrated_model(2, 224, 224, seed=3)
+    path = str(tmp_path / "model_textline_new.sbbw")
+    save_sbbw(path, cfg, w)
+    py = SegModel(cfg, w, device=0, max_batch=20, precision=precision)
+    nat = SegModel(cfg, None, device=0, max_batch=20, precision=precision, sbbw_path=path)
+    ops_py, ops_nat = py.ctx.ops(), nat.ctx.ops()
+    assert [(o["name"], o["flops"], o["issued_flops"]) for o in ops_py] == [(o["name"], o["flops"], o["issued_flops"]) for o in ops_nat]
+    assert py.ctx.device_bytes() == nat.ctx.device_bytes()
+    x = (patches_from_page(224, 224, 3, seed=2) / 255.0).astype(np.float32)
+    assert np.array_equal(py.predict(x), nat.predict(x))
+    page = synthetic_page(700, 610, seed=5)
+    assert np.array_equal(py.segment_page(page), nat.segment_page(page))
+    assert nat.plan.macs_per_patch() == py.plan.macs_per_patch()              # (lazy Python plan of a natively loaded model)
+    # the reference-shaped seam: start_new_session_and_model(<dir>/model.h5) resolves to the .sbbw and loads it with one C call
+    m = load_model(str(tmp_path / "model_textline_new.h5"), max_batch=20, precision=precision)
+    assert getattr(m, "_sbbw_path", None) == path and np.array_equal(m.predict(x), py.predict(x))
+    lib = _capi.load_library()
+    h = C_void = None
+    import ctypes as C
+    h = C.c_void_p()
+    assert lib.sbbseg_model_load_file(b"/nonexistent/model.sbbw", 0, _capi.PRECISIONS[precision], 4, 0, C.byref(h)) != 0
+    assert b"cannot open" in lib.sbbseg_last_error()
+    py.release(); nat.release()
+    from sbb_textline_detection_amd import clear_session
+    clear_session()
