@@ -260,7 +260,8 @@ int sbbseg_debug_read_tensor(sbbseg_ctx* c, int tensor_id, int n, float* out, si
  * bit 4 = half-K-step stages in a 4-deep ring; bit 5 = XCD-grouped tile walk on single-class layers too;
  * bit 6 = drain the epilogue stores before the next barrier; bit 7 = half-line (64-byte) epilogue stores; bits 8-15 = with bit 5: K limit (units of
  * 64) up to which every block walks a contiguous run of tiles (0 = keep the current limit);
- * bit 16 = 8-phase schedule on the 256x256 tile (half-tile restaging, staggered wave groups) */
+ * bit 16 = 8-phase schedule on the 256x256 tile (half-tile restaging, staggered wave groups);
+ * bit 17 = plain gather (per-load address arithmetic) instead of the fast gather on every layer */
 int sbbseg_debug_set_conv_variant(sbbseg_ctx* c, int variant);
 /* Test hook for the no-abort guarantee: the nth_check-th next internal host-allocation checkpoint throws
  * std::bad_alloc, which every entry point turns into a non-zero status + sbbseg_last_error() instead of

@@ -112,6 +112,8 @@ struct ConvOp {
                                           // only merged into one launch when these are identical (they share class 0's)
     uint16_t* d_stem_wfrag = nullptr;     // non-null: the op is the network stem and runs stem_conv_pairs
     uint16_t* d_d64_wfrag = nullptr;      // non-null: 3x3 s1 64->64 conv, runs conv3x3_c64_direct
+    bool fg_ok = true;                    // every K-step (of every class) regular with its tap inside [-1, 2]^2: the fast
+                                          // gather of conv_igemm_mfma applies (ConvParams::fast_gather)
 };
 
 struct PoolOp { int src, dst, k, stride, Ho, Wo; float *d_pre_scale = nullptr, *d_pre_shift = nullptr; int pre_relu = 0; };
@@ -186,6 +188,7 @@ struct sbbseg_ctx {
     bool profiling = false;
     int conv_variant = 0;
     bool ph8 = false;            // 8-phase schedule on the 256x256 tile (opt-in, conv variant bit 16)
+    bool plain_gather = false;   // A/B: per-load address arithmetic instead of the fast gather (conv variant bit 17)
     int contig_max_k = 0;        // short-K layers up to this K walk their tiles in per-block contiguous runs (tile map 2)
     int fused_heads = 0;
     int num_cus = 256;
@@ -309,6 +312,7 @@ int run_plan(sbbseg_ctx* c, int n, uint8_t* d_labels, float* d_probs)
             ConvParams p;
             memset(&p, 0, sizeof(p));
             p.n_src = co.d.n_src;
+            bool fg = co.fg_ok && !c->plain_gather;
             for (int s = 0; s < co.d.n_src; ++s) {
                 const Tensor& t = c->tensors[co.d.src[s].tensor];
                 SrcDesc& sd = p.src[s];
@@ -320,7 +324,12 @@ int run_plan(sbbseg_ctx* c, int n, uint8_t* d_labels, float* d_probs)
                 sd.lim_y = t.H << sd.shift; sd.lim_x = t.W << sd.shift;
                 sd.ksteps = co.ksteps[s];
                 sd.sy_shift = co.d.src[s].stride_y == 2; sd.sx_shift = co.d.src[s].stride_x == 2;
+                const size_t bytes = kZeroHeaderBytes + t.elems_per_patch * (size_t)n * c->elem * c->planes;
+                sd.bytes = (uint32_t)bytes;
+                // fast gather: bit 31 of a lane offset marks an out-of-bounds tap, so every real offset must stay below 2^31
+                if (sd.shift != 0 || bytes + (size_t)(t.W + 1) * sd.pix_bytes >= ((size_t)1 << 31)) fg = false;
             }
+            p.fast_gather = fg ? 1 : 0;
             p.ktab = co.d_ktab; p.kstep = co.d_kstep; p.half_stages = (c->conv_variant & 16) ? 1 : 0;
             p.variant = c->conv_variant & 3; p.persist_blocks = (c->conv_variant & 4) ? 0 : c->num_cus;
             p.M = n * co.Ho * co.Wo;
@@ -842,6 +851,7 @@ int sbbseg_add_conv(sbbseg_ctx* c, const sbbseg_conv_desc* d, const float* w_src
             if (e[g].dy != e[0].dy || e[g].dx != e[0].dx || e[g].coff != want) r.irregular = 1;
         }
         if (c->precision == kF32) r.irregular = 1;     // the fp32 check kernel only walks the granule table
+        if (r.irregular || r.dy < -1 || r.dy > 2 || r.dx < -1 || r.dx > 2) co.fg_ok = false;
         ksteps[t] = r;
     }
     if (upload(c, &co.d_kstep, ksteps.data(), ksteps.size())) return 1;
@@ -961,6 +971,7 @@ int sbbseg_add_conv(sbbseg_ctx* c, const sbbseg_conv_desc* d, const float* w_src
         }
         if (same) {
             const int q = pc.n_cls++;
+            pc.fg_ok = pc.fg_ok && co.fg_ok;
             pc.d_w_cls[q] = co.d_w; pc.d_kstep_cls[q] = co.d_kstep; pc.d_ktab_cls[q] = co.d_ktab;
             pc.ooy_cls[q] = d->out_off_y; pc.oox_cls[q] = d->out_off_x; pc.wmul_cls[q] = co.wmul_cls[0];
             (void)hipFree(co.d_scale); (void)hipFree(co.d_shift); (void)hipFree(co.d_head_w); (void)hipFree(co.d_head_scale); (void)hipFree(co.d_head_shift);
@@ -1709,9 +1720,10 @@ int sbbseg_debug_inject_alloc_failure(int nth_check)
 int sbbseg_debug_set_conv_variant(sbbseg_ctx* c, int variant)
 {
     API_BEGIN
-    REQUIRE(c && variant >= 0 && variant <= 0x1ffff, "variant: bits 0-1 = 0 auto | 1 4-wave/2-stage | 2 8-wave/3-stage; bit 2 = one block per tile (non-persistent); bit 3 = no XCD-grouped tile walk; bit 4 = half-K-step stages; bit 5 = XCD-grouped walk on single-class layers; bit 6 = drain epilogue stores; bit 7 = half-line epilogue stores; bits 8-15 = contiguous-run K limit / 64; bit 16 = 8-phase schedule on the 256x256 tile");
+    REQUIRE(c && variant >= 0 && variant <= 0x3ffff, "variant: bits 0-1 = 0 auto | 1 4-wave/2-stage | 2 8-wave/3-stage; bit 2 = one block per tile (non-persistent); bit 3 = no XCD-grouped tile walk; bit 4 = half-K-step stages; bit 5 = XCD-grouped walk on single-class layers; bit 6 = drain epilogue stores; bit 7 = half-line epilogue stores; bits 8-15 = contiguous-run K limit / 64; bit 16 = 8-phase schedule on the 256x256 tile; bit 17 = plain gather everywhere");
     c->conv_variant = variant & 0xff;
     c->ph8 = (variant >> 16) & 1;
+    c->plain_gather = (variant >> 17) & 1;
     if ((variant >> 8) & 0xff) c->contig_max_k = ((variant >> 8) & 0xff) * 64;
     return 0;
     API_END

@@ -24,6 +24,7 @@ struct SrcDesc {
     int lo_off;           // byte distance from slot 0-3's granules to slot 4-7's inside a K-step: 64 (the next four
                           // 8-channel granules) in the plain modes; channels * 2 in the split mode (the "lo" plane
                           // of the same 32 channels, see kF16X3)
+    uint32_t bytes;       // bytes of the buffer in use (header + the launch's patches): num_records of the fast gather
 };
 
 // one entry per 16-byte granule of the contraction axis
@@ -84,6 +85,8 @@ struct ConvParams {
     const float* head_shift;
     uint8_t* labels;          // [n][TH][TW]
     float* probs;             // [n][TH][TW][classes] or null
+    int fast_gather;          // every K-step regular, taps within [-1, 2]^2, no upsampling source, buffers < 2 GiB:
+                              // run the FG form of conv_igemm_mfma (kernels.hip)
 };
 
 // fused network tail: 3x3 conv over [nearest-x2-upsampled src0 (64 ch), image C8 (3 ch)] -> 32 ch

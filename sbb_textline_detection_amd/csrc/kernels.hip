@@ -149,6 +149,14 @@ __device__ inline uint32_t row_ror8(uint32_t v)
     return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xf, 0xf, false);
 }
 
+// one `buffer_load_dwordx4 ... offen lds`: lane l's 16 bytes at base + voff(l) + soff land at lds + 16 * l; a lane whose
+// voff + soff reaches past nrec gets zeros (the resource words are wave-uniform and hoisted out of the loops)
+__device__ inline void buffer_load_lds16(const void* base, uint32_t nrec, LDS_AS void* lds, uint32_t voff, uint32_t soff)
+{
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)nrec, 0x00020000);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, lds, 16, voff, soff, 0, 0);
+}
+
 template <int N> __device__ inline void wait_vmcnt()
 {
     // (the counter field holds 0..63: a larger count cannot be expressed -> drain)
@@ -165,11 +173,17 @@ template <int N> __device__ inline void wait_vmcnt()
 // X3 = the split mode (internal.h, kF16X3): a K-step is 32 channels of one tap staged as slots 0-3 = "hi" halves,
 // slots 4-7 = "lo" halves (same LDS image, same staging code: only the source offset of slots 4-7 differs, SrcDesc::lo_off);
 // three MFMAs per product; outputs are split again in the epilogue and stored as [C hi][C lo] per pixel.
-template <int BP, int BC, int WP, int WC, int NS, bool F16, int GS = 8, bool PH8 = false, bool X3 = false>
+// FG = the fast gather (ConvParams::fast_gather): every staged row keeps a per-source byte offset and a bit mask of its
+// out-of-bounds taps, set up once per tile; a K-step's tap/channel displacement is wave-uniform and rides in the buffer
+// load's scalar offset, an out-of-bounds tap sets bit 31 of the lane offset (past num_records -> the load writes zeros
+// to LDS, tools/probes/buffer_lds_oob_probe.hip).  Two VALU ops per load instead of ~18: on the long-K tiles the
+// address arithmetic of the plain gather costs 20-25 % of the loop (tools/probes/mfma_loop_probe.hip).
+template <int BP, int BC, int WP, int WC, int NS, bool F16, int GS = 8, bool PH8 = false, bool X3 = false, bool FG = false>
 __global__ __launch_bounds__(64 * WP * WC, (conv_blocks_per_cu(BP, BC, WP, WC, NS, GS) * (WP * WC) / 4))
 void conv_igemm_mfma(const ConvParams p)
 {
     static_assert(!X3 || (F16 && GS == 8 && !PH8), "split mode: fp16 halves, whole-K-step stages, plain loop");
+    static_assert(!FG || !PH8, "the 8-phase schedule keeps the plain gather");
     constexpr int PL = X3 ? 2 : 1;                       // 16-bit planes per stored activation element
     using T = ConvTile<BP, BC, WP, WC, NS, GS>;
     constexpr int RPI = T::kRowsPerInstr, RB = T::kRowBytes, SPK = T::kStagesPerKStep;
@@ -251,8 +265,26 @@ void conv_igemm_mfma(const ConvParams p)
     const KTabEntry* ktab = p.ktab;
 
     // ---- load side: rows of the tile being STAGED (runs D steps ahead of the compute side)
-    int r_oy[T::kPLoads], r_ox[T::kPLoads], r_n[T::kPLoads];   // output coords of the staged rows
+    // plain gather: output coords (oy, ox, n) of the staged rows.  Fast gather: r_oy = byte offset of the row's centre tap
+    // in source 0, r_ox = the same in source 1, r_n = mask of out-of-bounds taps (bit src*16 + (dy+1)*4 + (dx+1)).
+    int r_oy[T::kPLoads], r_ox[T::kPLoads], r_n[T::kPLoads];
     uint32_t w_off[T::kWLoads];
+    // fast gather: buffer resources.  A source's resource starts fg_bias bytes BEFORE its buffer so that the scalar
+    // offset (tap displacement + fg_bias) is never negative.
+    const uint32_t fg_bias0 = (uint32_t)((sd0.PW + 1) * sd0.pix_bytes), fg_bias1 = (uint32_t)((sd1.PW + 1) * sd1.pix_bytes);
+    // bytes from a source row's first granule to the granule this lane fetches
+    auto lane_part = [&](const SrcDesc& sd) __attribute__((always_inline)) -> uint32_t {
+        return X3 ? (uint32_t)((gsrc & 3) * 16 + (gsrc >> 2) * sd.lo_off) : (uint32_t)(gsrc * 16);
+    };
+    auto oob_mask = [&](const SrcDesc& sd, int oy, int ox) __attribute__((always_inline)) -> uint32_t {
+        const int cy = oy << sd.sy_shift, cx = ox << sd.sx_shift;
+        uint32_t xm = 0, m = 0;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) xm |= ((unsigned)(cx + b - 1) < (unsigned)sd.lim_x) ? 0u : (1u << b);
+#pragma unroll
+        for (int a = 0; a < 4; ++a) m |= (((unsigned)(cy + a - 1) < (unsigned)sd.lim_y) ? xm : 0xfu) << (4 * a);
+        return m;
+    };
     auto setup_rows = [&](int tile) __attribute__((always_inline)) {
         int ctile, cls, ptile;
         decode(tile, ctile, cls, ptile);
@@ -264,7 +296,29 @@ void conv_igemm_mfma(const ConvParams p)
 #pragma unroll
         for (int j = 0; j < T::kPLoads; ++j) {
             const int m = ptile * BP + (j * NW + wave) * RPI + lrow;
-            if (m < p.M) {
+            if constexpr (FG) {
+                if (m < p.M) {
+                    const int n = m / HoWo;
+                    const int rem = m - n * HoWo;
+                    const int oy = rem / p.Wo;
+                    const int ox = rem - oy * p.Wo;
+                    r_oy[j] = (int)((uint32_t)n * img0 + (uint32_t)(((oy << sd0.sy_shift) * sd0.PW + (ox << sd0.sx_shift)) * sd0.pix_bytes) +
+                                    lane_part(sd0) + (uint32_t)kZeroHeaderBytes);
+                    uint32_t inv = oob_mask(sd0, oy, ox);
+                    if (p.n_src > 1) {
+                        r_ox[j] = (int)((uint32_t)n * img1 + (uint32_t)(((oy << sd1.sy_shift) * sd1.PW + (ox << sd1.sx_shift)) * sd1.pix_bytes) +
+                                        lane_part(sd1) + (uint32_t)kZeroHeaderBytes);
+                        inv |= oob_mask(sd1, oy, ox) << 16;
+                    } else {
+                        r_ox[j] = 0;
+                    }
+                    r_n[j] = (int)inv;
+                } else {
+                    r_oy[j] = 0;
+                    r_ox[j] = 0;
+                    r_n[j] = -1;                            // every tap out of bounds -> zero rows
+                }
+            } else if (m < p.M) {
                 const int n = m / HoWo;
                 const int rem = m - n * HoWo;
                 const int oy = rem / p.Wo;
@@ -288,6 +342,29 @@ void conv_igemm_mfma(const ConvParams p)
     auto issue = [&](int buf) __attribute__((always_inline)) {
         const int t = l_t;
         const bool s1 = t >= ks0;
+        char* lds_p = smem + buf * T::kStageBytes;
+        char* lds_w = lds_p + BP * RB;
+        if constexpr (FG) {
+            const int dy = (int)(short)(rec_yx & 0xffff), dx = rec_yx >> 16;
+            const int rowbytes = s1 ? sd1.PW * sd1.pix_bytes : sd0.PW * sd0.pix_bytes;
+            const int pixb = s1 ? sd1.pix_bytes : sd0.pix_bytes;
+            // wave-uniform part of the address: tap displacement + channel offset (+ the stage's half of the K-step)
+            const uint32_t soff = (uint32_t)(dy * rowbytes + dx * pixb + rec_coff + (X3 ? 0 : l_h * GS * 16)) + (s1 ? fg_bias1 : fg_bias0);
+            const int tapbit = (s1 ? 16 : 0) + (dy + 1) * 4 + (dx + 1);
+            auto rows = [&](const char* rbase, uint32_t nrec, const int (&voff)[T::kPLoads]) __attribute__((always_inline)) {
+#pragma unroll
+                for (int j = 0; j < T::kPLoads; ++j) {
+                    const uint32_t oob = (uint32_t)__builtin_amdgcn_sbfe(r_n[j], tapbit, 1);      // 0 or ~0
+                    const uint32_t off = (oob & 0x80000000u) | (uint32_t)voff[j];
+                    buffer_load_lds16(rbase, nrec, (LDS_AS void*)(lds_p + (j * NW + wave) * 1024), off, soff);
+                }
+            };
+            if (s1) rows(sd1.base - fg_bias1, sd1.bytes + fg_bias1, r_ox); else rows(sd0.base - fg_bias0, sd0.bytes + fg_bias0, r_oy);
+            const uint32_t woff = (uint32_t)(t * (kBK * 2) + l_h * GS * 16);
+#pragma unroll
+            for (int j = 0; j < T::kWLoads; ++j)
+                buffer_load_lds16(wbase, 0x7fffffffu, (LDS_AS void*)(lds_w + (j * NW + wave) * 1024), w_off[j], woff);
+        } else {
         const char* base = s1 ? sd1.base : sd0.base;
         const int rowbytes = s1 ? sd1.PW * sd1.pix_bytes : sd0.PW * sd0.pix_bytes;
         const int pixb = s1 ? sd1.pix_bytes : sd0.pix_bytes;
@@ -303,8 +380,6 @@ void conv_igemm_mfma(const ConvParams p)
             const KTabEntry e = ktab[t * kGranulesPerStep + gfull];
             dy = e.dy; dx = e.dx; coff = e.coff + kZeroHeaderBytes;
         }
-        char* lds_p = smem + buf * T::kStageBytes;
-        char* lds_w = lds_p + BP * RB;
 #pragma unroll
         for (int j = 0; j < T::kPLoads; ++j) {
             const int uy = (r_oy[j] << ssy) + dy;           // dy/dx carry tap - pad - placement offset
@@ -322,6 +397,7 @@ void conv_igemm_mfma(const ConvParams p)
         for (int j = 0; j < T::kWLoads; ++j) {
             __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(wbase + w_off[j] + (uint32_t)(t * (kBK * 2) + l_h * GS * 16)),
                                              (LDS_AS void*)(lds_w + (j * NW + wave) * 1024), 16, 0, 0);
+        }
         }
         // advance the load side; crossing into the next tile re-derives the gather rows
         ++issued;
@@ -999,8 +1075,8 @@ int conv_row_channel(int row, int cout)
     return base + (mi >> 1) * 32 + (rho >> 2) * 8 + (mi & 1) * 4 + (rho & 3);
 }
 
-template <int BP, int BC, int WP, int WC, int NS, bool F16, int GS = 8, bool PH8 = false, bool X3 = false>
-static hipError_t launch_conv_t(const ConvParams& p, hipStream_t s)
+template <int BP, int BC, int WP, int WC, int NS, bool F16, int GS, bool PH8, bool X3, bool FG>
+static hipError_t launch_conv_impl(const ConvParams& p, hipStream_t s)
 {
     using T = ConvTile<BP, BC, WP, WC, NS, GS>;
     static bool attr_done[64] = {};
@@ -1008,7 +1084,7 @@ static hipError_t launch_conv_t(const ConvParams& p, hipStream_t s)
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
     if (!attr_done[dev & 63]) {
-        e = hipFuncSetAttribute((const void*)conv_igemm_mfma<BP, BC, WP, WC, NS, F16, GS, PH8, X3>,
+        e = hipFuncSetAttribute((const void*)conv_igemm_mfma<BP, BC, WP, WC, NS, F16, GS, PH8, X3, FG>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, T::kLdsBytes);
         if (e != hipSuccess) return e;
         attr_done[dev & 63] = true;
@@ -1021,8 +1097,17 @@ static hipError_t launch_conv_t(const ConvParams& p, hipStream_t s)
     const int resident = p.persist_blocks > 0 ? p.persist_blocks * T::kBlocksPerCU : n_tiles;
     int grid = n_tiles < resident ? n_tiles : resident;
     if (p.tile_map >= 1) grid = (grid + 7) & ~7;          // the XCD-grouped walk needs a multiple of 8 blocks
-    hipLaunchKernelGGL((conv_igemm_mfma<BP, BC, WP, WC, NS, F16, GS, PH8, X3>), dim3(grid), dim3(T::kThreads), T::kLdsBytes, s, p);
+    hipLaunchKernelGGL((conv_igemm_mfma<BP, BC, WP, WC, NS, F16, GS, PH8, X3, FG>), dim3(grid), dim3(T::kThreads), T::kLdsBytes, s, p);
     return hipGetLastError();
+}
+
+template <int BP, int BC, int WP, int WC, int NS, bool F16, int GS = 8, bool PH8 = false, bool X3 = false>
+static hipError_t launch_conv_t(const ConvParams& p, hipStream_t s)
+{
+    if constexpr (!PH8) {
+        if (p.fast_gather) return launch_conv_impl<BP, BC, WP, WC, NS, F16, GS, PH8, X3, true>(p, s);
+    }
+    return launch_conv_impl<BP, BC, WP, WC, NS, F16, GS, PH8, X3, false>(p, s);
 }
 
 // Tile choice.  Measured on MI355X (profiles/r01_conv_variants.md): with two 4-wave blocks per CU the
