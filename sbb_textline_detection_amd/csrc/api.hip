@@ -312,7 +312,9 @@ int run_plan(sbbseg_ctx* c, int n, uint8_t* d_labels, float* d_probs)
             ConvParams p;
             memset(&p, 0, sizeof(p));
             p.n_src = co.d.n_src;
-            bool fg = co.fg_ok && !c->plain_gather;
+            // (short-K layers keep the plain gather: the per-tile mask set-up costs them 1-10 %; from ~9 K-steps on the fast
+            // gather wins 2-10 %, profiles/r02_experiments.md)
+            bool fg = co.fg_ok && !c->plain_gather && co.total_ksteps >= 9;
             for (int s = 0; s < co.d.n_src; ++s) {
                 const Tensor& t = c->tensors[co.d.src[s].tensor];
                 SrcDesc& sd = p.src[s];
