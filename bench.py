@@ -229,7 +229,7 @@ def main():
         torch.cuda.synchronize()
         prof = c.profile()
         c.profile_enable(False)
-        convs = [o for o in prof if "conv" in o["name"] and o["launches"] > 0]       # incl. stem_conv*, direct_conv*, tail_conv*
+        convs = [o for o in prof if ("conv" in o["name"] or o["name"].startswith("block")) and o["launches"] > 0]       # incl. stem_conv*, direct_conv*, tail_conv*, fused bottleneck blocks
         tot_ms = sum(o["total_ms"] for o in prof)
 
         def rate(ops, key="flops"):

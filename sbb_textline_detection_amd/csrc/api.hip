@@ -8,6 +8,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <algorithm>
 #include <cmath>
 #include <new>
 #include <stdexcept>
@@ -90,7 +91,7 @@ struct Tensor {
     char* data() const { return buf + kZeroHeaderBytes; }
 };
 
-enum OpType { kConv = 0, kPool = 1, kHead = 2, kTail = 3 };
+enum OpType { kConv = 0, kPool = 1, kHead = 2, kTail = 3, kBlock = 4 };
 
 struct ConvOp {
     sbbseg_conv_desc d;
@@ -112,8 +113,13 @@ struct ConvOp {
                                           // only merged into one launch when these are identical (they share class 0's)
     uint16_t* d_stem_wfrag = nullptr;     // non-null: the op is the network stem and runs stem_conv_pairs
     uint16_t* d_d64_wfrag = nullptr;      // non-null: 3x3 s1 64->64 conv, runs conv3x3_c64_direct
-    bool fg_ok = true;                    // every K-step (of every class) regular with its tap inside [-1, 2]^2: the fast
-                                          // gather of conv_igemm_mfma applies (ConvParams::fast_gather)
+    std::vector<float> h_w[2];            // host copy of a small 1x1 conv's weights ([cin][cout] per source): bottleneck fusion
+                                          // (sbbseg_finalize) repacks them as MFMA A fragments
+    bool fg_ok = true;                    // every K-step (of every class) regular: the fast gather of conv_igemm_mfma applies
+                                          // (ConvParams::fast_gather) if each source's taps also span at most 4 x 4 offsets
+    int tap_lo[2][2] = {{127, 127}, {127, 127}}, tap_hi[2][2] = {{-127, -127}, {-127, -127}};   // [source][y|x] over all classes
+    std::vector<KStepRec> h_ksteps_cls[4];   // host copies: sbbseg_finalize builds the fast gather's tables from them
+    FgStepRec* d_fgstep_cls[4] = {nullptr, nullptr, nullptr, nullptr};
 };
 
 struct PoolOp { int src, dst, k, stride, Ho, Wo; float *d_pre_scale = nullptr, *d_pre_shift = nullptr; int pre_relu = 0; };
@@ -129,6 +135,14 @@ struct TailOp {
     float *d_scale = nullptr, *d_shift = nullptr, *d_head_w = nullptr, *d_head_scale = nullptr, *d_head_shift = nullptr;
 };
 
+// a fused ResNet bottleneck block (bottleneck_fused): the three convs it replaces stay alive as `parts` of the op
+// (they own the scale / shift arrays and the 3x3 fragments the fused kernel reads, and they are what runs when the
+// fusion is switched off at run time, conv variant bit 18)
+struct BlockOp {
+    int x_tensor = -1, out_tensor = -1, cin = 0, proj = 0, H = 0, W = 0;
+    uint16_t *d_w1 = nullptr, *d_w3 = nullptr;
+};
+
 struct Op {
     OpType type;
     std::string name;
@@ -138,6 +152,8 @@ struct Op {
     PoolOp pool;
     HeadOp head;
     TailOp tail;
+    BlockOp block;
+    std::vector<Op> parts;        // kBlock: the convs it fuses
     double prof_ms = 0;
     int64_t prof_launches = 0, prof_patches = 0;
 };
@@ -188,6 +204,7 @@ struct sbbseg_ctx {
     bool profiling = false;
     int conv_variant = 0;
     bool ph8 = false;            // 8-phase schedule on the 256x256 tile (opt-in, conv variant bit 16)
+    bool unfuse_blocks = false;  // A/B: run a fused bottleneck block as its three convs (conv variant bit 18)
     bool plain_gather = false;   // A/B: per-load address arithmetic instead of the fast gather (conv variant bit 17)
     int contig_max_k = 0;        // short-K layers up to this K walk their tiles in per-block contiguous runs (tile map 2)
     int fused_heads = 0;
@@ -298,23 +315,31 @@ int resolve_pending(sbbseg_ctx* c)
 }
 
 // ---- forward pass over n patches whose input forms are already filled -------------------------
-int run_plan(sbbseg_ctx* c, int n, uint8_t* d_labels, float* d_probs)
+int launch_op(sbbseg_ctx* c, Op& op, int n, uint8_t* d_labels, float* d_probs)
 {
-    for (size_t i = 0; i < c->ops.size(); ++i) {
-        Op& op = c->ops[i];
-        hipEvent_t ea = nullptr, eb = nullptr;
-        if (c->profiling) {
-            if (get_event(c, &ea) || get_event(c, &eb)) return 1;
-            HIPCHK(hipEventRecord(ea, c->stream));
-        }
-        if (op.type == kConv) {
+        if (op.type == kBlock) {
+            if (c->unfuse_blocks) {
+                for (auto& part : op.parts)
+                    if (launch_op(c, part, n, d_labels, d_probs)) return 1;
+                return 0;
+            }
+            const BlockOp& bo = op.block;
+            BlockParams bp;
+            bp.x = c->tensors[bo.x_tensor].buf; bp.n = n; bp.H = bo.H; bp.W = bo.W; bp.proj = bo.proj;
+            bp.w1 = bo.d_w1; bp.w2 = op.parts[1].conv.d_d64_wfrag; bp.w3 = bo.d_w3;
+            bp.s1 = op.parts[0].conv.d_scale; bp.b1 = op.parts[0].conv.d_shift;
+            bp.s2 = op.parts[1].conv.d_scale; bp.b2 = op.parts[1].conv.d_shift;
+            bp.s3 = op.parts[2].conv.d_scale; bp.b3 = op.parts[2].conv.d_shift;
+            bp.out = c->tensors[bo.out_tensor].data();
+            HIPCHK(launch_bottleneck(bp, c->precision, c->num_cus, c->stream));
+        } else if (op.type == kConv) {
             const ConvOp& co = op.conv;
             ConvParams p;
             memset(&p, 0, sizeof(p));
             p.n_src = co.d.n_src;
             // (short-K layers keep the plain gather: the per-tile mask set-up costs them 1-10 %; from ~9 K-steps on the fast
             // gather wins 2-10 %, profiles/r02_experiments.md)
-            bool fg = co.fg_ok && !c->plain_gather && co.total_ksteps >= 9;
+            bool fg = co.d_fgstep_cls[0] && !c->plain_gather;
             for (int s = 0; s < co.d.n_src; ++s) {
                 const Tensor& t = c->tensors[co.d.src[s].tensor];
                 SrcDesc& sd = p.src[s];
@@ -329,7 +354,8 @@ int run_plan(sbbseg_ctx* c, int n, uint8_t* d_labels, float* d_probs)
                 const size_t bytes = kZeroHeaderBytes + t.elems_per_patch * (size_t)n * c->elem * c->planes;
                 sd.bytes = (uint32_t)bytes;
                 // fast gather: bit 31 of a lane offset marks an out-of-bounds tap, so every real offset must stay below 2^31
-                if (sd.shift != 0 || bytes + (size_t)(t.W + 1) * sd.pix_bytes >= ((size_t)1 << 31)) fg = false;
+                sd.tap_lo_y = co.tap_lo[s][0]; sd.tap_lo_x = co.tap_lo[s][1];
+                if (bytes + (size_t)kFgBiasPixels(t.W) * sd.pix_bytes >= ((size_t)1 << 31)) fg = false;
             }
             p.fast_gather = fg ? 1 : 0;
             p.ktab = co.d_ktab; p.kstep = co.d_kstep; p.half_stages = (c->conv_variant & 16) ? 1 : 0;
@@ -353,7 +379,7 @@ int run_plan(sbbseg_ctx* c, int n, uint8_t* d_labels, float* d_probs)
                 p.tile_map = 1;
             }
             for (int q = 0; q < 4; ++q) {
-                p.w_cls[q] = co.d_w_cls[q]; p.kstep_cls[q] = co.d_kstep_cls[q]; p.ktab_cls[q] = co.d_ktab_cls[q];
+                p.w_cls[q] = co.d_w_cls[q]; p.kstep_cls[q] = co.d_kstep_cls[q]; p.ktab_cls[q] = co.d_ktab_cls[q]; p.fgstep_cls[q] = co.d_fgstep_cls[q];
                 p.ooy_cls[q] = co.ooy_cls[q]; p.oox_cls[q] = co.oox_cls[q]; p.wmul_cls[q] = co.wmul_cls[q];
             }
             p.head_classes = co.d.head_classes; p.head_w = co.d_head_w; p.head_scale = co.d_head_scale;
@@ -402,6 +428,19 @@ int run_plan(sbbseg_ctx* c, int n, uint8_t* d_labels, float* d_probs)
             hp.labels = d_labels; hp.probs = d_probs;
             HIPCHK(launch_head(hp, c->precision, c->stream));
         }
+    return 0;
+}
+
+int run_plan(sbbseg_ctx* c, int n, uint8_t* d_labels, float* d_probs)
+{
+    for (size_t i = 0; i < c->ops.size(); ++i) {
+        Op& op = c->ops[i];
+        hipEvent_t ea = nullptr, eb = nullptr;
+        if (c->profiling) {
+            if (get_event(c, &ea) || get_event(c, &eb)) return 1;
+            HIPCHK(hipEventRecord(ea, c->stream));
+        }
+        if (launch_op(c, op, n, d_labels, d_probs)) return 1;
         if (c->profiling) {
             HIPCHK(hipEventRecord(eb, c->stream));
             c->pending.push_back({(int)i, ea, eb, n});
@@ -529,7 +568,15 @@ int sbbseg_destroy(sbbseg_ctx* c)
         (void)hipFree(t.lane_buf[0]);
         (void)hipFree(t.lane_buf[1]);
     }
+    std::vector<Op*> all_ops;
     for (auto& op : c->ops) {
+        all_ops.push_back(&op);
+        for (auto& part : op.parts) all_ops.push_back(&part);
+    }
+    for (Op* opp : all_ops) {
+        Op& op = *opp;
+        (void)hipFree(op.block.d_w1); (void)hipFree(op.block.d_w3);
+        for (int q = 0; q < 4; ++q) (void)hipFree(op.conv.d_fgstep_cls[q]);
         (void)hipFree(op.conv.d_ktab); (void)hipFree(op.conv.d_kstep); (void)hipFree(op.conv.d_w); (void)hipFree(op.conv.d_scale); (void)hipFree(op.conv.d_shift);
         (void)hipFree(op.conv.d_rscale); (void)hipFree(op.conv.d_rshift);
         (void)hipFree(op.conv.d_head_w); (void)hipFree(op.conv.d_head_scale); (void)hipFree(op.conv.d_head_shift); (void)hipFree(op.conv.d_stem_wfrag); (void)hipFree(op.conv.d_d64_wfrag);
@@ -853,10 +900,16 @@ int sbbseg_add_conv(sbbseg_ctx* c, const sbbseg_conv_desc* d, const float* w_src
             if (e[g].dy != e[0].dy || e[g].dx != e[0].dx || e[g].coff != want) r.irregular = 1;
         }
         if (c->precision == kF32) r.irregular = 1;     // the fp32 check kernel only walks the granule table
-        if (r.irregular || r.dy < -1 || r.dy > 2 || r.dx < -1 || r.dx > 2) co.fg_ok = false;
+        if (r.irregular) co.fg_ok = false;
+        {
+            const int sidx = t < co.ksteps[0] ? 0 : 1;
+            co.tap_lo[sidx][0] = std::min(co.tap_lo[sidx][0], (int)r.dy); co.tap_hi[sidx][0] = std::max(co.tap_hi[sidx][0], (int)r.dy);
+            co.tap_lo[sidx][1] = std::min(co.tap_lo[sidx][1], (int)r.dx); co.tap_hi[sidx][1] = std::max(co.tap_hi[sidx][1], (int)r.dx);
+        }
         ksteps[t] = r;
     }
     if (upload(c, &co.d_kstep, ksteps.data(), ksteps.size())) return 1;
+    co.h_ksteps_cls[0] = ksteps;
     std::vector<float> pad_s(co.cout_pad, 0.f), pad_b(co.cout_pad, 0.f);
     memcpy(pad_s.data(), scale, sizeof(float) * d->cout);
     memcpy(pad_b.data(), shift, sizeof(float) * d->cout);
@@ -951,6 +1004,20 @@ int sbbseg_add_conv(sbbseg_ctx* c, const sbbseg_conv_desc* d, const float* w_src
             if (upload(c, &co.d_d64_wfrag, frag.data(), frag.size())) return 1;
             op.name = "direct_" + op.name;
         }
+        // small pointwise convs keep their weights on the host until sbbseg_finalize: candidates for bottleneck fusion
+        bool pw = plain16 && d->head_classes == 0 && d->raw_out_tensor < 0 && (d->cout == 64 || d->cout == 256) && d->out_stride_y == 1 &&
+                  d->out_stride_x == 1 && d->out_off_y == 0 && d->out_off_x == 0 && TH == d->out_h && TW == d->out_w;
+        for (int s2 = 0; pw && s2 < d->n_src; ++s2) {
+            const sbbseg_conv_src& q = d->src[s2];
+            const Tensor& qt = c->tensors[q.tensor];
+            pw = q.kh == 1 && q.kw == 1 && q.stride_y == 1 && q.stride_x == 1 && q.pad_top == 0 && q.pad_left == 0 && q.up_shift == 0 &&
+                 q.off_y == 0 && q.off_x == 0 && (q.channels == 64 || q.channels == 256) && q.channels == qt.C && !qt.is_input_form &&
+                 qt.H == d->out_h && qt.W == d->out_w;
+        }
+        if (pw) {
+            co.h_w[0].assign(w_src0, w_src0 + (size_t)d->src[0].channels * d->cout);
+            if (d->n_src == 2) co.h_w[1].assign(w_src1, w_src1 + (size_t)d->src[1].channels * d->cout);
+        }
     }
 
     // Output-placement siblings (same sources, taps geometry and outputs, only padding / placement
@@ -974,6 +1041,12 @@ int sbbseg_add_conv(sbbseg_ctx* c, const sbbseg_conv_desc* d, const float* w_src
         if (same) {
             const int q = pc.n_cls++;
             pc.fg_ok = pc.fg_ok && co.fg_ok;
+            pc.h_ksteps_cls[q] = co.h_ksteps_cls[0];
+            for (int s2 = 0; s2 < 2; ++s2)
+                for (int a = 0; a < 2; ++a) {
+                    pc.tap_lo[s2][a] = std::min(pc.tap_lo[s2][a], co.tap_lo[s2][a]);
+                    pc.tap_hi[s2][a] = std::max(pc.tap_hi[s2][a], co.tap_hi[s2][a]);
+                }
             pc.d_w_cls[q] = co.d_w; pc.d_kstep_cls[q] = co.d_kstep; pc.d_ktab_cls[q] = co.d_ktab;
             pc.ooy_cls[q] = d->out_off_y; pc.oox_cls[q] = d->out_off_x; pc.wmul_cls[q] = co.wmul_cls[0];
             (void)hipFree(co.d_scale); (void)hipFree(co.d_shift); (void)hipFree(co.d_head_w); (void)hipFree(co.d_head_scale); (void)hipFree(co.d_head_shift);
@@ -1114,11 +1187,128 @@ int sbbseg_add_head(sbbseg_ctx* c, int src_tensor, int cin, int classes, const f
     API_END
 }
 
+// ---- fast gather tables (conv_igemm_mfma<..., FG>): for every conv whose K-steps are all regular, whose sources are not
+// upsampled and whose taps span at most 4 x 4 offsets per source (over all merged classes), one FgStepRec per K-step.
+// Short-K layers keep the plain gather (the per-tile mask set-up costs them 1-10 %; from ~9 K-steps on the fast gather
+// wins 2-10 %, profiles/r02_experiments.md), and so do the split mode's 64-channel tiles (+13 % time there).
+static int build_fast_gather_tables(sbbseg_ctx* c)
+{
+    std::vector<ConvOp*> convs;
+    for (Op& op : c->ops) {
+        if (op.type == kConv) convs.push_back(&op.conv);
+        for (Op& part : op.parts)
+            if (part.type == kConv) convs.push_back(&part.conv);
+    }
+    for (ConvOp* cop : convs) {
+        ConvOp& co = *cop;
+        if (!co.fg_ok || c->precision == kF32 || co.total_ksteps < 9 || (c->precision == kF16X3 && co.d.cout < 128)) continue;
+        bool ok = true;
+        for (int s = 0; s < co.d.n_src; ++s)
+            ok = ok && co.d.src[s].up_shift == 0 && co.tap_hi[s][0] - co.tap_lo[s][0] <= 3 && co.tap_hi[s][1] - co.tap_lo[s][1] <= 3 &&
+                 co.tap_lo[s][0] >= -8 && co.tap_lo[s][1] >= -8;
+        if (!ok) continue;
+        for (int q = 0; q < co.n_cls; ++q) {
+            const std::vector<KStepRec>& ks = co.h_ksteps_cls[q];
+            std::vector<FgStepRec> fg(ks.size());
+            for (size_t t = 0; t < ks.size(); ++t) {
+                const int s = (int)t < co.ksteps[0] ? 0 : 1;
+                const Tensor& tt = c->tensors[co.d.src[s].tensor];
+                const long pixb = (long)tt.C * c->elem * c->planes, rowb = (long)tt.W * pixb;
+                const long soff = ks[t].dy * rowb + ks[t].dx * pixb + ks[t].coff + (long)kFgBiasPixels(tt.W) * pixb;
+                REQUIRE(soff >= 0 && soff < ((long)1 << 31), "fast gather: scalar offset out of range");
+                fg[t].soff = (uint32_t)soff;
+                fg[t].tapbit = s * 16 + (ks[t].dy - co.tap_lo[s][0]) * 4 + (ks[t].dx - co.tap_lo[s][1]);
+                fg[t].pad_[0] = fg[t].pad_[1] = 0;
+            }
+            if (upload(c, &co.d_fgstep_cls[q], fg.data(), fg.size())) return 1;
+        }
+    }
+    return 0;
+}
+
+// ---- bottleneck fusion: [1x1 CIN->64, ReLU] -> [3x3 64->64 direct, ReLU] -> [1x1 -> 256 (+ shortcut), ReLU] at one resolution,
+// the two 64-channel tensors in between read by nobody else  ==>  one kBlock op (bottleneck_fused).  The three convs
+// stay alive as its parts.  SBBSEG_FUSE_BLOCKS=0 keeps the plan unfused (per-layer tests read the intermediate tensors).
+static int fuse_bottlenecks(sbbseg_ctx* c)
+{
+    const char* env = getenv("SBBSEG_FUSE_BLOCKS");
+    if ((env && env[0] == '0') || !(c->precision == kF16 || c->precision == kBF16)) return 0;
+    auto readers = [&](int tensor) {
+        int nrd = 0;
+        for (const Op& o : c->ops) {
+            if (o.type == kConv) {
+                for (int s = 0; s < o.conv.d.n_src; ++s) nrd += o.conv.d.src[s].tensor == tensor;
+                nrd += o.conv.d.residual_tensor == tensor;
+            } else if (o.type == kPool) nrd += o.pool.src == tensor;
+            else if (o.type == kHead) nrd += o.head.src == tensor;
+            else if (o.type == kTail) nrd += (o.tail.src0 == tensor) + (o.tail.img == tensor);
+        }
+        return nrd;
+    };
+    const bool f16 = c->precision == kF16;
+    auto half = [&](float v) { return f16 ? f32_to_f16_rne(v) : f32_to_bf16_rne(v); };
+    for (size_t i = 0; i + 2 < c->ops.size(); ++i) {
+        if (c->ops[i].type != kConv || c->ops[i + 1].type != kConv || c->ops[i + 2].type != kConv) continue;
+        const ConvOp &A = c->ops[i].conv, &B = c->ops[i + 1].conv, &C = c->ops[i + 2].conv;
+        if (A.h_w[0].empty() || C.h_w[0].empty() || !B.d_d64_wfrag) continue;
+        if (A.d.n_src != 1 || A.d.cout != 64 || !A.d.relu || A.d.residual_tensor >= 0 || A.n_cls != 1 || !B.d.relu || !C.d.relu || C.d.cout != 256 ||
+            C.n_cls != 1 || A.d.out_tensor < 0 || B.d.out_tensor < 0 || C.d.out_tensor < 0)
+            continue;
+        const int X = A.d.src[0].tensor, T1 = A.d.out_tensor, T2 = B.d.out_tensor, cin = A.d.src[0].channels;
+        if (B.d.src[0].tensor != T1 || readers(T1) != 1 || readers(T2) != 1 || T1 == X || T2 == X || C.d.out_tensor == X) continue;
+        int proj = -1, b_src = 0;
+        if (C.d.n_src == 1 && C.d.src[0].tensor == T2 && C.d.residual_tensor == X && cin == 256) proj = 0;
+        else if (C.d.n_src == 2 && C.d.residual_tensor < 0 && cin == 64 &&
+                 ((C.d.src[0].tensor == T2 && C.d.src[1].tensor == X) || (C.d.src[1].tensor == T2 && C.d.src[0].tensor == X))) {
+            proj = 1;
+            b_src = C.d.src[0].tensor == T2 ? 0 : 1;
+        }
+        if (proj < 0) continue;
+        const Tensor& xt = c->tensors[X];
+        Op blk;
+        blk.type = kBlock;
+        blk.block.x_tensor = X; blk.block.out_tensor = C.d.out_tensor; blk.block.cin = cin; blk.block.proj = proj;
+        blk.block.H = xt.H; blk.block.W = xt.W;
+        // W1: [cin/32 kk][4 mi][64 lanes][8]; W3: [2|4 kk][16 mi][64 lanes][8]; rows = conv_row_channel, k = kk*32 + (lane>>4)*8 + e
+        std::vector<uint16_t> f1((size_t)(cin / 32) * 4 * 64 * 8), f3((size_t)(proj ? 4 : 2) * 16 * 64 * 8);
+        for (int kk = 0; kk < cin / 32; ++kk)
+            for (int mi = 0; mi < 4; ++mi)
+                for (int l = 0; l < 64; ++l) {
+                    const int o = conv_row_channel(mi * 16 + (l & 15), 64);
+                    for (int e = 0; e < 8; ++e)
+                        f1[((((size_t)kk * 4 + mi) * 64) + l) * 8 + e] = half(A.h_w[0][(size_t)(kk * 32 + (l >> 4) * 8 + e) * 64 + o]);
+                }
+        for (int kk = 0; kk < (proj ? 4 : 2); ++kk)
+            for (int mi = 0; mi < 16; ++mi)
+                for (int l = 0; l < 64; ++l) {
+                    const int o = conv_row_channel(mi * 16 + (l & 15), 256);
+                    const std::vector<float>& wsrc = C.h_w[kk < 2 ? b_src : 1 - b_src];      // K-steps 0-1 contract b, 2-3 the block input
+                    for (int e = 0; e < 8; ++e)
+                        f3[((((size_t)kk * 16 + mi) * 64) + l) * 8 + e] = half(wsrc[(size_t)((kk & 1) * 32 + (l >> 4) * 8 + e) * 256 + o]);
+                }
+        if (upload(c, &blk.block.d_w1, f1.data(), f1.size()) || upload(c, &blk.block.d_w3, f3.data(), f3.size())) return 1;
+        char nm[96];
+        snprintf(nm, sizeof(nm), "block%s_c%dto64to256_%dx%d", proj ? "_proj" : "", cin, xt.H, xt.W);
+        blk.name = nm;
+        for (int k = 0; k < 3; ++k) {
+            blk.flops += c->ops[i + k].flops;
+            blk.issued_flops += c->ops[i + k].issued_flops;
+        }
+        blk.min_bytes = (double)xt.H * xt.W * (cin + 256) * c->elem;        // x read once, y written once
+        blk.parts.assign(c->ops.begin() + i, c->ops.begin() + i + 3);
+        c->ops.erase(c->ops.begin() + i, c->ops.begin() + i + 3);
+        c->ops.insert(c->ops.begin() + i, std::move(blk));
+    }
+    return 0;
+}
+
 int sbbseg_finalize(sbbseg_ctx* c, int max_batch)
 {
     API_BEGIN
     REQUIRE(c && !c->finalized, "bad handle / already finalized");
     HIPCHK(hipSetDevice(c->device));
+    if (fuse_bottlenecks(c)) return 1;
+    if (build_fast_gather_tables(c)) return 1;
     REQUIRE(max_batch >= 1, "max_batch must be >= 1");
     REQUIRE(c->classes > 0 && !c->ops.empty(), "plan must contain a head (head op or a conv with a fused head)");
     c->max_batch = max_batch;
@@ -1722,10 +1912,11 @@ int sbbseg_debug_inject_alloc_failure(int nth_check)
 int sbbseg_debug_set_conv_variant(sbbseg_ctx* c, int variant)
 {
     API_BEGIN
-    REQUIRE(c && variant >= 0 && variant <= 0x3ffff, "variant: bits 0-1 = 0 auto | 1 4-wave/2-stage | 2 8-wave/3-stage; bit 2 = one block per tile (non-persistent); bit 3 = no XCD-grouped tile walk; bit 4 = half-K-step stages; bit 5 = XCD-grouped walk on single-class layers; bit 6 = drain epilogue stores; bit 7 = half-line epilogue stores; bits 8-15 = contiguous-run K limit / 64; bit 16 = 8-phase schedule on the 256x256 tile; bit 17 = plain gather everywhere");
+    REQUIRE(c && variant >= 0 && variant <= 0x7ffff, "variant: bits 0-1 = 0 auto | 1 4-wave/2-stage | 2 8-wave/3-stage; bit 2 = one block per tile (non-persistent); bit 3 = no XCD-grouped tile walk; bit 4 = half-K-step stages; bit 5 = XCD-grouped walk on single-class layers; bit 6 = drain epilogue stores; bit 7 = half-line epilogue stores; bits 8-15 = contiguous-run K limit / 64; bit 16 = 8-phase schedule on the 256x256 tile; bit 17 = plain gather everywhere; bit 18 = fused bottleneck blocks run as their three convs");
     c->conv_variant = variant & 0xff;
     c->ph8 = (variant >> 16) & 1;
     c->plain_gather = (variant >> 17) & 1;
+    c->unfuse_blocks = (variant >> 18) & 1;
     if ((variant >> 8) & 0xff) c->contig_max_k = ((variant >> 8) & 0xff) * 64;
     return 0;
     API_END

@@ -25,6 +25,7 @@ struct SrcDesc {
                           // 8-channel granules) in the plain modes; channels * 2 in the split mode (the "lo" plane
                           // of the same 32 channels, see kF16X3)
     uint32_t bytes;       // bytes of the buffer in use (header + the launch's patches): num_records of the fast gather
+    int tap_lo_y, tap_lo_x; // fast gather: smallest tap offset of this source over all K-steps / classes (its taps span <= 4 x 4)
 };
 
 // one entry per 16-byte granule of the contraction axis
@@ -41,6 +42,15 @@ struct KStepRec {
     int32_t irregular;
     int32_t pad_;
 };
+
+// fast gather (ConvParams::fast_gather): the table handed to the kernel in place of the KStepRec table, same stride.
+// A source's buffer resource starts kFgBiasPixels(PW) pixels before the buffer, so `soff` is never negative.
+struct FgStepRec {
+    uint32_t soff;        // dy * row bytes + dx * pixel bytes + channel byte offset + kFgBiasPixels(PW) * pixel bytes
+    int32_t tapbit;       // source * 16 + (dy - tap_lo_y) * 4 + (dx - tap_lo_x): bit of this tap in a row's out-of-bounds mask
+    int32_t pad_[2];
+};
+__host__ __device__ constexpr int kFgBiasPixels(int PW) { return 8 * PW + 8; }   // covers taps down to (-8, -8)
 
 struct ConvParams {
     SrcDesc src[2];
@@ -85,7 +95,8 @@ struct ConvParams {
     const float* head_shift;
     uint8_t* labels;          // [n][TH][TW]
     float* probs;             // [n][TH][TW][classes] or null
-    int fast_gather;          // every K-step regular, taps within [-1, 2]^2, no upsampling source, buffers < 2 GiB:
+    const FgStepRec* fgstep_cls[4];   // fast gather: per-class tables read in place of kstep / kstep_cls (class 0 = entry 0)
+    int fast_gather;          // every K-step regular, each source's taps within a 4 x 4 window, no upsampling source, buffers < 2 GiB:
                               // run the FG form of conv_igemm_mfma (kernels.hip)
 };
 
@@ -132,6 +143,20 @@ struct Direct64Params {
     const float* shift;
     int relu;
     void* out;                // data pointer [n][H][W][64]
+};
+
+// One ResNet bottleneck block at 64 internal channels (1x1 -> 3x3 -> 1x1 + shortcut) as ONE launch.  See bottleneck_fused.
+struct BlockParams {
+    const char* x;            // buffer start (zero header), [n][H][W][CIN] 16-bit; CIN = 256 (identity) | 64 (projection)
+    int n, H, W;
+    int proj;                 // 0: y = ReLU(BN(W3 b) + x);  1: y = ReLU(BN(W3 [b, x]))  (shortcut conv folded by the planner)
+    const void* w1;           // [CIN/32 kk][4 mi][64 lanes] x 16 bytes, MFMA A-fragment order, rows = conv_row_channel
+    const void* w2;           // [9 taps][2 kk][4 mi][64 lanes] x 16 bytes (Direct64Params::wfrag)
+    const void* w3;           // [2|4 kk][16 mi][64 lanes] x 16 bytes; projection: kk 0-1 contract b, kk 2-3 contract x
+    const float *s1, *b1;     // [64]  scale / shift after the first 1x1
+    const float *s2, *b2;     // [64]  ... after the 3x3
+    const float *s3, *b3;     // [256] ... after the last 1x1 (before the residual add)
+    void* out;                // data pointer [n][H][W][256]
 };
 
 struct HeadParams {
@@ -198,6 +223,7 @@ hipError_t launch_largest_component(const uint8_t* mask, int H, int W, int* pare
                                     hipStream_t s);
 hipError_t launch_replicate3(const uint8_t* src, uint8_t* dst, size_t n, hipStream_t s);
 hipError_t launch_to_f32(const void* src, float* dst, size_t n, int precision, hipStream_t s);
+hipError_t launch_bottleneck(const BlockParams& p, int precision, int num_cus, hipStream_t s);
 hipError_t launch_split_to_f32(const void* src, float* dst, size_t npix, int C, hipStream_t s);   // [pix][C hi][C lo] -> [pix][C]
 
 int conv_row_channel(int row, int cout);   // packed weight row -> output channel (16-bit modes)

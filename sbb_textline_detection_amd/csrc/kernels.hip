@@ -261,17 +261,17 @@ void conv_igemm_mfma(const ConvParams p)
     // load-side class state (weights, tap tables), switched in setup_rows
     const char* wbase = (const char*)p.w;
     const __attribute__((address_space(4))) int* kstep_tab =
-        (const __attribute__((address_space(4))) int*)(uintptr_t)p.kstep;
+        (const __attribute__((address_space(4))) int*)(uintptr_t)(FG ? (const void*)p.fgstep_cls[0] : (const void*)p.kstep);
     const KTabEntry* ktab = p.ktab;
 
     // ---- load side: rows of the tile being STAGED (runs D steps ahead of the compute side)
     // plain gather: output coords (oy, ox, n) of the staged rows.  Fast gather: r_oy = byte offset of the row's centre tap
-    // in source 0, r_ox = the same in source 1, r_n = mask of out-of-bounds taps (bit src*16 + (dy+1)*4 + (dx+1)).
+    // in source 0, r_ox = the same in source 1, r_n = mask of out-of-bounds taps (bit src*16 + (dy-tap_lo_y)*4 + (dx-tap_lo_x)).
     int r_oy[T::kPLoads], r_ox[T::kPLoads], r_n[T::kPLoads];
     uint32_t w_off[T::kWLoads];
     // fast gather: buffer resources.  A source's resource starts fg_bias bytes BEFORE its buffer so that the scalar
     // offset (tap displacement + fg_bias) is never negative.
-    const uint32_t fg_bias0 = (uint32_t)((sd0.PW + 1) * sd0.pix_bytes), fg_bias1 = (uint32_t)((sd1.PW + 1) * sd1.pix_bytes);
+    const uint32_t fg_bias0 = (uint32_t)(kFgBiasPixels(sd0.PW) * sd0.pix_bytes), fg_bias1 = (uint32_t)(kFgBiasPixels(sd1.PW) * sd1.pix_bytes);
     // bytes from a source row's first granule to the granule this lane fetches
     auto lane_part = [&](const SrcDesc& sd) __attribute__((always_inline)) -> uint32_t {
         return X3 ? (uint32_t)((gsrc & 3) * 16 + (gsrc >> 2) * sd.lo_off) : (uint32_t)(gsrc * 16);
@@ -280,9 +280,9 @@ void conv_igemm_mfma(const ConvParams p)
         const int cy = oy << sd.sy_shift, cx = ox << sd.sx_shift;
         uint32_t xm = 0, m = 0;
 #pragma unroll
-        for (int b = 0; b < 4; ++b) xm |= ((unsigned)(cx + b - 1) < (unsigned)sd.lim_x) ? 0u : (1u << b);
+        for (int b = 0; b < 4; ++b) xm |= ((unsigned)(cx + b + sd.tap_lo_x) < (unsigned)sd.lim_x) ? 0u : (1u << b);
 #pragma unroll
-        for (int a = 0; a < 4; ++a) m |= (((unsigned)(cy + a - 1) < (unsigned)sd.lim_y) ? xm : 0xfu) << (4 * a);
+        for (int a = 0; a < 4; ++a) m |= (((unsigned)(cy + a + sd.tap_lo_y) < (unsigned)sd.lim_y) ? xm : 0xfu) << (4 * a);
         return m;
     };
     auto setup_rows = [&](int tile) __attribute__((always_inline)) {
@@ -290,7 +290,7 @@ void conv_igemm_mfma(const ConvParams p)
         decode(tile, ctile, cls, ptile);
         if (p.n_cls > 1) {
             wbase = (const char*)p.w_cls[cls];
-            kstep_tab = (const __attribute__((address_space(4))) int*)(uintptr_t)p.kstep_cls[cls];
+            kstep_tab = (const __attribute__((address_space(4))) int*)(uintptr_t)(FG ? (const void*)p.fgstep_cls[cls] : (const void*)p.kstep_cls[cls]);
             ktab = p.ktab_cls[cls];
         }
 #pragma unroll
@@ -345,12 +345,10 @@ void conv_igemm_mfma(const ConvParams p)
         char* lds_p = smem + buf * T::kStageBytes;
         char* lds_w = lds_p + BP * RB;
         if constexpr (FG) {
-            const int dy = (int)(short)(rec_yx & 0xffff), dx = rec_yx >> 16;
-            const int rowbytes = s1 ? sd1.PW * sd1.pix_bytes : sd0.PW * sd0.pix_bytes;
-            const int pixb = s1 ? sd1.pix_bytes : sd0.pix_bytes;
-            // wave-uniform part of the address: tap displacement + channel offset (+ the stage's half of the K-step)
-            const uint32_t soff = (uint32_t)(dy * rowbytes + dx * pixb + rec_coff + (X3 ? 0 : l_h * GS * 16)) + (s1 ? fg_bias1 : fg_bias0);
-            const int tapbit = (s1 ? 16 : 0) + (dy + 1) * 4 + (dx + 1);
+            // the fast gather's K-step records (FgStepRec, built by the host) hold the wave-uniform part of the address --
+            // tap displacement + channel offset + the resource's bias -- and the tap's bit in the rows' out-of-bounds masks
+            const uint32_t soff = (uint32_t)rec_yx + (uint32_t)(X3 ? 0 : l_h * GS * 16);
+            const int tapbit = rec_coff;
             auto rows = [&](const char* rbase, uint32_t nrec, const int (&voff)[T::kPLoads]) __attribute__((always_inline)) {
 #pragma unroll
                 for (int j = 0; j < T::kPLoads; ++j) {
@@ -1728,6 +1726,298 @@ hipError_t launch_direct64(const Direct64Params& p, int precision, int num_cus, 
     if (precision == kF16) hipLaunchKernelGGL(conv3x3_c64_direct<true>, dim3(grid), dim3(256), kD64LdsBytes, s, p);
     else hipLaunchKernelGGL(conv3x3_c64_direct<false>, dim3(grid), dim3(256), kD64LdsBytes, s, p);
     return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// bottleneck_fused -- one whole ResNet stage-2 bottleneck block per launch (three of them at 111x111 in the sbb nets):
+//
+//   a = ReLU(BN(conv1x1(x, CIN -> 64)))              phase A, on the 10 x 18 halo of an 8 x 16 output tile
+//   b = ReLU(BN(conv3x3(a, 64 -> 64)))               phase B, from the halo tile in LDS (as conv3x3_c64_direct)
+//   y = ReLU(BN(conv1x1(b, 64 -> 256)) + x)          phase C, identity block (CIN = 256)
+//   y = ReLU(BN(conv1x1([b, x], 128 -> 256)))        phase C, projection block (CIN = 64; the planner has folded the
+//                                                    shortcut conv into one contraction over [b, x])
+//
+// Run as three launches these layers are HBM-bound and move the 256-channel tensor four times per block (read for
+// the first 1x1, residual read + write in the last) plus the 64-channel tensors four times; fused, x is read once
+// (halo overlap from L2) and y written once.  What a CU has to do per tile is small next to that traffic (~300 MFMAs
+// per wave), so the kernel is built for memory-level parallelism, not for MFMA rate: ONE block of four waves per CU
+// (up to 512 VGPRs per lane), the x fragments of the NEXT tile are requested into registers before the current tile's
+// phases run, and the fragments of the inner pixels double as the residual of phase C (the MFMA B-operand layout --
+// pixel = lane & 15, 8 channels per lane -- is exactly the layout of the epilogue's 16-byte channel groups).
+//   * halo pixel order: n-tiles 0-7 = the 8 inner rows (16 pixels each), n-tiles 8-11 = the 52 border pixels (+12
+//     dummies).  Wave w owns inner rows 2w, 2w+1 and border tile 8+w in phases A and C, and the 16 output channels
+//     of MFMA row block w in phase B (its 9 x 2 weight fragments live in 72 VGPRs).
+//   * W1 and W3 stay in LDS for the whole kernel (A-fragment order, linear 16-byte reads); a (halo, 192 rows x 128 B)
+//     and b (128 rows x 128 B) are XOR-swizzled rows; halo pixels outside the image are ZERO (the 3x3 conv pads a, not x).
+//   * tiles are walked so that every XCD owns one contiguous range of them: vertical halo neighbours share an L2.
+// ------------------------------------------------------------------------------------------------
+constexpr int kBlkHaloW = 18;
+constexpr int kBlkABytes = 192 * 128;                           // a: 180 halo rows (+12 dummy rows)
+constexpr int kBlkBBytes = 128 * 128;                           // b: 8 x 16 pixels
+constexpr int kBlkCstBytes = (4 * 64 + 2 * 256) * 4;            // s1, b1, s2, b2 [64]; s3, b3 [256]
+constexpr int block_lds_bytes(int cin, bool proj) { return (cin / 32) * 4 * 1024 + (proj ? 4 : 2) * 16 * 1024 + kBlkABytes + kBlkBBytes + kBlkCstBytes; }
+
+template <bool F16, int CIN, bool PROJ>
+__global__ __launch_bounds__(256, 1) void bottleneck_fused(const BlockParams p)
+{
+    static_assert((CIN == 256 && !PROJ) || (CIN == 64 && PROJ), "identity blocks read 256 channels, the projection block 64");
+    constexpr int KA = CIN / 32;                                // K-steps (32 channels) of phase A
+    constexpr int KC = PROJ ? 4 : 2;                            // K-steps of phase C
+    constexpr int PIXB = CIN * 2;                               // bytes per stored x pixel
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* lds_w1 = smem;
+    char* lds_w3 = lds_w1 + KA * 4 * 1024;
+    char* lds_a = lds_w3 + KC * 16 * 1024;
+    char* lds_b = lds_a + kBlkABytes;
+    float* cst = (float*)(lds_b + kBlkBBytes);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int frow = lane & 15, fg = lane >> 4;
+    const int tiles_x = (p.W + 15) / 16, tiles_y = (p.H + 7) / 8;
+    const int tiles_per_patch = tiles_x * tiles_y;
+    const int n_tiles = p.n * tiles_per_patch;
+    // XCD-contiguous walk: XCD x = block % 8 owns tiles [x * per_xcd, (x + 1) * per_xcd)
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, GX = gridDim.x >> 3;
+    const int per_xcd = (n_tiles + 7) >> 3;
+    const int xcd_lo = xcd * per_xcd, xcd_hi = min(n_tiles, xcd_lo + per_xcd);
+    const int my_tiles = xcd_lo + slot < xcd_hi ? (xcd_hi - xcd_lo - slot + GX - 1) / GX : 0;
+    if (my_tiles <= 0) return;
+
+    // ---- one-time: weights and constants to LDS, this wave's 3x3 fragments to registers
+    for (int i = tid; i < KA * 4 * 64; i += 256) ((uint4*)lds_w1)[i] = ((const uint4*)p.w1)[i];
+    for (int i = tid; i < KC * 16 * 64; i += 256) ((uint4*)lds_w3)[i] = ((const uint4*)p.w3)[i];
+    if (tid < 64) {
+        cst[tid] = p.s1[tid]; cst[64 + tid] = p.b1[tid]; cst[128 + tid] = p.s2[tid]; cst[192 + tid] = p.b2[tid];
+    }
+    cst[256 + tid] = p.s3[tid]; cst[512 + tid] = p.b3[tid];
+    bf16x8_t wf[9][2];                                          // [tap][kk], MFMA row block `wave`
+    {
+        const uint4* src = (const uint4*)p.w2 + lane;
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) wf[t][kk] = __builtin_bit_cast(bf16x8_t, src[(size_t)((t * 2 + kk) * 4 + wave) * 64]);
+    }
+
+    // ---- this lane's three halo pixels (fixed per kernel): (hy, hx) and the LDS row hr = hy * 18 + hx
+    int hy[3], hx[3], hr[3];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) { hy[j] = 2 * wave + j + 1; hx[j] = frow + 1; hr[j] = hy[j] * kBlkHaloW + hx[j]; }
+    {
+        const int bi = wave * 16 + frow;                       // border pixel index
+        int y, x;
+        if (bi < 18) { y = 0; x = bi; }
+        else if (bi < 36) { y = 9; x = bi - 18; }
+        else if (bi < 44) { y = 1 + (bi - 36); x = 0; }
+        else if (bi < 52) { y = 1 + (bi - 44); x = 17; }
+        else { y = 10; x = bi - 52; }                           // dummies: rows 180..191, never inside the image
+        hy[2] = y; hx[2] = x; hr[2] = y * kBlkHaloW + x;
+    }
+
+    bool inimg[3];
+    uint32_t xoff[3];
+    auto locate = [&](int tile, bool (&in)[3], uint32_t (&off)[3]) __attribute__((always_inline)) {
+        const int n = tile / tiles_per_patch;
+        const int rem = tile - n * tiles_per_patch;
+        const int ty = rem / tiles_x, tx = rem - ty * tiles_x;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int Y = ty * 8 - 1 + hy[j], X = tx * 16 - 1 + hx[j];
+            in[j] = ((unsigned)Y < (unsigned)p.H) & ((unsigned)X < (unsigned)p.W) & (hy[j] < 10);
+            // (pixels outside the image read the start of the buffer: finite or not, their column is replaced by zeros)
+            off[j] = in[j] ? (uint32_t)((n * p.H + Y) * p.W + X) * (uint32_t)PIXB + (uint32_t)(kZeroHeaderBytes + fg * 16) : 0u;
+        }
+    };
+    bf16x8_t xcur[3][KA], xnext[3][KA];
+    auto fetch = [&](const uint32_t (&off)[3], bf16x8_t (&dst)[3][KA]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int kk = 0; kk < KA; ++kk) dst[j][kk] = *(const bf16x8_t*)(p.x + off[j] + kk * 64);
+    };
+
+    auto tile_at = [&](int it) __attribute__((always_inline)) -> int { return xcd_lo + slot + it * GX; };
+    locate(tile_at(0), inimg, xoff);
+    fetch(xoff, xcur);
+    __syncthreads();                                            // weights / constants visible
+
+    for (int it = 0; it < my_tiles; ++it) {
+        const int tile = tile_at(it);
+        bool in_next[3];
+        uint32_t off_next[3];
+        if (it + 1 < my_tiles) {                                // the next tile's x: in flight across all three phases
+            locate(tile_at(it + 1), in_next, off_next);
+            fetch(off_next, xnext);
+        }
+
+        // ---- phase A: a[halo pixel][64] = ReLU(s1 * (W1 . x) + b1), zero outside the image
+        {
+            f32x4_t acc[4][3];
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) acc[mi][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kk = 0; kk < KA; ++kk) {
+                bf16x8_t wa[4];
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi) wa[mi] = *(const bf16x8_t*)(lds_w1 + (kk * 4 + mi) * 1024 + lane * 16);
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) acc[mi][j] = mfma16<F16>(wa[mi], xcur[j][kk], acc[mi][j]);
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const int c0 = s2 * 32 + fg * 8;
+                float sc[8], sh[8];
+                *(float4*)&sc[0] = *(const float4*)(cst + c0); *(float4*)&sc[4] = *(const float4*)(cst + c0 + 4);
+                *(float4*)&sh[0] = *(const float4*)(cst + 64 + c0); *(float4*)&sh[4] = *(const float4*)(cst + 64 + c0 + 4);
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    float y[8];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        y[q] = fmaxf(acc[2 * s2][j][q] * sc[q] + sh[q], 0.f);
+                        y[4 + q] = fmaxf(acc[2 * s2 + 1][j][q] * sc[4 + q] + sh[4 + q], 0.f);
+                    }
+                    uint4 r;
+                    r.x = pack2<F16>(y[0], y[1]); r.y = pack2<F16>(y[2], y[3]); r.z = pack2<F16>(y[4], y[5]); r.w = pack2<F16>(y[6], y[7]);
+                    if (!inimg[j]) r = make_uint4(0u, 0u, 0u, 0u);
+                    *(uint4*)(lds_a + hr[j] * 128 + (((s2 * 4 + fg) ^ (hr[j] & 7)) << 4)) = r;
+                }
+            }
+        }
+        __syncthreads();
+
+        // ---- phase B: b[pixel][16 channels of row block `wave`] = ReLU(s2 * conv3x3(a) + b2)
+        {
+            const int sB = wave >> 1, half = wave & 1;
+            const int cB = sB * 32 + fg * 8 + half * 4;
+            const float4 sc = *(const float4*)(cst + 128 + cB), sh = *(const float4*)(cst + 192 + cB);
+#pragma unroll
+            for (int g4 = 0; g4 < 2; ++g4) {                   // four output rows at a time: independent accumulator chains
+                f32x4_t acc[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int t = 0; t < 9; ++t)
+#pragma unroll
+                    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const int row = (g4 * 4 + i + t / 3) * kBlkHaloW + frow + t % 3;
+                            const bf16x8_t bq = *(const bf16x8_t*)(lds_a + row * 128 + (((kk * 4 + fg) ^ (row & 7)) << 4));
+                            acc[i] = mfma16<F16>(wf[t][kk], bq, acc[i]);
+                        }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int row = (g4 * 4 + i) * 16 + frow;
+                    uint2 r;
+                    r.x = pack2<F16>(fmaxf(acc[i][0] * sc.x + sh.x, 0.f), fmaxf(acc[i][1] * sc.y + sh.y, 0.f));
+                    r.y = pack2<F16>(fmaxf(acc[i][2] * sc.z + sh.z, 0.f), fmaxf(acc[i][3] * sc.w + sh.w, 0.f));
+                    *(uint2*)(lds_b + row * 128 + (((sB * 4 + fg) ^ (row & 7)) << 4) + half * 8) = r;
+                }
+            }
+        }
+        __syncthreads();
+
+        // ---- phase C: y[inner rows 2w, 2w+1][256] = ReLU(s3 * (W3 . [b, x?]) + b3 (+ x)), 32 channels at a time
+        {
+            const int n = tile / tiles_per_patch;
+            const int rem = tile - n * tiles_per_patch;
+            const int ty = rem / tiles_x, tx = rem - ty * tiles_x;
+            const int ox = tx * 16 + frow;
+            bf16x8_t bf[2][2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    const int row = (2 * wave + j) * 16 + frow;
+                    bf[j][kk] = *(const bf16x8_t*)(lds_b + row * 128 + (((kk * 4 + fg) ^ (row & 7)) << 4));
+                }
+#pragma unroll
+            for (int s3 = 0; s3 < 8; ++s3) {
+                f32x4_t acc[2][2];
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[m][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int kk = 0; kk < KC; ++kk)
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) {
+                        const bf16x8_t wa = *(const bf16x8_t*)(lds_w3 + (kk * 16 + 2 * s3 + m) * 1024 + lane * 16);
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            bf16x8_t bq;
+                            if constexpr (PROJ) bq = kk < 2 ? bf[j][kk & 1] : xcur[j][kk & 1];
+                            else bq = bf[j][kk & 1];
+                            acc[m][j] = mfma16<F16>(wa, bq, acc[m][j]);
+                        }
+                    }
+                const int c0 = s3 * 32 + fg * 8;
+                float sc[8], sh[8];
+                *(float4*)&sc[0] = *(const float4*)(cst + 256 + c0); *(float4*)&sc[4] = *(const float4*)(cst + 256 + c0 + 4);
+                *(float4*)&sh[0] = *(const float4*)(cst + 512 + c0); *(float4*)&sh[4] = *(const float4*)(cst + 512 + c0 + 4);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    float y[8];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        y[q] = acc[0][j][q] * sc[q] + sh[q];
+                        y[4 + q] = acc[1][j][q] * sc[4 + q] + sh[4 + q];
+                    }
+                    if constexpr (!PROJ) {                      // the residual: this lane's x fragment of K-step s3 = channels c0 .. c0+7
+                        const uint4 rv = __builtin_bit_cast(uint4, xcur[j][s3 % KA]);
+                        y[0] += unpack_lo<F16>(rv.x); y[1] += unpack_hi<F16>(rv.x); y[2] += unpack_lo<F16>(rv.y); y[3] += unpack_hi<F16>(rv.y);
+                        y[4] += unpack_lo<F16>(rv.z); y[5] += unpack_hi<F16>(rv.z); y[6] += unpack_lo<F16>(rv.w); y[7] += unpack_hi<F16>(rv.w);
+                    }
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) y[q] = fmaxf(y[q], 0.f);
+                    uint4 r;
+                    r.x = pack2<F16>(y[0], y[1]); r.y = pack2<F16>(y[2], y[3]); r.z = pack2<F16>(y[4], y[5]); r.w = pack2<F16>(y[6], y[7]);
+                    const int oy = ty * 8 + 2 * wave + j;
+                    if (oy < p.H && ox < p.W)
+                        *(uint4*)((uint16_t*)p.out + (((size_t)n * p.H + oy) * p.W + ox) * 256 + c0) = r;
+                }
+            }
+        }
+
+        if (it + 1 < my_tiles) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                inimg[j] = in_next[j];
+#pragma unroll
+                for (int kk = 0; kk < KA; ++kk) xcur[j][kk] = xnext[j][kk];
+            }
+        }
+    }
+}
+
+hipError_t launch_bottleneck(const BlockParams& p, int precision, int num_cus, hipStream_t s)
+{
+    const int n_tiles = p.n * ((p.H + 7) / 8) * ((p.W + 15) / 16);
+    int grid = n_tiles < num_cus ? n_tiles : num_cus;
+    grid = (grid + 7) & ~7;                                     // the XCD-contiguous walk needs a multiple of 8 blocks
+    auto go = [&](auto kernel, int lds) -> hipError_t {
+        static bool attr_done[4][64] = {};
+        int dev = 0;
+        hipError_t e = hipGetDevice(&dev);
+        if (e != hipSuccess) return e;
+        const int slot = (precision == kF16 ? 0 : 1) + (p.proj ? 2 : 0);
+        if (!attr_done[slot][dev & 63]) {
+            e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            if (e != hipSuccess) return e;
+            attr_done[slot][dev & 63] = true;
+        }
+        hipLaunchKernelGGL(kernel, dim3(grid), dim3(256), lds, s, p);
+        return hipGetLastError();
+    };
+    if (p.proj) return precision == kF16 ? go(bottleneck_fused<true, 64, true>, block_lds_bytes(64, true)) : go(bottleneck_fused<false, 64, true>, block_lds_bytes(64, true));
+    return precision == kF16 ? go(bottleneck_fused<true, 256, false>, block_lds_bytes(256, false)) : go(bottleneck_fused<false, 256, false>, block_lds_bytes(256, false));
 }
 
 // ------------------------------------------------------------------------------------------------

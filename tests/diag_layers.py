@@ -7,6 +7,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
+os.environ["SBBSEG_FUSE_BLOCKS"] = "0"   # reads intermediate tensors
 from gpu_common import make_model, patches_from_page  # noqa: E402
 from oracle import keras_forward as kf  # noqa: E402
 

@@ -53,7 +53,8 @@ def test_ingest_forms(precision):
 
 # --------------------------------------------------------------------------------- forward, by layer
 @pytest.mark.parametrize("precision", ["f32", "f16x3", "f16", "bf16"])
-def test_every_fused_layer_matches_oracle(precision):
+def test_every_fused_layer_matches_oracle(precision, monkeypatch):
+    monkeypatch.setenv("SBBSEG_FUSE_BLOCKS", "0")      # this test reads every intermediate tensor: keep the bottleneck blocks as three convs
     cfg, w, g, model = make_model(2, 64, 96, seed=2, precision=precision, max_batch=4, calib_hw=64)
     # (calibrating BN on 64x64 crops leaves stage 5 with 8 samples per channel: activations reach
     #  ~1e3 and the softmax of this tiny net is ill-conditioned -- it is only asserted for f32 here;
@@ -77,6 +78,55 @@ def test_every_fused_layer_matches_oracle(precision):
     print(f"[layers {precision}] worst layer {worst}, max|dsoftmax| {d:.4f}, label mismatches {mism}")
     if precision in ("f32", "f16x3"):
         assert d < TOL_SOFTMAX[precision] and bad == 0, (d, mism, bad, worst)
+    model.release()
+
+
+@pytest.mark.parametrize("precision,hw", [("f16", (64, 96)), ("bf16", (64, 96)), ("f16", (224, 256))])
+def test_fused_bottleneck_blocks_match_their_three_convs(precision, hw):
+    """sbbseg_finalize folds each stage-2 bottleneck block (1x1 -> 3x3 -> 1x1 + shortcut) into one bottleneck_fused launch.
+    Same network, fused vs the three convs it replaces (conv variant bit 18), every tensor the fused plan still writes,
+    and the block outputs against the fp32 oracle (main.py:225-380 runs whatever Keras graph the .h5 holds: Add/ReLU nodes
+    of keras_graph)."""
+    h, wd = hw
+    cfg, w, g, model = make_model(2, h, wd, seed=5, precision=precision, max_batch=4, calib_hw=min(160, max(h, wd)))
+    names = [o["name"] for o in model.ctx.ops()]
+    blocks = [n for n in names if n.startswith("block")]
+    assert len(blocks) == 3 and sum("proj" in n for n in blocks) == 1, names
+    x = (patches_from_page(h, wd, 3, seed=8) / 255.0).astype(np.float32)
+    taps = {name: None for name in model.plan.layer_tensor}
+    ref = kf.forward(g, w, x, taps=taps)
+    stage2 = None
+
+    def read_all():
+        out = {}
+        for name, tid in model.plan.layer_tensor.items():
+            t = model.plan.tensors[tid]
+            out[name] = model.ctx.debug_read_tensor(tid, 3, (t.H, t.W, t.C))
+        return out
+    got_fused = model.predict(x)
+    t_fused = read_all()
+    model.ctx.set_conv_variant(1 << 18)
+    got_parts = model.predict(x)
+    t_parts = read_all()
+    model.ctx.set_conv_variant(0)
+    stage2 = max(model.plan.tensors[tid].H for tid in model.plan.layer_tensor.values() if model.plan.tensors[tid].C == 256)
+    checked = 0
+    for name, tid in model.plan.layer_tensor.items():
+        t = model.plan.tensors[tid]
+        if t.C == 64 and t.H == stage2:
+            continue                                   # the blocks' internal 64-channel tensors are not written by the fused plan
+        a, b = t_fused[name], t_parts[name]
+        scale = np.abs(b).max() + 1e-6
+        assert np.abs(a - b).max() / scale < (4e-3 if precision == "f16" else 3e-2), (name, np.abs(a - b).max() / scale)
+        if t.C == 256 and t.H == stage2:
+            r = taps[name]
+            rel = float(np.abs(a - r).max() / (np.abs(r).max() + 1e-6))
+            assert rel < TOL_LAYER_REL[precision], (name, rel)
+            checked += 1
+    assert checked >= 3
+    d = float(np.abs(got_fused - got_parts).max())
+    print(f"[fused blocks {precision} {h}x{wd}] max|dsoftmax| fused vs three convs {d:.2e}; vs oracle {float(np.abs(got_fused - ref).max()):.2e}")
+    assert d < (0.02 if precision == "f16" else 0.15)
     model.release()
 
 

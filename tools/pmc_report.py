@@ -5,9 +5,13 @@ import os
 import sys
 from collections import defaultdict
 
+# usage: tools/pmc_report.py <tag> [ops.json from SBBSEG_BENCH_OPS] [summary.json to write] [precision] [patches per launch]
 tag = sys.argv[1] if len(sys.argv) > 1 else "pmc1"
 root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
 ops_json = sys.argv[2] if len(sys.argv) > 2 else None
+summary_out = sys.argv[3] if len(sys.argv) > 3 else None
+precision = sys.argv[4] if len(sys.argv) > 4 else "f16"
+patches_per_launch = float(sys.argv[5]) if len(sys.argv) > 5 else 140.0
 
 
 def load(name):
@@ -27,7 +31,7 @@ fe, meta_f = load("fetch")
 wr, meta_w = load("write")
 # plan kernels only (conv / maxpool / head), in dispatch order; one chunk = 61 ops
 def plan_ids(meta):
-    return [d for d in sorted(meta) if any(s in meta[d][0] for s in ("conv_igemm", "maxpool", "head_kernel", "dec_tail", "stem_conv", "conv3x3_c64_direct"))]
+    return [d for d in sorted(meta) if any(s in meta[d][0] for s in ("conv_igemm", "maxpool", "head_kernel", "dec_tail", "stem_conv", "conv3x3_c64_direct", "bottleneck_fused"))]
 ids, idf, idw = plan_ids(meta), plan_ids(meta_f), plan_ids(meta_w)
 names = None
 if ops_json:
@@ -35,7 +39,8 @@ if ops_json:
 n_ops = len(names) if names else 61
 # take the LAST full chunk (steady state)
 ids, idf, idw = ids[-n_ops:], idf[-n_ops:], idw[-n_ops:]
-print(f"{'op':46s} {'us':>7s} {'grid':>6s} {'mfma%':>6s} {'wait%':>6s} {'instwait%':>9s} {'active%':>8s} {'ldsconf%':>8s} {'fetchMB':>8s} {'writeMB':>8s} {'GB/s':>7s} {'L2hit%':>6s}")
+summary = {}
+print(f"{'op':46s} {'us':>7s} {'grid':>6s} {'MHz':>5s} {'mfma%':>6s} {'wait%':>6s} {'instwait%':>9s} {'active%':>8s} {'ldsconf%':>8s} {'fetchMB':>8s} {'writeMB':>8s} {'HBM GB/s':>8s} {'L2hit%':>6s}")
 for k, (d, df, dw) in enumerate(zip(ids, idf, idw)):
     c = sq[d]; nm = names[k] if names else meta[d][0][:40]
     us = meta[d][4] / 1e3
@@ -49,5 +54,18 @@ for k, (d, df, dw) in enumerate(zip(ids, idf, idw)):
     fetch = fe[df].get("FETCH_SIZE", 0) * 1024 * 2 / 1e6        # gfx950: FETCH_SIZE reads half (MI355X_MICROARCH.md)
     write = wr[dw].get("WRITE_SIZE", 0) * 1024 / 1e6
     hit = wr[dw].get("TCC_HIT_sum", 0); miss = wr[dw].get("TCC_MISS_sum", 0)
-    print(f"{nm:46s} {us:7.1f} {meta[d][1]//meta[d][2]:6d} {mfma:6.1f} {c.get('SQ_WAIT_ANY',0)/wc*100:6.1f} {c.get('SQ_WAIT_INST_ANY',0)/wc*100:9.1f} "
-          f"{c.get('SQ_ACTIVE_INST_ANY',0)/wc*100:8.1f} {c.get('SQ_LDS_BANK_CONFLICT',0)/busy*100:8.2f} {fetch:8.1f} {write:8.1f} {(fetch+write)/us*1e3/1e3:7.0f} {hit/(hit+miss+1e-9)*100:6.1f}")
+    us_f = meta_f[df][4] / 1e3
+    mhz = gui / 8 / us_f                  # GRBM_GUI_ACTIVE = busy shader-clock cycles summed over the 8 XCDs: the launch's average clock
+                                          # (short launches read high: the counter also covers the dispatch's lead-in / drain)
+    gbps = (fetch + write) / us * 1e3     # MB / us = TB/s -> GB/s
+    print(f"{nm:46s} {us:7.1f} {meta[d][1]//meta[d][2]:6d} {mhz:5.0f} {mfma:6.1f} {c.get('SQ_WAIT_ANY',0)/wc*100:6.1f} {c.get('SQ_WAIT_INST_ANY',0)/wc*100:9.1f} "
+          f"{c.get('SQ_ACTIVE_INST_ANY',0)/wc*100:8.1f} {c.get('SQ_LDS_BANK_CONFLICT',0)/busy*100:8.2f} {fetch:8.1f} {write:8.1f} {gbps:8.0f} {hit/(hit+miss+1e-9)*100:6.1f}")
+    summary[nm] = {"us": round(us, 1), "shader_clock_mhz": round(mhz), "mfma_busy_pct": round(mfma, 1), "fetch_bytes": round(fetch * 1e6), "write_bytes": round(write * 1e6),
+                   "hbm_gbps": round(gbps), "l2_hit_pct": round(hit / (hit + miss + 1e-9) * 100, 1), "lds_conflict_pct": round(c.get('SQ_LDS_BANK_CONFLICT', 0) / busy * 100, 2)}
+if summary_out:
+    json.dump({"source": "rocprofv3 --pmc passes over `python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-second-mode` (tools/pmc_run.sh: SQ_*, "
+                         "FETCH_SIZE+GRBM_GUI_ACTIVE, WRITE_SIZE+TCC_HIT/MISS in separate runs); last launch of every op = the bench's roofline pass "
+                         "(one whole chunk per launch on one lane); FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 counts half of wide coalesced reads); "
+                         "duplicate op names keep the last launch; mfma_busy_pct = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x 32 CUs x 4 SIMDs) "
+                         "(the SQ totals of this rocprofv3 build cover one XCD); shader_clock_mhz = GRBM_GUI_ACTIVE / 8 XCDs / launch duration",
+               "precision": precision, "patches_per_launch": patches_per_launch, "ops": summary}, open(summary_out, "w"), indent=1)

@@ -193,12 +193,21 @@ __global__ __launch_bounds__(512, 2) void probe(float* out, int iters, const cha
     if (tid == 0 && blockIdx.x == 0) { clk[0] = clock64() - c0; clk[1] = wall_clock64() - r0; }
 }
 
+__global__ void fill_random(_Float16* p, size_t n)
+{
+    unsigned s = (blockIdx.x * 256u + threadIdx.x) * 2654435761u + 99u;
+    for (size_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += (size_t)gridDim.x * 256u) {
+        s = s * 1664525u + 1013904223u;
+        p[i] = (_Float16)(((int)(s >> 9) & 0xffff) / 32768.f - 1.f);
+    }
+}
+
 template <int VAR, int NV = 0>
 static void run(const char* name, float* d_out, int iters)
 {
     static char* d_src = nullptr;
     static unsigned long long* d_clk = nullptr;
-    if (!d_src) { hipMalloc((void**)&d_src, 1 << 26); hipMemset(d_src, 0, 1 << 26); hipMalloc((void**)&d_clk, 16); }
+    if (!d_src) { hipMalloc((void**)&d_src, 1 << 26); hipLaunchKernelGGL(fill_random, dim3(1024), dim3(256), 0, 0, (_Float16*)d_src, (size_t)(1 << 25)); hipMalloc((void**)&d_clk, 16); }
     hipFuncSetAttribute((const void*)probe<VAR, NV>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kStage);
     hipEvent_t a, b;
     hipEventCreate(&a); hipEventCreate(&b);
@@ -235,6 +244,7 @@ int main()
     run<2 | 16 | 4>("16x16x32, NO LDS reads, no barrier", d_out, iters);
     run<32>("16x16x32 product loop + 8 staging loads per wave", d_out, iters);
     run<2 | 16 | 32>("16x16x32, NO LDS reads + 8 staging loads per wave", d_out, iters);
+    run<4 | 32>("16x16x32 product loop + 8 staging loads, no barrier (racy)", d_out, iters);
     run<0, 32>("16x16x32 product loop + 32 VALU per K-step", d_out, iters);
     run<0, 64>("16x16x32 product loop + 64 VALU per K-step", d_out, iters);
     run<0, 128>("16x16x32 product loop + 128 VALU per K-step", d_out, iters);
