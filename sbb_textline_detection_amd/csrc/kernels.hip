@@ -1102,7 +1102,7 @@ static hipError_t launch_conv_impl(const ConvParams& p, hipStream_t s)
 template <int BP, int BC, int WP, int WC, int NS, bool F16, int GS = 8, bool PH8 = false, bool X3 = false>
 static hipError_t launch_conv_t(const ConvParams& p, hipStream_t s)
 {
-    if constexpr (!PH8) {
+    if constexpr (!PH8 && GS == 8 && NS == 2) {        // (the opt-in half-stage, 3-stage and 8-phase forms keep the plain gather)
         if (p.fast_gather) return launch_conv_impl<BP, BC, WP, WC, NS, F16, GS, PH8, X3, true>(p, s);
     }
     return launch_conv_impl<BP, BC, WP, WC, NS, F16, GS, PH8, X3, false>(p, s);

@@ -23,7 +23,7 @@ def test_conv_kernels_have_no_scratch(tmp_path):
     seen = 0
     for b in blocks:
         name = b.split()[0]
-        if not any(k in name for k in ("conv_igemm_mfma", "stem_conv_pairs", "dec_tail_fused", "conv3x3_c64_direct")):
+        if not any(k in name for k in ("conv_igemm_mfma", "stem_conv_pairs", "dec_tail_fused", "conv3x3_c64_direct", "bottleneck_fused")):
             continue
         seen += 1
         scratch = int(re.search(r"ScratchSize \[bytes/lane\]: (\d+)", b).group(1))
