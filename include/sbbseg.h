@@ -233,6 +233,24 @@ int sbbseg_page_box_dev(sbbseg_ctx* c, const void* d_mask_hw, int H, int W, int3
 int sbbseg_extract_page_box(sbbseg_ctx* c, const uint8_t* page_hwc, int Hp, int Wp, int Hs, int Ws, uint8_t* mask_out,
                             int32_t* box_xywh, int64_t* pixels);
 
+/* ---- stage glue: the rotate-and-project of the deskew search (return_deskew_slope, main.py:1601-1718; per text region,
+ * 80 angles in [-25, 25] and 30 more in [-90, -50] -- the reference spreads the regions over cpu_count() processes,
+ * main.py:1760-1799).  The H x W u8 region mask is centred on a zero square of side S = (int)(1.4 * max(H, W))
+ * (sbbseg_deskew_side; main.py:1613-1621), rotated by every angle exactly as rotate_image does (main.py:159-163:
+ * cv2.getRotationMatrix2D((S/2, S/2), angle, 1.0) + cv2.warpAffine INTER_CUBIC / BORDER_REPLICATE), binarised (!= 0,
+ * main.py:1642) and summed along its rows (main.py:1546).  counts: host int32 [n_angles][S].  One launch for the sweep.
+ * matrices (optional, [n_angles][6] forward 2 x 3 maps) overrides angles_deg; otherwise sbbseg_rotation_matrix is used.
+ * The 1-D peak logic on the profiles (scipy gaussian_filter1d / find_peaks, main.py:1545-1599) stays on the host
+ * (stages.return_deskew_slope).  [EXT, unpinned]: OpenCV 4.5.1's warpAffine arithmetic is restated (fixed-point source
+ * coordinates with 5 fractional bits, float bicubic table with A = -0.75, replicated borders); cv2 is not available to
+ * pin it against. */
+int sbbseg_deskew_side(int H, int W, int* side);
+int sbbseg_rotation_matrix(double cx, double cy, double angle_deg, double* m6);
+int sbbseg_deskew_profiles_dev(sbbseg_ctx* c, const void* d_mask_hw, int H, int W, const double* matrices, const double* angles_deg,
+                               int n_angles, int32_t* counts);
+int sbbseg_deskew_profiles(sbbseg_ctx* c, const uint8_t* mask_hw, int H, int W, const double* matrices, const double* angles_deg,
+                           int n_angles, int32_t* counts);
+
 /* ---- building blocks (multi-GPU sharding, tests).  tile_xy: host int32 [n][2] = (x0, y0) origins.
  * d_tile_labels: device uint8 [n][H][W]. */
 int sbbseg_tile_grid(int Hp, int Wp, int H, int W, int32_t* tile_xy, int capacity, int* nxf, int* nyf);

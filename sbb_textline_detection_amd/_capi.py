@@ -28,6 +28,7 @@ EXPORTS = [
     "sbbseg_segment_tile_range_dev", "sbbseg_stitch_dev", "sbbseg_debug_ingest", "sbbseg_debug_read_tensor",
     "sbbseg_debug_set_conv_variant", "sbbseg_debug_inject_alloc_failure",
     "sbbseg_morph_dev", "sbbseg_morph", "sbbseg_page_box_dev", "sbbseg_extract_page_box",
+    "sbbseg_deskew_side", "sbbseg_rotation_matrix", "sbbseg_deskew_profiles_dev", "sbbseg_deskew_profiles",
     "sbbseg_profile_enable", "sbbseg_profile_reset", "sbbseg_profile_get",
 ]
 
@@ -108,6 +109,10 @@ def load_library(path: Optional[str] = None):
         "sbbseg_morph": [vp, vp, i32, i32, i32, i32, i32, vp],
         "sbbseg_page_box_dev": [vp, vp, i32, i32, vp, C.POINTER(C.c_int64)],
         "sbbseg_extract_page_box": [vp, vp, i32, i32, i32, i32, vp, vp, C.POINTER(C.c_int64)],
+        "sbbseg_deskew_side": [i32, i32, C.POINTER(C.c_int)],
+        "sbbseg_rotation_matrix": [C.c_double, C.c_double, C.c_double, vp],
+        "sbbseg_deskew_profiles_dev": [vp, vp, i32, i32, vp, vp, i32, vp],
+        "sbbseg_deskew_profiles": [vp, vp, i32, i32, vp, vp, i32, vp],
         "sbbseg_debug_inject_alloc_failure": [i32],
         "sbbseg_profile_enable": [vp, i32],
         "sbbseg_profile_reset": [vp],
@@ -405,6 +410,22 @@ class Context:
                                                C.byref(px)), "sbbseg_extract_page_box")
         return mask, tuple(int(v) for v in box), int(px.value)
 
+    def deskew_profiles(self, mask: np.ndarray, angles_deg=None, matrices=None) -> np.ndarray:
+        """Rotate-and-project of the deskew search: int32 [n_angles][side] row counts of the rotated, binarised region mask."""
+        mask = np.ascontiguousarray(mask, np.uint8)
+        H, W = mask.shape
+        side = deskew_side(H, W)
+        if matrices is not None:
+            matrices = np.ascontiguousarray(matrices, np.float64).reshape(-1, 6)
+            n = matrices.shape[0]
+        else:
+            angles_deg = np.ascontiguousarray(angles_deg, np.float64).reshape(-1)
+            n = angles_deg.shape[0]
+        counts = np.zeros((n, side), np.int32)
+        check(self.lib.sbbseg_deskew_profiles(self.h, _ptr(mask), H, W, _ptr(matrices) if matrices is not None else None,
+                                              _ptr(angles_deg) if matrices is None else None, n, _ptr(counts)), "sbbseg_deskew_profiles")
+        return counts
+
     def set_conv_variant(self, variant: int):
         check(self.lib.sbbseg_debug_set_conv_variant(self.h, int(variant)))
 
@@ -433,6 +454,20 @@ def tile_grid(Hp: int, Wp: int, H: int, W: int):
     xy = np.empty((nx.value * ny.value, 2), np.int32)
     check(lib.sbbseg_tile_grid(Hp, Wp, H, W, _ptr(xy), xy.shape[0], None, None), "sbbseg_tile_grid")
     return xy, nx.value, ny.value
+
+
+def deskew_side(H: int, W: int) -> int:
+    """Side of the zero square the deskew search centres a region mask on: int(1.4 * max(H, W)) (main.py:1613)."""
+    side = C.c_int(0)
+    check(load_library().sbbseg_deskew_side(int(H), int(W), C.byref(side)), "sbbseg_deskew_side")
+    return int(side.value)
+
+
+def rotation_matrix(cx: float, cy: float, angle_deg: float) -> np.ndarray:
+    """cv2.getRotationMatrix2D((cx, cy), angle, 1.0) as the library computes it: float64 [2][3]."""
+    m = np.zeros(6, np.float64)
+    check(load_library().sbbseg_rotation_matrix(float(cx), float(cy), float(angle_deg), _ptr(m)), "sbbseg_rotation_matrix")
+    return m.reshape(2, 3)
 
 
 def nearest_map(src_len: int, dst_len: int) -> np.ndarray:

@@ -198,6 +198,7 @@ struct sbbseg_ctx {
     int *d_map = nullptr; size_t map_cap = 0;
     // stage glue scratch (morphology planes, union-find arrays, result words)
     uint8_t *d_morph_a = nullptr, *d_morph_b = nullptr; size_t morph_a_cap = 0, morph_b_cap = 0;
+    void* d_deskew = nullptr; size_t deskew_cap = 0;      // inverse maps | bicubic table | row counts of sbbseg_deskew_profiles
     int *d_cc_parent = nullptr, *d_cc_count = nullptr; size_t cc_parent_cap = 0, cc_count_cap = 0;
     unsigned long long* d_cc_small = nullptr;      // [0] best key, [1..2] box (4 ints)
     // profiling
@@ -589,6 +590,7 @@ int sbbseg_destroy(sbbseg_ctx* c)
     (void)hipFree(c->d_lut); (void)hipFree(c->d_hist); (void)hipFree(c->d_tile_xy); (void)hipFree(c->d_batch_labels); (void)hipFree(c->d_probs); (void)hipFree(c->d_xin);
     (void)hipFree(c->d_page); (void)hipFree(c->d_page_labels); (void)hipFree(c->d_page_labels3); (void)hipFree(c->d_tile_labels);
     (void)hipFree(c->d_own_x); (void)hipFree(c->d_own_y); (void)hipFree(c->d_map);
+    (void)hipFree(c->d_deskew);
     (void)hipFree(c->d_morph_a); (void)hipFree(c->d_morph_b); (void)hipFree(c->d_cc_parent); (void)hipFree(c->d_cc_count); (void)hipFree(c->d_cc_small);
     for (auto& pe : c->pending) { (void)hipEventDestroy(pe.a); (void)hipEventDestroy(pe.b); }
     for (auto e : c->free_events) (void)hipEventDestroy(e);
@@ -1844,6 +1846,106 @@ int sbbseg_extract_page_box(sbbseg_ctx* c, const uint8_t* page_hwc, int Hp, int 
     if (sbbseg_segment_whole_scaled(c, page_hwc, Hp, Wp, Hs, Ws, Hs, Ws, host_mask)) return 1;
     // ... whose label plane is still in d_page_labels: threshold, dilate x 6, largest component, bounding box (main.py:394-404)
     return sbbseg_page_box_dev(c, c->d_page_labels, Hs, Ws, box_xywh, pixels);
+    API_END
+}
+
+// ---- stage glue: the rotate-and-project of the deskew search (main.py:1601-1718) ----------------------------------
+int sbbseg_deskew_side(int H, int W, int* side)
+{
+    API_BEGIN
+    REQUIRE(side && H > 0 && W > 0, "bad arguments");
+    *side = (int)((double)(H > W ? H : W) * 1.4);              // main.py:1613  int(max_x_y * (1.4))
+    return 0;
+    API_END
+}
+
+// cv2.getRotationMatrix2D(center, angle, 1.0) [EXT OpenCV 4.5.1]: positive angle = counter-clockwise
+int sbbseg_rotation_matrix(double cx, double cy, double angle_deg, double* m6)
+{
+    API_BEGIN
+    REQUIRE(m6, "bad arguments");
+    const double a = angle_deg * 3.14159265358979323846 / 180.0;
+    const double alpha = std::cos(a), beta = std::sin(a);
+    m6[0] = alpha; m6[1] = beta; m6[2] = (1 - alpha) * cx - beta * cy;
+    m6[3] = -beta; m6[4] = alpha; m6[5] = beta * cx + (1 - alpha) * cy;
+    return 0;
+    API_END
+}
+
+static void invert_affine(const double* M, double* o)
+{
+#pragma clang fp contract(off)
+    // the in-place inversion of cv::warpAffine (no WARP_INVERSE_MAP), same operation order
+    double m[6] = {M[0], M[1], M[2], M[3], M[4], M[5]};
+    double D = m[0] * m[4] - m[1] * m[3];
+    D = D != 0 ? 1.0 / D : 0.0;
+    const double A11 = m[4] * D, A22 = m[0] * D;
+    m[0] = A11; m[1] *= -D; m[3] *= -D; m[4] = A22;
+    const double b1 = -m[0] * m[2] - m[1] * m[5];
+    const double b2 = -m[3] * m[2] - m[4] * m[5];
+    m[2] = b1; m[5] = b2;
+    for (int i = 0; i < 6; ++i) o[i] = m[i];
+}
+
+static void cubic_table(float* tab)
+{
+#pragma clang fp contract(off)
+    // interpolateCubic of imgwarp.cpp, A = -0.75, float arithmetic
+    const float A = -0.75f;
+    for (int i = 0; i < 32; ++i) {
+        const float x = (float)i * (1.0f / 32);
+        float* c = tab + i * 4;
+        c[0] = ((A * (x + 1) - 5 * A) * (x + 1) + 8 * A) * (x + 1) - 4 * A;
+        c[1] = ((A + 2) * x - (A + 3)) * x * x + 1;
+        c[2] = ((A + 2) * (1 - x) - (A + 3)) * (1 - x) * (1 - x) + 1;
+        c[3] = 1.f - c[0] - c[1] - c[2];
+    }
+}
+
+int sbbseg_deskew_profiles_dev(sbbseg_ctx* c, const void* d_mask_hw, int H, int W, const double* matrices, const double* angles_deg,
+                               int n_angles, int32_t* counts)
+{
+    API_BEGIN
+    if (check_ready(c)) return 1;
+    REQUIRE(d_mask_hw && counts && H > 0 && W > 0 && n_angles >= 1 && n_angles <= 4096 && (matrices || angles_deg), "bad arguments");
+    const int S = (int)((double)(H > W ? H : W) * 1.4);
+    REQUIRE(S >= 1 && S <= 32767, "deskew square side %d out of range", S);
+    const int cp = (int)(S / 2.0), top = cp - (int)(H / 2.0), left = cp - (int)(W / 2.0);      // main.py:1615-1619
+    alloc_check();
+    std::vector<double> minv((size_t)n_angles * 6);
+    for (int a = 0; a < n_angles; ++a) {
+        double M[6];
+        if (matrices) memcpy(M, matrices + (size_t)a * 6, sizeof(M));
+        else if (sbbseg_rotation_matrix((double)(S / 2), (double)(S / 2), angles_deg[a], M)) return 1;     // main.py:161  center = (w // 2, h // 2)
+        invert_affine(M, &minv[(size_t)a * 6]);
+    }
+    float tab[128];
+    cubic_table(tab);
+    const size_t need = (size_t)n_angles * 6 * sizeof(double) + sizeof(tab) + (size_t)n_angles * S * sizeof(int);
+    if (ensure(c, (void**)&c->d_deskew, &c->deskew_cap, need)) return 1;
+    double* d_minv = (double*)c->d_deskew;
+    float* d_tab = (float*)(d_minv + (size_t)n_angles * 6);
+    int* d_counts = (int*)(d_tab + 128);
+    HIPCHK(hipMemcpyAsync(d_minv, minv.data(), minv.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(d_tab, tab, sizeof(tab), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));                       // (pageable host staging buffers die with this frame)
+    HIPCHK(launch_deskew_profiles((const uint8_t*)d_mask_hw, H, W, S, top, left, d_minv, d_tab, n_angles, d_counts, c->stream));
+    HIPCHK(hipMemcpyAsync(counts, d_counts, (size_t)n_angles * S * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+    API_END
+}
+
+int sbbseg_deskew_profiles(sbbseg_ctx* c, const uint8_t* mask_hw, int H, int W, const double* matrices, const double* angles_deg, int n_angles,
+                           int32_t* counts)
+{
+    API_BEGIN
+    if (check_ready(c)) return 1;
+    REQUIRE(mask_hw && H > 0 && W > 0, "bad arguments");
+    const size_t pix = (size_t)H * W;
+    if (ensure(c, (void**)&c->d_morph_b, &c->morph_b_cap, pix)) return 1;
+    HIPCHK(hipMemcpyAsync(c->d_morph_b, mask_hw, pix, hipMemcpyHostToDevice, c->stream));
+    return sbbseg_deskew_profiles_dev(c, c->d_morph_b, H, W, matrices, angles_deg, n_angles, counts);
     API_END
 }
 

@@ -223,6 +223,8 @@ hipError_t launch_largest_component(const uint8_t* mask, int H, int W, int* pare
                                     hipStream_t s);
 hipError_t launch_replicate3(const uint8_t* src, uint8_t* dst, size_t n, hipStream_t s);
 hipError_t launch_to_f32(const void* src, float* dst, size_t n, int precision, hipStream_t s);
+hipError_t launch_deskew_profiles(const uint8_t* mask, int H, int W, int S, int top, int left, const double* minv, const float* cubic,
+                                  int n_angles, int* counts, hipStream_t s);
 hipError_t launch_bottleneck(const BlockParams& p, int precision, int num_cus, hipStream_t s);
 hipError_t launch_split_to_f32(const void* src, float* dst, size_t npix, int C, hipStream_t s);   // [pix][C hi][C lo] -> [pix][C]
 

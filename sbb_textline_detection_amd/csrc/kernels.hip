@@ -2655,6 +2655,79 @@ hipError_t launch_largest_component(const uint8_t* mask, int H, int W, int* pare
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------
+// deskew_profile_kernel -- the rotate-and-project of the deskew search (main.py:1601-1718): for every angle of a sweep,
+// the region mask (centred on a zero square of side S, main.py:1613-1621) is rotated as rotate_image does (main.py:159-163:
+// cv2.warpAffine, INTER_CUBIC, BORDER_REPLICATE), binarised (!= 0, main.py:1642) and summed along its rows (main.py:1546).
+// One block per (row, angle).  OpenCV's arithmetic [EXT, 4.5.1 imgwarp.cpp]: source coordinates in fixed point with 5
+// fractional bits (AB_BITS = 10, round-half-even), 4 x 4 taps with the float bicubic table (A = -0.75), taps accumulated
+// one by one in float64.  Floating-point contraction is off: the integer coordinates must come out of the same roundings
+// as on the host.  HBM-trivial (the mask is L2-resident); 16 taps are only evaluated where the 4 x 4 window meets the patch.
+// ------------------------------------------------------------------------------------------------
+struct DeskewParams {
+    const uint8_t* mask;      // [H][W] region mask (device)
+    int H, W, S, top, left;   // square side, placement of the patch inside the square
+    const double* minv;       // [n_angles][6] inverse affine maps (destination -> source), row-major 2 x 3
+    const float* cubic;       // [32][4]
+    int* counts;              // [n_angles][S]
+};
+
+__global__ __launch_bounds__(256) void deskew_profile_kernel(const DeskewParams p)
+{
+#pragma clang fp contract(off)
+    __shared__ float tab[32 * 4];
+    __shared__ int total;
+    const int y = blockIdx.x, a = blockIdx.y, tid = threadIdx.x;
+    if (tid < 128) tab[tid] = p.cubic[tid];
+    if (tid == 0) total = 0;
+    __syncthreads();
+    const double* m = p.minv + (size_t)a * 6;
+    const long long X0 = __double2ll_rn((m[1] * (double)y + m[2]) * 1024.0) + 16;
+    const long long Y0 = __double2ll_rn((m[4] * (double)y + m[5]) * 1024.0) + 16;
+    int cnt = 0;
+    for (int x = tid; x < p.S; x += 256) {
+        const long long X = (X0 + __double2ll_rn(m[0] * (double)x * 1024.0)) >> 5;
+        const long long Y = (Y0 + __double2ll_rn(m[3] * (double)x * 1024.0)) >> 5;
+        long long sx = X >> 5, sy = Y >> 5;
+        sx = sx < -32768 ? -32768 : (sx > 32767 ? 32767 : sx);
+        sy = sy < -32768 ? -32768 : (sy > 32767 ? 32767 : sy);
+        const int ax = (int)(X & 31), ay = (int)(Y & 31);
+        // window rows sy-1 .. sy+2, columns sx-1 .. sx+2, clamped to the square; non-zero source pixels only inside the patch
+        const int x_lo = (int)min(max(sx - 1, 0LL), (long long)p.S - 1), x_hi = (int)min(max(sx + 2, 0LL), (long long)p.S - 1);
+        const int y_lo = (int)min(max(sy - 1, 0LL), (long long)p.S - 1), y_hi = (int)min(max(sy + 2, 0LL), (long long)p.S - 1);
+        if (x_hi < p.left || x_lo >= p.left + p.W || y_hi < p.top || y_lo >= p.top + p.H) continue;
+        double sum = 0.0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int yy = (int)min(max(sy - 1 + r, 0LL), (long long)p.S - 1) - p.top;
+            const float wy = tab[ay * 4 + r];
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) {
+                const int xx = (int)min(max(sx - 1 + cc, 0LL), (long long)p.S - 1) - p.left;
+                const float w2 = wy * tab[ax * 4 + cc];                          // the 2-D table entry: a float product
+                const bool in = (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
+                const double v = in ? (double)p.mask[(size_t)yy * p.W + xx] : 0.0;
+                sum = sum + v * (double)w2;
+            }
+        }
+        cnt += sum != 0.0;
+    }
+    // wave reduction, then one atomic per wave
+    for (int off = 32; off > 0; off >>= 1) cnt += __shfl_down(cnt, off, 64);
+    if ((tid & 63) == 0 && cnt) atomicAdd(&total, cnt);
+    __syncthreads();
+    if (tid == 0) p.counts[(size_t)a * p.S + y] = total;
+}
+
+hipError_t launch_deskew_profiles(const uint8_t* mask, int H, int W, int S, int top, int left, const double* minv, const float* cubic,
+                                  int n_angles, int* counts, hipStream_t s)
+{
+    DeskewParams p;
+    p.mask = mask; p.H = H; p.W = W; p.S = S; p.top = top; p.left = left; p.minv = minv; p.cubic = cubic; p.counts = counts;
+    hipLaunchKernelGGL(deskew_profile_kernel, dim3(S, n_angles), dim3(256), 0, s, p);
+    return hipGetLastError();
+}
+
 template <typename E>
 __global__ __launch_bounds__(256) void to_f32_kernel(const E* src, float* dst, size_t n)
 {

@@ -10,6 +10,9 @@ it that section 8(f) ranks next, with the reference's names and call pattern:
     extract_page   (glue part)      main.py:394-426   border mask -> dilate x 6 -> largest blob -> box -> crop (device)
     erode x 3 / dilate x 4          main.py:2074-2075 on the layout map (device)
 
+    return_deskew_slope             main.py:1601-1718 the per-region deskew search: rotate-and-project on the device (one launch
+                                                      per sweep), the 1-D peak logic on the host with the reference's own scipy calls
+
 The rest of the cv2 contour post-processing (text-region contours, line separation, ...) is out of scope.
 """
 from __future__ import annotations
@@ -94,6 +97,61 @@ def host_page_box(mask: np.ndarray):
     best = int(np.argmax(counts)) + 1
     ys, xs = np.nonzero(lab == best)
     return (int(xs.min()), int(ys.min()), int(xs.max() - xs.min() + 1), int(ys.max() - ys.min() + 1)), int(counts[best - 1])
+
+
+def _profile_statistics(y: np.ndarray, sigma: float, multiplier: float):
+    """get_standard_deviation_of_summed_textline_patch_along_width (main.py:1545-1599) from the row sums on: smoothed profile z,
+    its maxima and the minima of the padded, negated profile (scipy, as the reference), the "deep" minima below
+    mean(maxima > 10) * (1 - 1/multiplier), and std(z)."""
+    from scipy.ndimage import gaussian_filter1d
+    from scipy.signal import find_peaks
+    y = np.asarray(y, np.float64)
+    padded = np.zeros(len(y) + 20)
+    padded[10:10 + len(y)] = y
+    flipped = np.zeros(len(padded) + 20)
+    flipped[10:10 + len(padded)] = padded.max() - padded
+    z = gaussian_filter1d(y, sigma)
+    minima = find_peaks(gaussian_filter1d(flipped, sigma), height=0)[0] - 20
+    maxima = find_peaks(z, height=0)[0]
+    tops = z[maxima]
+    tops = tops[tops > 10]
+    lows = z[minima]                                        # IndexError for a minimum in the right-hand padding: caller's except
+    with np.errstate(all="ignore"):
+        level = np.mean(tops) if tops.size else np.float64("nan")
+    return lows[lows < level - level / multiplier], np.std(z)
+
+
+def _deskew_sweep(profiles: np.ndarray, angles: np.ndarray, sigma: float) -> float:
+    """One angle loop of return_deskew_slope (main.py:1630-1667): std of the smoothed profile per angle, arg max.  Kept: an angle
+    without deep minima (their mean is NaN) is left out of the list, and the winner's position in the SHORTENED list indexes
+    the full angle array (main.py:1655-1665)."""
+    spread = []
+    for k in range(len(angles)):
+        try:
+            lows, sd = _profile_statistics(profiles[k], sigma, 20.3)
+            if lows.size == 0:
+                continue                                    # np.mean([]) is NaN -> the reference skips the append
+        except Exception:                                   # main.py:1652-1655
+            sd = 0
+        spread.append(sd)
+    return float(angles[int(np.argmax(np.array(spread)))]) if spread else 0.0
+
+
+def return_deskew_slope(img_patch: np.ndarray, sigma_des: float, ctx=None) -> float:
+    """``textline_detector.return_deskew_slope`` (main.py:1601-1718): the rotation angle, out of 80 in [-25, 25] (and 30 in
+    [-90, -50] when the first answer is steeper than 15 degrees), whose row profile of the rotated region mask varies most.
+    The reference rotates the padded mask 80-110 times with cv2.warpAffine on the CPU (and forks cpu_count() processes over
+    the regions, main.py:1760-1799); here one sweep is ONE launch (``sbbseg_deskew_profiles``).  ``ctx``: a
+    ``_capi.Context`` (any finalized handle: the call does not touch the network)."""
+    if ctx is None:
+        raise RuntimeError("return_deskew_slope needs a library handle (SegModel.ctx): there is no CPU fallback")
+    mask = np.ascontiguousarray(np.asarray(img_patch) != 0, np.uint8) if np.asarray(img_patch).dtype != np.uint8 else np.ascontiguousarray(img_patch)
+    angles = np.linspace(-25, 25, 80)                                              # main.py:1622
+    ang = _deskew_sweep(ctx.deskew_profiles(mask, angles), angles, sigma_des)
+    if abs(ang) > 15:                                                              # main.py:1669-1670
+        angles = np.linspace(-90, -50, 30)
+        ang = _deskew_sweep(ctx.deskew_profiles(mask, angles), angles, sigma_des)
+    return ang
 
 
 class InferenceStages:

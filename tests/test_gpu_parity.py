@@ -798,3 +798,64 @@ def test_one_call_native_load_equals_python_planned_context(tmp_path, precision)
     py.release(); nat.release()
     from sbb_textline_detection_amd import clear_session
     clear_session()
+
+
+# ----------------------------------------------------------------------------- stage glue: deskew search (f-4)
+def _region_mask(h, w, seed):
+    """A text-region-like mask: slanted bars of uneven length + a few specks."""
+    rng = np.random.RandomState(seed)
+    m = np.zeros((h, w), np.uint8)
+    period = max(8, h // 9)
+    for y in range(period // 2, h - period // 2, period):
+        x0, x1 = rng.randint(0, w // 5), w - rng.randint(0, w // 5)
+        for x in range(x0, x1):
+            yy = y + int(0.06 * (x - w / 2))
+            if 0 <= yy < h - period // 3:
+                m[yy:yy + period // 3, x] = 1
+    ys, xs = rng.randint(0, h, 12), rng.randint(0, w, 12)
+    m[ys, xs] = 1
+    return m
+
+
+@pytest.mark.parametrize("h,w,seed", [(37, 53, 0), (120, 80, 1), (90, 211, 2), (1, 1, 3), (64, 64, 4)])
+def test_deskew_profiles_equal_oracle(h, w, seed, stitch_model):
+    """sbbseg_deskew_profiles (one launch for the whole sweep) vs oracle/deskew.py::row_profiles, bit for bit, on both angle
+    sweeps of return_deskew_slope (main.py:1622, 1670) -- with the library's own rotation matrices handed to the oracle (numpy's
+    and libm's cos/sin may differ in the last bit; test_oracle_deskew pins them to 1e-12 of each other)."""
+    from oracle import deskew as dk
+    from sbb_textline_detection_amd import _capi
+    model = stitch_model
+    m = _region_mask(h, w, seed) if h > 1 else np.ones((1, 1), np.uint8)
+    side = _capi.deskew_side(h, w)
+    angles = np.concatenate([np.linspace(-25, 25, 80), np.linspace(-90, -50, 30)])
+    if h * w > 12000:
+        angles = angles[::5]
+    got = model.ctx.deskew_profiles(m, angles)
+    assert got.shape == (len(angles), side) and got.dtype == np.int32
+    sq = dk.padded_square(m)
+    ref = np.stack([(dk.warp_affine_cubic_replicate(sq, _capi.rotation_matrix(side // 2, side // 2, a)) != 0).sum(axis=1) for a in angles])
+    assert np.array_equal(got, ref), (np.abs(got - ref).max(), np.argwhere(got != ref)[:5])
+    # explicit matrices = the same answer; an empty mask projects to nothing
+    mats = np.stack([_capi.rotation_matrix(side // 2, side // 2, a) for a in angles[:7]])
+    assert np.array_equal(model.ctx.deskew_profiles(m, matrices=mats), got[:7])
+    assert not model.ctx.deskew_profiles(np.zeros((h, w), np.uint8), angles[:3]).any()
+
+
+def test_return_deskew_slope_equals_oracle(stitch_model):
+    """The whole search (stages.return_deskew_slope: device profiles + host peak logic) against the oracle's, on region masks
+    skewed by known angles -- including one steep enough for the second sweep (main.py:1669-1716)."""
+    from oracle import deskew as dk
+    from sbb_textline_detection_amd import stages
+    model = stitch_model
+    base = np.zeros((100, 170), np.uint8)
+    for y in range(12, 88, 15):
+        base[y:y + 6, 10:160] = 1
+    sq = dk.padded_square(base)
+    for true, sigma in ((4.0, 1.0), (-9.5, 1.0), (0.0, 2.0), (-70.0, 1.0)):
+        skewed = (dk.rotate_image(sq, true) != 0).astype(np.uint8)
+        got = stages.return_deskew_slope(skewed, sigma, ctx=model.ctx)
+        ref = dk.return_deskew_slope(skewed, sigma)
+        print(f"[deskew] skew {true:+.1f}: device {got:+.3f}, oracle {ref:+.3f}")
+        assert got == ref
+        if abs(true) < 15:
+            assert abs(got + true) < 1.0

@@ -1,0 +1,105 @@
+"""CPU: the deskew oracle (oracle/deskew.py) and the product's host half of return_deskew_slope (stages.py) -- no GPU.
+
+The rotation arithmetic is an [EXT] restatement of OpenCV 4.5.1 (cv2 is not installable here): these tests hold it to
+its own invariants (identity at 0 degrees, exact quarter turns, table properties) and hold the PRODUCT's host logic
+(stages._deskew_sweep: scipy peak logic + the reference's list-index quirk, main.py:1655-1665) to the oracle's on the same
+profiles.  The device half is compared with the oracle bit for bit in tests/test_gpu_parity.py."""
+import numpy as np
+import pytest
+
+from oracle import deskew as dk
+from sbb_textline_detection_amd import _capi, stages
+
+
+def bars(h, w, period=24, thick=10, margin=20):
+    m = np.zeros((h, w), np.uint8)
+    for y in range(margin, h - margin, period):
+        m[y:y + thick, margin:w - margin] = 1
+    return m
+
+
+def test_cubic_table_properties():
+    t = dk.cubic_table()
+    assert t.dtype == np.float32 and t.shape == (32, 4)
+    assert np.array_equal(t[0], np.array([0, 1, 0, 0], np.float32))            # integer positions copy the pixel
+    assert np.allclose(t.sum(1), 1.0, atol=1e-6)
+    assert np.allclose(t[16], [-0.09375, 0.59375, 0.59375, -0.09375])          # A = -0.75 at x = 1/2
+    assert np.allclose(t[1:], t[:0:-1, ::-1], atol=1e-6)                       # mirror symmetry x <-> 1 - x
+
+
+def test_rotation_by_zero_is_identity_and_quarter_turn_is_exact():
+    rng = np.random.RandomState(0)
+    img = (rng.rand(41, 41) > 0.5).astype(np.float64)
+    assert np.array_equal(dk.rotate_image(img, 0.0), img)
+    r = dk.rotate_image(img, 90.0)           # centre (20, 20) of an odd square: a quarter turn maps pixels onto pixels
+    assert np.abs(r - np.rot90(img, 1)).max() < 1e-6
+
+
+def test_library_rotation_matrix_and_side_match_oracle():
+    for (h, w) in [(37, 53), (200, 310), (1000, 999), (1, 1), (5, 4)]:
+        assert _capi.deskew_side(h, w) == dk.padded_square(np.zeros((h, w))).shape[0]
+    for ang in list(np.linspace(-25, 25, 80)) + list(np.linspace(-90, -50, 30)) + [0.0, 90.0, 7.3]:
+        a = _capi.rotation_matrix(210, 210, ang)
+        b = dk.rotation_matrix((210, 210), ang)
+        assert np.allclose(a, b, rtol=0, atol=1e-12), (ang, a, b)
+
+
+def test_padded_square_placement():
+    m = np.arange(1, 3 * 5 + 1, dtype=np.float64).reshape(3, 5)
+    sq = dk.padded_square(m)
+    assert sq.shape == (7, 7)                                      # int(5 * 1.4)
+    assert np.array_equal(sq[3 - 1:3 - 1 + 3, 3 - 2:3 - 2 + 5], m) and sq.sum() == m.sum()
+
+
+def test_oracle_recovers_a_known_skew():
+    m = bars(120, 200)
+    sq = dk.padded_square(m)
+    for true in (6.0, -11.0):
+        rot = (dk.rotate_image(sq, true) != 0).astype(np.uint8)
+        got = dk.return_deskew_slope(rot, 1.0)
+        assert abs(got + true) < 1.0, (true, got)                  # rotating back by -true levels the bars
+
+
+def test_host_sweep_equals_oracle_sweep_on_the_same_profiles():
+    """stages._deskew_sweep (product) vs oracle._sweep, including angles that drop out of the list (no deep minima)."""
+    rng = np.random.RandomState(3)
+    m = bars(90, 150, period=18, thick=7, margin=10)
+    angles = np.linspace(-25, 25, 80)
+    prof = dk.row_profiles(m, angles[::4])
+    for sigma in (1.0, 2.0):
+        assert stages._deskew_sweep(prof, angles[::4], sigma) == dk._sweep(prof, angles[::4], sigma)
+    # synthetic profiles: flat, all-zero (nothing above 10 -> no level -> every angle dropped -> 0), noisy, bumps
+    flat = np.full((5, 100), 7, np.int64)
+    assert stages._deskew_sweep(flat, angles[:5], 1.0) == dk._sweep(flat, angles[:5], 1.0)
+    zero = np.zeros((5, 100), np.int64)
+    assert stages._deskew_sweep(zero, angles[:5], 1.0) == dk._sweep(zero, angles[:5], 1.0) == 0.0
+    noisy = rng.randint(0, 60, size=(12, 140))
+    assert stages._deskew_sweep(noisy, angles[:12], 1.5) == dk._sweep(noisy, angles[:12], 1.5)
+    bump = np.zeros((6, 80), np.int64)
+    for k in range(6):
+        bump[k, 10 + 5 * k:30 + 5 * k] = 40 + k
+        bump[k, 50:60] = 30
+    assert stages._deskew_sweep(bump, angles[:6], 1.0) == dk._sweep(bump, angles[:6], 1.0)
+
+
+def test_profile_statistics_hand_case():
+    y = np.zeros(100)
+    for a in (20, 40, 60):
+        y[a:a + 10] = 50
+    lows, sd = dk.profile_statistics(y, 1.0, 20.3)
+    lows2, sd2 = stages._profile_statistics(y, 1.0, 20.3)
+    assert np.array_equal(lows, lows2) and sd == sd2
+    assert len(lows) >= 2 and (lows < 1.0).all() and 15 < sd < 30    # the two gaps between the three bars (+ the dark ends)
+    # a bar closer than 10 rows to the END puts the right-hand minimum into the padding: z[index] raises, as in the
+    # reference (main.py:1583; return_deskew_slope's except turns it into "spread 0", main.py:1652-1655)
+    y2 = np.zeros(60)
+    y2[45:55] = 50
+    with pytest.raises(IndexError):
+        dk.profile_statistics(y2, 1.0, 20.3)
+    with pytest.raises(IndexError):
+        stages._profile_statistics(y2, 1.0, 20.3)
+
+
+def test_return_deskew_slope_fails_loudly_without_a_handle():
+    with pytest.raises(RuntimeError):
+        stages.return_deskew_slope(np.ones((10, 10), np.uint8), 1.0)
