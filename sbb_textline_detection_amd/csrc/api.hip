@@ -205,6 +205,7 @@ struct sbbseg_ctx {
     bool profiling = false;
     int conv_variant = 0;
     bool ph8 = false;            // 8-phase schedule on the 256x256 tile (opt-in, conv variant bit 16)
+    bool ranged_walk = false;    // A/B: grouped launches walk XCD-contiguous tile ranges (conv variant bit 19)
     bool unfuse_blocks = false;  // A/B: run a fused bottleneck block as its three convs (conv variant bit 18)
     bool plain_gather = false;   // A/B: per-load address arithmetic instead of the fast gather (conv variant bit 17)
     int contig_max_k = 0;        // short-K layers up to this K walk their tiles in per-block contiguous runs (tile map 2)
@@ -377,7 +378,7 @@ int launch_op(sbbseg_ctx* c, Op& op, int n, uint8_t* d_labels, float* d_probs)
             if (co.n_cls > 1 && !(c->conv_variant & 8) && !(c->conv_variant & 4) &&
                 (size_t)co.cout_pad * co.Ktot * c->elem <= ((size_t)16 << 20)) {     // (dec1/dec2 too: fetch -30 / -53 %, time unchanged)
                 p.cls_minor = 1;      // small weights: let the classes share their source pixels in one L2
-                p.tile_map = 1;
+                p.tile_map = c->ranged_walk ? 3 : 1;
             }
             for (int q = 0; q < 4; ++q) {
                 p.w_cls[q] = co.d_w_cls[q]; p.kstep_cls[q] = co.d_kstep_cls[q]; p.ktab_cls[q] = co.d_ktab_cls[q]; p.fgstep_cls[q] = co.d_fgstep_cls[q];
@@ -2014,11 +2015,12 @@ int sbbseg_debug_inject_alloc_failure(int nth_check)
 int sbbseg_debug_set_conv_variant(sbbseg_ctx* c, int variant)
 {
     API_BEGIN
-    REQUIRE(c && variant >= 0 && variant <= 0x7ffff, "variant: bits 0-1 = 0 auto | 1 4-wave/2-stage | 2 8-wave/3-stage; bit 2 = one block per tile (non-persistent); bit 3 = no XCD-grouped tile walk; bit 4 = half-K-step stages; bit 5 = XCD-grouped walk on single-class layers; bit 6 = drain epilogue stores; bit 7 = half-line epilogue stores; bits 8-15 = contiguous-run K limit / 64; bit 16 = 8-phase schedule on the 256x256 tile; bit 17 = plain gather everywhere; bit 18 = fused bottleneck blocks run as their three convs");
+    REQUIRE(c && variant >= 0 && variant <= 0xfffff, "variant: bits 0-1 = 0 auto | 1 4-wave/2-stage | 2 8-wave/3-stage; bit 2 = one block per tile (non-persistent); bit 3 = no XCD-grouped tile walk; bit 4 = half-K-step stages; bit 5 = XCD-grouped walk on single-class layers; bit 6 = drain epilogue stores; bit 7 = half-line epilogue stores; bits 8-15 = contiguous-run K limit / 64; bit 16 = 8-phase schedule on the 256x256 tile; bit 17 = plain gather everywhere; bit 18 = fused bottleneck blocks run as their three convs");
     c->conv_variant = variant & 0xff;
     c->ph8 = (variant >> 16) & 1;
     c->plain_gather = (variant >> 17) & 1;
     c->unfuse_blocks = (variant >> 18) & 1;
+    c->ranged_walk = (variant >> 19) & 1;
     if ((variant >> 8) & 0xff) c->contig_max_k = ((variant >> 8) & 0xff) * 64;
     return 0;
     API_END

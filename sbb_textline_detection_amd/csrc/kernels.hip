@@ -227,10 +227,17 @@ void conv_igemm_mfma(const ConvParams p)
     // channel tiles of one pixel tile run back to back in the SAME block.  Blocks of a short-K layer
     // march in lockstep; under map 1 the sibling blocks miss on the same pixel rows at the same moment
     // and the rows are fetched from HBM once per channel tile (PMC: fetch = n_ct x the input tensor).
+    // map 3 (grouped launches): XCD x owns a CONTIGUOUS range of the extended pixel tiles (whole groups of 8 pixel tiles x
+    // classes), its blocks walk that range together: the four classes of a pixel tile AND its neighbours above / below
+    // meet in one L2, so the halo rows between consecutive pixel tiles are fetched from HBM once, not once per XCD.
     const bool pshare = p.tile_map >= 1 && (G & 7) == 0;
     const bool contig = p.tile_map == 2;
+    const bool ranged = p.tile_map == 3 && pshare;
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, GX = G >> 3;
-    const int xcd_tiles = pshare ? ((n_pt - xcd + 7) >> 3) * n_ct : 0;
+    const int unit = 8 * p.n_cls, n_units = n_pt / unit;          // (n_pt is a multiple of 8 * n_cls under cls_minor)
+    const int e_lo = ranged ? (int)((long long)xcd * n_units / 8) * unit : 0;
+    const int e_hi = ranged ? (int)((long long)(xcd + 1) * n_units / 8) * unit : 0;
+    const int xcd_tiles = ranged ? (e_hi - e_lo) * n_ct : pshare ? ((n_pt - xcd + 7) >> 3) * n_ct : 0;
     const int run_lo = contig ? (int)((long long)slot * xcd_tiles / GX) : 0;
     const int run_hi = contig ? (int)((long long)(slot + 1) * xcd_tiles / GX) : 0;
     const int my_tiles = !pshare ? (n_tiles - (int)blockIdx.x + G - 1) / G
@@ -239,6 +246,7 @@ void conv_igemm_mfma(const ConvParams p)
     auto tile_at = [&](int q) __attribute__((always_inline)) -> int {
         if (!pshare) return blockIdx.x + q * G;
         const int li = contig ? run_lo + q : slot + q * GX;
+        if (ranged) return (e_lo + li / n_ct) * n_ct + li % n_ct;
         return ((li / n_ct) * 8 + xcd) * n_ct + li % n_ct;
     };
     const int nts = nt * SPK;                           // LDS stages per tile
