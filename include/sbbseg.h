@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SBBSEG_ABI_VERSION 2
+#define SBBSEG_ABI_VERSION 3
 
 typedef struct sbbseg_ctx sbbseg_ctx;
 
@@ -279,7 +279,9 @@ int sbbseg_debug_read_tensor(sbbseg_ctx* c, int tensor_id, int n, float* out, si
  * bit 6 = drain the epilogue stores before the next barrier; bit 7 = half-line (64-byte) epilogue stores; bits 8-15 = with bit 5: K limit (units of
  * 64) up to which every block walks a contiguous run of tiles (0 = keep the current limit);
  * bit 16 = 8-phase schedule on the 256x256 tile (half-tile restaging, staggered wave groups);
- * bit 17 = plain gather (per-load address arithmetic) instead of the fast gather on every layer */
+ * bit 17 = plain gather (per-load address arithmetic) instead of the fast gather on every layer;
+ * bit 18 = fused bottleneck blocks run as the three convs they replace; bit 19 = grouped (parity-class) launches walk
+ * XCD-contiguous tile ranges */
 int sbbseg_debug_set_conv_variant(sbbseg_ctx* c, int variant);
 /* Test hook for the no-abort guarantee: the nth_check-th next internal host-allocation checkpoint throws
  * std::bad_alloc, which every entry point turns into a non-zero status + sbbseg_last_error() instead of

@@ -122,7 +122,7 @@ def load_library(path: Optional[str] = None):
         fn = getattr(lib, name)
         fn.argtypes = args
         fn.restype = C.c_int
-    if lib.sbbseg_abi_version() != 2:
+    if lib.sbbseg_abi_version() != 3:
         raise RuntimeError("libsbbseg ABI version mismatch")
     if path is None:
         _lib = lib
