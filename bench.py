@@ -75,9 +75,10 @@ def main():
         raise SystemExit(f"WORLD_SIZE={world} but --gpus {args.gpus}")
     workload = args.workload if args.workload != "auto" else ("page" if world == 1 else "batch64")
     if args.max_batch <= 0:
-        # tiles per chunk: two pages' worth (2 x 70 / 2 x 108), pooled across pages by sbbseg_segment_pages_dev and run as two
-        # concurrent halves -- one page's 70 tiles leave the persistent conv grids a ragged last round (profiles/r02_experiments.md)
-        args.max_batch = 216 if workload == "batch64" else (140 if workload == "page" else 70)
+        # tiles per chunk: four pages' worth (4 x 70 / 4 x 108), pooled across pages by sbbseg_segment_pages_dev and run as two
+        # concurrent halves -- one page's 70 tiles leave the persistent conv grids a ragged last round; 140 / 280 / 374 / 560
+        # tiles per chunk measured 9 997 / 10 176 / 10 214 / 10 209 patches/s (profiles/r02_experiments.md)
+        args.max_batch = 432 if workload == "batch64" else (280 if workload == "page" else 70)
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
