@@ -157,6 +157,14 @@ __device__ inline void buffer_load_lds16(const void* base, uint32_t nrec, LDS_AS
     __builtin_amdgcn_raw_ptr_buffer_load_lds(r, lds, 16, voff, soff, 0, 0);
 }
 
+// n / d for n < 2^31 with a host-made (magic, shift) pair (FastDiv, internal.h): one v_mul_hi_u32 + shift instead of the
+// ~40-instruction division sequence -- setup_rows divides twice per staged row, which on short-K tiles rivals the MFMA time
+__device__ inline int fast_div(int n, uint32_t magic, uint32_t shift)
+{
+    const uint32_t q = magic ? __umulhi((uint32_t)n, magic) : (uint32_t)n;
+    return (int)(q >> shift);
+}
+
 template <int N> __device__ inline void wait_vmcnt()
 {
     // (the counter field holds 0..63: a larger count cannot be expressed -> drain)
@@ -306,9 +314,9 @@ void conv_igemm_mfma(const ConvParams p)
             const int m = ptile * BP + (j * NW + wave) * RPI + lrow;
             if constexpr (FG) {
                 if (m < p.M) {
-                    const int n = m / HoWo;
+                    const int n = fast_div(m, p.howo_magic, p.howo_shift);
                     const int rem = m - n * HoWo;
-                    const int oy = rem / p.Wo;
+                    const int oy = fast_div(rem, p.wo_magic, p.wo_shift);
                     const int ox = rem - oy * p.Wo;
                     r_oy[j] = (int)((uint32_t)n * img0 + (uint32_t)(((oy << sd0.sy_shift) * sd0.PW + (ox << sd0.sx_shift)) * sd0.pix_bytes) +
                                     lane_part(sd0) + (uint32_t)kZeroHeaderBytes);
@@ -327,9 +335,9 @@ void conv_igemm_mfma(const ConvParams p)
                     r_n[j] = -1;                            // every tap out of bounds -> zero rows
                 }
             } else if (m < p.M) {
-                const int n = m / HoWo;
+                const int n = fast_div(m, p.howo_magic, p.howo_shift);
                 const int rem = m - n * HoWo;
-                const int oy = rem / p.Wo;
+                const int oy = fast_div(rem, p.wo_magic, p.wo_shift);
                 const int ox = rem - oy * p.Wo;
                 r_oy[j] = oy;
                 r_ox[j] = ox;
@@ -439,9 +447,9 @@ void conv_igemm_mfma(const ConvParams p)
     const bool placed = (p.osy != 1) | (p.osx != 1) | (p.ooy != 0) | (p.oox != 0) | (p.TH != p.Ho) | (p.TW != p.Wo) | (p.n_cls > 1);
     auto out_pixel = [&](int m, int cls) __attribute__((always_inline)) -> int {
         if (!placed) return m;
-        const int n = m / HoWo;
+        const int n = fast_div(m, p.howo_magic, p.howo_shift);
         const int rem = m - n * HoWo;
-        const int oy = rem / p.Wo;
+        const int oy = fast_div(rem, p.wo_magic, p.wo_shift);
         const int ox = rem - oy * p.Wo;
         const int ooy = p.n_cls > 1 ? p.ooy_cls[cls] : p.ooy, oox = p.n_cls > 1 ? p.oox_cls[cls] : p.oox;
         return (n * p.TH + oy * p.osy + ooy) * p.TW + ox * p.osx + oox;
@@ -750,9 +758,9 @@ void conv_igemm_mfma(const ConvParams p)
                 const int rho = ((j & 1) * 8 + wave) * 8 + lrow;            // row inside the half-tile
                 const int m = ptile * BP + (rho >> 6) * 128 + (j >> 1) * 64 + (rho & 63);
                 if (m < p.M) {
-                    const int n = m / HoWo;
+                    const int n = fast_div(m, p.howo_magic, p.howo_shift);
                     const int rem = m - n * HoWo;
-                    const int oy = rem / p.Wo;
+                    const int oy = fast_div(rem, p.wo_magic, p.wo_shift);
                     q_oy[j] = oy; q_ox[j] = rem - oy * p.Wo; q_n[j] = n;
                 } else {
                     q_oy[j] = -(1 << 20); q_ox[j] = 0; q_n[j] = 0;
@@ -1081,6 +1089,18 @@ int conv_row_channel(int row, int cout)
     return base + (mi >> 1) * 32 + (rho >> 2) * 8 + (mi & 1) * 4 + (rho & 3);
 }
 
+// (magic, shift) with n / d == umulhi(n, magic) >> shift for every 0 <= n < 2^31; magic == 0: d is a power of two, n >> shift
+static void make_fast_div(uint32_t d, uint32_t* magic, uint32_t* shift)
+{
+    if (d == 0) d = 1;
+    uint32_t s2 = 0;
+    while ((1u << (s2 + 1)) <= d && s2 < 31) ++s2;              // 2^s2 <= d < 2^(s2+1)
+    if ((d & (d - 1)) == 0) { *magic = 0; *shift = s2; return; }
+    const unsigned long long num = 1ull << (32 + s2);
+    *magic = (uint32_t)((num + d - 1) / d);                       // ceil(2^(32+s2) / d), in (2^31, 2^32)
+    *shift = s2;
+}
+
 template <int BP, int BC, int WP, int WC, int NS, bool F16, int GS, bool PH8, bool X3, bool FG>
 static hipError_t launch_conv_impl(const ConvParams& p, hipStream_t s)
 {
@@ -1103,7 +1123,10 @@ static hipError_t launch_conv_impl(const ConvParams& p, hipStream_t s)
     const int resident = p.persist_blocks > 0 ? p.persist_blocks * T::kBlocksPerCU : n_tiles;
     int grid = n_tiles < resident ? n_tiles : resident;
     if (p.tile_map >= 1) grid = (grid + 7) & ~7;          // the XCD-grouped walk needs a multiple of 8 blocks
-    hipLaunchKernelGGL((conv_igemm_mfma<BP, BC, WP, WC, NS, F16, GS, PH8, X3, FG>), dim3(grid), dim3(T::kThreads), T::kLdsBytes, s, p);
+    ConvParams q = p;
+    make_fast_div((uint32_t)(p.Ho * p.Wo), &q.howo_magic, &q.howo_shift);
+    make_fast_div((uint32_t)p.Wo, &q.wo_magic, &q.wo_shift);
+    hipLaunchKernelGGL((conv_igemm_mfma<BP, BC, WP, WC, NS, F16, GS, PH8, X3, FG>), dim3(grid), dim3(T::kThreads), T::kLdsBytes, s, q);
     return hipGetLastError();
 }
 
