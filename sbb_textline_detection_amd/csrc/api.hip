@@ -375,7 +375,7 @@ int launch_op(sbbseg_ctx* c, Op& op, int n, uint8_t* d_labels, float* d_probs)
             p.ooy = co.d.out_off_y; p.oox = co.d.out_off_x;
             p.n_cls = co.n_cls;
             p.cls_minor = 0;
-            if (co.n_cls > 1 && !(c->conv_variant & 8) && !(c->conv_variant & 4) &&
+            if (co.n_cls > 1 && (co.n_cls & (co.n_cls - 1)) == 0 && !(c->conv_variant & 8) && !(c->conv_variant & 4) &&
                 (size_t)co.cout_pad * co.Ktot * c->elem <= ((size_t)16 << 20)) {     // (dec1/dec2 too: fetch -30 / -53 %, time unchanged)
                 p.cls_minor = 1;      // small weights: let the classes share their source pixels in one L2
                 p.tile_map = c->ranged_walk ? 3 : 1;

@@ -95,7 +95,8 @@ struct ConvParams {
     const float* head_shift;
     uint8_t* labels;          // [n][TH][TW]
     float* probs;             // [n][TH][TW][classes] or null
-    uint32_t howo_magic, howo_shift, wo_magic, wo_shift;   // FastDiv pairs for Ho * Wo and Wo, filled by the launcher (kernels.hip)
+    uint32_t howo_magic, howo_shift, wo_magic, wo_shift, nct_magic, nct_shift;   // FastDiv pairs for Ho * Wo, Wo and the number of
+                                                           // channel tiles, filled by the launcher (kernels.hip)
     const FgStepRec* fgstep_cls[4];   // fast gather: per-class tables read in place of kstep / kstep_cls (class 0 = entry 0)
     int fast_gather;          // every K-step regular, each source's taps within a 4 x 4 window, no upsampling source, buffers < 2 GiB:
                               // run the FG form of conv_igemm_mfma (kernels.hip)

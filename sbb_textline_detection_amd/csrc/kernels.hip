@@ -220,15 +220,19 @@ void conv_igemm_mfma(const ConvParams p)
     // back and the pixel operand is fetched into that L2 once instead of once per XCD.
     const int n_pt = p.n_cls * n_pt1e;                  // "extended" pixel tiles (class x pixel tile)
     auto decode = [&](int tile, int& ctile, int& cls, int& ptile) __attribute__((always_inline)) {
-        ctile = tile % n_ct;
-        const int e = tile / n_ct;
-        if (p.cls_minor) {
-            const int grp = e / (8 * p.n_cls), r = e - grp * 8 * p.n_cls;
+        const int e = fast_div(tile, p.nct_magic, p.nct_shift);
+        ctile = tile - e * n_ct;
+        if (p.cls_minor) {                              // (n_cls is 1, 2 or 4)
+            const int lg = 3 + (p.n_cls >> 1);
+            const int grp = e >> lg, r = e & ((1 << lg) - 1);
             cls = r >> 3;
             ptile = grp * 8 + (r & 7);
-        } else {
+        } else if (p.n_cls > 1) {
             cls = e / n_pt1;
             ptile = e - cls * n_pt1;
+        } else {
+            cls = 0;
+            ptile = e;
         }
     };
     // map 2 (short-K layers): as map 1, but every block owns a CONTIGUOUS run of its XCD's list, so the
@@ -254,8 +258,9 @@ void conv_igemm_mfma(const ConvParams p)
     auto tile_at = [&](int q) __attribute__((always_inline)) -> int {
         if (!pshare) return blockIdx.x + q * G;
         const int li = contig ? run_lo + q : slot + q * GX;
-        if (ranged) return (e_lo + li / n_ct) * n_ct + li % n_ct;
-        return ((li / n_ct) * 8 + xcd) * n_ct + li % n_ct;
+        const int lq = fast_div(li, p.nct_magic, p.nct_shift), lr = li - lq * n_ct;
+        if (ranged) return (e_lo + lq) * n_ct + lr;
+        return (lq * 8 + xcd) * n_ct + lr;
     };
     const int nts = nt * SPK;                           // LDS stages per tile
     const int total = my_tiles * nts;                   // stages this block walks
@@ -1126,6 +1131,7 @@ static hipError_t launch_conv_impl(const ConvParams& p, hipStream_t s)
     ConvParams q = p;
     make_fast_div((uint32_t)(p.Ho * p.Wo), &q.howo_magic, &q.howo_shift);
     make_fast_div((uint32_t)p.Wo, &q.wo_magic, &q.wo_shift);
+    make_fast_div((uint32_t)n_ct, &q.nct_magic, &q.nct_shift);
     hipLaunchKernelGGL((conv_igemm_mfma<BP, BC, WP, WC, NS, F16, GS, PH8, X3, FG>), dim3(grid), dim3(T::kThreads), T::kLdsBytes, s, q);
     return hipGetLastError();
 }
