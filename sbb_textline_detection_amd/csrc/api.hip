@@ -120,6 +120,7 @@ struct ConvOp {
     int tap_lo[2][2] = {{127, 127}, {127, 127}}, tap_hi[2][2] = {{-127, -127}, {-127, -127}};   // [source][y|x] over all classes
     std::vector<KStepRec> h_ksteps_cls[4];   // host copies: sbbseg_finalize builds the fast gather's tables from them
     FgStepRec* d_fgstep_cls[4] = {nullptr, nullptr, nullptr, nullptr};
+    bool fg_pointwise = false;            // all taps (0, 0) in bounds: ConvParams::fast_gather = 2 (no masks)
 };
 
 struct PoolOp { int src, dst, k, stride, Ho, Wo; float *d_pre_scale = nullptr, *d_pre_shift = nullptr; int pre_relu = 0; };
@@ -205,6 +206,7 @@ struct sbbseg_ctx {
     bool profiling = false;
     int conv_variant = 0;
     bool ph8 = false;            // 8-phase schedule on the 256x256 tile (opt-in, conv variant bit 16)
+    int fg_pointwise_min_ksteps = 4;   // pointwise convs take the fast gather from this many K-steps on (SBBSEG_FG_POINTWISE_MIN)
     bool ranged_walk = false;    // A/B: grouped launches walk XCD-contiguous tile ranges (conv variant bit 19)
     bool unfuse_blocks = false;  // A/B: run a fused bottleneck block as its three convs (conv variant bit 18)
     bool plain_gather = false;   // A/B: per-load address arithmetic instead of the fast gather (conv variant bit 17)
@@ -359,7 +361,7 @@ int launch_op(sbbseg_ctx* c, Op& op, int n, uint8_t* d_labels, float* d_probs)
                 sd.tap_lo_y = co.tap_lo[s][0]; sd.tap_lo_x = co.tap_lo[s][1];
                 if (bytes + (size_t)kFgBiasPixels(t.W) * sd.pix_bytes >= ((size_t)1 << 31)) fg = false;
             }
-            p.fast_gather = fg ? 1 : 0;
+            p.fast_gather = fg ? (co.fg_pointwise ? 2 : 1) : 0;
             p.ktab = co.d_ktab; p.kstep = co.d_kstep; p.half_stages = (c->conv_variant & 16) ? 1 : 0;
             p.variant = c->conv_variant & 3; p.persist_blocks = (c->conv_variant & 4) ? 0 : c->num_cus;
             p.M = n * co.Ho * co.Wo;
@@ -1196,6 +1198,7 @@ int sbbseg_add_head(sbbseg_ctx* c, int src_tensor, int cin, int classes, const f
 // wins 2-10 %, profiles/r02_experiments.md), and so do the split mode's 64-channel tiles (+13 % time there).
 static int build_fast_gather_tables(sbbseg_ctx* c)
 {
+    if (const char* e = getenv("SBBSEG_FG_POINTWISE_MIN")) c->fg_pointwise_min_ksteps = atoi(e);
     std::vector<ConvOp*> convs;
     for (Op& op : c->ops) {
         if (op.type == kConv) convs.push_back(&op.conv);
@@ -1204,7 +1207,13 @@ static int build_fast_gather_tables(sbbseg_ctx* c)
     }
     for (ConvOp* cop : convs) {
         ConvOp& co = *cop;
-        if (!co.fg_ok || c->precision == kF32 || co.total_ksteps < 9 || (c->precision == kF16X3 && co.d.cout < 128)) continue;
+        bool pointwise = true;                             // every tap (0, 0): no bounds masks to set up
+        for (int s = 0; s < co.d.n_src; ++s)
+            pointwise = pointwise && co.tap_lo[s][0] == 0 && co.tap_hi[s][0] == 0 && co.tap_lo[s][1] == 0 && co.tap_hi[s][1] == 0 &&
+                        co.d.src[s].pad_top == 0 && co.d.src[s].pad_left == 0 && co.d.src[s].off_y == 0 && co.d.src[s].off_x == 0;
+        co.fg_pointwise = pointwise;
+        const int min_ksteps = pointwise ? c->fg_pointwise_min_ksteps : 9;
+        if (!co.fg_ok || c->precision == kF32 || co.total_ksteps < min_ksteps || (c->precision == kF16X3 && co.d.cout < 128)) continue;
         bool ok = true;
         for (int s = 0; s < co.d.n_src; ++s)
             ok = ok && co.d.src[s].up_shift == 0 && co.tap_hi[s][0] - co.tap_lo[s][0] <= 3 && co.tap_hi[s][1] - co.tap_lo[s][1] <= 3 &&

@@ -325,11 +325,12 @@ void conv_igemm_mfma(const ConvParams p)
                     const int ox = rem - oy * p.Wo;
                     r_oy[j] = (int)((uint32_t)n * img0 + (uint32_t)(((oy << sd0.sy_shift) * sd0.PW + (ox << sd0.sx_shift)) * sd0.pix_bytes) +
                                     lane_part(sd0) + (uint32_t)kZeroHeaderBytes);
-                    uint32_t inv = oob_mask(sd0, oy, ox);
+                    // (fast_gather == 2: every tap is (0, 0) -- pointwise convs -- and in bounds for every real row)
+                    uint32_t inv = p.fast_gather == 2 ? 0u : oob_mask(sd0, oy, ox);
                     if (p.n_src > 1) {
                         r_ox[j] = (int)((uint32_t)n * img1 + (uint32_t)(((oy << sd1.sy_shift) * sd1.PW + (ox << sd1.sx_shift)) * sd1.pix_bytes) +
                                         lane_part(sd1) + (uint32_t)kZeroHeaderBytes);
-                        inv |= oob_mask(sd1, oy, ox) << 16;
+                        if (p.fast_gather != 2) inv |= oob_mask(sd1, oy, ox) << 16;
                     } else {
                         r_ox[j] = 0;
                     }
