@@ -257,6 +257,10 @@ def main():
             "flops_note": "achieved/frac = ALGORITHMIC FLOPs (reference formulation: 2*MACs of the 3x3 conv over the upsampled+"
                           "concatenated input); achieved_issued/frac_issued = the MFMA work the kernel really issues (parity-split "
                           "decoder convs pre-sum coincident taps: 13/18 of the algorithmic MACs; the split mode issues 3 MFMAs per product)",
+            # the five longest conv launches (the reported kernel is the first): which one is longest changes as they are tuned
+            "longest_launches": [{"name": o["name"], "avg_launch_ms": round(o["total_ms"] / o["launches"], 4),
+                                  "frac": round(rate([o]) / MFMA_PEAK_TFLOPS, 4), "frac_issued": round(rate([o], "issued_flops") / MFMA_PEAK_TFLOPS, 4)}
+                                 for o in sorted(convs, key=lambda o: -o["total_ms"] / o["launches"])[:5]],
             "conv3x3_stages": {"achieved": round(rate(k3), 2), "frac": round(rate(k3) / MFMA_PEAK_TFLOPS, 4),
                                "frac_issued": round(rate(k3, "issued_flops") / MFMA_PEAK_TFLOPS, 4),
                                "share_of_gpu_time": round(sum(o["total_ms"] for o in k3) / tot_ms, 4)},
