@@ -859,3 +859,13 @@ def test_return_deskew_slope_equals_oracle(stitch_model):
         assert got == ref
         if abs(true) < 15:
             assert abs(got + true) < 1.0
+
+
+def test_deskew_golden_vectors(stitch_model):
+    """The device path against the COMMITTED vectors (tests/golden/deskew_golden.npz), not a freshly run oracle."""
+    from sbb_textline_detection_amd import stages
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "deskew_golden.npz"))
+    for k in range(3):
+        m = g[f"mask{k}"]
+        assert np.array_equal(stitch_model.ctx.deskew_profiles(m, g["angles"]), g[f"counts{k}"])
+        assert stages.return_deskew_slope(m, 1.0, ctx=stitch_model.ctx) == float(g[f"slope{k}"])

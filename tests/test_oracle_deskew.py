@@ -103,3 +103,14 @@ def test_profile_statistics_hand_case():
 def test_return_deskew_slope_fails_loudly_without_a_handle():
     with pytest.raises(RuntimeError):
         stages.return_deskew_slope(np.ones((10, 10), np.uint8), 1.0)
+
+
+def test_oracle_reproduces_the_committed_deskew_vectors():
+    """tests/golden/deskew_golden.npz (make_deskew_golden.py): guards the oracle against drifting away from the vectors
+    the device path is also held to (tests/test_gpu_parity.py::test_deskew_golden_vectors)."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "deskew_golden.npz"))
+    for k in range(3):
+        m = g[f"mask{k}"]
+        assert np.array_equal(dk.row_profiles(m, g["angles"]), g[f"counts{k}"])
+    assert dk.return_deskew_slope(g["mask2"], 1.0) == float(g["slope2"])          # (the smallest mask: the others run in the GPU test)
