@@ -314,32 +314,44 @@ void conv_igemm_mfma(const ConvParams p)
             kstep_tab = (const __attribute__((address_space(4))) int*)(uintptr_t)(FG ? (const void*)p.fgstep_cls[cls] : (const void*)p.kstep_cls[cls]);
             ktab = p.ktab_cls[cls];
         }
+        if constexpr (FG) {
+            // The 8 lanes of an LDS row (lane & 7 = granule) stage the same kPLoads pixel rows: lane g works out row j = g
+            // only, and the group shares the results through ds_bpermute -- instead of every lane repeating all kPLoads
+            // rows (~75 VALU ops each; on a 17-K-step decoder tile that was a quarter of the wave's MFMA time).
+            static_assert(T::kPLoads <= 8 && RPI == 8, "one row per lane of the 8-lane group");
+            const int g8 = lane & 7;
+            int my_a = 0, my_b = 0, my_c = -1;              // row past M: every tap out of bounds -> zero rows
+            const int mm = ptile * BP + ((g8 < T::kPLoads ? g8 : 0) * NW + wave) * RPI + lrow;
+            if (g8 < T::kPLoads && mm < p.M) {
+                const int n = fast_div(mm, p.howo_magic, p.howo_shift);
+                const int rem = mm - n * HoWo;
+                const int oy = fast_div(rem, p.wo_magic, p.wo_shift);
+                const int ox = rem - oy * p.Wo;
+                my_a = (int)((uint32_t)n * img0 + (uint32_t)(((oy << sd0.sy_shift) * sd0.PW + (ox << sd0.sx_shift)) * sd0.pix_bytes) +
+                             (uint32_t)kZeroHeaderBytes);
+                // (fast_gather == 2: every tap is (0, 0) -- pointwise convs -- and in bounds for every real row)
+                uint32_t inv = p.fast_gather == 2 ? 0u : oob_mask(sd0, oy, ox);
+                if (p.n_src > 1) {
+                    my_b = (int)((uint32_t)n * img1 + (uint32_t)(((oy << sd1.sy_shift) * sd1.PW + (ox << sd1.sx_shift)) * sd1.pix_bytes) +
+                                 (uint32_t)kZeroHeaderBytes);
+                    if (p.fast_gather != 2) inv |= oob_mask(sd1, oy, ox) << 16;
+                }
+                my_c = (int)inv;
+            }
+            const int lp0 = (int)lane_part(sd0), lp1 = (int)lane_part(sd1);
+#pragma unroll
+            for (int j = 0; j < T::kPLoads; ++j) {
+                const int srcl = (lane & ~7) | j;
+                r_oy[j] = __shfl(my_a, srcl, 64) + lp0;
+                r_ox[j] = __shfl(my_b, srcl, 64) + lp1;
+                r_n[j] = __shfl(my_c, srcl, 64);
+            }
+        }
 #pragma unroll
         for (int j = 0; j < T::kPLoads; ++j) {
             const int m = ptile * BP + (j * NW + wave) * RPI + lrow;
             if constexpr (FG) {
-                if (m < p.M) {
-                    const int n = fast_div(m, p.howo_magic, p.howo_shift);
-                    const int rem = m - n * HoWo;
-                    const int oy = fast_div(rem, p.wo_magic, p.wo_shift);
-                    const int ox = rem - oy * p.Wo;
-                    r_oy[j] = (int)((uint32_t)n * img0 + (uint32_t)(((oy << sd0.sy_shift) * sd0.PW + (ox << sd0.sx_shift)) * sd0.pix_bytes) +
-                                    lane_part(sd0) + (uint32_t)kZeroHeaderBytes);
-                    // (fast_gather == 2: every tap is (0, 0) -- pointwise convs -- and in bounds for every real row)
-                    uint32_t inv = p.fast_gather == 2 ? 0u : oob_mask(sd0, oy, ox);
-                    if (p.n_src > 1) {
-                        r_ox[j] = (int)((uint32_t)n * img1 + (uint32_t)(((oy << sd1.sy_shift) * sd1.PW + (ox << sd1.sx_shift)) * sd1.pix_bytes) +
-                                        lane_part(sd1) + (uint32_t)kZeroHeaderBytes);
-                        if (p.fast_gather != 2) inv |= oob_mask(sd1, oy, ox) << 16;
-                    } else {
-                        r_ox[j] = 0;
-                    }
-                    r_n[j] = (int)inv;
-                } else {
-                    r_oy[j] = 0;
-                    r_ox[j] = 0;
-                    r_n[j] = -1;                            // every tap out of bounds -> zero rows
-                }
+                (void)m;
             } else if (m < p.M) {
                 const int n = fast_div(m, p.howo_magic, p.howo_shift);
                 const int rem = m - n * HoWo;
