@@ -206,6 +206,7 @@ struct sbbseg_ctx {
     bool profiling = false;
     int conv_variant = 0;
     bool ph8 = false;            // 8-phase schedule on the 256x256 tile (opt-in, conv variant bit 16)
+    int fg_min_ksteps = 9;             // convs with real taps take the fast gather from this many K-steps on (SBBSEG_FG_MIN)
     int fg_pointwise_min_ksteps = 4;   // pointwise convs take the fast gather from this many K-steps on (SBBSEG_FG_POINTWISE_MIN)
     bool ranged_walk = false;    // A/B: grouped launches walk XCD-contiguous tile ranges (conv variant bit 19)
     bool unfuse_blocks = false;  // A/B: run a fused bottleneck block as its three convs (conv variant bit 18)
@@ -1199,6 +1200,7 @@ int sbbseg_add_head(sbbseg_ctx* c, int src_tensor, int cin, int classes, const f
 static int build_fast_gather_tables(sbbseg_ctx* c)
 {
     if (const char* e = getenv("SBBSEG_FG_POINTWISE_MIN")) c->fg_pointwise_min_ksteps = atoi(e);
+    if (const char* e = getenv("SBBSEG_FG_MIN")) c->fg_min_ksteps = atoi(e);
     std::vector<ConvOp*> convs;
     for (Op& op : c->ops) {
         if (op.type == kConv) convs.push_back(&op.conv);
@@ -1212,7 +1214,7 @@ static int build_fast_gather_tables(sbbseg_ctx* c)
             pointwise = pointwise && co.tap_lo[s][0] == 0 && co.tap_hi[s][0] == 0 && co.tap_lo[s][1] == 0 && co.tap_hi[s][1] == 0 &&
                         co.d.src[s].pad_top == 0 && co.d.src[s].pad_left == 0 && co.d.src[s].off_y == 0 && co.d.src[s].off_x == 0;
         co.fg_pointwise = pointwise;
-        const int min_ksteps = pointwise ? c->fg_pointwise_min_ksteps : 9;
+        const int min_ksteps = pointwise ? c->fg_pointwise_min_ksteps : c->fg_min_ksteps;
         if (!co.fg_ok || c->precision == kF32 || co.total_ksteps < min_ksteps || (c->precision == kF16X3 && co.d.cout < 128)) continue;
         bool ok = true;
         for (int s = 0; s < co.d.n_src; ++s)
