@@ -1108,7 +1108,8 @@ int sbbseg_add_tail(sbbseg_ctx* c, int src0_tensor, int img_c8_tensor, const flo
     API_BEGIN
     REQUIRE(c && !c->finalized && w_src0 && w_img && scale && shift && head_w && head_scale && head_shift, "bad arguments");
     HIPCHK(hipSetDevice(c->device));
-    REQUIRE(c->precision == kF16 || c->precision == kBF16, "the fused tail is a plain 16-bit-mode kernel");
+    REQUIRE(c->precision == kF16 || c->precision == kBF16 || c->precision == kF16X3, "the fused tail is a 16-bit-mode kernel");
+    const bool split = c->precision == kF16X3;
     const int ntens = (int)c->tensors.size();
     REQUIRE(src0_tensor >= 0 && src0_tensor < ntens && img_c8_tensor >= 0 && img_c8_tensor < ntens, "tail tensors undefined");
     const Tensor& s0 = c->tensors[src0_tensor];
@@ -1119,7 +1120,9 @@ int sbbseg_add_tail(sbbseg_ctx* c, int src0_tensor, int img_c8_tensor, const flo
     REQUIRE(classes >= 1 && classes <= 4 && c->classes == 0, "fused tail: 1..4 classes, one head per plan");
     static const int taps[2][2][2] = {{{0, 0}, {1, 2}}, {{0, 1}, {2, 2}}};   // [parity][t] -> first,last ky summed
     const int C0 = 64, CO = 32;
-    std::vector<uint16_t> frag((size_t)4 * kTailKSteps * 4 * 64 * 8, 0);
+    // pre-summed fp32 weights in fragment order first; then 16-bit (plain modes) or hi | lo after the power-of-two pre-scale
+    // (split mode: per class [hi fragments][lo fragments], scale divided by the pre-scale, see sbbseg_add_conv)
+    std::vector<float> fragf((size_t)4 * kTailKSteps * 4 * 64 * 8, 0.f);
     for (int q = 0; q < 4; ++q) {
         const int py = q >> 1, px = q & 1;
         for (int ks = 0; ks < kTailKSteps; ++ks)
@@ -1128,7 +1131,7 @@ int sbbseg_add_tail(sbbseg_ctx* c, int src0_tensor, int img_c8_tensor, const flo
                     for (int l = 0; l < 64; ++l) {
                         const int o = conv_row_channel(mi * 16 + (l & 15), CO);
                         const int gidx = kk * 4 + (l >> 4);
-                        uint16_t* dst = &frag[((((size_t)q * kTailKSteps + ks) * 4 + kk * 2 + mi) * 64 + l) * 8];
+                        float* dst = &fragf[((((size_t)q * kTailKSteps + ks) * 4 + kk * 2 + mi) * 64 + l) * 8];
                         for (int e = 0; e < 8; ++e) {
                             float v = 0.f;
                             if (ks < 4) {
@@ -1140,14 +1143,41 @@ int sbbseg_add_tail(sbbseg_ctx* c, int src0_tensor, int img_c8_tensor, const flo
                                 const int t = (ks - 4) * 8 + gidx;
                                 if (t < 9 && e < 3) v = w_img[((size_t)t * 3 + e) * CO + o];
                             }
-                            dst[e] = c->precision == kF16 ? f32_to_f16_rne(v) : f32_to_bf16_rne(v);
+                            dst[e] = v;
                         }
                     }
+    }
+    const size_t per_class = (size_t)kTailKSteps * 4 * 64 * 8;
+    std::vector<uint16_t> frag(fragf.size() * (split ? 2 : 1), 0);
+    std::vector<float> scale_v(scale, scale + CO);
+    if (!split) {
+        for (size_t i = 0; i < fragf.size(); ++i) frag[i] = c->precision == kF16 ? f32_to_f16_rne(fragf[i]) : f32_to_bf16_rne(fragf[i]);
+    } else {
+        float wmax = 0.f;
+        for (float v : fragf) wmax = std::fmax(wmax, std::fabs(v));
+        REQUIRE(std::isfinite(wmax), "%s: non-finite weights", "tail");
+        float wpre = 1.f;
+        if (wmax > 0.f) {
+            int ex = 0;
+            (void)std::frexp(wmax, &ex);
+            int sexp = 9 - ex;                               // wmax * 2^sexp in [256, 512)
+            sexp = sexp > 60 ? 60 : (sexp < -60 ? -60 : sexp);
+            wpre = std::ldexp(1.f, sexp);
+        }
+        for (int q = 0; q < 4; ++q)
+            for (size_t i = 0; i < per_class; ++i) {
+                const float sv = fragf[q * per_class + i] * wpre;            // exact (power of two)
+                const uint16_t hb = f32_to_f16_rne(sv);
+                const _Float16 hh = __builtin_bit_cast(_Float16, hb);
+                frag[(size_t)q * 2 * per_class + i] = hb;
+                frag[(size_t)q * 2 * per_class + per_class + i] = f32_to_f16_rne(sv - (float)hh);
+            }
+        for (float& v : scale_v) v /= wpre;
     }
     Op op;
     op.type = kTail;
     op.tail.src0 = src0_tensor; op.tail.img = img_c8_tensor; op.tail.classes = classes;
-    if (upload(c, (uint16_t**)&op.tail.d_wfrag, frag.data(), frag.size()) || upload(c, &op.tail.d_scale, scale, CO) ||
+    if (upload(c, (uint16_t**)&op.tail.d_wfrag, frag.data(), frag.size()) || upload(c, &op.tail.d_scale, scale_v.data(), CO) ||
         upload(c, &op.tail.d_shift, shift, CO) || upload(c, &op.tail.d_head_w, head_w, (size_t)CO * classes) ||
         upload(c, &op.tail.d_head_scale, head_scale, classes) || upload(c, &op.tail.d_head_shift, head_shift, classes))
         return 1;
@@ -1155,8 +1185,8 @@ int sbbseg_add_tail(sbbseg_ctx* c, int src0_tensor, int img_c8_tensor, const flo
     snprintf(nm, sizeof(nm), "tail_conv3x3_c67to32_up_cat_head%d_%dx%d", classes, c->in_H, c->in_W);
     op.name = nm;
     op.flops = 2.0 * (algorithmic_macs > 0 ? algorithmic_macs : (double)c->in_H * c->in_W * CO * (9.0 * 67 + classes));
-    op.issued_flops = 2.0 * c->in_H * c->in_W * CO * (double)(kTailKSteps * kBK);
-    op.min_bytes = (double)s0.H * s0.W * 64 * c->elem + (double)c->in_H * c->in_W * (8 * c->elem + 1);
+    op.issued_flops = 2.0 * c->in_H * c->in_W * CO * (double)(kTailKSteps * kBK) * (split ? 3 : 1);
+    op.min_bytes = (double)s0.H * s0.W * 64 * c->elem * c->planes + (double)c->in_H * c->in_W * (8 * c->elem * c->planes + 1);
     c->classes = classes;
     c->ops.push_back(op);
     return 0;

@@ -314,7 +314,7 @@ void conv_igemm_mfma(const ConvParams p)
             kstep_tab = (const __attribute__((address_space(4))) int*)(uintptr_t)(FG ? (const void*)p.fgstep_cls[cls] : (const void*)p.kstep_cls[cls]);
             ktab = p.ktab_cls[cls];
         }
-        if constexpr (FG) {
+        if constexpr (FG && !X3) {              // (the split-mode tiles have no registers to spare for it: every lane does every row)
             // The 8 lanes of an LDS row (lane & 7 = granule) stage the same kPLoads pixel rows: lane g works out row j = g
             // only, and the group shares the results through ds_bpermute -- instead of every lane repeating all kPLoads
             // rows (~75 VALU ops each; on a 17-K-step decoder tile that was a quarter of the wave's MFMA time).
@@ -338,20 +338,41 @@ void conv_igemm_mfma(const ConvParams p)
                 }
                 my_c = (int)inv;
             }
-            const int lp0 = (int)lane_part(sd0), lp1 = (int)lane_part(sd1);
 #pragma unroll
             for (int j = 0; j < T::kPLoads; ++j) {
-                const int srcl = (lane & ~7) | j;
-                r_oy[j] = __shfl(my_a, srcl, 64) + lp0;
-                r_ox[j] = __shfl(my_b, srcl, 64) + lp1;
-                r_n[j] = __shfl(my_c, srcl, 64);
+                const int srcl4 = ((lane & ~7) | j) << 2;          // ds_bpermute takes the source lane's byte address
+                r_n[j] = __builtin_amdgcn_ds_bpermute(srcl4, my_c);
+                r_oy[j] = __builtin_amdgcn_ds_bpermute(srcl4, my_a) + gsrc * 16;      // + lane_part (plain modes: the lane's granule)
+                r_ox[j] = __builtin_amdgcn_ds_bpermute(srcl4, my_b) + gsrc * 16;
             }
         }
 #pragma unroll
         for (int j = 0; j < T::kPLoads; ++j) {
             const int m = ptile * BP + (j * NW + wave) * RPI + lrow;
-            if constexpr (FG) {
+            if constexpr (FG && !X3) {
                 (void)m;
+            } else if constexpr (FG) {
+                if (m < p.M) {
+                    const int n = fast_div(m, p.howo_magic, p.howo_shift);
+                    const int rem = m - n * HoWo;
+                    const int oy = fast_div(rem, p.wo_magic, p.wo_shift);
+                    const int ox = rem - oy * p.Wo;
+                    r_oy[j] = (int)((uint32_t)n * img0 + (uint32_t)(((oy << sd0.sy_shift) * sd0.PW + (ox << sd0.sx_shift)) * sd0.pix_bytes) +
+                                    lane_part(sd0) + (uint32_t)kZeroHeaderBytes);
+                    uint32_t inv = p.fast_gather == 2 ? 0u : oob_mask(sd0, oy, ox);
+                    if (p.n_src > 1) {
+                        r_ox[j] = (int)((uint32_t)n * img1 + (uint32_t)(((oy << sd1.sy_shift) * sd1.PW + (ox << sd1.sx_shift)) * sd1.pix_bytes) +
+                                        lane_part(sd1) + (uint32_t)kZeroHeaderBytes);
+                        if (p.fast_gather != 2) inv |= oob_mask(sd1, oy, ox) << 16;
+                    } else {
+                        r_ox[j] = 0;
+                    }
+                    r_n[j] = (int)inv;
+                } else {
+                    r_oy[j] = 0;
+                    r_ox[j] = 0;
+                    r_n[j] = -1;                            // every tap out of bounds -> zero rows
+                }
             } else if (m < p.M) {
                 const int n = fast_div(m, p.howo_magic, p.howo_shift);
                 const int rem = m - n * HoWo;
@@ -1469,6 +1490,232 @@ __global__ __launch_bounds__(256, 2) void dec_tail_fused(const TailParams p)
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// dec_tail_fused_x3 -- the same tail in the split mode (kF16X3): src0 pixels are [64 hi][64 lo] (256 B), image pixels
+// [8 hi][8 lo] (32 B), the wave's weights are hi + lo fragments (192 VGPRs), three MFMAs per product (lo*hi, hi*lo, hi*hi),
+// everything after the accumulators as in dec_tail_fused.  One block per CU (up to 512 registers per lane).  The generic
+// kernel needs 5.1 ms per 140 patches for this layer (32 output channels: 24 MFMAs per 288 staged rows).
+// ------------------------------------------------------------------------------------------------
+constexpr int kT3SrcBytes = 10 * 16 * 256;              // 40 KB: 10 rows x 16 pixels (10 used) x 256 B
+constexpr int kT3ImgBytes = 18 * 32 * 32;               // 18 KB: 18 rows x 32 pixels (18 used) x 32 B
+constexpr int kT3BufBytes = kT3SrcBytes + kT3ImgBytes;
+constexpr int kT3LdsBytes = 2 * kT3BufBytes + 256 + 64 + kTailConstBytes;
+
+template <int NC>
+__global__ __launch_bounds__(256, 1) void dec_tail_fused_x3(const TailParams p)
+{
+    constexpr bool F16 = true;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* lbl_tile = smem + 2 * kT3BufBytes;                   // [16][16] u8
+    char* zero_gran = lbl_tile + 256;                          // 16 zero bytes (image taps 9..15)
+    float* cst = (float*)(zero_gran + 64);                     // [32 channels][CR]: scale, shift, head_w
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int py = wave >> 1, px = wave & 1;
+    const int frow = lane & 15, fg = lane >> 4;
+
+    const int H = 2 * p.PH, W = 2 * p.PW;
+    const int tiles_x = W / 16, tiles_y = H / 16;
+    const int tiles_per_patch = tiles_x * tiles_y;
+    const int n_tiles = p.n * tiles_per_patch;
+    const int G = gridDim.x;
+    const int my_tiles = (n_tiles - (int)blockIdx.x + G - 1) / G;
+    if (my_tiles <= 0) return;
+    if (tid < 4) ((uint32_t*)zero_gran)[tid] = 0u;
+    constexpr int CR = NC <= 2 ? 4 : 8;
+    if (tid < 32) {
+        float* row = cst + ((tid & 7) * 4 + (tid >> 3)) * CR;
+        row[0] = p.scale[tid];
+        row[1] = p.shift[tid];
+        for (int c = 0; c < CR - 2; ++c) row[2 + c] = c < p.classes ? p.head_w[tid * p.classes + c] : 0.f;
+    }
+
+    // ---- this wave's weights: [plane hi|lo][half-K-step 12][mi 2] fragments
+    bf16x8_t whi[kTailKSteps * 4], wlo[kTailKSteps * 4];
+    {
+        const uint4* src = (const uint4*)p.wfrag + (size_t)(wave * 2 * kTailKSteps * 4) * 64 + lane;
+#pragma unroll
+        for (int f = 0; f < kTailKSteps * 4; ++f) {
+            whi[f] = __builtin_bit_cast(bf16x8_t, src[(size_t)f * 64]);
+            wlo[f] = __builtin_bit_cast(bf16x8_t, src[(size_t)(kTailKSteps * 4 + f) * 64]);
+        }
+    }
+    float hsc[NC], hsh[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) { hsc[c] = c < p.classes ? p.head_scale[c] : 0.f; hsh[c] = c < p.classes ? p.head_shift[c] : 0.f; }
+
+    int src_base[4], img_base[4];
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+        const int i = ni * 16 + frow;
+        const int sy = i >> 3, sx = i & 7;
+        src_base[ni] = (sy + py) * 16 + (sx + px);
+        img_base[ni] = (2 * sy + py) * 32 + (2 * sx + px);
+    }
+    int img_toff[2][2];
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int t = s2 * 8 + kk * 4 + fg;
+            img_toff[s2][kk] = t < 9 ? (t / 3) * 32 + (t % 3) : -1;
+        }
+
+    auto issue_tile = [&](int tile, int buf) __attribute__((always_inline)) {
+        const int n = tile / tiles_per_patch;
+        const int rem = tile - n * tiles_per_patch;
+        const int ty = rem / tiles_x, tx = rem - ty * tiles_x;
+        const int y0 = ty * 16, x0 = tx * 16;
+        char* lds_src = smem + buf * kT3BufBytes;
+        char* lds_img = lds_src + kT3SrcBytes;
+        // src0 halo: 160 pixels x 16 granules (8 hi, 8 lo) = 40 wave-instructions of 4 pixels; pixel hp keeps granule g at slot g ^ (hp & 15)
+#pragma unroll
+        for (int j = 0; j < 10; ++j) {
+            const int ii = wave + 4 * j;
+            const int hp = ii * 4 + (lane >> 4);
+            const int r = hp >> 4, c = hp & 15;
+            const int g = (lane & 15) ^ c;
+            const int Y = (y0 >> 1) - 1 + r, X = (x0 >> 1) - 1 + c;
+            const bool ok = ((unsigned)Y < (unsigned)p.PH) & ((unsigned)X < (unsigned)p.PW) & (c < 10);
+            uint32_t off = (uint32_t)((n * p.PH + Y) * p.PW + X) * 256u + (uint32_t)(g * 16 + kZeroHeaderBytes);
+            off = ok ? off : 0u;
+            __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(p.src0 + off), (LDS_AS void*)(lds_src + ii * 1024), 16, 0, 0);
+        }
+        // image halo: 18 rows x 32 pixels x (hi 16 B, lo 16 B) = 18 wave-instructions of one row
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            const int ii = wave + 4 * j;
+            if (ii < 18) {
+                const int c = lane >> 1;
+                const int Y = y0 - 1 + ii, X = x0 - 1 + c;
+                const bool ok = ((unsigned)Y < (unsigned)H) & ((unsigned)X < (unsigned)W) & (c < 18);
+                uint32_t off = (uint32_t)((n * H + Y) * W + X) * 32u + (uint32_t)((lane & 1) * 16 + kZeroHeaderBytes);
+                off = ok ? off : 0u;
+                __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(p.img + off), (LDS_AS void*)(lds_img + ii * 1024), 16, 0, 0);
+            }
+        }
+    };
+
+    issue_tile(blockIdx.x, 0);
+    for (int it = 0; it < my_tiles; ++it) {
+        const int tile = blockIdx.x + it * G;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (it + 1 < my_tiles) issue_tile(tile + G, (it + 1) & 1);
+
+        const char* lds_src = smem + (it & 1) * kT3BufBytes;
+        const char* lds_img = lds_src + kT3SrcBytes;
+        f32x4_t acc[2][4];
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+        auto load_b = [&](int h, bf16x8_t (&bh)[4], bf16x8_t (&bl)[4]) __attribute__((always_inline)) {
+            if (h < 8) {
+                const int ks = h >> 1, kk = h & 1;
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) {
+                    const int hp = src_base[ni] + (ks >> 1) * 16 + (ks & 1);
+                    const char* px_ = lds_src + hp * 256;
+                    bh[ni] = *(const bf16x8_t*)(px_ + (((kk * 4 + fg) ^ (hp & 15)) << 4));
+                    bl[ni] = *(const bf16x8_t*)(px_ + (((8 + kk * 4 + fg) ^ (hp & 15)) << 4));
+                }
+            } else {
+                const int toff = img_toff[(h - 8) >> 1][(h - 8) & 1];
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) {
+                    const char* a = toff >= 0 ? lds_img + (img_base[ni] + toff) * 32 : zero_gran;
+                    bh[ni] = *(const bf16x8_t*)a;
+                    bl[ni] = *(const bf16x8_t*)(toff >= 0 ? a + 16 : zero_gran);
+                }
+            }
+        };
+        auto mac = [&](int h, const bf16x8_t (&bh)[4], const bf16x8_t (&bl)[4]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi) {
+                    acc[mi][ni] = mfma16<F16>(wlo[h * 2 + mi], bh[ni], acc[mi][ni]);
+                    acc[mi][ni] = mfma16<F16>(whi[h * 2 + mi], bl[ni], acc[mi][ni]);
+                    acc[mi][ni] = mfma16<F16>(whi[h * 2 + mi], bh[ni], acc[mi][ni]);
+                }
+        };
+        bf16x8_t b0h[4], b0l[4], b1h[4], b1l[4];
+        load_b(0, b0h, b0l);
+#pragma unroll
+        for (int h = 0; h < 12; h += 2) {
+            load_b(h + 1, b1h, b1l);
+            mac(h, b0h, b0l);
+            if (h + 2 < 12) load_b(h + 2, b0h, b0l);
+            mac(h + 1, b1h, b1l);
+        }
+
+        // ---- epilogue: BN/ReLU, head, softmax, argmax (as dec_tail_fused)
+        const int n = tile / tiles_per_patch;
+        const int rem = tile - n * tiles_per_patch;
+        const int tyy = rem / tiles_x, txx = rem - tyy * tiles_x;
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+            float logit[NC];
+#pragma unroll
+            for (int c = 0; c < NC; ++c) logit[c] = 0.f;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const float* row = cst + (q * 4 + fg) * CR;
+                const float4 c0 = *(const float4*)row;
+                const float v = q < 4 ? acc[0][ni][q] : acc[1][ni][q - 4];
+                const float yq = fmaxf(v * c0.x + c0.y, 0.f);
+                logit[0] = fmaf(yq, c0.z, logit[0]);
+                if constexpr (NC > 1) logit[1] = fmaf(yq, c0.w, logit[1]);
+                if constexpr (NC > 2) {
+                    const float2 c1 = *(const float2*)(row + 4);
+                    logit[2] = fmaf(yq, c1.x, logit[2]);
+                    logit[3] = fmaf(yq, c1.y, logit[3]);
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                float a = logit[c];
+                a += __shfl_xor(a, 16);
+                a += __shfl_xor(a, 32);
+                logit[c] = a * hsc[c] + hsh[c];
+            }
+            if (fg == 0) {
+                float mx = -3.0e38f;
+#pragma unroll
+                for (int c = 0; c < NC; ++c)
+                    if (c < p.classes) mx = fmaxf(mx, logit[c]);
+                float pr[NC], sum = 0.f;
+#pragma unroll
+                for (int c = 0; c < NC; ++c) { pr[c] = c < p.classes ? expf(logit[c] - mx) : 0.f; sum += pr[c]; }
+                int best = 0;
+                float bestp = -1.f;
+#pragma unroll
+                for (int c = 0; c < NC; ++c)
+                    if (c < p.classes) {
+                        pr[c] = pr[c] / sum;
+                        if (pr[c] > bestp) { bestp = pr[c]; best = c; }
+                    }
+                const int i = ni * 16 + frow;
+                const int oy = 2 * (i >> 3) + py, ox = 2 * (i & 7) + px;
+                lbl_tile[oy * 16 + ox] = (char)best;
+                if (p.probs) {
+                    float* dst = p.probs + ((size_t)(n * H + tyy * 16 + oy) * W + txx * 16 + ox) * p.classes;
+#pragma unroll
+                    for (int c = 0; c < NC; ++c)
+                        if (c < p.classes) dst[c] = pr[c];
+                }
+            }
+        }
+        __syncthreads();
+        if (tid < 16)
+            *(uint4*)(p.labels + (size_t)(n * H + tyy * 16 + tid) * W + txx * 16) = *(const uint4*)(lbl_tile + tid * 16);
+    }
+}
+
 hipError_t launch_tail(const TailParams& p, int precision, int num_cus, hipStream_t s)
 {
     const int n_tiles = p.n * (p.PH / 8) * (p.PW / 8);
@@ -1480,6 +1727,18 @@ hipError_t launch_tail(const TailParams& p, int precision, int num_cus, hipStrea
         return hipSuccess;
     };
     hipError_t e;
+    if (precision == kF16X3) {
+        const int grid3 = n_tiles < num_cus ? n_tiles : num_cus;
+        auto go3 = [&](auto kern) -> hipError_t {
+            hipError_t e3 = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, kT3LdsBytes);
+            if (e3 != hipSuccess) return e3;
+            hipLaunchKernelGGL(kern, dim3(grid3), dim3(256), kT3LdsBytes, s, p);
+            return hipSuccess;
+        };
+        e = p.classes <= 2 ? go3(dec_tail_fused_x3<2>) : go3(dec_tail_fused_x3<4>);
+        if (e != hipSuccess) return e;
+        return hipGetLastError();
+    }
     if (precision == kF16) e = p.classes <= 2 ? go(dec_tail_fused<true, 2>) : go(dec_tail_fused<true, 4>);
     else e = p.classes <= 2 ? go(dec_tail_fused<false, 2>) : go(dec_tail_fused<false, 4>);
     if (e != hipSuccess) return e;

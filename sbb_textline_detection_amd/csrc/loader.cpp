@@ -1111,7 +1111,7 @@ Options options_for(int precision, int flags)
     opt.parity_split = !(flags & SBBSEG_LOAD_NO_PARITY_SPLIT);
     opt.merge_shortcut = !(flags & SBBSEG_LOAD_NO_SHORTCUT_MERGE);
     opt.fuse_head = precision != SBBSEG_PREC_F32 && !(flags & SBBSEG_LOAD_NO_FUSED_HEAD);
-    opt.fuse_tail = (precision == SBBSEG_PREC_F16 || precision == SBBSEG_PREC_BF16) && !(flags & SBBSEG_LOAD_NO_FUSED_TAIL);
+    opt.fuse_tail = (precision == SBBSEG_PREC_F16 || precision == SBBSEG_PREC_BF16 || precision == SBBSEG_PREC_F16X3) && !(flags & SBBSEG_LOAD_NO_FUSED_TAIL);
     return opt;
 }
 

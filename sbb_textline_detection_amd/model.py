@@ -55,8 +55,8 @@ class SegModel:
         self.graph: Graph = parse_model_config(model_config)
         self._plan_args = dict(parity_split=os.environ.get("SBBSEG_PARITY_SPLIT", "1") != "0",
                                fuse_head=precision != "f32" and os.environ.get("SBBSEG_FUSE_HEAD", "1") != "0",
-                               # the dedicated tail kernel reads the one-plane 16-bit layout (f16 / bf16 only)
-                               fuse_tail=precision in ("f16", "bf16") and os.environ.get("SBBSEG_FUSE_TAIL", "1") != "0",
+                               # the dedicated tail kernels: one-plane 16-bit layout (f16 / bf16) and the split layout (f16x3)
+                               fuse_tail=precision in ("f16", "bf16", "f16x3") and os.environ.get("SBBSEG_FUSE_TAIL", "1") != "0",
                                merge_shortcut=os.environ.get("SBBSEG_MERGE_SHORTCUT", "1") != "0")
         self._weights = weights
         self._plan: Optional[Plan] = None
@@ -68,7 +68,7 @@ class SegModel:
         if sbbw_path is not None:
             a = self._plan_args
             flags = (0 if a["parity_split"] else 1) | (0 if a["merge_shortcut"] else 2) | (0 if a["fuse_head"] or precision == "f32" else 4) | \
-                    (0 if a["fuse_tail"] or precision not in ("f16", "bf16") else 8)
+                    (0 if a["fuse_tail"] or precision not in ("f16", "bf16", "f16x3") else 8)
             if int(os.environ.get("SBBSEG_LANES", "2")) != 2:
                 raise ValueError("the native loader builds two-lane handles; use the Python planner path for SBBSEG_LANES=1")
             self._ctx: Optional[_capi.Context] = _capi.Context.from_sbbw(sbbw_path, device, prec, self.max_batch, flags)

@@ -15,10 +15,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_conv_kernels_have_no_scratch(tmp_path):
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     src = os.path.join(ROOT, "sbb_textline_detection_amd", "csrc", "kernels.hip")
-    res = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", src, "-o",
-                          str(tmp_path / "k.o"), "-Rpass-analysis=kernel-resource-usage"],
-                         capture_output=True, text=True)
+    asm = tmp_path / "k.s"
+    res = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", src, "-o", str(asm),
+                          "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True)
     assert res.returncode == 0, res.stderr[-2000:]
+    text = asm.read_text()
     blocks = re.split(r"remark: [^\n]*Function Name: ", res.stderr)[1:]
     seen = 0
     for b in blocks:
@@ -29,6 +30,11 @@ def test_conv_kernels_have_no_scratch(tmp_path):
         scratch = int(re.search(r"ScratchSize \[bytes/lane\]: (\d+)", b).group(1))
         vgprs = int(re.search(r" VGPRs: (\d+)", b).group(1))
         spill = int(re.search(r"VGPRs Spill: (\d+)", b).group(1))
-        assert scratch == 0 and spill == 0, f"{name}: scratch {scratch} B/lane, {spill} VGPR spills"
+        # no VGPR spills, and no instruction that touches private memory: the backend may still reserve a few dozen bytes
+        # of frame for SGPR-spill bookkeeping that the final code never accesses (seen: 36-68 B) -- an array demoted to
+        # private memory would show up as scratch_/buffer accesses and a bigger frame
+        body = re.search(r"^%s:.*?\n(.*?)\n\s*s_endpgm" % re.escape(name), text, re.S | re.M).group(1)
+        touches = [ln.strip() for ln in body.split("\n") if re.match(r"\s*(scratch_|buffer_(load|store)_dword[^\n]*\bs\[0:3\])", ln)]
+        assert spill == 0 and not touches and scratch <= 128, f"{name}: {spill} VGPR spills, frame {scratch} B/lane, private accesses {touches[:3]}"
         assert vgprs <= 256, f"{name}: {vgprs} VGPRs"
     assert seen >= 6

@@ -78,7 +78,7 @@ def test_native_planner_equals_python_planner(tmp_path, name, make, precision, f
     blob = container(cfg, w, tmp_path)
     native = _capi.native_plan_summary(blob, _capi.PRECISIONS[precision], flags)
     plan = build_plan(parse_model_config(cfg), w, parity_split=not (flags & 1), merge_shortcut=not (flags & 2),
-                      fuse_head=precision != "f32" and not (flags & 4), fuse_tail=precision in ("f16", "bf16") and not (flags & 8))
+                      fuse_head=precision != "f32" and not (flags & 4), fuse_tail=precision in ("f16", "bf16", "f16x3") and not (flags & 8))
     py = python_summary(plan)
     assert native.splitlines() == py.splitlines()
 
