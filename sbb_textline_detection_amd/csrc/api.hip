@@ -406,6 +406,7 @@ int launch_op(sbbseg_ctx* c, Op& op, int n, uint8_t* d_labels, float* d_probs)
                 Direct64Params dp;
                 dp.src = st.buf; dp.n = n; dp.H = st.H; dp.W = st.W; dp.wfrag = co.d_d64_wfrag;
                 dp.scale = co.d_scale; dp.shift = co.d_shift; dp.relu = co.d.relu; dp.out = c->tensors[co.d.out_tensor].data();
+                dp.wmul = co.wmul_cls[0];
                 HIPCHK(launch_direct64(dp, c->precision, c->num_cus, c->stream));
             } else {
                 HIPCHK(launch_conv(p, c->precision, c->stream));
@@ -990,12 +991,13 @@ int sbbseg_add_conv(sbbseg_ctx* c, const sbbseg_conv_desc* d, const float* w_src
         }
         // 3x3 / stride 1 / pad 1, 64 -> 64 channels: direct conv on an LDS halo tile, weights in registers
         const char* env2 = getenv("SBBSEG_DIRECT64_KERNEL");
-        if (plain16 && !(env2 && env2[0] == '0') && d->n_src == 1 && !st.is_input_form && st.C == 64 && cs.channels == 64 &&
+        if ((plain16 || split) && !(env2 && env2[0] == '0') && d->n_src == 1 && !st.is_input_form && st.C == 64 && cs.channels == 64 &&
             cs.kh == 3 && cs.kw == 3 && cs.stride_y == 1 && cs.stride_x == 1 && cs.pad_top == 1 && cs.pad_left == 1 && cs.up_shift == 0 &&
             cs.off_y == 0 && cs.off_x == 0 && d->cout == 64 && d->out_h == st.H && d->out_w == st.W && d->residual_tensor < 0 &&
             d->raw_out_tensor < 0 && d->head_classes == 0 && d->out_tensor >= 0 && d->out_stride_y == 1 && d->out_stride_x == 1 &&
             d->out_off_y == 0 && d->out_off_x == 0 && TH == d->out_h && TW == d->out_w) {
-            std::vector<uint16_t> frag((size_t)9 * 2 * 4 * 64 * 8);
+            const size_t fsz = (size_t)9 * 2 * 4 * 64 * 8;
+            std::vector<uint16_t> frag(fsz * (split ? 2 : 1));
             for (int t = 0; t < 9; ++t)
                 for (int kk = 0; kk < 2; ++kk)
                     for (int mi = 0; mi < 4; ++mi)
@@ -1004,7 +1006,15 @@ int sbbseg_add_conv(sbbseg_ctx* c, const sbbseg_conv_desc* d, const float* w_src
                             const int chb = (kk * 4 + (l >> 4)) * 8;
                             for (int e = 0; e < 8; ++e) {
                                 const float v = w_src0[((size_t)t * 64 + chb + e) * 64 + o];
-                                frag[(((((size_t)t * 2 + kk) * 4 + mi) * 64) + l) * 8 + e] = c->precision == kF16 ? f32_to_f16_rne(v) : f32_to_bf16_rne(v);
+                                const size_t at = (((((size_t)t * 2 + kk) * 4 + mi) * 64) + l) * 8 + e;
+                                if (split) {                     // hi | lo of the pre-scaled weight (the conv's wpre, see above)
+                                    const float sv = v * wpre;
+                                    const uint16_t hb = f32_to_f16_rne(sv);
+                                    frag[at] = hb;
+                                    frag[fsz + at] = f32_to_f16_rne(sv - (float)__builtin_bit_cast(_Float16, hb));
+                                } else {
+                                    frag[at] = c->precision == kF16 ? f32_to_f16_rne(v) : f32_to_bf16_rne(v);
+                                }
                             }
                         }
             if (upload(c, &co.d_d64_wfrag, frag.data(), frag.size())) return 1;

@@ -140,11 +140,13 @@ struct StemParams {
 struct Direct64Params {
     const char* src;          // buffer start (zero header), [n][H][W][64] 16-bit
     int n, H, W;
-    const void* wfrag;        // [9 taps][2 kk][4 mi][64 lanes] x 16 bytes, MFMA A-fragment order, rows = conv_row_channel
+    const void* wfrag;        // [9 taps][2 kk][4 mi][64 lanes] x 16 bytes, MFMA A-fragment order, rows = conv_row_channel;
+                              // split mode: that block twice (hi fragments, then lo fragments of the pre-scaled weights)
     const float* scale;       // [64]
     const float* shift;
     int relu;
-    void* out;                // data pointer [n][H][W][64]
+    float wmul;               // multiplier of `scale` (split mode: 2^-s of the power-of-two weight pre-scale; else 1)
+    void* out;                // data pointer [n][H][W][64] (split mode: [64 hi][64 lo] per pixel)
 };
 
 // One ResNet bottleneck block at 64 internal channels (1x1 -> 3x3 -> 1x1 + shortcut) as ONE launch.  See bottleneck_fused.

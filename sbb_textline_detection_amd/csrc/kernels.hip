@@ -2028,10 +2028,155 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_direct(const Direct64Param
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// conv3x3_c64_direct_x3 -- the same direct conv in the split mode (kF16X3): pixels are [64 hi][64 lo] (256 B, 16 granules,
+// slot = granule ^ (halo row & 15)), the wave's weights are hi + lo fragments (288 VGPRs: one block per CU), three MFMAs per
+// product, outputs split again.  The generic split kernel needs 0.82 ms per 140 patches for each of these layers.
+// ------------------------------------------------------------------------------------------------
+constexpr int kD64x3Instr = 48;                                 // wave-instructions of 4 pixels (192 >= 180)
+constexpr int kD64x3BufBytes = kD64x3Instr * 1024;
+constexpr int kD64x3LdsBytes = 2 * kD64x3BufBytes + 512;
+
+__global__ __launch_bounds__(256, 1) void conv3x3_c64_direct_x3(const Direct64Params p)
+{
+    constexpr bool F16 = true;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wp = wave >> 1, wc = wave & 1;
+    const int frow = lane & 15, fg = lane >> 4;
+    const int tiles_x = (p.W + 15) / 16, tiles_y = (p.H + 7) / 8;
+    const int tiles_per_patch = tiles_x * tiles_y;
+    const int n_tiles = p.n * tiles_per_patch;
+    const int G = gridDim.x;
+    const int my_tiles = (n_tiles - (int)blockIdx.x + G - 1) / G;
+    if (my_tiles <= 0) return;
+    float* cst = (float*)(smem + 2 * kD64x3BufBytes);
+    if (tid < 64) { cst[tid] = p.scale[tid] * p.wmul; cst[64 + tid] = p.shift[tid]; }
+
+    bf16x8_t whi[9][2][2], wlo[9][2][2];                        // [tap][kk][mi of this wave]; wfrag = [hi | lo][9][2][4 mi][64 lanes]
+    {
+        const uint4* src = (const uint4*)p.wfrag + lane;
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    const size_t f = (size_t)((t * 2 + kk) * 4 + wc * 2 + m) * 64;
+                    whi[t][kk][m] = __builtin_bit_cast(bf16x8_t, src[f]);
+                    wlo[t][kk][m] = __builtin_bit_cast(bf16x8_t, src[(size_t)9 * 2 * 4 * 64 + f]);
+                }
+    }
+
+    auto issue_tile = [&](int tile, int buf) __attribute__((always_inline)) {
+        const int n = tile / tiles_per_patch;
+        const int rem = tile - n * tiles_per_patch;
+        const int ty = rem / tiles_x, tx = rem - ty * tiles_x;
+        char* lds = smem + buf * kD64x3BufBytes;
+#pragma unroll
+        for (int j = 0; j < kD64x3Instr / 4; ++j) {
+            const int ii = wave + 4 * j;
+            const int hr = ii * 4 + (lane >> 4);                // halo row index = hy * 18 + hx
+            const int hy = hr / kD64HaloW, hx = hr - hy * kD64HaloW;
+            const int g = (lane & 15) ^ (hr & 15);
+            const int Y = ty * 8 - 1 + hy, X = tx * 16 - 1 + hx;
+            const bool ok = ((unsigned)Y < (unsigned)p.H) & ((unsigned)X < (unsigned)p.W) & (hr < kD64Rows);
+            uint32_t off = (uint32_t)((n * p.H + Y) * p.W + X) * 256u + (uint32_t)(g * 16 + kZeroHeaderBytes);
+            off = ok ? off : 0u;
+            __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(p.src + off), (LDS_AS void*)(lds + ii * 1024), 16, 0, 0);
+        }
+    };
+
+    int hbase[4];
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) hbase[ni] = (wp * 4 + ni) * kD64HaloW + frow;
+
+    issue_tile(blockIdx.x, 0);
+    for (int it = 0; it < my_tiles; ++it) {
+        const int tile = blockIdx.x + it * G;
+        wait_vmcnt<0>();
+        __syncthreads();
+        if (it + 1 < my_tiles) issue_tile(tile + G, (it + 1) & 1);
+
+        const char* lds = smem + (it & 1) * kD64x3BufBytes;
+        f32x4_t acc[2][4];
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) acc[m][ni] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        int zero;
+        asm volatile("v_mov_b32 %0, 0" : "=v"(zero));           // (keeps the 72 tile-invariant fragment addresses out of registers)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int toff = (t / 3) * kD64HaloW + (t % 3) + zero;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) {
+                    const int hr = hbase[ni] + toff;
+                    const char* px = lds + hr * 256;
+                    const bf16x8_t bh = *(const bf16x8_t*)(px + (((kk * 4 + fg) ^ (hr & 15)) << 4));
+                    const bf16x8_t bl = *(const bf16x8_t*)(px + (((8 + kk * 4 + fg) ^ (hr & 15)) << 4));
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) {
+                        acc[m][ni] = mfma16<F16>(wlo[t][kk][m], bh, acc[m][ni]);
+                        acc[m][ni] = mfma16<F16>(whi[t][kk][m], bl, acc[m][ni]);
+                        acc[m][ni] = mfma16<F16>(whi[t][kk][m], bh, acc[m][ni]);
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+
+        // ---- epilogue: lane holds channels wc*32 + fg*8 .. +7 of pixel (wp*4 + ni, frow); hi at [c], lo at [64 + c]
+        const int n = tile / tiles_per_patch;
+        const int rem = tile - n * tiles_per_patch;
+        const int ty = rem / tiles_x, tx = rem - ty * tiles_x;
+        const int c0 = wc * 32 + fg * 8;
+        float sc[8], sh[8];
+        *(float4*)&sc[0] = *(const float4*)(cst + c0);
+        *(float4*)&sc[4] = *(const float4*)(cst + c0 + 4);
+        *(float4*)&sh[0] = *(const float4*)(cst + 64 + c0);
+        *(float4*)&sh[4] = *(const float4*)(cst + 64 + c0 + 4);
+        const int ox = tx * 16 + frow;
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+            const int oy = ty * 8 + wp * 4 + ni;
+            float y[8];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                y[q] = acc[0][ni][q] * sc[q] + sh[q];
+                y[4 + q] = acc[1][ni][q] * sc[4 + q] + sh[4 + q];
+            }
+            if (p.relu) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) y[q] = fmaxf(y[q], 0.f);
+            }
+            if (oy < p.H && ox < p.W)
+                store_split8((uint16_t*)p.out + (((size_t)n * p.H + oy) * p.W + ox) * 128 + c0, 64, y);
+        }
+    }
+}
+
 hipError_t launch_direct64(const Direct64Params& p, int precision, int num_cus, hipStream_t s)
 {
     const int n_tiles = p.n * ((p.H + 7) / 8) * ((p.W + 15) / 16);
     const int grid = n_tiles < 2 * num_cus ? n_tiles : 2 * num_cus;
+    if (precision == kF16X3) {
+        static bool attr_done[64] = {};
+        int dev = 0;
+        hipError_t e = hipGetDevice(&dev);
+        if (e != hipSuccess) return e;
+        if (!attr_done[dev & 63]) {
+            e = hipFuncSetAttribute((const void*)conv3x3_c64_direct_x3, hipFuncAttributeMaxDynamicSharedMemorySize, kD64x3LdsBytes);
+            if (e != hipSuccess) return e;
+            attr_done[dev & 63] = true;
+        }
+        hipLaunchKernelGGL(conv3x3_c64_direct_x3, dim3(n_tiles < num_cus ? n_tiles : num_cus), dim3(256), kD64x3LdsBytes, s, p);
+        return hipGetLastError();
+    }
     if (precision == kF16) hipLaunchKernelGGL(conv3x3_c64_direct<true>, dim3(grid), dim3(256), kD64LdsBytes, s, p);
     else hipLaunchKernelGGL(conv3x3_c64_direct<false>, dim3(grid), dim3(256), kD64LdsBytes, s, p);
     return hipGetLastError();
