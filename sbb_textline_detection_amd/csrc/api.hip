@@ -1255,7 +1255,8 @@ static int build_fast_gather_tables(sbbseg_ctx* c)
                         co.d.src[s].pad_top == 0 && co.d.src[s].pad_left == 0 && co.d.src[s].off_y == 0 && co.d.src[s].off_x == 0;
         co.fg_pointwise = pointwise;
         const int min_ksteps = pointwise ? c->fg_pointwise_min_ksteps : c->fg_min_ksteps;
-        if (!co.fg_ok || c->precision == kF32 || co.total_ksteps < min_ksteps || (c->precision == kF16X3 && co.d.cout < 128)) continue;
+        static const bool x3_small = getenv("SBBSEG_FG_X3_SMALL") != nullptr;       // experiment knob: fast gather on the split mode's 64-channel tiles too
+        if (!co.fg_ok || c->precision == kF32 || co.total_ksteps < min_ksteps || (c->precision == kF16X3 && co.d.cout < 128 && !x3_small)) continue;
         bool ok = true;
         for (int s = 0; s < co.d.n_src; ++s)
             ok = ok && co.d.src[s].up_shift == 0 && co.tap_hi[s][0] - co.tap_lo[s][0] <= 3 && co.tap_hi[s][1] - co.tap_lo[s][1] <= 3 &&
