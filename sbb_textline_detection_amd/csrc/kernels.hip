@@ -1,16 +1,21 @@
 // kernels.hip -- gfx950 (MI355X, CDNA4) device code of libsbbseg.
 //
-// Hot kernel: conv_igemm_bf16 -- im2col-free implicit-GEMM convolution on MFMA.
-//   D[channel][pixel] = sum_k W[channel][k] * X[pixel][k]     (v_mfma_f32_16x16x32_bf16, fp32 acc)
-//   * the contraction axis k walks (source, tap, channel) in 16-byte granules described by a small
-//     table (KTabEntry); nearest x2 upsampling, channel concat of two sources, zero padding and
-//     the one_side_pad shift are address arithmetic in the gather -- no tensor is materialised
-//   * operands go HBM/L2 -> LDS with global_load_lds_dwordx4 (per-lane source address = gather,
-//     lane-linear LDS image, XOR-swizzled through the *source* granule choice), double buffered
-//   * MFMA "A" operand = weights, "B" = pixels, so a lane ends up with 4 consecutive channels of
-//     one pixel: the NHWC epilogue store is 8 contiguous bytes per lane, BN scale/shift, residual
-//     add and ReLU are applied in fp32 registers.
-// Everything else here (ingest, max-pool, head, stitch, resize) is HBM-bound byte shuffling.
+// Hot kernel: conv_igemm_mfma -- im2col-free implicit-GEMM convolution on MFMA.
+//   D[channel][pixel] = sum_k W[channel][k] * X[pixel][k]     (v_mfma_f32_16x16x32_{f16,bf16}, fp32 acc)
+//   * the contraction axis k walks (source, channel group, tap) in 16-byte granules; nearest x2 upsampling, channel
+//     concat of two sources, zero padding and the one_side_pad shift are address arithmetic in the gather -- no tensor
+//     is materialised
+//   * operands go HBM/L2 -> LDS with 16-byte LDS-DMA loads (lane-linear LDS image, XOR-swizzled through the *source*
+//     granule choice), double buffered: `buffer_load ... lds` with the tap displacement in the scalar offset and
+//     out-of-bounds taps zero-filled by the hardware (fast gather), or `global_load_lds` with per-lane address
+//     arithmetic (plain gather: irregular K-steps, upsampling sources, short-K layers)
+//   * MFMA "A" operand = weights, "B" = pixels, so a lane ends up with consecutive channels of one pixel: 16-byte NHWC
+//     epilogue stores; BN scale/shift, residual add and ReLU are applied in fp32 registers
+//   * X3 = the split-fp16 (label-exact) mode: hi + lo operands, three MFMAs per product.
+// Direct kernels on LDS halo tiles where an output tile has few channels: stem_conv_pairs, conv3x3_c64_direct(+_x3),
+// dec_tail_fused(+_x3); bottleneck_fused = a whole stage-2 ResNet block per launch.
+// Everything else here (ingest, max-pool, head, stitch, resize, Otsu, morphology, components, deskew profiles) is
+// HBM-bound byte and integer work.
 #include "internal.h"
 
 namespace sbbseg {
