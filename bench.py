@@ -288,6 +288,24 @@ def main():
 
     roofline, per_op = (roofline_of(model) if rank == 0 else (None, []))
 
+    # ---- the same pages starting (and ending) in HOST memory: never `value`, reported beside it -------------------------
+    host_path = None
+    if rank == 0 and world == 1 and workload == "page" and not args.no_second_mode:
+        hp_pages = [page0 if k == 0 else synthetic_page(PAGE_H, PAGE_W, seed=k) for k in range(max(1, args.pages_per_step))]
+        model.ctx.segment_pages(hp_pages[:4])                                  # allocates the pinned staging
+        t0 = time.perf_counter()
+        for _ in range(2):
+            model.ctx.segment_pages(hp_pages)
+        t_pipe = (time.perf_counter() - t0) / 2
+        t0 = time.perf_counter()
+        for p_ in hp_pages:
+            model.ctx.segment_page(p_)
+        t_serial = time.perf_counter() - t0
+        host_path = {"what": "numpy pages in host memory -> numpy label maps in host memory (PCIe both ways inside the time)",
+                     "pipelined_patches_per_s": round(tiles_per_page * len(hp_pages) / t_pipe, 1),
+                     "page_by_page_patches_per_s": round(tiles_per_page * len(hp_pages) / t_serial, 1),
+                     "pages": len(hp_pages), "entry_points": "sbbseg_segment_pages / sbbseg_segment_page"}
+
     # ---- the other arithmetic mode + live label agreement of both modes with the fp32 oracle ------
     modes, label_match, cpu_baseline, cpu_port = None, None, None, None
     if rank == 0 and world == 1:
@@ -394,7 +412,7 @@ def main():
                         "max": round(max(rates), 2), "timed_region_s": [round(t, 3) for t in dts]},
             "patches_per_s_per_gpu": round(value / world, 2),
             "achieved_tflops_end_to_end": round(value / world * 2 * model.plan.macs_per_patch() / 1e12, 1),
-            "roofline": roofline, "cpu_baseline": cpu_baseline, "label_match": label_match, "modes": modes, "exchange": exchange,
+            "roofline": roofline, "cpu_baseline": cpu_baseline, "label_match": label_match, "modes": modes, "exchange": exchange, "host_path": host_path,
         }
         print(json.dumps(out))
         if os.environ.get("SBBSEG_BENCH_OPS"):

@@ -175,6 +175,12 @@ int sbbseg_predict(sbbseg_ctx* c, const float* x_nhwc, int n, float* probs_nhwc)
  * forward, argmax, margin-crop + last-writer-wins stitch.  page: uint8 [Hp][Wp][3];
  * labels: uint8 [Hp][Wp] (the reference returns this plane replicated x3). */
 int sbbseg_segment_page(sbbseg_ctx* c, const uint8_t* page_hwc, int Hp, int Wp, uint8_t* labels_hw);
+/* do_prediction(patches=True) for n_pages HOST pages of one size (uint8 [Hp][Wp][3] each; pages_hwc / labels_hw are arrays of
+ * n_pages pointers; labels as in sbbseg_segment_page, x3 with sbbseg_set_label_channels(3)).  Pipelined in groups of as many
+ * pages as fill a chunk: while one group runs, the next is staged into pinned memory and uploaded on a copy stream and the
+ * previous group's label planes come back on another -- page-at-a-time callers (main.py:490-503 per page) pay the PCIe
+ * copies serially.  Results equal n_pages sbbseg_segment_page calls. */
+int sbbseg_segment_pages(sbbseg_ctx* c, int n_pages, const uint8_t* const* pages_hwc, int Hp, int Wp, uint8_t* const* labels_hw);
 /* Many equally sized pages in one call (the reference walks them one by one: ocrd_cli.py:51 -> main.py:2056 per page): their
  * tiles are pooled into chunks of up to max_batch tiles, so launches stay large when a page has few tiles (a 3500x2500 page has
  * 70; the persistent conv grids want a few hundred).  d_pages_hwc / d_labels_hw: HOST arrays of n_pages DEVICE pointers

@@ -29,6 +29,7 @@ EXPORTS = [
     "sbbseg_debug_set_conv_variant", "sbbseg_debug_inject_alloc_failure",
     "sbbseg_morph_dev", "sbbseg_morph", "sbbseg_page_box_dev", "sbbseg_extract_page_box",
     "sbbseg_deskew_side", "sbbseg_rotation_matrix", "sbbseg_deskew_profiles_dev", "sbbseg_deskew_profiles",
+    "sbbseg_segment_pages",
     "sbbseg_profile_enable", "sbbseg_profile_reset", "sbbseg_profile_get",
 ]
 
@@ -109,6 +110,7 @@ def load_library(path: Optional[str] = None):
         "sbbseg_morph": [vp, vp, i32, i32, i32, i32, i32, vp],
         "sbbseg_page_box_dev": [vp, vp, i32, i32, vp, C.POINTER(C.c_int64)],
         "sbbseg_extract_page_box": [vp, vp, i32, i32, i32, i32, vp, vp, C.POINTER(C.c_int64)],
+        "sbbseg_segment_pages": [vp, i32, vp, i32, i32, vp],
         "sbbseg_deskew_side": [i32, i32, C.POINTER(C.c_int)],
         "sbbseg_rotation_matrix": [C.c_double, C.c_double, C.c_double, vp],
         "sbbseg_deskew_profiles_dev": [vp, vp, i32, i32, vp, vp, i32, vp],
@@ -409,6 +411,20 @@ class Context:
         check(self.lib.sbbseg_extract_page_box(self.h, _ptr(page), page.shape[0], page.shape[1], scaled_h, scaled_w, _ptr(mask), _ptr(box),
                                                C.byref(px)), "sbbseg_extract_page_box")
         return mask, tuple(int(v) for v in box), int(px.value)
+
+    def segment_pages(self, pages, channels: int = 1):
+        """do_prediction(patches=True) for a list of HOST pages of one size, upload / compute / download pipelined:
+        list of uint8 label maps ([Hp][Wp], or [Hp][Wp][3] with channels=3)."""
+        pages = [np.ascontiguousarray(p_, np.uint8) for p_ in pages]
+        Hp, Wp = pages[0].shape[:2]
+        if any(p_.shape != (Hp, Wp, 3) for p_ in pages):
+            raise ValueError("segment_pages: all pages must be uint8 [Hp][Wp][3] of one size")
+        outs = [self._label_out(Hp, Wp, channels) for _ in pages]
+        n = len(pages)
+        pin = (C.c_void_p * n)(*[p_.ctypes.data for p_ in pages])
+        pout = (C.c_void_p * n)(*[o.ctypes.data for o in outs])
+        check(self.lib.sbbseg_segment_pages(self.h, n, pin, Hp, Wp, pout), "sbbseg_segment_pages")
+        return outs
 
     def deskew_profiles(self, mask: np.ndarray, angles_deg=None, matrices=None) -> np.ndarray:
         """Rotate-and-project of the deskew search: int32 [n_angles][side] row counts of the rotated, binarised region mask."""

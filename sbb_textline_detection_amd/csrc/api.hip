@@ -199,6 +199,12 @@ struct sbbseg_ctx {
     int *d_map = nullptr; size_t map_cap = 0;
     // stage glue scratch (morphology planes, union-find arrays, result words)
     uint8_t *d_morph_a = nullptr, *d_morph_b = nullptr; size_t morph_a_cap = 0, morph_b_cap = 0;
+    // pipelined multi-page host path (sbbseg_segment_pages): copy streams, two slots of pinned staging + device buffers
+    hipStream_t copy_in = nullptr, copy_out = nullptr;
+    hipEvent_t pp_in[2] = {nullptr, nullptr}, pp_comp[2] = {nullptr, nullptr}, pp_out[2] = {nullptr, nullptr};
+    uint8_t *pp_h_in[2] = {nullptr, nullptr}, *pp_h_out[2] = {nullptr, nullptr}, *pp_d_in[2] = {nullptr, nullptr}, *pp_d_out[2] = {nullptr, nullptr},
+            *pp_d_out3[2] = {nullptr, nullptr};
+    size_t pp_in_cap = 0, pp_out_cap = 0, pp_out3_cap = 0;
     void* d_deskew = nullptr; size_t deskew_cap = 0;      // inverse maps | bicubic table | row counts of sbbseg_deskew_profiles
     int *d_cc_parent = nullptr, *d_cc_count = nullptr; size_t cc_parent_cap = 0, cc_count_cap = 0;
     unsigned long long* d_cc_small = nullptr;      // [0] best key, [1..2] box (4 ints)
@@ -596,6 +602,15 @@ int sbbseg_destroy(sbbseg_ctx* c)
     (void)hipFree(c->d_page); (void)hipFree(c->d_page_labels); (void)hipFree(c->d_page_labels3); (void)hipFree(c->d_tile_labels);
     (void)hipFree(c->d_own_x); (void)hipFree(c->d_own_y); (void)hipFree(c->d_map);
     (void)hipFree(c->d_deskew);
+    for (int k = 0; k < 2; ++k) {
+        (void)hipHostFree(c->pp_h_in[k]); (void)hipHostFree(c->pp_h_out[k]);
+        (void)hipFree(c->pp_d_in[k]); (void)hipFree(c->pp_d_out[k]); (void)hipFree(c->pp_d_out3[k]);
+        if (c->pp_in[k]) (void)hipEventDestroy(c->pp_in[k]);
+        if (c->pp_comp[k]) (void)hipEventDestroy(c->pp_comp[k]);
+        if (c->pp_out[k]) (void)hipEventDestroy(c->pp_out[k]);
+    }
+    if (c->copy_in) (void)hipStreamDestroy(c->copy_in);
+    if (c->copy_out) (void)hipStreamDestroy(c->copy_out);
     (void)hipFree(c->d_morph_a); (void)hipFree(c->d_morph_b); (void)hipFree(c->d_cc_parent); (void)hipFree(c->d_cc_count); (void)hipFree(c->d_cc_small);
     for (auto& pe : c->pending) { (void)hipEventDestroy(pe.a); (void)hipEventDestroy(pe.b); }
     for (auto e : c->free_events) (void)hipEventDestroy(e);
@@ -1666,6 +1681,102 @@ int sbbseg_segment_pages_dev(sbbseg_ctx* c, int n_pages, const void* const* d_pa
     if (tile_range_impl(c, d_pages_hwc, n_pages, Hp, Wp, nullptr, nullptr, Hp, Wp, 0, (int)(tpp * n_pages), c->d_tile_labels)) return 1;
     for (int k = 0; k < n_pages; ++k)
         if (sbbseg_stitch_dev(c, c->d_tile_labels + (size_t)k * tpp * per, Hp, Wp, d_labels_hw[k])) return 1;
+    return 0;
+    API_END
+}
+
+// do_prediction(patches=True) for several HOST pages of one size, pipelined in groups of as many pages as fill a chunk:
+// while group g runs on the handle's stream, the caller's thread stages group g+1 into pinned memory and starts its upload on
+// a copy stream, and the label planes of group g-1 come back on another.  Results equal n_pages sbbseg_segment_page calls.
+int sbbseg_segment_pages(sbbseg_ctx* c, int n_pages, const uint8_t* const* pages_hwc, int Hp, int Wp, uint8_t* const* labels_hw)
+{
+    API_BEGIN
+    if (check_ready(c)) return 1;
+    REQUIRE(n_pages >= 1 && pages_hwc && labels_hw, "bad arguments");
+    for (int k = 0; k < n_pages; ++k) REQUIRE(pages_hwc[k] && labels_hw[k], "null page / label pointer (page %d)", k);
+    REQUIRE(Hp >= c->in_H && Wp >= c->in_W, "page %dx%d is smaller than the model input %dx%d (unsupported by the reference too, main.py:278-281)", Hp, Wp, c->in_H, c->in_W);
+    int nx = 0, ny = 0;
+    if (sbbseg_tile_grid(Hp, Wp, c->in_H, c->in_W, nullptr, 0, &nx, &ny)) return 1;
+    const size_t pix = (size_t)Hp * Wp, in_b = pix * 3, ch = c->label_channels == 3 ? 3 : 1, out_b = pix * ch;
+    const size_t out3_b = (pix + 3) / 4 * 12;                          // launch_replicate3 writes whole 12-byte groups
+    int G = c->max_batch / (nx * ny);
+    G = G < 1 ? 1 : (G > n_pages ? n_pages : G);
+    if (!c->copy_in) {
+        HIPCHK(hipStreamCreateWithFlags(&c->copy_in, hipStreamNonBlocking));
+        HIPCHK(hipStreamCreateWithFlags(&c->copy_out, hipStreamNonBlocking));
+        for (int k = 0; k < 2; ++k) {
+            HIPCHK(hipEventCreateWithFlags(&c->pp_in[k], hipEventDisableTiming));
+            HIPCHK(hipEventCreateWithFlags(&c->pp_comp[k], hipEventDisableTiming));
+            HIPCHK(hipEventCreateWithFlags(&c->pp_out[k], hipEventDisableTiming));
+        }
+    }
+    HIPCHK(hipStreamSynchronize(c->stream));                            // (buffers below may be re-allocated)
+    if (c->pp_in_cap < G * in_b) {
+        for (int k = 0; k < 2; ++k) {
+            (void)hipHostFree(c->pp_h_in[k]); (void)hipFree(c->pp_d_in[k]);
+            c->pp_h_in[k] = nullptr; c->pp_d_in[k] = nullptr;
+            HIPCHK(hipHostMalloc((void**)&c->pp_h_in[k], G * in_b, hipHostMallocDefault));
+            if (dmalloc(c, (void**)&c->pp_d_in[k], G * in_b)) return 1;
+        }
+        c->pp_in_cap = G * in_b;
+    }
+    if (c->pp_out_cap < G * out_b) {
+        for (int k = 0; k < 2; ++k) {
+            (void)hipHostFree(c->pp_h_out[k]); (void)hipFree(c->pp_d_out[k]);
+            c->pp_h_out[k] = nullptr; c->pp_d_out[k] = nullptr;
+            HIPCHK(hipHostMalloc((void**)&c->pp_h_out[k], G * out_b, hipHostMallocDefault));
+            if (dmalloc(c, (void**)&c->pp_d_out[k], G * (pix + 4))) return 1;
+        }
+        c->pp_out_cap = G * out_b;
+    }
+    if (ch == 3 && c->pp_out3_cap < G * out3_b) {
+        for (int k = 0; k < 2; ++k) {
+            (void)hipFree(c->pp_d_out3[k]);
+            c->pp_d_out3[k] = nullptr;
+            if (dmalloc(c, (void**)&c->pp_d_out3[k], G * out3_b)) return 1;
+        }
+        c->pp_out3_cap = G * out3_b;
+    }
+    const int n_groups = (n_pages + G - 1) / G;
+    auto group_pages = [&](int g) { return g * G + G <= n_pages ? G : n_pages - g * G; };
+    auto drain = [&](int g) -> int {                                      // labels of group g: staging -> caller
+        const int slot = g & 1;
+        HIPCHK(hipEventSynchronize(c->pp_out[slot]));
+        for (int k = 0; k < group_pages(g); ++k) memcpy(labels_hw[g * G + k], c->pp_h_out[slot] + (size_t)k * out_b, out_b);
+        return 0;
+    };
+    alloc_check();
+    std::vector<const void*> d_pages(G);
+    std::vector<void*> d_labels(G);
+    for (int g = 0; g < n_groups; ++g) {
+        const int slot = g & 1, np = group_pages(g);
+        if (g >= 2 && drain(g - 2)) return 1;                             // frees this slot's staging and device buffers
+        for (int k = 0; k < np; ++k) memcpy(c->pp_h_in[slot] + (size_t)k * in_b, pages_hwc[g * G + k], in_b);
+        HIPCHK(hipMemcpyAsync(c->pp_d_in[slot], c->pp_h_in[slot], (size_t)np * in_b, hipMemcpyHostToDevice, c->copy_in));
+        HIPCHK(hipEventRecord(c->pp_in[slot], c->copy_in));
+        HIPCHK(hipStreamWaitEvent(c->stream, c->pp_in[slot], 0));
+        for (int k = 0; k < np; ++k) {
+            d_pages[k] = c->pp_d_in[slot] + (size_t)k * in_b;
+            d_labels[k] = c->pp_d_out[slot] + (size_t)k * (pix + 4);
+        }
+        if (sbbseg_segment_pages_dev(c, np, d_pages.data(), Hp, Wp, d_labels.data())) return 1;
+        const uint8_t* d_src = c->pp_d_out[slot];
+        size_t d_stride = pix + 4;
+        if (ch == 3) {
+            for (int k = 0; k < np; ++k)
+                HIPCHK(launch_replicate3(c->pp_d_out[slot] + (size_t)k * (pix + 4), c->pp_d_out3[slot] + (size_t)k * out3_b, pix, c->stream));
+            d_src = c->pp_d_out3[slot];
+            d_stride = out3_b;
+        }
+        HIPCHK(hipEventRecord(c->pp_comp[slot], c->stream));
+        HIPCHK(hipStreamWaitEvent(c->copy_out, c->pp_comp[slot], 0));
+        for (int k = 0; k < np; ++k)
+            HIPCHK(hipMemcpyAsync(c->pp_h_out[slot] + (size_t)k * out_b, d_src + (size_t)k * d_stride, out_b, hipMemcpyDeviceToHost, c->copy_out));
+        HIPCHK(hipEventRecord(c->pp_out[slot], c->copy_out));
+    }
+    for (int g = n_groups >= 2 ? n_groups - 2 : 0; g < n_groups; ++g)
+        if (drain(g)) return 1;
+    HIPCHK(hipStreamSynchronize(c->stream));
     return 0;
     API_END
 }

@@ -869,3 +869,26 @@ def test_deskew_golden_vectors(stitch_model):
         m = g[f"mask{k}"]
         assert np.array_equal(stitch_model.ctx.deskew_profiles(m, g["angles"]), g[f"counts{k}"])
         assert stages.return_deskew_slope(m, 1.0, ctx=stitch_model.ctx) == float(g[f"slope{k}"])
+
+
+# ----------------------------------------------------------------------------- pipelined multi-page host path
+@pytest.mark.parametrize("channels", [1, 3])
+def test_segment_pages_host_pipeline_equals_page_by_page(channels):
+    """sbbseg_segment_pages (groups of pages: staging / upload / compute / download overlapped on three streams) returns what
+    page-by-page sbbseg_segment_page calls return (= do_prediction(True, img, model) per page, main.py:231-366) -- with a
+    page count that is not a multiple of the group size, and on a second call that reuses the staging slots."""
+    from sbb_textline_detection_amd.model import SegModel
+    from sbb_textline_detection_amd.synthetic import synthetic_page
+    from tools.synth_model import calibrated_model
+    cfg, w = calibrated_model(2, 224, 224, seed=0)
+    m = SegModel(cfg, w, device=0, max_batch=40, precision="f16")
+    pages = [synthetic_page(500, 640, seed=30 + k) for k in range(7)]      # 12 tiles per page -> groups of 3, 3, 1
+    want = [m.ctx.segment_page(p_, channels=channels) for p_ in pages]
+    for rep in range(2):
+        got = m.ctx.segment_pages(pages if rep == 0 else pages[::-1], channels=channels)
+        ref = want if rep == 0 else want[::-1]
+        assert len(got) == len(ref)
+        for a, b in zip(got, ref):
+            assert a.shape == b.shape and np.array_equal(a, b)
+    assert np.array_equal(m.ctx.segment_pages(pages[:1], channels=channels)[0], want[0])      # a single page (one group)
+    m.release()
