@@ -86,6 +86,17 @@ def do_prediction(patches, img, model, full_image_shape=None, batch_size=None):
     return resize_nearest(seg3, int(shp[0]), int(shp[1])).astype(np.uint8)
 
 
+def do_prediction_pages(imgs, model):
+    """``[do_prediction(True, img, model) for img in imgs]`` for a list of uint8 pages (main.py:490-503 over a batch of pages):
+    same-sized pages go through the library's pipelined multi-page path (``sbbseg_segment_pages``: their tiles share
+    full-sized chunks, and upload / compute / download overlap); anything else falls back to one call per page."""
+    imgs = list(imgs)
+    fused = isinstance(model, SegModel) and all(_is_u8_image(i) for i in imgs)
+    if not fused or len({np.asarray(i).shape for i in imgs}) != 1 or len(imgs) < 2:
+        return [do_prediction(True, i, model) for i in imgs]
+    return model.ctx.segment_pages(imgs, channels=3)
+
+
 class PatchSegmenter:
     """Carrier of the three reference methods that make up the hot path, with their original names
     and signatures, so reference-side code can be pointed here unchanged:

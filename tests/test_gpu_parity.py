@@ -891,4 +891,10 @@ def test_segment_pages_host_pipeline_equals_page_by_page(channels):
         for a, b in zip(got, ref):
             assert a.shape == b.shape and np.array_equal(a, b)
     assert np.array_equal(m.ctx.segment_pages(pages[:1], channels=channels)[0], want[0])      # a single page (one group)
+    if channels == 3:                                       # the seam: a list of pages in, the reference's return layout out
+        from sbb_textline_detection_amd import do_prediction, do_prediction_pages
+        outs = do_prediction_pages(pages[:4], m)
+        assert all(np.array_equal(o, do_prediction(True, p_, m)) for o, p_ in zip(outs, pages[:4]))
+        mixed = do_prediction_pages([pages[0], pages[1][:400]], m)          # different sizes: one call per page
+        assert mixed[1].shape == (400, 640, 3)
     m.release()
