@@ -1436,25 +1436,35 @@ __global__ __launch_bounds__(256, 2) void dec_tail_fused(const TailParams p)
         const int n = tile / tiles_per_patch;
         const int rem = tile - n * tiles_per_patch;
         const int tyy = rem / tiles_x, txx = rem - tyy * tiles_x;
+        // (channel constants are read once per tile -- q outer, the four pixel blocks inner -- not once per pixel block)
+        float lg[4][NC];
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+            for (int c = 0; c < NC; ++c) lg[ni][c] = 0.f;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const float* row = cst + (q * 4 + fg) * CR;
+            const float4 c0 = *(const float4*)row;                                // scale, shift, hw0, hw1
+            float2 c1 = make_float2(0.f, 0.f);
+            if constexpr (NC > 2) c1 = *(const float2*)(row + 4);                 // hw2, hw3
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+                const float v = q < 4 ? acc[0][ni][q] : acc[1][ni][q - 4];
+                const float yq = fmaxf(v * c0.x + c0.y, 0.f);
+                lg[ni][0] = fmaf(yq, c0.z, lg[ni][0]);
+                if constexpr (NC > 1) lg[ni][1] = fmaf(yq, c0.w, lg[ni][1]);
+                if constexpr (NC > 2) {
+                    lg[ni][2] = fmaf(yq, c1.x, lg[ni][2]);
+                    lg[ni][3] = fmaf(yq, c1.y, lg[ni][3]);
+                }
+            }
+        }
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) {
             float logit[NC];
 #pragma unroll
-            for (int c = 0; c < NC; ++c) logit[c] = 0.f;
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const float* row = cst + (q * 4 + fg) * CR;
-                const float4 c0 = *(const float4*)row;                            // scale, shift, hw0, hw1
-                const float v = q < 4 ? acc[0][ni][q] : acc[1][ni][q - 4];
-                const float yq = fmaxf(v * c0.x + c0.y, 0.f);
-                logit[0] = fmaf(yq, c0.z, logit[0]);
-                if constexpr (NC > 1) logit[1] = fmaf(yq, c0.w, logit[1]);
-                if constexpr (NC > 2) {
-                    const float2 c1 = *(const float2*)(row + 4);                  // hw2, hw3
-                    logit[2] = fmaf(yq, c1.x, logit[2]);
-                    logit[3] = fmaf(yq, c1.y, logit[3]);
-                }
-            }
+            for (int c = 0; c < NC; ++c) logit[c] = lg[ni][c];
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
                 float a = logit[c];
@@ -1662,25 +1672,35 @@ __global__ __launch_bounds__(256, 1) void dec_tail_fused_x3(const TailParams p)
         const int n = tile / tiles_per_patch;
         const int rem = tile - n * tiles_per_patch;
         const int tyy = rem / tiles_x, txx = rem - tyy * tiles_x;
+        // (channel constants are read once per tile -- q outer, the four pixel blocks inner -- not once per pixel block)
+        float lg[4][NC];
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+            for (int c = 0; c < NC; ++c) lg[ni][c] = 0.f;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const float* row = cst + (q * 4 + fg) * CR;
+            const float4 c0 = *(const float4*)row;                                // scale, shift, hw0, hw1
+            float2 c1 = make_float2(0.f, 0.f);
+            if constexpr (NC > 2) c1 = *(const float2*)(row + 4);                 // hw2, hw3
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+                const float v = q < 4 ? acc[0][ni][q] : acc[1][ni][q - 4];
+                const float yq = fmaxf(v * c0.x + c0.y, 0.f);
+                lg[ni][0] = fmaf(yq, c0.z, lg[ni][0]);
+                if constexpr (NC > 1) lg[ni][1] = fmaf(yq, c0.w, lg[ni][1]);
+                if constexpr (NC > 2) {
+                    lg[ni][2] = fmaf(yq, c1.x, lg[ni][2]);
+                    lg[ni][3] = fmaf(yq, c1.y, lg[ni][3]);
+                }
+            }
+        }
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) {
             float logit[NC];
 #pragma unroll
-            for (int c = 0; c < NC; ++c) logit[c] = 0.f;
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const float* row = cst + (q * 4 + fg) * CR;
-                const float4 c0 = *(const float4*)row;
-                const float v = q < 4 ? acc[0][ni][q] : acc[1][ni][q - 4];
-                const float yq = fmaxf(v * c0.x + c0.y, 0.f);
-                logit[0] = fmaf(yq, c0.z, logit[0]);
-                if constexpr (NC > 1) logit[1] = fmaf(yq, c0.w, logit[1]);
-                if constexpr (NC > 2) {
-                    const float2 c1 = *(const float2*)(row + 4);
-                    logit[2] = fmaf(yq, c1.x, logit[2]);
-                    logit[3] = fmaf(yq, c1.y, logit[3]);
-                }
-            }
+            for (int c = 0; c < NC; ++c) logit[c] = lg[ni][c];
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
                 float a = logit[c];
