@@ -125,25 +125,25 @@ def row_profiles(img_patch: np.ndarray, angles) -> np.ndarray:
 
 
 def profile_statistics(y: np.ndarray, sigma: float, multiplier: float = 3.8):
-    """main.py:1545-1599 on an already summed row profile y: (z values at the deep minima, std of the smoothed profile)."""
+    """main.py:1545-1599 on an already summed row profile y: (smoothed values at the deep minima, std of the smoothed profile).
+
+    The reference pads the profile by 10 zeros on each side, mirrors it about its maximum, pads THAT by 10 more, smooths both
+    the profile and the mirrored one with the same Gaussian, takes the maxima of each with scipy's find_peaks(height=0),
+    shifts the mirrored maxima back by 20 and keeps those whose smoothed value lies below
+    mean(maxima above 10) * (1 - 1/multiplier)."""
     y = np.asarray(y, np.float64)
-    y_help = np.zeros(len(y) + 20)
-    y_help[10:len(y) + 10] = y
-    zneg_rev = -y_help + np.max(y_help)
-    zneg = np.zeros(len(zneg_rev) + 20)
-    zneg[10:len(zneg_rev) + 10] = zneg_rev
-    z = gaussian_filter1d(y, sigma)
-    zneg = gaussian_filter1d(zneg, sigma)
-    peaks_neg, _ = find_peaks(zneg, height=0)
-    peaks, _ = find_peaks(z, height=0)
-    peaks_neg = peaks_neg - 10 - 10
-    interest_pos = z[peaks]
-    interest_pos = interest_pos[interest_pos > 10]
-    interest_neg = z[peaks_neg]                       # (negative indices wrap, an index >= len(z) raises -- as in the reference)
+    padded = np.concatenate([np.zeros(10), y, np.zeros(10)])
+    mirrored = np.concatenate([np.zeros(10), padded.max() - padded, np.zeros(10)])
+    smooth = gaussian_filter1d(y, sigma)
+    valleys = find_peaks(gaussian_filter1d(mirrored, sigma), height=0)[0] - 20
+    hills = find_peaks(smooth, height=0)[0]
+    hill_values = smooth[hills]
+    hill_values = hill_values[hill_values > 10]
+    valley_values = smooth[valleys]                   # (negative indices wrap, an index >= len(y) raises -- as in the reference)
     with np.errstate(all="ignore"):
-        min_peaks_pos = np.mean(interest_pos) if interest_pos.size else np.float64("nan")
-    grenze = min_peaks_pos - (min_peaks_pos - 0) / multiplier
-    return interest_neg[interest_neg < grenze], np.std(z)
+        level = np.mean(hill_values) if hill_values.size else np.float64("nan")
+    limit = level - (level - 0) / multiplier
+    return valley_values[valley_values < limit], np.std(smooth)
 
 
 def _sweep(sq_profiles: np.ndarray, angles: np.ndarray, sigma: float) -> float:
