@@ -898,3 +898,32 @@ def test_segment_pages_host_pipeline_equals_page_by_page(channels):
         mixed = do_prediction_pages([pages[0], pages[1][:400]], m)          # different sizes: one call per page
         assert mixed[1].shape == (400, 640, 3)
     m.release()
+
+
+# ----------------------------------------------------------------------------- full-size properties (BASELINE configs[1])
+def test_full_size_pages_do_not_depend_on_chunking():
+    """Three 3500x2500 pages (210 tiles of 448x448, BASELINE configs[1]) through the pooled path: the label maps are the same
+    bytes whether the tiles run as 280-tile chunks on two lanes, as 70-tile chunks, or page by page; running twice changes
+    nothing; and every page equals its own single-page call (a patch's result does not depend on its batch neighbours)."""
+    import torch
+    from sbb_textline_detection_amd.model import SegModel
+    from sbb_textline_detection_amd.synthetic import synthetic_page
+    from tools.synth_model import calibrated_model
+    cfg, w = calibrated_model(2, 448, 448, seed=0)
+    pages = [torch.from_numpy(synthetic_page(3500, 2500, seed=70 + k)).cuda() for k in range(3)]
+    crcs = {}
+    for mb in (280, 70):
+        m = SegModel(cfg, w, device=0, max_batch=mb, precision="f16")
+        outs = [torch.empty((3500, 2500), dtype=torch.uint8, device="cuda") for _ in pages]
+        for rep in range(2):
+            m.ctx.segment_pages_dev([p_.data_ptr() for p_ in pages], 3500, 2500, [o.data_ptr() for o in outs])
+            torch.cuda.synchronize()
+            crcs[(mb, rep)] = tuple(zlib.crc32(o.cpu().numpy().tobytes()) for o in outs)
+        single = torch.empty((3500, 2500), dtype=torch.uint8, device="cuda")
+        m.ctx.segment_page_dev(pages[1].data_ptr(), 3500, 2500, single.data_ptr())
+        torch.cuda.synchronize()
+        assert zlib.crc32(single.cpu().numpy().tobytes()) == crcs[(mb, 0)][1]
+        hist = np.bincount(outs[0].cpu().numpy().reshape(-1), minlength=2)
+        assert hist[0] > 0 and hist[1] > 0                      # a non-trivial label map
+        m.release()
+    assert len(set(crcs.values())) == 1, crcs
