@@ -1951,9 +1951,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_direct(const Direct64Param
     const int tiles_x = (p.W + 15) / 16, tiles_y = (p.H + 7) / 8;
     const int tiles_per_patch = tiles_x * tiles_y;
     const int n_tiles = p.n * tiles_per_patch;
-    const int G = gridDim.x;
-    const int my_tiles = (n_tiles - (int)blockIdx.x + G - 1) / G;
+    // XCD-contiguous walk (grid = a multiple of 8 blocks), as in the tail kernels
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, GX = gridDim.x >> 3;
+    const int per_xcd = (n_tiles + 7) >> 3;
+    const int xcd_lo = xcd * per_xcd, xcd_hi = min(n_tiles, xcd_lo + per_xcd);
+    const int my_tiles = xcd_lo + slot < xcd_hi ? (xcd_hi - xcd_lo - slot + GX - 1) / GX : 0;
     if (my_tiles <= 0) return;
+    auto tile_at = [&](int it) __attribute__((always_inline)) -> int { return xcd_lo + slot + it * GX; };
     float* cst = (float*)(smem + 2 * kD64BufBytes);
     if (tid < 64) { cst[tid] = p.scale[tid]; cst[64 + tid] = p.shift[tid]; }
 
@@ -1994,16 +1998,16 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_direct(const Direct64Param
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni) hbase[ni] = (wp * 4 + ni) * kD64HaloW + frow;
 
-    issue_tile(blockIdx.x, 0);
+    issue_tile(tile_at(0), 0);
     bool prev_full = false;
     for (int it = 0; it < my_tiles; ++it) {
-        const int tile = blockIdx.x + it * G;
+        const int tile = tile_at(it);
         // the halo copies of tile `it` are older than the previous tile's stores (4 per wave when that tile
         // was full): leave those in flight
         if (prev_full) wait_vmcnt<4>();
         else wait_vmcnt<0>();
         __syncthreads();
-        if (it + 1 < my_tiles) issue_tile(tile + G, (it + 1) & 1);
+        if (it + 1 < my_tiles) issue_tile(tile_at(it + 1), (it + 1) & 1);
 
         const char* lds = smem + (it & 1) * kD64BufBytes;
         f32x4_t acc[2][4];
@@ -2086,9 +2090,13 @@ __global__ __launch_bounds__(256, 1) void conv3x3_c64_direct_x3(const Direct64Pa
     const int tiles_x = (p.W + 15) / 16, tiles_y = (p.H + 7) / 8;
     const int tiles_per_patch = tiles_x * tiles_y;
     const int n_tiles = p.n * tiles_per_patch;
-    const int G = gridDim.x;
-    const int my_tiles = (n_tiles - (int)blockIdx.x + G - 1) / G;
+    // XCD-contiguous walk (grid = a multiple of 8 blocks), as in the tail kernels
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, GX = gridDim.x >> 3;
+    const int per_xcd = (n_tiles + 7) >> 3;
+    const int xcd_lo = xcd * per_xcd, xcd_hi = min(n_tiles, xcd_lo + per_xcd);
+    const int my_tiles = xcd_lo + slot < xcd_hi ? (xcd_hi - xcd_lo - slot + GX - 1) / GX : 0;
     if (my_tiles <= 0) return;
+    auto tile_at = [&](int it) __attribute__((always_inline)) -> int { return xcd_lo + slot + it * GX; };
     float* cst = (float*)(smem + 2 * kD64x3BufBytes);
     if (tid < 64) { cst[tid] = p.scale[tid] * p.wmul; cst[64 + tid] = p.shift[tid]; }
 
@@ -2130,12 +2138,12 @@ __global__ __launch_bounds__(256, 1) void conv3x3_c64_direct_x3(const Direct64Pa
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni) hbase[ni] = (wp * 4 + ni) * kD64HaloW + frow;
 
-    issue_tile(blockIdx.x, 0);
+    issue_tile(tile_at(0), 0);
     for (int it = 0; it < my_tiles; ++it) {
-        const int tile = blockIdx.x + it * G;
+        const int tile = tile_at(it);
         wait_vmcnt<0>();
         __syncthreads();
-        if (it + 1 < my_tiles) issue_tile(tile + G, (it + 1) & 1);
+        if (it + 1 < my_tiles) issue_tile(tile_at(it + 1), (it + 1) & 1);
 
         const char* lds = smem + (it & 1) * kD64x3BufBytes;
         f32x4_t acc[2][4];
@@ -2200,7 +2208,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_c64_direct_x3(const Direct64Pa
 hipError_t launch_direct64(const Direct64Params& p, int precision, int num_cus, hipStream_t s)
 {
     const int n_tiles = p.n * ((p.H + 7) / 8) * ((p.W + 15) / 16);
-    const int grid = n_tiles < 2 * num_cus ? n_tiles : 2 * num_cus;
+    const int grid = ((n_tiles < 2 * num_cus ? n_tiles : 2 * num_cus) + 7) & ~7;      // (XCD-contiguous walk: a multiple of 8)
     if (precision == kF16X3) {
         static bool attr_done[64] = {};
         int dev = 0;
@@ -2211,7 +2219,7 @@ hipError_t launch_direct64(const Direct64Params& p, int precision, int num_cus, 
             if (e != hipSuccess) return e;
             attr_done[dev & 63] = true;
         }
-        hipLaunchKernelGGL(conv3x3_c64_direct_x3, dim3(n_tiles < num_cus ? n_tiles : num_cus), dim3(256), kD64x3LdsBytes, s, p);
+        hipLaunchKernelGGL(conv3x3_c64_direct_x3, dim3(((n_tiles < num_cus ? n_tiles : num_cus) + 7) & ~7), dim3(256), kD64x3LdsBytes, s, p);
         return hipGetLastError();
     }
     if (precision == kF16) hipLaunchKernelGGL(conv3x3_c64_direct<true>, dim3(grid), dim3(256), kD64LdsBytes, s, p);
