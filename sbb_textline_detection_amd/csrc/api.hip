@@ -404,7 +404,7 @@ int launch_op(sbbseg_ctx* c, Op& op, int n, uint8_t* d_labels, float* d_probs)
                 const Tensor& st = c->tensors[co.d.src[0].tensor];
                 StemParams sp;
                 sp.pairs = st.buf; sp.PHt = st.H; sp.PWt = st.W; sp.n = n; sp.Ho = co.Ho; sp.Wo = co.Wo;
-                sp.wfrag = co.d_stem_wfrag; sp.scale = co.d_scale; sp.shift = co.d_shift; sp.relu = co.d.relu;
+                sp.wfrag = co.d_stem_wfrag; sp.scale = co.d_scale; sp.shift = co.d_shift; sp.relu = co.d.relu; sp.wmul = co.wmul_cls[0];
                 sp.out = c->tensors[co.d.out_tensor].data();
                 HIPCHK(launch_stem(sp, c->precision, c->num_cus, c->stream));
             } else if (co.d_d64_wfrag && !(c->conv_variant & 3)) {
@@ -984,13 +984,14 @@ int sbbseg_add_conv(sbbseg_ctx* c, const sbbseg_conv_desc* d, const float* w_src
         const Tensor& st = c->tensors[cs.tensor];
         const char* env = getenv("SBBSEG_STEM_KERNEL");
         const bool plain16 = c->precision == kF16 || c->precision == kBF16;     // the dedicated kernels read the one-plane layout
-        if (plain16 && !(env && env[0] == '0') && d->n_src == 1 && st.is_input_form && st.form == SBBSEG_INPUT_PAIRS &&
+        if ((plain16 || split) && !(env && env[0] == '0') && d->n_src == 1 && st.is_input_form && st.form == SBBSEG_INPUT_PAIRS &&
             cs.channels == 8 && cs.kh == 7 && cs.kw == 4 && cs.stride_y == 2 && cs.stride_x == 1 && cs.pad_top == 0 && cs.pad_left == 0 &&
             cs.up_shift == 0 && cs.off_y == 0 && cs.off_x == 0 && d->cout == 64 && d->out_h % 16 == 0 && d->out_w % 16 == 0 &&
             st.H >= 2 * d->out_h + 5 && st.W >= d->out_w + 3 &&
             d->residual_tensor < 0 && d->raw_out_tensor < 0 && d->head_classes == 0 && d->out_tensor >= 0 && d->out_stride_y == 1 &&
             d->out_stride_x == 1 && d->out_off_y == 0 && d->out_off_x == 0 && TH == d->out_h && TW == d->out_w) {
-            std::vector<uint16_t> frag((size_t)7 * 4 * 64 * 8);
+            const size_t ssz = (size_t)7 * 4 * 64 * 8;
+            std::vector<uint16_t> frag(ssz * (split ? 2 : 1));
             for (int ky = 0; ky < 7; ++ky)
                 for (int mi = 0; mi < 4; ++mi)
                     for (int l = 0; l < 64; ++l) {
@@ -998,7 +999,15 @@ int sbbseg_add_conv(sbbseg_ctx* c, const sbbseg_conv_desc* d, const float* w_src
                         const int g = l >> 4;                                   // two-pixel granule = kernel column pair
                         for (int e = 0; e < 8; ++e) {
                             const float v = w_src0[(((size_t)ky * 4 + g) * 8 + e) * 64 + o];
-                            frag[((((size_t)ky * 4 + mi) * 64) + l) * 8 + e] = c->precision == kF16 ? f32_to_f16_rne(v) : f32_to_bf16_rne(v);
+                            const size_t at = ((((size_t)ky * 4 + mi) * 64) + l) * 8 + e;
+                            if (split) {                     // hi | lo of the pre-scaled weight (the conv's wpre, see above)
+                                const float sv = v * wpre;
+                                const uint16_t hb = f32_to_f16_rne(sv);
+                                frag[at] = hb;
+                                frag[ssz + at] = f32_to_f16_rne(sv - (float)__builtin_bit_cast(_Float16, hb));
+                            } else {
+                                frag[at] = c->precision == kF16 ? f32_to_f16_rne(v) : f32_to_bf16_rne(v);
+                            }
                         }
                     }
             if (upload(c, &co.d_stem_wfrag, frag.data(), frag.size())) return 1;

@@ -129,9 +129,11 @@ struct StemParams {
     int n;                    // patches
     int Ho, Wo;               // output size, multiples of 16
     const void* wfrag;        // [7 ky][4 mi][64 lanes] x 16 bytes, MFMA A-fragment order, rows = conv_row_channel
+                              // (split mode: that block twice -- hi fragments, then lo fragments of the pre-scaled weights)
     const float* scale;       // [64]
     const float* shift;
     int relu;
+    float wmul;               // multiplier of `scale` (split mode: 2^-s of the weight pre-scale; else 1)
     void* out;                // data pointer [n][Ho][Wo][64]
 };
 

@@ -1916,10 +1916,129 @@ __global__ __launch_bounds__(256, 2) void stem_conv_pairs(const StemParams p)
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// stem_conv_pairs_x3 -- the stem in the split mode (kF16X3): a PAIRS granule is 32 bytes ([2 px x 4 ch] hi, then lo); the
+// halo tile is kept as two LDS images (hi, lo) with the plain kernel's conflict-free slot layout; hi + lo weight fragments
+// in 224 VGPRs (one block per CU), three MFMAs per product, outputs split again ([64 hi][64 lo] per pixel).
+// ------------------------------------------------------------------------------------------------
+constexpr int kStemX3BufBytes = 2 * kStemBufBytes;      // hi image | lo image
+constexpr int kStemX3LdsBytes = 2 * kStemX3BufBytes + 512;
+
+__global__ __launch_bounds__(256, 1) void stem_conv_pairs_x3(const StemParams p)
+{
+    constexpr bool F16 = true;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int frow = lane & 15, fg = lane >> 4;
+    const int tiles_x = p.Wo / 16, tiles_y = p.Ho / 16;
+    const int tiles_per_patch = tiles_x * tiles_y;
+    const int n_tiles = p.n * tiles_per_patch;
+    const int G = gridDim.x;
+    const int my_tiles = (n_tiles - (int)blockIdx.x + G - 1) / G;
+    if (my_tiles <= 0) return;
+    float* cst = (float*)(smem + 2 * kStemX3BufBytes);
+    if (tid < 64) { cst[tid] = p.scale[tid] * p.wmul; cst[64 + tid] = p.shift[tid]; }
+    bf16x8_t whi[7][4], wlo[7][4];                      // wfrag = [hi | lo][7 ky][4 mi][64 lanes]
+    {
+        const uint4* src = (const uint4*)p.wfrag + lane;
+#pragma unroll
+        for (int ky = 0; ky < 7; ++ky)
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) {
+                whi[ky][mi] = __builtin_bit_cast(bf16x8_t, src[(size_t)(ky * 4 + mi) * 64]);
+                wlo[ky][mi] = __builtin_bit_cast(bf16x8_t, src[(size_t)(28 + ky * 4 + mi) * 64]);
+            }
+    }
+
+    auto issue_tile = [&](int tile, int buf) __attribute__((always_inline)) {
+        const int n = tile / tiles_per_patch;
+        const int rem = tile - n * tiles_per_patch;
+        const int ty = rem / tiles_x, tx = rem - ty * tiles_x;
+        char* lds = smem + buf * kStemX3BufBytes;
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+            for (int j = 0; j < kStemInstr / 4; ++j) {
+                const int ii = wave + 4 * j;
+                const int slot = ii * 64 + lane;
+                const int r = slot / kStemRowSlots, cc = slot - r * kStemRowSlots;
+                const int Y = 32 * ty + r, X = 16 * tx + cc;
+                uint32_t off = (uint32_t)((n * p.PHt + Y) * p.PWt + X) * 32u + (uint32_t)(pl * 16 + kZeroHeaderBytes);
+                off = r < kStemRows ? off : 0u;
+                __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(p.pairs + off), (LDS_AS void*)(lds + pl * kStemBufBytes + ii * 1024), 16, 0, 0);
+            }
+    };
+
+    issue_tile(blockIdx.x, 0);
+    for (int it = 0; it < my_tiles; ++it) {
+        const int tile = blockIdx.x + it * G;
+        wait_vmcnt<0>();
+        __syncthreads();
+        if (it + 1 < my_tiles) issue_tile(tile + G, (it + 1) & 1);
+
+        const char* lds = smem + (it & 1) * kStemX3BufBytes;
+        f32x4_t acc[4][4];
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ky = 0; ky < 7; ++ky) {
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+                const int row = 2 * (wave * 4 + ni) + ky;
+                const int at = (row * kStemRowSlots + frow + fg) * 16;
+                const bf16x8_t bh = *(const bf16x8_t*)(lds + at);
+                const bf16x8_t bl = *(const bf16x8_t*)(lds + kStemBufBytes + at);
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi) {
+                    acc[mi][ni] = mfma16<F16>(wlo[ky][mi], bh, acc[mi][ni]);
+                    acc[mi][ni] = mfma16<F16>(whi[ky][mi], bl, acc[mi][ni]);
+                    acc[mi][ni] = mfma16<F16>(whi[ky][mi], bh, acc[mi][ni]);
+                }
+            }
+        }
+
+        const int n = tile / tiles_per_patch;
+        const int rem = tile - n * tiles_per_patch;
+        const int ty = rem / tiles_x, tx = rem - ty * tiles_x;
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+            const int oy = ty * 16 + wave * 4 + ni;
+            const size_t pix = ((size_t)n * p.Ho + oy) * p.Wo + tx * 16 + frow;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int c0 = h * 32 + fg * 8;
+                float sc[8], sh[8], y[8];
+                *(float4*)&sc[0] = *(const float4*)(cst + c0);
+                *(float4*)&sc[4] = *(const float4*)(cst + c0 + 4);
+                *(float4*)&sh[0] = *(const float4*)(cst + 64 + c0);
+                *(float4*)&sh[4] = *(const float4*)(cst + 64 + c0 + 4);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    y[q] = acc[2 * h][ni][q] * sc[q] + sh[q];
+                    y[4 + q] = acc[2 * h + 1][ni][q] * sc[4 + q] + sh[4 + q];
+                }
+                if (p.relu) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) y[q] = fmaxf(y[q], 0.f);
+                }
+                store_split8((uint16_t*)p.out + pix * 128 + c0, 64, y);
+            }
+        }
+    }
+}
+
 hipError_t launch_stem(const StemParams& p, int precision, int num_cus, hipStream_t s)
 {
     const int n_tiles = p.n * (p.Ho / 16) * (p.Wo / 16);
     const int grid = n_tiles < 2 * num_cus ? n_tiles : 2 * num_cus;
+    if (precision == kF16X3) {
+        hipLaunchKernelGGL(stem_conv_pairs_x3, dim3(n_tiles < num_cus ? n_tiles : num_cus), dim3(256), kStemX3LdsBytes, s, p);
+        return hipGetLastError();
+    }
     if (precision == kF16) hipLaunchKernelGGL(stem_conv_pairs<true>, dim3(grid), dim3(256), kStemLdsBytes, s, p);
     else hipLaunchKernelGGL(stem_conv_pairs<false>, dim3(grid), dim3(256), kStemLdsBytes, s, p);
     return hipGetLastError();
