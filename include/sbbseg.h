@@ -287,7 +287,8 @@ int sbbseg_debug_read_tensor(sbbseg_ctx* c, int tensor_id, int n, float* out, si
  * bit 16 = 8-phase schedule on the 256x256 tile (half-tile restaging, staggered wave groups);
  * bit 17 = plain gather (per-load address arithmetic) instead of the fast gather on every layer;
  * bit 18 = fused bottleneck blocks run as the three convs they replace; bit 19 = grouped (parity-class) launches walk
- * XCD-contiguous tile ranges */
+ * XCD-contiguous tile ranges; bit 20 = fused bottleneck blocks run bottleneck_fused (one group of four waves per tile)
+ * instead of bottleneck_fused_pq (producer / consumer wave groups) */
 int sbbseg_debug_set_conv_variant(sbbseg_ctx* c, int variant);
 /* Test hook for the no-abort guarantee: the nth_check-th next internal host-allocation checkpoint throws
  * std::bad_alloc, which every entry point turns into a non-zero status + sbbseg_last_error() instead of

@@ -215,6 +215,7 @@ struct sbbseg_ctx {
     int fg_min_ksteps = 9;             // convs with real taps take the fast gather from this many K-steps on (SBBSEG_FG_MIN)
     int fg_pointwise_min_ksteps = 4;   // pointwise convs take the fast gather from this many K-steps on (SBBSEG_FG_POINTWISE_MIN)
     bool ranged_walk = false;    // A/B: grouped launches walk XCD-contiguous tile ranges (conv variant bit 19)
+    bool block_pq = true;        // fused bottleneck blocks run the producer / consumer form (conv variant bit 20: the one-group form)
     bool unfuse_blocks = false;  // A/B: run a fused bottleneck block as its three convs (conv variant bit 18)
     bool plain_gather = false;   // A/B: per-load address arithmetic instead of the fast gather (conv variant bit 17)
     int contig_max_k = 0;        // short-K layers up to this K walk their tiles in per-block contiguous runs (tile map 2)
@@ -336,7 +337,7 @@ int launch_op(sbbseg_ctx* c, Op& op, int n, uint8_t* d_labels, float* d_probs)
             }
             const BlockOp& bo = op.block;
             BlockParams bp;
-            bp.x = c->tensors[bo.x_tensor].buf; bp.n = n; bp.H = bo.H; bp.W = bo.W; bp.proj = bo.proj;
+            bp.x = c->tensors[bo.x_tensor].buf; bp.n = n; bp.H = bo.H; bp.W = bo.W; bp.proj = bo.proj; bp.pq = c->block_pq ? 1 : 0;
             bp.w1 = bo.d_w1; bp.w2 = op.parts[1].conv.d_d64_wfrag; bp.w3 = bo.d_w3;
             bp.s1 = op.parts[0].conv.d_scale; bp.b1 = op.parts[0].conv.d_shift;
             bp.s2 = op.parts[1].conv.d_scale; bp.b2 = op.parts[1].conv.d_shift;
@@ -2187,12 +2188,13 @@ int sbbseg_debug_inject_alloc_failure(int nth_check)
 int sbbseg_debug_set_conv_variant(sbbseg_ctx* c, int variant)
 {
     API_BEGIN
-    REQUIRE(c && variant >= 0 && variant <= 0xfffff, "variant: bits 0-1 = 0 auto | 1 4-wave/2-stage | 2 8-wave/3-stage; bit 2 = one block per tile (non-persistent); bit 3 = no XCD-grouped tile walk; bit 4 = half-K-step stages; bit 5 = XCD-grouped walk on single-class layers; bit 6 = drain epilogue stores; bit 7 = half-line epilogue stores; bits 8-15 = contiguous-run K limit / 64; bit 16 = 8-phase schedule on the 256x256 tile; bit 17 = plain gather everywhere; bit 18 = fused bottleneck blocks run as their three convs");
+    REQUIRE(c && variant >= 0 && variant <= 0x1fffff, "variant: bits 0-1 = 0 auto | 1 4-wave/2-stage | 2 8-wave/3-stage; bit 2 = one block per tile (non-persistent); bit 3 = no XCD-grouped tile walk; bit 4 = half-K-step stages; bit 5 = XCD-grouped walk on single-class layers; bit 6 = drain epilogue stores; bit 7 = half-line epilogue stores; bits 8-15 = contiguous-run K limit / 64; bit 16 = 8-phase schedule on the 256x256 tile; bit 17 = plain gather everywhere; bit 18 = fused bottleneck blocks run as their three convs; bit 19 = XCD-contiguous walk for grouped launches; bit 20 = one-group form of the fused block kernel");
     c->conv_variant = variant & 0xff;
     c->ph8 = (variant >> 16) & 1;
     c->plain_gather = (variant >> 17) & 1;
     c->unfuse_blocks = (variant >> 18) & 1;
     c->ranged_walk = (variant >> 19) & 1;
+    c->block_pq = !((variant >> 20) & 1);
     if ((variant >> 8) & 0xff) c->contig_max_k = ((variant >> 8) & 0xff) * 64;
     return 0;
     API_END

@@ -156,6 +156,7 @@ struct BlockParams {
     const char* x;            // buffer start (zero header), [n][H][W][CIN] 16-bit; CIN = 256 (identity) | 64 (projection)
     int n, H, W;
     int proj;                 // 0: y = ReLU(BN(W3 b) + x);  1: y = ReLU(BN(W3 [b, x]))  (shortcut conv folded by the planner)
+    int pq;                   // 1: bottleneck_fused_pq (producer / consumer wave groups), 0: bottleneck_fused
     const void* w1;           // [CIN/32 kk][4 mi][64 lanes] x 16 bytes, MFMA A-fragment order, rows = conv_row_channel
     const void* w2;           // [9 taps][2 kk][4 mi][64 lanes] x 16 bytes (Direct64Params::wfrag)
     const void* w3;           // [2|4 kk][16 mi][64 lanes] x 16 bytes; projection: kk 0-1 contract b, kk 2-3 contract x

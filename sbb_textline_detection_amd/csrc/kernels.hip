@@ -2615,6 +2615,283 @@ __global__ __launch_bounds__(256, 1) void bottleneck_fused(const BlockParams p)
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// bottleneck_fused_pq -- the same block with its phases split over two groups of four waves (one of each per SIMD):
+//   P ("producer") waves run phases A and B of tile i:  x halo -> a (LDS) -> b (LDS, double buffered)
+//   Q ("consumer") waves run phase C of tile i-1:        b, x -> y
+// In the one-group kernel a wave's MFMA, VALU (epilogues) and LDS work serialise (one wave per SIMD); here the MFMA / LDS-
+// heavy phases of one tile overlap the VALU / store-heavy phase of the previous one.  Two block-wide barriers per iteration:
+// after phase A (a visible to the P waves; Q has done the first half of its channel groups) and at the end (b[i & 1]
+// complete, b[(i-1) & 1] and a free).  P requests the next tile's x right after phase A into the registers that phase just
+// freed; Q reads its inner-pixel x (the residual; the projection block's second operand) itself, one tile ahead.
+// ------------------------------------------------------------------------------------------------
+constexpr int block_pq_lds_bytes(int cin, bool proj) { return block_lds_bytes(cin, proj) + kBlkBBytes; }
+
+template <bool F16, int CIN, bool PROJ>
+__global__ __launch_bounds__(512, 1) void bottleneck_fused_pq(const BlockParams p)
+{
+    static_assert((CIN == 256 && !PROJ) || (CIN == 64 && PROJ), "identity blocks read 256 channels, the projection block 64");
+    constexpr int KA = CIN / 32;
+    constexpr int KC = PROJ ? 4 : 2;
+    constexpr int PIXB = CIN * 2;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* lds_w1 = smem;
+    char* lds_w3 = lds_w1 + KA * 4 * 1024;
+    char* lds_a = lds_w3 + KC * 16 * 1024;
+    char* lds_b = lds_a + kBlkABytes;                           // two buffers of kBlkBBytes
+    float* cst = (float*)(lds_b + 2 * kBlkBBytes);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool is_q = wave8 >= 4;
+    const int wave = wave8 & 3;                                 // index inside the group
+    const int frow = lane & 15, fg = lane >> 4;
+    const int tiles_x = (p.W + 15) / 16, tiles_y = (p.H + 7) / 8;
+    const int tiles_per_patch = tiles_x * tiles_y;
+    const int n_tiles = p.n * tiles_per_patch;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, GX = gridDim.x >> 3;
+    const int per_xcd = (n_tiles + 7) >> 3;
+    const int xcd_lo = xcd * per_xcd, xcd_hi = min(n_tiles, xcd_lo + per_xcd);
+    const int my_tiles = xcd_lo + slot < xcd_hi ? (xcd_hi - xcd_lo - slot + GX - 1) / GX : 0;
+    if (my_tiles <= 0) return;
+    auto tile_at = [&](int it) __attribute__((always_inline)) -> int { return xcd_lo + slot + it * GX; };
+
+    for (int i = tid; i < KA * 4 * 64; i += 512) ((uint4*)lds_w1)[i] = ((const uint4*)p.w1)[i];
+    for (int i = tid; i < KC * 16 * 64; i += 512) ((uint4*)lds_w3)[i] = ((const uint4*)p.w3)[i];
+    if (tid < 64) {
+        cst[tid] = p.s1[tid]; cst[64 + tid] = p.b1[tid]; cst[128 + tid] = p.s2[tid]; cst[192 + tid] = p.b2[tid];
+    }
+    if (tid < 256) { cst[256 + tid] = p.s3[tid]; cst[512 + tid] = p.b3[tid]; }
+
+    if (!is_q) {
+        // =============================================== P: phases A and B ===============================================
+        bf16x8_t wf[9][2];
+        {
+            const uint4* src = (const uint4*)p.w2 + lane;
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) wf[t][kk] = __builtin_bit_cast(bf16x8_t, src[(size_t)((t * 2 + kk) * 4 + wave) * 64]);
+        }
+        int hy[3], hx[3], hr[3];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) { hy[j] = 2 * wave + j + 1; hx[j] = frow + 1; hr[j] = hy[j] * kBlkHaloW + hx[j]; }
+        {
+            const int bi = wave * 16 + frow;
+            int y, x;
+            if (bi < 18) { y = 0; x = bi; }
+            else if (bi < 36) { y = 9; x = bi - 18; }
+            else if (bi < 44) { y = 1 + (bi - 36); x = 0; }
+            else if (bi < 52) { y = 1 + (bi - 44); x = 17; }
+            else { y = 10; x = bi - 52; }
+            hy[2] = y; hx[2] = x; hr[2] = y * kBlkHaloW + x;
+        }
+        bool inimg[3];
+        uint32_t xoff[3];
+        auto locate = [&](int tile) __attribute__((always_inline)) {
+            const int n = tile / tiles_per_patch;
+            const int rem = tile - n * tiles_per_patch;
+            const int ty = rem / tiles_x, tx = rem - ty * tiles_x;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const int Y = ty * 8 - 1 + hy[j], X = tx * 16 - 1 + hx[j];
+                inimg[j] = ((unsigned)Y < (unsigned)p.H) & ((unsigned)X < (unsigned)p.W) & (hy[j] < 10);
+                xoff[j] = inimg[j] ? (uint32_t)((n * p.H + Y) * p.W + X) * (uint32_t)PIXB + (uint32_t)(kZeroHeaderBytes + fg * 16) : 0u;
+            }
+        };
+        bf16x8_t xf[3][KA];
+        auto fetch = [&]() __attribute__((always_inline)) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+#pragma unroll
+                for (int kk = 0; kk < KA; ++kk) xf[j][kk] = *(const bf16x8_t*)(p.x + xoff[j] + kk * 64);
+        };
+        locate(tile_at(0));
+        fetch();
+        __syncthreads();                                        // weights / constants visible (all eight waves)
+
+        for (int it = 0; it <= my_tiles; ++it) {
+            bool in_cur[3] = {inimg[0], inimg[1], inimg[2]};
+            if (it < my_tiles) {
+                // ---- phase A of tile `it`, 32 output channels (two MFMA row blocks) at a time: 24 accumulator registers
+                // instead of 48 -- with 96 registers of x fragments and 72 of 3x3 weights this wave has no more to give
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    f32x4_t acc[2][3];
+#pragma unroll
+                    for (int m = 0; m < 2; ++m)
+#pragma unroll
+                        for (int j = 0; j < 3; ++j) acc[m][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int kk = 0; kk < KA; ++kk) {
+                        bf16x8_t wa[2];
+#pragma unroll
+                        for (int m = 0; m < 2; ++m) wa[m] = *(const bf16x8_t*)(lds_w1 + (kk * 4 + 2 * s2 + m) * 1024 + lane * 16);
+#pragma unroll
+                        for (int m = 0; m < 2; ++m)
+#pragma unroll
+                            for (int j = 0; j < 3; ++j) acc[m][j] = mfma16<F16>(wa[m], xf[j][kk], acc[m][j]);
+                    }
+                    const int c0 = s2 * 32 + fg * 8;
+                    float sc[8], sh[8];
+                    *(float4*)&sc[0] = *(const float4*)(cst + c0); *(float4*)&sc[4] = *(const float4*)(cst + c0 + 4);
+                    *(float4*)&sh[0] = *(const float4*)(cst + 64 + c0); *(float4*)&sh[4] = *(const float4*)(cst + 64 + c0 + 4);
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) {
+                        float y[8];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            y[q] = fmaxf(acc[0][j][q] * sc[q] + sh[q], 0.f);
+                            y[4 + q] = fmaxf(acc[1][j][q] * sc[4 + q] + sh[4 + q], 0.f);
+                        }
+                        uint4 r;
+                        r.x = pack2<F16>(y[0], y[1]); r.y = pack2<F16>(y[2], y[3]); r.z = pack2<F16>(y[4], y[5]); r.w = pack2<F16>(y[6], y[7]);
+                        if (!in_cur[j]) r = make_uint4(0u, 0u, 0u, 0u);
+                        *(uint4*)(lds_a + hr[j] * 128 + (((s2 * 4 + fg) ^ (hr[j] & 7)) << 4)) = r;
+                    }
+                }
+                if (it + 1 < my_tiles) {                        // x of the next tile into the registers phase A just freed
+                    locate(tile_at(it + 1));
+                    fetch();
+                }
+            }
+            __syncthreads();                                    // B1: a visible
+            if (it < my_tiles) {
+                // ---- phase B of tile `it` -> b[it & 1]
+                char* bb = lds_b + (it & 1) * kBlkBBytes;
+                const int sB = wave >> 1, half = wave & 1;
+                const int cB = sB * 32 + fg * 8 + half * 4;
+                const float4 sc = *(const float4*)(cst + 128 + cB), sh = *(const float4*)(cst + 192 + cB);
+#pragma unroll
+                for (int g4 = 0; g4 < 2; ++g4) {
+                    f32x4_t acc[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int t = 0; t < 9; ++t) {
+#pragma unroll
+                        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                const int row = (g4 * 4 + i + t / 3) * kBlkHaloW + frow + t % 3;
+                                const bf16x8_t bq = *(const bf16x8_t*)(lds_a + row * 128 + (((kk * 4 + fg) ^ (row & 7)) << 4));
+                                acc[i] = mfma16<F16>(wf[t][kk], bq, acc[i]);
+                            }
+                        __builtin_amdgcn_sched_barrier(0);      // (keeps later taps' reads from being hoisted: registers)
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int row = (g4 * 4 + i) * 16 + frow;
+                        uint2 r;
+                        r.x = pack2<F16>(fmaxf(acc[i][0] * sc.x + sh.x, 0.f), fmaxf(acc[i][1] * sc.y + sh.y, 0.f));
+                        r.y = pack2<F16>(fmaxf(acc[i][2] * sc.z + sh.z, 0.f), fmaxf(acc[i][3] * sc.w + sh.w, 0.f));
+                        *(uint2*)(bb + row * 128 + (((sB * 4 + fg) ^ (row & 7)) << 4) + half * 8) = r;
+                    }
+                }
+            }
+            __syncthreads();                                    // B2: b[it & 1] complete; a and b[(it-1) & 1] free
+        }
+    } else {
+        // =============================================== Q: phase C ===============================================
+        // inner-pixel x of this wave's two output rows (2w, 2w+1): residual (identity) / second operand (projection)
+        bf16x8_t xq[2][KA], xq_next[2][KA];
+        auto fetch_q = [&](int tile, bf16x8_t (&dst)[2][KA]) __attribute__((always_inline)) {
+            const int n = tile / tiles_per_patch;
+            const int rem = tile - n * tiles_per_patch;
+            const int ty = rem / tiles_x, tx = rem - ty * tiles_x;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int Y = ty * 8 + 2 * wave + j, X = tx * 16 + frow;
+                const bool in = (Y < p.H) & (X < p.W);
+                const uint32_t off = in ? (uint32_t)((n * p.H + Y) * p.W + X) * (uint32_t)PIXB + (uint32_t)(kZeroHeaderBytes + fg * 16) : 0u;
+#pragma unroll
+                for (int kk = 0; kk < KA; ++kk) dst[j][kk] = *(const bf16x8_t*)(p.x + off + kk * 64);
+            }
+        };
+        fetch_q(tile_at(0), xq_next);
+        __syncthreads();                                        // weights / constants visible (all eight waves)
+
+        for (int it = 0; it <= my_tiles; ++it) {
+            const bool work = it >= 1;
+            const int tile = work ? tile_at(it - 1) : 0;
+            const int n = tile / tiles_per_patch;
+            const int rem = tile - n * tiles_per_patch;
+            const int ty = rem / tiles_x, tx = rem - ty * tiles_x;
+            const int ox = tx * 16 + frow;
+            bf16x8_t bf[2][2];
+            if (work) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int kk = 0; kk < KA; ++kk) xq[j][kk] = xq_next[j][kk];
+                const char* bb = lds_b + ((it - 1) & 1) * kBlkBBytes;
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int kk = 0; kk < 2; ++kk) {
+                        const int row = (2 * wave + j) * 16 + frow;
+                        bf[j][kk] = *(const bf16x8_t*)(bb + row * 128 + (((kk * 4 + fg) ^ (row & 7)) << 4));
+                    }
+            }
+            if (it < my_tiles) fetch_q(tile_at(it), xq_next);   // one tile ahead
+            auto channel_groups = [&](int s_lo, int s_hi) __attribute__((always_inline)) {
+#pragma unroll
+                for (int s3 = s_lo; s3 < s_hi; ++s3) {
+                    f32x4_t acc[2][2];
+#pragma unroll
+                    for (int m = 0; m < 2; ++m)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) acc[m][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int kk = 0; kk < KC; ++kk)
+#pragma unroll
+                        for (int m = 0; m < 2; ++m) {
+                            const bf16x8_t wa = *(const bf16x8_t*)(lds_w3 + (kk * 16 + 2 * s3 + m) * 1024 + lane * 16);
+#pragma unroll
+                            for (int j = 0; j < 2; ++j) {
+                                bf16x8_t bq;
+                                if constexpr (PROJ) bq = kk < 2 ? bf[j][kk & 1] : xq[j][kk & 1];
+                                else bq = bf[j][kk & 1];
+                                acc[m][j] = mfma16<F16>(wa, bq, acc[m][j]);
+                            }
+                        }
+                    const int c0 = s3 * 32 + fg * 8;
+                    float sc[8], sh[8];
+                    *(float4*)&sc[0] = *(const float4*)(cst + 256 + c0); *(float4*)&sc[4] = *(const float4*)(cst + 256 + c0 + 4);
+                    *(float4*)&sh[0] = *(const float4*)(cst + 512 + c0); *(float4*)&sh[4] = *(const float4*)(cst + 512 + c0 + 4);
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        float y[8];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            y[q] = acc[0][j][q] * sc[q] + sh[q];
+                            y[4 + q] = acc[1][j][q] * sc[4 + q] + sh[4 + q];
+                        }
+                        if constexpr (!PROJ) {
+                            const uint4 rv = __builtin_bit_cast(uint4, xq[j][s3 % KA]);
+                            y[0] += unpack_lo<F16>(rv.x); y[1] += unpack_hi<F16>(rv.x); y[2] += unpack_lo<F16>(rv.y); y[3] += unpack_hi<F16>(rv.y);
+                            y[4] += unpack_lo<F16>(rv.z); y[5] += unpack_hi<F16>(rv.z); y[6] += unpack_lo<F16>(rv.w); y[7] += unpack_hi<F16>(rv.w);
+                        }
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) y[q] = fmaxf(y[q], 0.f);
+                        uint4 r;
+                        r.x = pack2<F16>(y[0], y[1]); r.y = pack2<F16>(y[2], y[3]); r.z = pack2<F16>(y[4], y[5]); r.w = pack2<F16>(y[6], y[7]);
+                        const int oy = ty * 8 + 2 * wave + j;
+                        if (oy < p.H && ox < p.W)
+                            *(uint4*)((uint16_t*)p.out + (((size_t)n * p.H + oy) * p.W + ox) * 256 + c0) = r;
+                    }
+                    __builtin_amdgcn_sched_barrier(0);          // (keeps later groups' weight reads from being hoisted: registers)
+                }
+            };
+            if (work) channel_groups(0, 4);
+            __syncthreads();                                    // B1
+            if (work) channel_groups(4, 8);
+            __syncthreads();                                    // B2
+        }
+    }
+}
+
 hipError_t launch_bottleneck(const BlockParams& p, int precision, int num_cus, hipStream_t s)
 {
     const int n_tiles = p.n * ((p.H + 7) / 8) * ((p.W + 15) / 16);
@@ -2634,6 +2911,24 @@ hipError_t launch_bottleneck(const BlockParams& p, int precision, int num_cus, h
         hipLaunchKernelGGL(kernel, dim3(grid), dim3(256), lds, s, p);
         return hipGetLastError();
     };
+    if (p.pq) {
+        auto go8 = [&](auto kernel, int lds) -> hipError_t {
+            static bool attr_done8[4][64] = {};
+            int dev = 0;
+            hipError_t e = hipGetDevice(&dev);
+            if (e != hipSuccess) return e;
+            const int slot = (precision == kF16 ? 0 : 1) + (p.proj ? 2 : 0);
+            if (!attr_done8[slot][dev & 63]) {
+                e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+                if (e != hipSuccess) return e;
+                attr_done8[slot][dev & 63] = true;
+            }
+            hipLaunchKernelGGL(kernel, dim3(grid), dim3(512), lds, s, p);
+            return hipGetLastError();
+        };
+        if (p.proj) return precision == kF16 ? go8(bottleneck_fused_pq<true, 64, true>, block_pq_lds_bytes(64, true)) : go8(bottleneck_fused_pq<false, 64, true>, block_pq_lds_bytes(64, true));
+        return precision == kF16 ? go8(bottleneck_fused_pq<true, 256, false>, block_pq_lds_bytes(256, false)) : go8(bottleneck_fused_pq<false, 256, false>, block_pq_lds_bytes(256, false));
+    }
     if (p.proj) return precision == kF16 ? go(bottleneck_fused<true, 64, true>, block_lds_bytes(64, true)) : go(bottleneck_fused<false, 64, true>, block_lds_bytes(64, true));
     return precision == kF16 ? go(bottleneck_fused<true, 256, false>, block_lds_bytes(256, false)) : go(bottleneck_fused<false, 256, false>, block_lds_bytes(256, false));
 }

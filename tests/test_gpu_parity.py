@@ -108,7 +108,15 @@ def test_fused_bottleneck_blocks_match_their_three_convs(precision, hw):
     model.ctx.set_conv_variant(1 << 18)
     got_parts = model.predict(x)
     t_parts = read_all()
+    model.ctx.set_conv_variant(1 << 20)                  # the one-group form of the fused kernel (default: producer / consumer): same bytes
+    got_pq = model.predict(x)
+    t_pq = read_all()
     model.ctx.set_conv_variant(0)
+    assert np.array_equal(got_pq, got_fused)
+    for name, tid in model.plan.layer_tensor.items():
+        t = model.plan.tensors[tid]
+        if not (t.C == 64 and t.H == max(model.plan.tensors[k].H for k in model.plan.layer_tensor.values() if model.plan.tensors[k].C == 256)):
+            assert np.array_equal(t_pq[name], t_fused[name]), name
     stage2 = max(model.plan.tensors[tid].H for tid in model.plan.layer_tensor.values() if model.plan.tensors[tid].C == 256)
     checked = 0
     for name, tid in model.plan.layer_tensor.items():
