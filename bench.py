@@ -10,13 +10,19 @@ of 448x448 per page; a step is `--pages-per-step` (16) such pages back to back, 
 seconds, not a fraction of one (the clocks settle).  value = tiles / time, the median of `--repeats` (3) timed
 regions of exactly K steps each (all repeats are reported).
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): BASELINE.json configs[3] -- 64 pages of 4000x3000
-(108 tiles each) sharded as whole pages over the ranks, one RCCL all-gather of the u8 masks per step (the
-"stitch" exchange north_star names); strong scaling.  `--workload page` keeps the weak-scaling page workload.
+N > 1: BASELINE.json configs[3] -- 64 pages of 4000x3000 (108 tiles each) sharded as whole pages over the ranks,
+one RCCL all-gather of the u8 masks per step (the "stitch" exchange north_star names); strong scaling.
+`--workload page` keeps the weak-scaling page workload.  One rank per GPU: either launched by
+`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...` (RANK / LOCAL_RANK / WORLD_SIZE in the
+environment) or as plain `python bench.py --gpus N`, which re-executes itself under torch.distributed.run on
+127.0.0.1 and relays the ranks' output.  The N > 1 line carries `ranks_seen` (world size and device of every rank, read
+inside the process group), `exchange` (all-gather ms, algbw / busbw GB/s) and `per_rank` (each rank's rate on its own
+shard with no collective).  NO multi-GPU curve has been measured by the builder: the build pool has 1-GPU boxes only.
 
-Two arithmetic modes are measured in the same run (N = 1): the one `--precision` names is `value`; the other one
-is reported under `modes`.  "f16" = the fast mode (plain fp16 operands), "f16x3" = the label-exact split mode
-(the default of the Python seams).  Each carries its live label agreement with the fp32 oracle.
+Arithmetic modes.  `value` is the mode `--precision` names -- by default "f16x3", the label-exact split-fp16 mode
+(hi + lo operands, three MFMAs per product; the default of the Python seams): it is the mode whose labels meet
+north_star's "argmax label map bit-exact" bar against the fp32 oracle.  The fast plain-fp16 mode ("f16", BASELINE
+configs[4]) is measured in the same run and reported under `modes` with its own roofline and label agreement.
 
 Prints ONE JSON line on rank 0.  Extra objects: `roofline` (dominant conv launch, HIP-event timed per launch on
 the library's stream) and `cpu_baseline` (torch-CPU fp32 proxy of the Keras/TF CPU path on the host cores;
@@ -40,7 +46,71 @@ PAGE_H, PAGE_W = 3500, 2500    # BASELINE.json configs[1]
 if os.environ.get("SBBSEG_BENCH_PAGE"):      # experiment knob (A/B of chunk sizes): "HxW" of the page workload's pages
     PAGE_H, PAGE_W = (int(v) for v in os.environ["SBBSEG_BENCH_PAGE"].lower().split("x"))
 MODEL_HW, CLASSES = 448, 2
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r02_pmc_summary.json")
+# committed rocprofv3 PMC summaries (tools/pmc_run.sh + tools/pmc_report.py) the `roofline.traffic` figure is read from: STATIC
+# numbers (counters need their own profiling passes), valid only for the kernel sources they were collected on (csrc_sha)
+PMC_SUMMARY = {"f16x3": os.path.join(ROOT, "profiles", "r03_x3_pmc_summary.json"),
+               "f16": os.path.join(ROOT, "profiles", "r03_f16_pmc_summary.json")}
+
+
+def csrc_sha():
+    """Hash of the device / host sources libsbbseg is built from: ties a committed PMC summary to the kernels it measured."""
+    import hashlib
+    h = hashlib.sha1()
+    for name in ("kernels.hip", "api.hip", "internal.h"):
+        with open(os.path.join(ROOT, "sbb_textline_detection_amd", "csrc", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:12]
+
+
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _self_launch(n):
+    """`python bench.py --gpus N` without a launcher: re-execute under torch.distributed.run, one rank per GPU, rendezvous on
+    127.0.0.1, and relay the ranks' output (rank 0 prints the JSON line).  Returns the launcher's exit code."""
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def _ranks_seen(dist, world, rank, local_rank, device_name):
+    """What the process group itself reports: world size and (rank, local rank, device) of every member."""
+    mine = {"rank": rank, "local_rank": local_rank, "device": device_name, "pid": os.getpid()}
+    everyone = [None] * world
+    dist.all_gather_object(everyone, mine)
+    return {"world_size": dist.get_world_size(), "backend": dist.get_backend(), "ranks": everyone}
+
+
+def _plumbing_check(args):
+    """Launch + rendezvous + collective only (no GPU, no model): gloo on CPU.  Exercised by the CPU tests at world 2 and 4 so
+    that the round-end multi-GPU run cannot die in argument / launcher / process-group plumbing."""
+    import torch
+    import torch.distributed as dist
+    world, rank, local_rank = int(os.environ["WORLD_SIZE"]), int(os.environ["RANK"]), int(os.environ.get("LOCAL_RANK", "0"))
+    dist.init_process_group("gloo")
+    seen = _ranks_seen(dist, world, rank, local_rank, "cpu")
+    from sbb_textline_detection_amd.distributed import shard_block
+    first, count, block = shard_block(64, rank, world)
+    mine = torch.full((block, 4), rank, dtype=torch.uint8)
+    everything = torch.empty((world * block, 4), dtype=torch.uint8)
+    dist.all_gather_into_tensor(everything.view(-1), mine.view(-1))
+    ok = all(int(everything[r * block, 0]) == r for r in range(world))
+    dist.barrier()
+    if rank == 0:
+        print(json.dumps({"plumbing_check": True, "n_gpus": world, "ranks_seen": seen, "all_gather_ok": ok,
+                          "pages_per_rank": [shard_block(64, r, world)[1] for r in range(world)]}))
+    dist.destroy_process_group()
+    return 0 if ok else 1
 
 
 def main():
@@ -49,19 +119,33 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--repeats", type=int, default=3, help="timed regions of exactly --steps steps each; value = their median")
-    ap.add_argument("--precision", default=os.environ.get("SBBSEG_BENCH_PRECISION", "f16"), choices=["f16", "bf16", "f16x3"])
+    ap.add_argument("--precision", default=os.environ.get("SBBSEG_BENCH_PRECISION", "f16x3"), choices=["f16", "bf16", "f16x3"],
+                    help="arithmetic mode of `value`: f16x3 = label-exact split-fp16 (default), f16 = fast plain fp16")
     ap.add_argument("--max-batch", type=int, default=int(os.environ.get("SBBSEG_MAX_BATCH", "0")),
-                    help="tiles per chunk (0 = one page per chunk: 70 for the 3500x2500 page, 108 for the 4000x3000 pages of batch64)")
+                    help="tiles per chunk (0 = four pages' worth: 280 for the 3500x2500 page, 432 for the 4000x3000 pages of batch64)")
     ap.add_argument("--conv-variant", type=int, default=int(os.environ.get("SBBSEG_CONV_VARIANT", "0")),
                     help="A/B knob of the conv kernel (see sbbseg.h sbbseg_debug_set_conv_variant)")
     ap.add_argument("--workload", default="auto", choices=["auto", "page", "pipeline3", "batch64"],
                     help="auto = page at 1 GPU (BASELINE configs[1], the metric's config), batch64 at N > 1 (configs[3]: 64 pages of "
                          "4000x3000 sharded over the ranks, strong scaling); pipeline3 = configs[2] (border + layout + textline)")
     ap.add_argument("--pages-per-step", type=int, default=16, help="page workload: pages segmented back to back per step")
+    ap.add_argument("--batch-pages", type=int, default=64, help="batch64 workload: pages in the batch (64 = BASELINE configs[3])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-second-mode", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the one-page and pipeline3 side measurements of the default line")
     ap.add_argument("--cpu-patches", type=int, default=8)
+    ap.add_argument("--plumbing-check", action="store_true",
+                    help="launcher / rendezvous / all-gather only, gloo on CPU, no model (CPU tests of the N > 1 launch path)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(_self_launch(args.gpus))           # plain `python bench.py --gpus N`: become the launcher
+    if "WORLD_SIZE" in os.environ and int(os.environ["WORLD_SIZE"]) != args.gpus:
+        raise SystemExit(f"WORLD_SIZE={os.environ['WORLD_SIZE']} but --gpus {args.gpus}")
+    if args.plumbing_check:
+        if "WORLD_SIZE" not in os.environ:                  # --gpus 1: a world of one
+            os.environ.update(WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+        raise SystemExit(_plumbing_check(args))
 
     import torch
     import torch.distributed as dist
@@ -70,19 +154,40 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
         raise SystemExit(f"WORLD_SIZE={world} but --gpus {args.gpus}")
+    # SBBSEG_BENCH_BACKEND=gloo: the N > 1 code path on a box with fewer GPUs than ranks (ranks share devices, the all-gather
+    # is staged through host memory) -- a functional check of the sharded workload, never a scaling number
+    backend = os.environ.get("SBBSEG_BENCH_BACKEND", "nccl")
+    n_dev = torch.cuda.device_count()
+    if n_dev < 1:
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    if backend == "nccl" and world > n_dev:
+        raise SystemExit(f"--gpus {world} but only {n_dev} GPU(s) visible (RCCL needs one device per rank)")
+    device_index = local_rank % n_dev
     workload = args.workload if args.workload != "auto" else ("page" if world == 1 else "batch64")
     if args.max_batch <= 0:
         # tiles per chunk: four pages' worth (4 x 70 / 4 x 108), pooled across pages by sbbseg_segment_pages_dev and run as two
         # concurrent halves -- one page's 70 tiles leave the persistent conv grids a ragged last round; 140 / 280 / 374 / 560
         # tiles per chunk measured 9 997 / 10 176 / 10 214 / 10 209 patches/s (profiles/r02_experiments.md)
         args.max_batch = 432 if workload == "batch64" else (280 if workload == "page" else 70)
-    torch.cuda.set_device(local_rank)
+    torch.cuda.set_device(device_index)
+    ranks_seen = None
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device_index))
+        else:
+            dist.init_process_group(backend)
+        ranks_seen = _ranks_seen(dist, world, rank, local_rank, torch.cuda.get_device_name(device_index))
+
+    def all_gather_u8(dst, src_t):
+        """the stitch exchange: every rank's u8 masks to every rank (RCCL; host-staged under the gloo check backend)"""
+        if backend == "nccl":
+            dist.all_gather_into_tensor(dst.view(-1), src_t.view(-1))
+        else:
+            h = torch.empty(dst.numel(), dtype=torch.uint8)
+            dist.all_gather_into_tensor(h, src_t.view(-1).cpu())
+            dst.view(-1).copy_(h)
 
     from sbb_textline_detection_amd import _capi
     from sbb_textline_detection_amd.model import SegModel
@@ -94,7 +199,7 @@ def main():
 
     def make_model(precision, classes_cfg=None, max_batch=None):
         c, w = classes_cfg or (cfg, weights)
-        m = SegModel(c, w, device=local_rank, max_batch=max_batch or args.max_batch, precision=precision)
+        m = SegModel(c, w, device=device_index, max_batch=max_batch or args.max_batch, precision=precision)
         m.ctx.set_stream(stream)
         m.ctx.set_conv_variant(args.conv_variant)
         return m
@@ -111,7 +216,7 @@ def main():
         d_all = torch.empty((world, P, PAGE_H, PAGE_W), dtype=torch.uint8, device="cuda") if world > 1 else None
 
         def gather():
-            dist.all_gather_into_tensor(d_all.view(-1), labels.view(-1))
+            all_gather_u8(d_all, labels)
 
         page_ptrs, label_ptrs = [p_.data_ptr() for p_ in pages], [labels[k].data_ptr() for k in range(P)]
 
@@ -121,10 +226,12 @@ def main():
                 gather()
         desc = (f"{P} pages of {PAGE_H}x{PAGE_W} per GPU per step (BASELINE configs[1]: one such page = {tiles_per_page} tiles of 448x448, "
                 f"margin 0.1), textline model (ResNet-50-U-Net, {CLASSES} classes, seeded synthetic weights)")
-        return step, tiles_per_page * P * world, desc, "weak", (gather if world > 1 else None), P * PAGE_H * PAGE_W * world
+        def step_local():
+            m.ctx.segment_pages_dev(page_ptrs, PAGE_H, PAGE_W, label_ptrs)
+        return step, tiles_per_page * P * world, desc, "weak", (gather if world > 1 else None), P * PAGE_H * PAGE_W * world, step_local, tiles_per_page * P
 
     def build_batch64(m):
-        BH, BW, NPAGES = 4000, 3000, 64
+        BH, BW, NPAGES = 4000, 3000, max(1, args.batch_pages)
         from sbb_textline_detection_amd.distributed import shard_block
         first, count, block = shard_block(NPAGES, rank, world)
         pages = [torch.from_numpy(synthetic_page(BH, BW, seed=100 + first + k)).cuda() for k in range(count)]
@@ -133,7 +240,7 @@ def main():
         tpp = _capi.tile_grid(BH, BW, MODEL_HW, MODEL_HW)[0].shape[0]
 
         def gather():
-            dist.all_gather_into_tensor(d_everything.view(-1), d_mine.view(-1))
+            all_gather_u8(d_everything, d_mine)
 
         page_ptrs, label_ptrs = [p_.data_ptr() for p_ in pages], [d_mine[k].data_ptr() for k in range(count)]
 
@@ -144,7 +251,10 @@ def main():
                 gather()
         desc = (f"BASELINE configs[3]: {NPAGES} pages of {BH}x{BW} ({tpp} tiles each) sharded as whole pages over the ranks, textline model, "
                 f"one RCCL all-gather of the u8 masks per step")
-        return step, tpp * NPAGES, desc, "strong", (gather if world > 1 else None), world * block * BH * BW
+        def step_local():
+            if count:
+                m.ctx.segment_pages_dev(page_ptrs, BH, BW, label_ptrs)
+        return step, tpp * NPAGES, desc, "strong", (gather if world > 1 else None), world * block * BH * BW, step_local, tpp * count
 
     def build_pipeline3(m):
         cfg_b, w_b = calibrated_model(2, MODEL_HW, MODEL_HW, seed=11)
@@ -167,7 +277,7 @@ def main():
             m.ctx.segment_page_dev(d_page.data_ptr(), PAGE_H, PAGE_W, d_labels.data_ptr())
         desc = (f"BASELINE configs[2]: three-model pipeline on one {PAGE_H}x{PAGE_W} page per GPU: border (whole image, 1 forward) + layout "
                 f"(device Otsu + binarising gather, 4 classes, {tiles_per_page} tiles) + textline ({tiles_per_page} tiles); models resident")
-        return step, (1 + 2 * tiles_per_page) * world, desc, "weak", None, 0
+        return step, (1 + 2 * tiles_per_page) * world, desc, "weak", None, 0, None, 1 + 2 * tiles_per_page
 
     builders = {"page": build_page, "batch64": build_batch64, "pipeline3": build_pipeline3}
 
@@ -194,13 +304,13 @@ def main():
             out.append(dt)
         return out
 
-    step, tiles_per_step, workload_desc, scaling, gather, gathered_bytes = builders[workload](model)
+    step, tiles_per_step, workload_desc, scaling, gather, gathered_bytes, step_local, local_tiles = builders[workload](model)
     dts = timed(step, args.steps, args.warmup, max(1, args.repeats))
     dt = statistics.median(dts)
     value = tiles_per_step * args.steps / dt
     rates = [tiles_per_step * args.steps / t for t in dts]
 
-    exchange = None
+    exchange, per_rank = None, None
     if gather is not None:                                          # the exchange alone: all-gather GB/s over xGMI
         for _ in range(2):
             gather()
@@ -210,10 +320,30 @@ def main():
             gather()
         fence()
         gdt = (time.perf_counter() - t0) / 10
-        exchange = {"collective": "all_gather_into_tensor (RCCL) of the u8 page masks", "bytes_gathered_per_rank": gathered_bytes,
+        exchange = {"collective": "all_gather_into_tensor (RCCL) of the u8 page masks" if backend == "nccl" else f"all-gather staged through host memory ({backend} check backend)",
+                    "bytes_gathered_per_rank": gathered_bytes,
                     "ms": round(gdt * 1e3, 3), "algbw_GBps": round(gathered_bytes / gdt / 1e9, 1),
                     "busbw_GBps": round(gathered_bytes * (world - 1) / world / gdt / 1e9, 1),
                     "share_of_step": round(gdt / (dt / args.steps), 4)}
+        # every rank's rate on its own shard with NO collective and no barrier inside the loop (what the exchange and the
+        # slowest-rank wait cost is value vs the sum of these)
+        local_step = step_local if step_local is not None else step
+        n_loc = max(2, args.steps // 4)
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(n_loc):
+            local_step()
+        torch.cuda.synchronize()
+        mine = torch.tensor([local_tiles * n_loc / (time.perf_counter() - t0)], dtype=torch.float64, device="cuda")
+        rates_all = [torch.zeros_like(mine) for _ in range(world)]
+        if backend == "nccl":
+            dist.all_gather(rates_all, mine)
+        else:
+            rl = [None] * world
+            dist.all_gather_object(rl, float(mine.item()))
+            rates_all = [torch.tensor([v]) for v in rl]
+        pr = [round(float(t.item()), 1) for t in rates_all]
+        per_rank = {"compute_only_patches_per_s": pr, "sum": round(sum(pr), 1), "what": "each rank segmenting its own shard, no all-gather, no barrier"}
 
     # ---- roofline of the dominant kernel: per-launch HIP events on the library's stream ----------
     def roofline_of(m):
@@ -268,16 +398,29 @@ def main():
                           "frac_issued": round(rate(convs, "issued_flops") / MFMA_PEAK_TFLOPS, 4),
                           "share_of_gpu_time": round(sum(o["total_ms"] for o in convs) / tot_ms, 4)},
         }
-        # HBM-side traffic of that launch from the committed rocprofv3 PMC passes of this same command
-        # (tools/pmc_run.sh; counters need their own runs, see profiles/): bytes per launch
+        if m.precision == "f16x3":
+            # the split mode issues three f16 MFMAs per product: algorithmic work cannot exceed a third of the dense f16 peak
+            r["peak_note"] = ("peak = dense f16 MFMA peak; f16x3 spends 3 MFMAs per product, so algorithmic FLOPs are bounded by peak/3 = "
+                              "%.1f TFLOP/s: frac_of_split_peak = achieved / (peak/3)" % (MFMA_PEAK_TFLOPS / 3))
+            r["frac_of_split_peak"] = round(ach / (MFMA_PEAK_TFLOPS / 3), 4)
+        # HBM-side traffic of that launch from the committed rocprofv3 PMC passes of this same command (tools/pmc_run.sh;
+        # counters need their own runs, see profiles/): bytes per launch.  STATIC: read from a file, not measured in this run;
+        # dropped (null) when the file was collected on other kernel sources than the ones this library was built from.
         try:
-            pmc = json.load(open(PMC_SUMMARY))
-            ent = pmc["ops"].get(dom["name"]) if pmc.get("precision", "f16") == m.precision else None
+            path = PMC_SUMMARY.get(m.precision)
+            pmc = json.load(open(path)) if path and os.path.exists(path) else None
+            if pmc is not None and pmc.get("csrc_sha") != csrc_sha():
+                r["traffic_note"] = "committed PMC summary %s is stale (collected on csrc %s, this build is %s): traffic dropped" % (
+                    os.path.relpath(path, ROOT), pmc.get("csrc_sha"), csrc_sha())
+                pmc = None
+            ent = pmc["ops"].get(dom["name"]) if pmc is not None and pmc.get("precision", "f16") == m.precision else None
             if ent and abs(dom["patches"] / dom["launches"] - pmc.get("patches_per_launch", 70)) < 1e-6:
                 r["traffic"] = round(ent["fetch_bytes"] + ent["write_bytes"])
+                r["traffic_static"] = True
                 if "mfma_busy_pct" in ent:
                     r["mfma_pipe_busy_pct_pmc"] = ent["mfma_busy_pct"]
-                r["traffic_source"] = "%s (FETCH_SIZE x2 + WRITE_SIZE per launch, L2 hit %.0f %%)" % (os.path.relpath(PMC_SUMMARY, ROOT), ent["l2_hit_pct"])
+                r["traffic_source"] = "STATIC, from %s (FETCH_SIZE x2 + WRITE_SIZE per launch, L2 hit %.0f %%, csrc %s)" % (
+                    os.path.relpath(path, ROOT), ent["l2_hit_pct"], pmc.get("csrc_sha"))
         except Exception:
             pass
         per_op = [{"name": o["name"], "ms_per_launch": round(o["total_ms"] / o["launches"], 4),
@@ -385,17 +528,43 @@ def main():
         other = {"f16": "f16x3", "f16x3": "f16"}.get(args.precision)
         if other and not args.no_second_mode and workload == "page":
             m2 = make_model(other)
-            step2, tps2, _, _, _, _ = build_page(m2)
+            step2, tps2 = build_page(m2)[:2]
             n2 = max(3, args.steps // 4)
             dts2 = timed(step2, n2, 1, 1)
             r2, _ = roofline_of(m2)
             modes[other] = {"patches_per_s": round(tps2 * n2 / dts2[0], 2), "label_match": match(m2),
                             "roofline_kernel": r2["kernel"], "roofline_frac": r2["frac"], "roofline_frac_issued": r2["frac_issued"],
+                            "roofline": {k: r2[k] for k in ("kernel", "achieved", "peak", "unit", "frac", "achieved_issued", "frac_issued", "traffic",
+                                                            "avg_launch_ms", "conv3x3_stages", "all_convs") if k in r2},
                             "steps": n2}
             m2.release()
         for k, v in modes.items():
             v["what"] = ("label-exact split-fp16 mode (hi+lo operands, 3 MFMAs per product; default of the Python seams)" if k == "f16x3"
                          else "fast mode: plain fp16 operands, fp32 accumulate")
+
+    extras = None
+    if rank == 0 and world == 1 and workload == "page" and not args.no_extras:
+        extras = {}
+        # one page per step (BASELINE configs[1] literally: ONE 3500x2500 page = 70 tiles per call)
+        keep = args.pages_per_step
+        args.pages_per_step = 1
+        step1, tps1 = build_page(model)[:2]
+        n1 = max(10, args.steps)
+        d1 = timed(step1, n1, 2, 1)[0]
+        args.pages_per_step = keep
+        extras["one_page_patches_per_s"] = round(tps1 * n1 / d1, 1)
+        extras["one_page_ms"] = round(d1 / n1 * 1e3, 3)
+        # BASELINE configs[2]: border (whole image) + layout (Otsu'd, 4 classes) + textline on ONE page, models resident
+        try:
+            step3, tps3, desc3 = build_pipeline3(model)[:3]
+            n3 = max(5, args.steps // 2)
+            d3 = timed(step3, n3, 2, 1)[0]
+            extras["pipeline3_ms_per_page"] = round(d3 / n3 * 1e3, 3)
+            extras["pipeline3_forwards_per_page"] = tps3
+            extras["pipeline3_patches_per_s"] = round(tps3 * n3 / d3, 1)
+            extras["pipeline3_what"] = desc3
+        except Exception as e:                                         # never lose the headline over a side measurement
+            extras["pipeline3_error"] = repr(e)
 
     if rank == 0:
         out = {
@@ -406,13 +575,14 @@ def main():
             "config": {"workload": workload_desc, "workload_id": workload,
                        "tiles_per_step": tiles_per_step, "max_batch": args.max_batch,
                        "lanes": int(os.environ.get("SBBSEG_LANES", "2")),
-                       "exchange": "all_gather of u8 label maps over RCCL" if world > 1 else "none (1 GPU)",
+                       "exchange": ("all_gather of u8 label maps over RCCL" if backend == "nccl" else f"all_gather staged through the host ({backend})") if world > 1 else "none (1 GPU)",
                        "flops_per_patch": 2 * model.plan.macs_per_patch()},
             "repeats": {"patches_per_s": [round(r, 2) for r in rates], "min": round(min(rates), 2), "median": round(value, 2),
                         "max": round(max(rates), 2), "timed_region_s": [round(t, 3) for t in dts]},
             "patches_per_s_per_gpu": round(value / world, 2),
             "achieved_tflops_end_to_end": round(value / world * 2 * model.plan.macs_per_patch() / 1e12, 1),
-            "roofline": roofline, "cpu_baseline": cpu_baseline, "label_match": label_match, "modes": modes, "exchange": exchange, "host_path": host_path,
+            "roofline": roofline, "cpu_baseline": cpu_baseline, "label_match": label_match, "modes": modes, "exchange": exchange,
+            "per_rank": per_rank, "ranks_seen": ranks_seen, "host_path": host_path, "extras": extras,
         }
         print(json.dumps(out))
         if os.environ.get("SBBSEG_BENCH_OPS"):

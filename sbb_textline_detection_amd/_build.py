@@ -1,22 +1,39 @@
-"""Compile libsbbseg.so for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+"""Compile libsbbseg.so for gfx950 in-tree (hipcc cross-compiles without a GPU).
+
+Every source is compiled to its own object under ``build/`` (git-ignored, not shipped) and only stale objects are
+rebuilt, in parallel; the link step produces ``libsbbseg.so`` next to this file, which is what travels to the GPU box."""
 from __future__ import annotations
 
 import os
 import shutil
 import subprocess
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
+OBJ_DIR = os.path.join(HERE, "..", "build", "obj")
 LIB = os.path.join(HERE, "libsbbseg.so")
-SOURCES = ["kernels.hip", "api.hip", "loader.cpp"]
+SOURCES = ["kernels.hip", "block_x3.hip", "api.hip", "comm.cpp", "loader.cpp"]
 HEADERS = [os.path.join(CSRC, "internal.h"), os.path.join(HERE, "..", "include", "sbbseg.h")]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
+
+
+def _sources():
+    return [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
 
 
 def needs_build() -> bool:
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    return any(os.path.getmtime(p) > t for p in [os.path.join(CSRC, s) for s in SOURCES] + HEADERS)
+    return any(os.path.getmtime(p) > t for p in _sources() + HEADERS)
+
+
+def _stale(src: str, obj: str) -> bool:
+    if not os.path.exists(obj):
+        return True
+    t = os.path.getmtime(obj)
+    return any(os.path.getmtime(p) > t for p in [src] + HEADERS)
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
@@ -25,16 +42,36 @@ def build(force: bool = False, verbose: bool = False) -> str:
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         raise RuntimeError("hipcc not found: libsbbseg.so cannot be built (and there is no CPU fallback)")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-result",
-           *[os.path.join(CSRC, s) for s in SOURCES], "-o", LIB + ".tmp"]
-    res = subprocess.run(cmd, capture_output=True, text=True)
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    jobs = []
+    for src in _sources():
+        obj = os.path.join(OBJ_DIR, os.path.basename(src) + ".o")
+        if force or _stale(src, obj):
+            jobs.append((src, obj))
+
+    def compile_one(job):
+        src, obj = job
+        lang = ["-x", "hip"] if src.endswith(".hip") else []
+        res = subprocess.run([hipcc, *FLAGS, *lang, "-c", src, "-o", obj + ".tmp"], capture_output=True, text=True)
+        if res.returncode != 0:
+            return "hipcc failed on %s:\n%s%s" % (os.path.basename(src), res.stdout, res.stderr)
+        os.replace(obj + ".tmp", obj)
+        return None
+
+    with ThreadPoolExecutor(max_workers=max(1, min(len(jobs), os.cpu_count() or 1))) as ex:
+        errors = [e for e in ex.map(compile_one, jobs) if e]
+    if errors:
+        raise RuntimeError("\n".join(errors))
+    objs = [os.path.join(OBJ_DIR, os.path.basename(s) + ".o") for s in _sources()]
+    res = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB + ".tmp"], capture_output=True, text=True)
     if res.returncode != 0:
-        raise RuntimeError("hipcc failed:\n" + res.stdout + res.stderr)
+        raise RuntimeError("link failed:\n" + res.stdout + res.stderr)
     os.replace(LIB + ".tmp", LIB)
     if verbose:
-        print("built", LIB)
+        print("built", LIB, "(recompiled: %s)" % (", ".join(os.path.basename(s) for s, _ in jobs) or "nothing, relinked"))
     return LIB
 
 
 if __name__ == "__main__":
-    build(force=True, verbose=True)
+    import sys
+    build(force="--incremental" not in sys.argv, verbose=True)

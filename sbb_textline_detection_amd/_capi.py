@@ -376,6 +376,8 @@ class Context:
         return out
 
     def debug_read_tensor(self, plan_tensor: int, n: int, shape) -> np.ndarray:
+        if not self.tensor_ids and getattr(self, "ids_provider", None) is not None:
+            self.ids_provider()                       # natively planned handle: ids re-derived from the mirror plan (model.py)
         out = np.empty((n,) + tuple(shape), np.float32)
         check(self.lib.sbbseg_debug_read_tensor(self.h, self.tensor_ids[plan_tensor], n, _ptr(out), out.size),
               "sbbseg_debug_read_tensor")

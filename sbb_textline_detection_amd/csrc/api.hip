@@ -204,7 +204,9 @@ struct sbbseg_ctx {
     hipEvent_t pp_in[2] = {nullptr, nullptr}, pp_comp[2] = {nullptr, nullptr}, pp_out[2] = {nullptr, nullptr};
     uint8_t *pp_h_in[2] = {nullptr, nullptr}, *pp_h_out[2] = {nullptr, nullptr}, *pp_d_in[2] = {nullptr, nullptr}, *pp_d_out[2] = {nullptr, nullptr},
             *pp_d_out3[2] = {nullptr, nullptr};
-    size_t pp_in_cap = 0, pp_out_cap = 0, pp_out3_cap = 0;
+    size_t pp_in_cap = 0, pp_out_cap = 0, pp_out3_cap = 0;        // device buffers (bytes each)
+    size_t pp_hin_cap = 0, pp_hout_cap = 0;                       // pinned host staging (bytes each)
+    bool pp_ready = false;                                        // streams + events of the page pipeline exist
     void* d_deskew = nullptr; size_t deskew_cap = 0;      // inverse maps | bicubic table | row counts of sbbseg_deskew_profiles
     int *d_cc_parent = nullptr, *d_cc_count = nullptr; size_t cc_parent_cap = 0, cc_count_cap = 0;
     unsigned long long* d_cc_small = nullptr;      // [0] best key, [1..2] box (4 ints)
@@ -1687,10 +1689,25 @@ int sbbseg_segment_pages_dev(sbbseg_ctx* c, int n_pages, const void* const* d_pa
     int nx = 0, ny = 0;
     if (sbbseg_tile_grid(Hp, Wp, c->in_H, c->in_W, nullptr, 0, &nx, &ny)) return 1;
     const size_t per = (size_t)c->in_H * c->in_W, tpp = (size_t)nx * ny;
-    if (ensure(c, (void**)&c->d_tile_labels, &c->tile_labels_cap, tpp * n_pages * per)) return 1;
-    if (tile_range_impl(c, d_pages_hwc, n_pages, Hp, Wp, nullptr, nullptr, Hp, Wp, 0, (int)(tpp * n_pages), c->d_tile_labels)) return 1;
-    for (int k = 0; k < n_pages; ++k)
-        if (sbbseg_stitch_dev(c, c->d_tile_labels + (size_t)k * tpp * per, Hp, Wp, d_labels_hw[k])) return 1;
+    // Pages are pooled in GROUPS whose tile count is a whole number of chunks where that is possible with few pages
+    // (lcm(tiles per page, max_batch)), else about eight chunks: the tile-label scratch stays bounded by the group, not
+    // by the caller's page count (64 pages of 4000x3000 would otherwise hold 1.4 GB of tile labels at once), and no
+    // chunk is cut short except the very last.  Groups run back to back on the handle's stream (stream order protects the
+    // scratch buffer that every group reuses).
+    size_t a = tpp, b = (size_t)c->max_batch;
+    while (b) { const size_t t = a % b; a = b; b = t; }                 // a = gcd
+    size_t G = (size_t)c->max_batch / a;                                 // pages per group with G * tpp = lcm
+    if (G > 32) G = (8 * (size_t)c->max_batch + tpp - 1) / tpp;
+    if (G < 1) G = 1;
+    if (G > (size_t)n_pages) G = (size_t)n_pages;
+    REQUIRE(tpp * G < (size_t)1 << 30, "page group of %zu tiles is too large", tpp * G);
+    if (ensure(c, (void**)&c->d_tile_labels, &c->tile_labels_cap, tpp * G * per)) return 1;
+    for (size_t g0 = 0; g0 < (size_t)n_pages; g0 += G) {
+        const size_t np = g0 + G <= (size_t)n_pages ? G : (size_t)n_pages - g0;
+        if (tile_range_impl(c, d_pages_hwc + g0, (int)np, Hp, Wp, nullptr, nullptr, Hp, Wp, 0, (int)(tpp * np), c->d_tile_labels)) return 1;
+        for (size_t k = 0; k < np; ++k)
+            if (sbbseg_stitch_dev(c, c->d_tile_labels + k * tpp * per, Hp, Wp, d_labels_hw[g0 + k])) return 1;
+    }
     return 0;
     API_END
 }
@@ -1711,42 +1728,43 @@ int sbbseg_segment_pages(sbbseg_ctx* c, int n_pages, const uint8_t* const* pages
     const size_t out3_b = (pix + 3) / 4 * 12;                          // launch_replicate3 writes whole 12-byte groups
     int G = c->max_batch / (nx * ny);
     G = G < 1 ? 1 : (G > n_pages ? n_pages : G);
-    if (!c->copy_in) {
-        HIPCHK(hipStreamCreateWithFlags(&c->copy_in, hipStreamNonBlocking));
-        HIPCHK(hipStreamCreateWithFlags(&c->copy_out, hipStreamNonBlocking));
+    if (!c->pp_ready) {                                                   // set LAST: a failed creation is retried by the next call
+        if (!c->copy_in) HIPCHK(hipStreamCreateWithFlags(&c->copy_in, hipStreamNonBlocking));
+        if (!c->copy_out) HIPCHK(hipStreamCreateWithFlags(&c->copy_out, hipStreamNonBlocking));
         for (int k = 0; k < 2; ++k) {
-            HIPCHK(hipEventCreateWithFlags(&c->pp_in[k], hipEventDisableTiming));
-            HIPCHK(hipEventCreateWithFlags(&c->pp_comp[k], hipEventDisableTiming));
-            HIPCHK(hipEventCreateWithFlags(&c->pp_out[k], hipEventDisableTiming));
+            if (!c->pp_in[k]) HIPCHK(hipEventCreateWithFlags(&c->pp_in[k], hipEventDisableTiming));
+            if (!c->pp_comp[k]) HIPCHK(hipEventCreateWithFlags(&c->pp_comp[k], hipEventDisableTiming));
+            if (!c->pp_out[k]) HIPCHK(hipEventCreateWithFlags(&c->pp_out[k], hipEventDisableTiming));
         }
+        c->pp_ready = true;
     }
     HIPCHK(hipStreamSynchronize(c->stream));                            // (buffers below may be re-allocated)
-    if (c->pp_in_cap < G * in_b) {
-        for (int k = 0; k < 2; ++k) {
-            (void)hipHostFree(c->pp_h_in[k]); (void)hipFree(c->pp_d_in[k]);
-            c->pp_h_in[k] = nullptr; c->pp_d_in[k] = nullptr;
-            HIPCHK(hipHostMalloc((void**)&c->pp_h_in[k], G * in_b, hipHostMallocDefault));
-            if (dmalloc(c, (void**)&c->pp_d_in[k], G * in_b)) return 1;
-        }
-        c->pp_in_cap = G * in_b;
-    }
-    if (c->pp_out_cap < G * out_b) {
-        for (int k = 0; k < 2; ++k) {
-            (void)hipHostFree(c->pp_h_out[k]); (void)hipFree(c->pp_d_out[k]);
-            c->pp_h_out[k] = nullptr; c->pp_d_out[k] = nullptr;
-            HIPCHK(hipHostMalloc((void**)&c->pp_h_out[k], G * out_b, hipHostMallocDefault));
-            if (dmalloc(c, (void**)&c->pp_d_out[k], G * (pix + 4))) return 1;
-        }
-        c->pp_out_cap = G * out_b;
-    }
-    if (ch == 3 && c->pp_out3_cap < G * out3_b) {
-        for (int k = 0; k < 2; ++k) {
-            (void)hipFree(c->pp_d_out3[k]);
-            c->pp_d_out3[k] = nullptr;
-            if (dmalloc(c, (void**)&c->pp_d_out3[k], G * out3_b)) return 1;
-        }
-        c->pp_out3_cap = G * out3_b;
-    }
+    // Every buffer has its own capacity in the units it was allocated in; a capacity is zeroed BEFORE its buffers are
+    // freed and set only after all of them exist again, so a failed allocation leaves "nothing allocated", not a stale size.
+    auto host_pair = [&](uint8_t* (&h)[2], size_t* cap, size_t bytes) -> int {
+        if (*cap >= bytes) return 0;
+        *cap = 0;
+        for (int k = 0; k < 2; ++k) { (void)hipHostFree(h[k]); h[k] = nullptr; }
+        for (int k = 0; k < 2; ++k) HIPCHK(hipHostMalloc((void**)&h[k], bytes, hipHostMallocDefault));
+        *cap = bytes;
+        return 0;
+    };
+    auto dev_pair = [&](uint8_t* (&d)[2], size_t* cap, size_t bytes) -> int {
+        if (*cap >= bytes) return 0;
+        const size_t old = *cap;
+        *cap = 0;
+        for (int k = 0; k < 2; ++k)
+            if (d[k]) { (void)hipFree(d[k]); d[k] = nullptr; c->device_bytes -= old; }
+        for (int k = 0; k < 2; ++k)
+            if (dmalloc(c, (void**)&d[k], bytes)) return 1;
+        *cap = bytes;
+        return 0;
+    };
+    if (host_pair(c->pp_h_in, &c->pp_hin_cap, G * in_b)) return 1;
+    if (dev_pair(c->pp_d_in, &c->pp_in_cap, G * in_b)) return 1;
+    if (host_pair(c->pp_h_out, &c->pp_hout_cap, G * out_b)) return 1;
+    if (dev_pair(c->pp_d_out, &c->pp_out_cap, G * (pix + 4))) return 1;   // one u8 plane (+4 bytes slack) per page, whatever label_channels is
+    if (ch == 3 && dev_pair(c->pp_d_out3, &c->pp_out3_cap, G * out3_b)) return 1;
     const int n_groups = (n_pages + G - 1) / G;
     auto group_pages = [&](int g) { return g * G + G <= n_pages ? G : n_pages - g * G; };
     auto drain = [&](int g) -> int {                                      // labels of group g: staging -> caller

@@ -10,6 +10,7 @@
 //
 // Container (.sbbw, written by weights.save_sbbw / tools/h5_to_sbbw.py):
 //   "SBBW0001" | u64 header_len | header JSON {"model_config": {...}, "tensors": [{"name","shape","offset"}]} | pad to 64 | f32 data
+#include <ctype.h>
 #include <math.h>
 #include <stdarg.h>
 #include <stdint.h>
@@ -67,6 +68,7 @@ struct JVal {
     long integer() const
     {
         if (t != Num) fail("JSON: number expected");
+        if (!(num >= -9.0e15 && num <= 9.0e15)) fail("JSON: integer out of range");      // (also NaN / inf: the cast would be undefined)
         return (long)num;
     }
 };
@@ -116,8 +118,11 @@ struct JParser {
         ++p;
         return out;
     }
+    int depth = 0;
+    struct DepthGuard { int& d; explicit DepthGuard(int& d_) : d(d_) { if (++d > 256) fail("JSON: nesting deeper than 256"); } ~DepthGuard() { --d; } };
     JVal value()
     {
+        DepthGuard guard(depth);
         ws();
         if (p >= end) fail("JSON: unexpected end");
         JVal v;
@@ -155,10 +160,16 @@ struct JParser {
         if (end - p >= 5 && !strncmp(p, "false", 5)) { p += 5; v.t = JVal::Bool; v.b = false; return v; }
         if (end - p >= 4 && !strncmp(p, "null", 4)) { p += 4; return v; }
         if (end - p >= 3 && !strncmp(p, "NaN", 3)) { p += 3; v.t = JVal::Num; v.num = NAN; return v; }
+        // number token: copied to a bounded, NUL-terminated buffer first (the header is not NUL-terminated: strtod on the
+        // raw range could run past `end`)
+        char tok[64];
+        size_t len = 0;
+        while (p + len < end && len < sizeof(tok) - 1 && (isdigit((unsigned char)p[len]) || strchr("+-.eEInfity", p[len]))) { tok[len] = p[len]; ++len; }
+        tok[len] = 0;
         char* e = nullptr;
-        v.num = strtod(p, &e);
-        if (e == p) fail("JSON: value expected at offset %ld", (long)(end - p));
-        p = e;
+        v.num = strtod(tok, &e);
+        if (e == tok) fail("JSON: value expected %ld bytes before the end of the header", (long)(end - p));
+        p += e - tok;
         v.t = JVal::Num;
         return v;
     }
@@ -743,6 +754,7 @@ Plan build_plan(const Graph& graph, const WeightMap& weights, const Options& opt
             p->shift.assign(cout, 0.0);
             if (n.use_bias) {
                 const WTensor& b = weight(weights, n.name + "/bias:0");
+                if (b.n != (size_t)cout) fail("%s: bias size", n.name.c_str());
                 for (int c = 0; c < cout; ++c) p->shift[c] = (double)b.data[c];
             }
             p->raw_scale = p->scale; p->raw_shift = p->shift;
@@ -770,6 +782,7 @@ Plan build_plan(const Graph& graph, const WeightMap& weights, const Options& opt
             const WTensor* g = n.scale ? &weight(weights, n.name + "/gamma:0") : nullptr;
             const WTensor* be = n.center ? &weight(weights, n.name + "/beta:0") : nullptr;
             if (mu.n != (size_t)p->cout || var.n != (size_t)p->cout) fail("%s: BN statistics size", n.name.c_str());
+            if ((g && g->n != (size_t)p->cout) || (be && be->n != (size_t)p->cout)) fail("%s: BN gamma / beta size", n.name.c_str());
             for (int c = 0; c < p->cout; ++c) {
                 const double a = (g ? (double)g->data[c] : 1.0) / sqrt((double)var.data[c] + n.eps);
                 p->scale[c] = p->scale[c] * a;
@@ -1095,9 +1108,15 @@ Container read_container(const void* sbbw, size_t n_bytes)
     for (const JVal& t : c.header.at("tensors").a) {
         WTensor w;
         size_t n = 1;
-        for (const JVal& d : t.at("shape").a) { w.shape.push_back(d.integer()); n *= (size_t)d.integer(); }
-        const size_t off = (size_t)t.at("offset").integer();
-        if (off + n > n_floats) fail("tensor %s leaves the container", t.at("name").s.c_str());
+        for (const JVal& d : t.at("shape").a) {
+            const long long dim = d.integer();
+            if (dim <= 0 || (unsigned long long)dim > n_floats || n > n_floats / (size_t)dim) fail("tensor %s: bad shape", t.at("name").s.c_str());
+            w.shape.push_back(dim);
+            n *= (size_t)dim;
+        }
+        const long long off_ll = t.at("offset").integer();
+        if (off_ll < 0 || (unsigned long long)off_ll > n_floats || n > n_floats - (size_t)off_ll) fail("tensor %s leaves the container", t.at("name").s.c_str());
+        const size_t off = (size_t)off_ll;
         w.data = data + off;
         w.n = n;
         c.weights[t.at("name").s] = w;
@@ -1161,7 +1180,8 @@ int sbbseg_model_load_file(const char* path, int device, int precision, int max_
 {
     try {
         if (!path || !out) return sbbseg::set_error("sbbseg_model_load_file: bad arguments");
-        FILE* f = fopen(path, "rb");
+        struct FileGuard { FILE* f; ~FileGuard() { if (f) fclose(f); } } fg{fopen(path, "rb")};      // closed on every path, incl. a throwing resize
+        FILE* f = fg.f;
         if (!f) return sbbseg::set_error("cannot open %s", path);
         std::vector<char> buf;
         if (fseek(f, 0, SEEK_END) == 0) {
@@ -1169,11 +1189,10 @@ int sbbseg_model_load_file(const char* path, int device, int precision, int max_
             rewind(f);
             if (n > 0) {
                 buf.resize((size_t)n + 8);                             // (keeps the float data 4-byte aligned: vector storage is)
-                if (fread(buf.data(), 1, (size_t)n, f) != (size_t)n) { fclose(f); return sbbseg::set_error("short read on %s", path); }
+                if (fread(buf.data(), 1, (size_t)n, f) != (size_t)n) return sbbseg::set_error("short read on %s", path);
                 buf.resize((size_t)n);
             }
         }
-        fclose(f);
         if (buf.empty()) return sbbseg::set_error("%s is empty", path);
         return sbbseg_model_load(buf.data(), buf.size(), device, precision, max_batch, flags, out);
     } catch (const std::bad_alloc&) {

@@ -102,7 +102,11 @@ def segment_pages_sharded(backend, pages: Sequence[np.ndarray], group=None):
     first, count, block = shard_block(n, rank, world)
     mine = backend.empty((block, Hp, Wp))
     if count and hasattr(backend, "whole_pages"):
-        backend.whole_pages([backend.to_device(pages[first + k]) for k in range(count)], [mine[k] for k in range(count)])
+        # groups of at most 8 pages on the device at once (the library pools the tiles of a group into full chunks): device
+        # memory stays bounded by the group, not by the shard
+        for g0 in range(0, count, 8):
+            ks = range(g0, min(g0 + 8, count))
+            backend.whole_pages([backend.to_device(pages[first + k]) for k in ks], [mine[k] for k in ks])
     else:
         for k in range(count):
             backend.whole_page(backend.to_device(pages[first + k]), mine[k])

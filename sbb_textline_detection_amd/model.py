@@ -21,7 +21,7 @@ import numpy as np
 from . import _capi
 from .keras_graph import Graph, parse_model_config
 from .planner import Plan, build_plan
-from .weights import load_sbbw, read_sbbw_config
+from .weights import load_sbbw, read_sbbw_config, sbbw_bytes
 
 _CACHE: Dict[Tuple, "SegModel"] = {}
 
@@ -45,10 +45,13 @@ class SegModel:
     """A segmentation net resident on one MI355X, duck-typed like the Keras model the reference uses."""
 
     def __init__(self, model_config, weights, device: int = 0, max_batch: Optional[int] = None,
-                 precision: Optional[str] = None, sbbw_path: Optional[str] = None):
-        """``weights``: {Keras weight name: array} -> lowered by the Python planner (planner.py) and uploaded step by step.
-        ``sbbw_path`` (instead of weights): the library reads the container itself and lowers it with its own planner
-        (``sbbseg_model_load_file``, csrc/loader.cpp) -- one C call, same plan value for value (tests/test_native_planner.py)."""
+                 precision: Optional[str] = None, sbbw_path: Optional[str] = None, planner: Optional[str] = None):
+        """The handle is built by the LIBRARY's own graph reader + planner (csrc/loader.cpp) in one C call:
+        ``sbbw_path`` -> ``sbbseg_model_load_file`` (the container is read by the library), in-memory ``weights``
+        ({Keras weight name: array}) -> serialised to container bytes -> ``sbbseg_model_load``.
+        ``planner="python"`` (or ``SBBSEG_PLANNER=python``, or a one-lane handle via ``SBBSEG_LANES=1``) lowers the graph with
+        the Python planner (planner.py) instead and uploads the plan step by step: the TEST MIRROR of the native planner --
+        the two are compared value for value in tests/test_native_planner.py -- not the product path."""
         precision = precision or default_precision()
         if precision not in _capi.PRECISIONS:
             raise ValueError(f"precision must be one of {sorted(_capi.PRECISIONS)}, got {precision!r}")
@@ -64,23 +67,36 @@ class SegModel:
         self.device = device
         self.precision = precision
         self.max_batch = int(max_batch or default_max_batch())
+        self._sbbw_path = sbbw_path
         prec = _capi.PRECISIONS[precision]
-        if sbbw_path is not None:
+        lanes = int(os.environ.get("SBBSEG_LANES", "2"))
+        planner = planner or os.environ.get("SBBSEG_PLANNER", "native")
+        if planner not in ("native", "python"):
+            raise ValueError(f"planner must be 'native' or 'python', got {planner!r}")
+        if sbbw_path is None and weights is None:
+            raise ValueError("SegModel needs weights or sbbw_path")
+        if lanes != 2 and planner == "native":
+            if sbbw_path is not None and weights is None:
+                raise ValueError("the native loader builds two-lane handles; use planner='python' for SBBSEG_LANES=1")
+            planner = "python"                             # (one-lane handles are an A/B / test configuration)
+        self.planner = planner
+        if planner == "native":
             a = self._plan_args
             flags = (0 if a["parity_split"] else 1) | (0 if a["merge_shortcut"] else 2) | (0 if a["fuse_head"] or precision == "f32" else 4) | \
                     (0 if a["fuse_tail"] or precision not in ("f16", "bf16", "f16x3") else 8)
-            if int(os.environ.get("SBBSEG_LANES", "2")) != 2:
-                raise ValueError("the native loader builds two-lane handles; use the Python planner path for SBBSEG_LANES=1")
-            self._ctx: Optional[_capi.Context] = _capi.Context.from_sbbw(sbbw_path, device, prec, self.max_batch, flags)
-            self._sbbw_path = sbbw_path
+            source = sbbw_path if sbbw_path is not None else sbbw_bytes(model_config, weights)
+            self._ctx: Optional[_capi.Context] = _capi.Context.from_sbbw(source, device, prec, self.max_batch, flags)
         else:
+            if weights is None:
+                _, self._weights = load_sbbw(sbbw_path)
             self._ctx = _capi.Context(device, prec)
             try:
-                self._ctx.set_lanes(int(os.environ.get("SBBSEG_LANES", "2")))   # before finalize: 1 skips the second buffer set
+                self._ctx.set_lanes(lanes)                 # before finalize: 1 skips the second buffer set
                 self._ctx.load_plan(self.plan, self.max_batch)
             except Exception:
                 self._ctx.close()
                 raise
+        self._ctx.ids_provider = self.plan_tensor_ids
         self.input_shape = (None,) + tuple(self.graph.input_shape)
         self.output_shape = (None,) + tuple(self.graph.output_shape)
 
@@ -113,6 +129,27 @@ class SegModel:
         if self._ctx is None or self._ctx.h is None:
             raise RuntimeError("model has been released (session closed)")
         return self._ctx
+
+    def plan_tensor_ids(self):
+        """Library tensor id of every plan tensor (debug reads of intermediate activations).  The native planner creates its
+        tensors in the Python plan's order (ids are sequential; the two input forms are created once), so for a natively
+        loaded handle the ids are re-derived from the mirror plan."""
+        if self._ctx.tensor_ids:
+            return self._ctx.tensor_ids
+        ids, nxt, forms = [], 0, {}
+        for t in self.plan.tensors:
+            if t.kind == "unused":
+                ids.append(-1)
+            elif t.kind in ("input_c8", "input_pairs"):
+                if t.kind not in forms:
+                    forms[t.kind] = nxt
+                    nxt += 1
+                ids.append(forms[t.kind])
+            else:
+                ids.append(nxt)
+                nxt += 1
+        self._ctx.tensor_ids = ids
+        return ids
 
     def release(self):
         if self._ctx is not None:

@@ -25,7 +25,8 @@ from .keras_graph import Graph, parse_model_config, resnet50_unet_config
 MAGIC = b"SBBW0001"
 
 
-def save_sbbw(path: str, model_config: dict, weights: Dict[str, np.ndarray]) -> None:
+def sbbw_bytes(model_config: dict, weights: Dict[str, np.ndarray]) -> bytes:
+    """The container as one bytes object (what ``sbbseg_model_load`` takes)."""
     graph = parse_model_config(model_config)
     tensors, chunks, off = [], [], 0
     for name, shape in graph.weight_specs():
@@ -39,13 +40,12 @@ def save_sbbw(path: str, model_config: dict, weights: Dict[str, np.ndarray]) -> 
         off += w.size
     header = json.dumps({"model_config": model_config, "tensors": tensors}).encode("utf-8")
     pad = (-(16 + len(header))) % 64
+    return b"".join([MAGIC, struct.pack("<Q", len(header)), header, b"\0" * pad] + [c.tobytes() for c in chunks])
+
+
+def save_sbbw(path: str, model_config: dict, weights: Dict[str, np.ndarray]) -> None:
     with open(path, "wb") as f:
-        f.write(MAGIC)
-        f.write(struct.pack("<Q", len(header)))
-        f.write(header)
-        f.write(b"\0" * pad)
-        for c in chunks:
-            f.write(c.tobytes())
+        f.write(sbbw_bytes(model_config, weights))
 
 
 def load_sbbw(path: str) -> Tuple[dict, Dict[str, np.ndarray]]:

@@ -13,17 +13,18 @@ from tools.synth_model import calibrated_model
 #   f32  check path   : fp32 everywhere, only summation order differs          -> 2e-3  (measured 5e-5)
 #   f16  fast path    : 11-bit significands, fp32 accumulate/epilogue           -> 0.115 (measured 0.084-0.095)
 # Labels must agree wherever the oracle's top-2 margin exceeds 2 x tolerance.
-#   f16x3 label-exact : split fp16 (hi + lo, ~22 bits), 3 MFMAs per product       -> 2e-3  (measured: see DESIGN.md)
+#   f16x3 label-exact : split fp16 (hi + lo, ~22 bits), 3 MFMAs per product       -> 1e-3  (measured 9e-5 at 448x448)
 # (f16: measured 0.084-0.095 on the 448x448 seeded nets, r02 -> measured + 20 %; bf16 is an A/B mode only -- 8-bit
 #  significands through ~60 layers give 0.34 / 7 % labels -- and carries no softmax tolerance: a bound of 0.6 on a
 #  quantity in [0, 1] would assert nothing)
-TOL_SOFTMAX = {"f16": 0.115, "f32": 2e-3, "f16x3": 2e-3}
+TOL_SOFTMAX = {"f16": 0.115, "f32": 2e-3, "f16x3": 1e-3}
 # fp16 fast mode: measured label mismatch fractions 1.9 % (2 classes) / 2.8 % (4 classes) on the noise-like seeded nets
 TOL_LABEL_FRAC_F16 = 0.035
 # max |err| / max |ref| per fused layer output
 TOL_LAYER_REL = {"bf16": 0.25, "f16": 0.04, "f32": 2e-4, "f16x3": 2e-4}
-# label-exact modes: labels must equal the oracle's wherever its top-2 softmax margin exceeds this
-EXACT_MARGIN = 1e-3
+# label-exact modes: labels must equal the oracle's wherever its top-2 softmax margin exceeds this (measured worst margin
+# among differing pixels: 7e-5, the fp32 oracle's own reassociation noise; tightened from 1e-3 in round 3)
+EXACT_MARGIN = 2e-4
 
 
 def make_model(classes, h, w, seed=0, precision="f16", max_batch=8, calib_hw=None, decisive=False):

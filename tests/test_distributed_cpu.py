@@ -102,3 +102,40 @@ def test_shard_block_covers_everything():
                 assert first == min(r * block, n) and count <= block
                 seen += list(range(first, first + count))
             assert seen == list(range(n))
+
+
+def _worker_pages(rank, world, port, n_pages, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        be = NumpyBackend(224, 224, 7)
+        base = tiling.coord_page(500, 460)
+        pages = [np.roll(base, 37 * k, axis=1).copy() for k in range(n_pages)]
+        maps = D.segment_pages_sharded(be, pages).numpy()
+        ok = maps.shape == (n_pages, 500, 460)
+        for k, p in enumerate(pages):                      # every rank holds every page's map, equal to the single-process result
+            one = torch.zeros(p.shape[:2], dtype=torch.uint8)
+            be.whole_page(be.to_device(p), one)
+            ok = ok and bool(np.array_equal(maps[k], one.numpy()))
+        q.put((rank, ok, D.shard_block(n_pages, rank, world)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_pages", [5, 6])
+def test_sharded_pages_world4_with_padding_rows(n_pages):
+    """A page count the world does not divide: shard_block pads every rank's contribution to ceil(n/world) rows (rank 3 owns
+    nothing at 5 or 6 pages over 4 ranks), the all-gather carries the padding, and the result is cut back to n pages."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_pages, args=(r, 4, port, n_pages, q)) for r in range(4)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _ in res)
+    counts = {rank: blk[1] for rank, _, blk in res}
+    assert sum(counts.values()) == n_pages and counts[3] == 0 and all(blk[2] == 2 for _, _, blk in res)

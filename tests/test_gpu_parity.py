@@ -229,7 +229,14 @@ def test_whole_image_branch_matches_oracle():
     ref = tiling.do_prediction(False, page, om, full_image_shape=(840, 624, 3))
     got = predict.do_prediction(False, page, model, full_image_shape=(840, 624, 3))
     assert got.shape == (840, 624, 3) and got.dtype == np.uint8
-    assert (got != ref).mean() < 1e-3
+    # f32 tolerance: a label may differ only where the oracle's own top-2 softmax margin (at the model-resolution pixel the
+    # output pixel is resized from) is inside 2 x the f32 softmax tolerance
+    x = tiling.resize_nearest(page / 255.0, 224, 224)[None].astype(np.float32)
+    pr = np.sort(om.predict(x)[0], axis=-1)
+    margin = tiling.resize_nearest((pr[..., -1] - pr[..., -2])[:, :, None], 840, 624)[:, :, 0]
+    mism = got[:, :, 0] != ref[:, :, 0]
+    assert not (mism & (margin > 2 * TOL_SOFTMAX["f32"])).any()
+    assert mism.mean() < 2e-4
     model.release()
 
 
@@ -375,8 +382,15 @@ def test_three_model_pipeline(tmp_path):
     om = kf.OracleModel(cfg, w)
     crop = ots[:448, :448]
     ref = tiling.do_prediction(True, crop, om)[:, :, 0]
-    got = predict.do_prediction(True, crop, load_model(str(tmp_path / "model_strukturerkennung.h5"), max_batch=16))[:, :, 0]
-    assert (ref != got).mean() < 0.06
+    layout = load_model(str(tmp_path / "model_strukturerkennung.h5"), max_batch=16)          # default precision: label-exact f16x3
+    got = predict.do_prediction(True, crop, layout)[:, :, 0]
+    # label-exact: probabilities of three tiles of the Otsu'd page against the oracle, labels equal outside EXACT_MARGIN
+    xs = np.stack([ots[y0:y0 + 224, x0:x0 + 224] for (y0, x0) in ((0, 0), (300, 500), (1000, 800))]).astype(np.float32) / np.float32(255.0)
+    pref, pgot = om.predict(xs), layout.predict(xs)
+    assert float(np.abs(pref - pgot).max()) < TOL_SOFTMAX["f16x3"]
+    total, outside = exact_label_check(pref, pgot)
+    assert outside == 0 and total <= 1e-3 * pref[..., 0].size
+    assert (ref != got).mean() <= 1e-3
     clear_session()
 
 
