@@ -1,0 +1,204 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/glue_golden.npz by running the REFERENCE's OWN glue functions (imported from /root/reference).
+
+Runs only in the build container (needs /root/reference); never on the GPU box.  ``main.py`` is imported exactly as
+``make_tiling_golden.py`` does it (empty stub modules for cv2 / keras / tensorflow / shapely / seaborn); scipy is real
+(``gaussian_filter1d`` / ``find_peaks`` are the reference's own dependency).  The handful of cv2 entry points these
+functions call are bound to the oracle's restatements of the OpenCV arithmetic:
+
+    cv2.getRotationMatrix2D, cv2.warpAffine(INTER_CUBIC, BORDER_REPLICATE)  -> oracle/deskew.py
+    cv2.threshold(THRESH_BINARY + THRESH_OTSU), cv2.threshold(x, 0, 255, 0) -> oracle/stage_glue.py
+    cv2.resize(INTER_NEAREST), cv2.imread                                    -> oracle/tiling.py, a seeded page
+    cv2.cvtColor(BGR2GRAY), cv2.dilate, cv2.findContours / contourArea / boundingRect -> oracle/stage_glue.py
+
+What this pins: everything the reference does AROUND those calls -- padding geometry, the angle lists, the binarise-after-
+rotate step, the padded / flipped profile, which minima count as "deep", the NaN / exception handling and the list-index
+quirk of the sweep (main.py:1545-1718); the channel-0 quirk and dtypes of otsu_copy (main.py:178-194); the upscale rule and
+scale factors (main.py:196-214); the border-mask -> box -> crop -> cont_page sequence of extract_page (main.py:394-426).
+What it cannot pin: the OpenCV arithmetic inside the stubs ([EXT], cv2 is not installable) -- those stay "unpinned".
+
+The fixture holds inputs (masks, pages) and the reference's outputs only.
+    python tests/golden/make_glue_golden.py [out.npz]"""
+import os
+import sys
+import zlib
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+from make_tiling_golden import load_reference, stub_cv2_resize  # noqa: E402
+from oracle import deskew as dk  # noqa: E402
+from oracle import stage_glue as sg  # noqa: E402
+from sbb_textline_detection_amd.synthetic import synthetic_page  # noqa: E402  (seeded test pages: data, not product logic)
+
+
+def text_mask(h, w, seed, slope, thick_div=3):
+    """Seeded text-line-like region mask (0/1), lines following y = slope * x."""
+    rng = np.random.RandomState(seed)
+    m = np.zeros((h, w), np.uint8)
+    period = max(8, h // 7)
+    for y in range(period // 2, h - period // 2, period):
+        x0, x1 = rng.randint(0, w // 6), w - rng.randint(0, w // 6)
+        for x in range(x0, x1):
+            yy = y + int(round(slope * (x - w / 2)))
+            if 0 <= yy < h - period // thick_div:
+                m[yy:yy + period // thick_div, x] = 1
+    return m
+
+
+DESKEW_MASKS = [(60, 90, 0, 0.05), (75, 48, 1, -0.12), (33, 33, 2, 0.0), (90, 140, 3, 0.30), (120, 80, 4, -0.45), (64, 64, 5, 0.0)]
+# (mask index, rotation angle of the padded square, sigma, multiplier): the inputs return_deskew_slope hands over (main.py:1631-1640);
+# the last one is an UNPADDED mask, where a minimum lands in the right-hand padding and the reference raises IndexError
+PROFILE_CASES = [(0, 0.0, 1.0, 20.3), (1, -7.9, 1.0, 20.3), (3, 12.0, 2.0, 20.3), (5, 0.0, 0.5, 3.8), (4, -25.0, 1.5, 3.8), (0, None, 1.0, 3.8)]
+OTSU_PAGES = [(300, 420, 0), (511, 333, 1), (256, 256, 2)]
+SCALE_PAGES = [(180, 140, 3), (2600, 40, 4)]            # < 2500 high -> 2800; >= 2500 -> x 1.2
+BORDER_CASES = [(300, 240, 7, (40, 30, 200, 150)), (280, 360, 8, (0, 0, 280, 360)), (200, 200, 9, (90, 60, 40, 100))]
+
+
+def install_cv2_stubs(cv2, pages_by_name):
+    cv2.INTER_NEAREST, cv2.INTER_CUBIC, cv2.BORDER_REPLICATE = 0, 2, 1
+    cv2.THRESH_BINARY, cv2.THRESH_OTSU, cv2.COLOR_BGR2GRAY, cv2.RETR_TREE, cv2.CHAIN_APPROX_SIMPLE = 0, 8, 6, 3, 2
+    cv2.resize = stub_cv2_resize
+    cv2.imread = lambda path: pages_by_name[path].copy()
+    cv2.getRotationMatrix2D = lambda center, angle, scale: dk.rotation_matrix(center, angle)
+
+    def warp_affine(src, M, dsize, flags=None, borderMode=None):
+        assert flags == cv2.INTER_CUBIC and borderMode == cv2.BORDER_REPLICATE and tuple(dsize) == (src.shape[1], src.shape[0])
+        return dk.warp_affine_cubic_replicate(src, M)
+    cv2.warpAffine = warp_affine
+
+    def threshold(src, thresh, maxval, typ):
+        if typ == cv2.THRESH_BINARY + cv2.THRESH_OTSU:
+            t = sg.otsu_threshold(np.ascontiguousarray(src, np.uint8))
+            return float(t), np.where(src > t, maxval, 0).astype(np.uint8)
+        assert typ == 0                                   # THRESH_BINARY with a fixed threshold (main.py:395)
+        return float(thresh), np.where(src > thresh, maxval, 0).astype(np.uint8)
+    cv2.threshold = threshold
+
+    def cvt_color(img, code):
+        assert code == cv2.COLOR_BGR2GRAY and np.array_equal(img[:, :, 0], img[:, :, 1]) and np.array_equal(img[:, :, 0], img[:, :, 2])
+        return img[:, :, 0].copy()                        # equal channels: the fixed-point luma weights sum to one -> the value itself
+    cv2.cvtColor = cvt_color
+    cv2.dilate = lambda src, kernel, iterations=1: sg.morph(src, "dilate", kernel.shape[0], iterations)
+
+    class Blob:                                           # stands in for one traced contour: its component's pixels
+        def __init__(self, ys, xs):
+            self.ys, self.xs = ys, xs
+
+    def find_contours(mask, mode, method):
+        from scipy import ndimage
+        lab, n = ndimage.label(mask > 0, structure=np.ones((3, 3), int))
+        return [Blob(*np.nonzero(lab == k)) for k in range(1, n + 1)], None
+    cv2.findContours = find_contours
+    cv2.contourArea = lambda b: float(len(b.ys))          # [EXT] ranking stand-in: pixel count (the oracle's documented choice)
+    cv2.boundingRect = lambda b: (int(b.xs.min()), int(b.ys.min()), int(b.xs.max() - b.xs.min() + 1), int(b.ys.max() - b.ys.min() + 1))
+
+
+class BorderModel:
+    """Fake border model: class 1 inside a seeded rectangle of the MODEL-sized input (plus a one-pixel speck elsewhere)."""
+
+    class _L:
+        def __init__(self, shp):
+            self.output_shape = shp
+
+    def __init__(self, H, W, box, speck):
+        self.layers = [self._L((None, H, W, 2))]
+        self.H, self.W, self.box, self.speck = H, W, box, speck
+
+    def predict(self, x):
+        p = np.zeros((1, self.H, self.W, 2), np.float32)
+        p[..., 0] = 1.0
+        y, x0, h, w = self.box[1], self.box[0], self.box[3], self.box[2]
+        p[0, y:y + h, x0:x0 + w, 1] = 2.0
+        p[0, self.speck[0], self.speck[1], 1] = 2.0
+        return p
+
+
+def main():
+    out_path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(HERE, "glue_golden.npz")
+    ref = load_reference()
+    import cv2
+    pages = {}
+    install_cv2_stubs(cv2, pages)
+    det = ref.textline_detector.__new__(ref.textline_detector)
+    det.kernel = np.ones((5, 5), np.uint8)                # main.py:57
+    out = {}
+
+    # ---- return_deskew_slope / get_standard_deviation_of_summed_textline_patch_along_width (main.py:1545-1718)
+    masks = [text_mask(*c) for c in DESKEW_MASKS]
+    for k, m in enumerate(masks):
+        out[f"deskew_mask{k}"] = m
+        out[f"deskew_slope{k}"] = np.float64(det.return_deskew_slope(m, 1.0))
+        print("deskew", k, m.shape, float(out[f"deskew_slope{k}"]))
+    out["deskew_n"] = np.int64(len(masks))
+    for j, (mi, angle, sigma, mult) in enumerate(PROFILE_CASES):
+        out[f"profile_case{j}"] = np.array([mi, np.nan if angle is None else angle, sigma, mult], np.float64)
+        if angle is None:
+            patch = masks[mi].astype(np.float64)
+        else:
+            patch = det.rotate_image(dk.padded_square(masks[mi]), angle)          # the reference's own method over the stubs
+            patch[patch != 0] = 1                                                  # main.py:1633
+        out[f"profile_patch{j}"] = np.packbits(patch != 0)
+        out[f"profile_patch_shape{j}"] = np.array(patch.shape, np.int64)
+        try:
+            lows, sd = det.get_standard_deviation_of_summed_textline_patch_along_width(patch, sigma, mult)
+            out[f"profile_raises{j}"] = np.int64(0)
+        except IndexError:                                # a minimum found in the right-hand padding (main.py:1586): the sweep's
+            lows, sd = [], 0.0                            # except clause turns it into var_spectrum = 0 (main.py:1652-1655)
+            out[f"profile_raises{j}"] = np.int64(1)
+        out[f"profile_lows{j}"] = np.asarray(lows, np.float64)
+        out[f"profile_std{j}"] = np.float64(sd)
+        print("profile", j, len(lows), float(sd), "raises" if out[f"profile_raises{j}"] else "")
+    out["profile_n"] = np.int64(len(PROFILE_CASES))
+
+    # ---- otsu_copy (main.py:178-194): the page itself is regenerated from its seed by the tests
+    for k, (h, w, seed) in enumerate(OTSU_PAGES):
+        page = synthetic_page(h, w, seed=seed)
+        r = det.otsu_copy(page)
+        assert r.dtype == np.float64 and r.shape == page.shape
+        assert np.array_equal(r[:, :, 0], r[:, :, 1]) and np.array_equal(r[:, :, 0], r[:, :, 2])
+        out[f"otsu_case{k}"] = np.array([h, w, seed], np.int64)
+        out[f"otsu_plane{k}"] = np.packbits(r[:, :, 0] > 0)
+        out[f"otsu_values{k}"] = np.unique(r)
+        print("otsu", k, page.shape, np.unique(r), float((r[:, :, 0] > 0).mean()))
+    out["otsu_n"] = np.int64(len(OTSU_PAGES))
+
+    # ---- get_image_and_scales (main.py:196-214)
+    for k, (h, w, seed) in enumerate(SCALE_PAGES):
+        page = synthetic_page(max(h, 8), max(w, 8), seed=seed)[:h, :w]
+        pages[f"page{k}"] = page
+        det.image_dir = f"page{k}"
+        det.get_image_and_scales()
+        out[f"scale_case{k}"] = np.array([h, w, seed], np.int64)
+        out[f"scale_result{k}"] = np.array([det.img_hight_int, det.img_width_int, det.height_org, det.width_org], np.int64)
+        out[f"scale_factors{k}"] = np.array([det.scale_y, det.scale_x], np.float64)
+        out[f"scale_crc{k}"] = np.int64(zlib.crc32(np.ascontiguousarray(det.image).tobytes()) & 0xFFFFFFFF)
+        print("scale", k, (h, w), "->", det.image.shape, det.scale_y, det.scale_x)
+    out["scale_n"] = np.int64(len(SCALE_PAGES))
+
+    # ---- extract_page glue (main.py:384-437) around a fake border model
+    for k, (h, w, seed, box) in enumerate(BORDER_CASES):
+        page = synthetic_page(h, w, seed=seed)
+        det.image = page
+        mh = mw = 64
+        bx = (box[0] * mw // w, box[1] * mh // h, max(1, box[2] * mw // w), max(1, box[3] * mh // h))
+        fm = BorderModel(mh, mw, bx, (mh - 2, 1))
+        det.start_new_session_and_model = lambda _dir, fm=fm: (fm, type("S", (), {"close": lambda self: None})())
+        det.model_page_dir = "unused"
+        croped, coord = det.extract_page()
+        out[f"border_case{k}"] = np.array([h, w, seed, mh, mw, *bx, mh - 2, 1], np.int64)
+        out[f"border_coord{k}"] = np.array(coord, np.int64)
+        out[f"border_cont{k}"] = np.asarray(det.cont_page[0], np.int64)
+        out[f"border_crop_shape{k}"] = np.array(croped.shape, np.int64)
+        out[f"border_crop_crc{k}"] = np.int64(zlib.crc32(np.ascontiguousarray(croped).tobytes()) & 0xFFFFFFFF)
+        print("border", k, (h, w), "box", bx, "->", coord, croped.shape)
+    out["border_n"] = np.int64(len(BORDER_CASES))
+    np.savez_compressed(out_path, **out)
+    print("wrote", out_path, os.path.getsize(out_path), "bytes")
+
+
+if __name__ == "__main__":
+    main()

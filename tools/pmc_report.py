@@ -14,6 +14,17 @@ precision = sys.argv[4] if len(sys.argv) > 4 else "f16"
 patches_per_launch = float(sys.argv[5]) if len(sys.argv) > 5 else 140.0
 
 
+def csrc_sha():
+    """hash of the kernel / host sources the profiled library was built from (bench.py drops `traffic` when it differs)"""
+    import hashlib
+    h = hashlib.sha1()
+    base = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "sbb_textline_detection_amd", "csrc")
+    for name in ("kernels.hip", "api.hip", "internal.h"):
+        with open(os.path.join(base, name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:12]
+
+
 def load(name):
     rows = defaultdict(dict)
     meta = {}
@@ -31,7 +42,7 @@ fe, meta_f = load("fetch")
 wr, meta_w = load("write")
 # plan kernels only (conv / maxpool / head), in dispatch order; one chunk = 61 ops
 def plan_ids(meta):
-    return [d for d in sorted(meta) if any(s in meta[d][0] for s in ("conv_igemm", "maxpool", "head_kernel", "dec_tail", "stem_conv", "conv3x3_c64_direct", "bottleneck_fused"))]
+    return [d for d in sorted(meta) if any(s in meta[d][0] for s in ("conv_igemm", "maxpool", "head_kernel", "dec_tail", "stem_conv", "conv3x3_c64_direct", "bottleneck_fused", "block_x3"))]
 ids, idf, idw = plan_ids(meta), plan_ids(meta_f), plan_ids(meta_w)
 names = None
 if ops_json:
@@ -68,4 +79,4 @@ if summary_out:
                          "(one whole chunk per launch on one lane); FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 counts half of wide coalesced reads); "
                          "duplicate op names keep the last launch; mfma_busy_pct = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x 32 CUs x 4 SIMDs) "
                          "(the SQ totals of this rocprofv3 build cover one XCD); shader_clock_mhz = GRBM_GUI_ACTIVE / 8 XCDs / launch duration",
-               "precision": precision, "patches_per_launch": patches_per_launch, "ops": summary}, open(summary_out, "w"), indent=1)
+               "precision": precision, "patches_per_launch": patches_per_launch, "csrc_sha": csrc_sha(), "ops": summary}, open(summary_out, "w"), indent=1)
