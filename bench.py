@@ -169,7 +169,9 @@ def main():
         # tiles per chunk: four pages' worth (4 x 70 / 4 x 108), pooled across pages by sbbseg_segment_pages_dev and run as two
         # concurrent halves -- one page's 70 tiles leave the persistent conv grids a ragged last round; 140 / 280 / 374 / 560
         # tiles per chunk measured 9 997 / 10 176 / 10 214 / 10 209 patches/s (profiles/r02_experiments.md)
-        args.max_batch = 432 if workload == "batch64" else (280 if workload == "page" else 70)
+        # (f16x3 stores 4 bytes per activation element: a tensor x batch must stay inside the 4 GiB gather window -- the largest,
+        # 224x224x64, allows 334 patches -- so the 4000x3000 pages pool two at a time there, 2 x 108 tiles)
+        args.max_batch = (216 if args.precision == "f16x3" else 432) if workload == "batch64" else (280 if workload == "page" else 70)
     torch.cuda.set_device(device_index)
     ranks_seen = None
     if world > 1:

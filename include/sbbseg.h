@@ -208,6 +208,19 @@ int sbbseg_otsu_dev(sbbseg_ctx* c, const void* d_page_hwc, int Hp, int Wp, int* 
 int sbbseg_segment_tile_range_bin_dev(sbbseg_ctx* c, const void* d_page_hwc, int Hp, int Wp, int first_tile,
                                       int n_tiles, const int* d_threshold, void* d_tile_labels);
 
+/* The two patch stages as textline_detector.run() really calls them (main.py:2061, 2072, 2102): on extract_page's CROPPED page.
+ * page = the STORED image [Hs][Ws][3]; Hp x Wp = its size after get_image_and_scales (main.py:196-214); {cx, cy, cw, ch} =
+ * extract_page's box on the upscaled page (cv2.boundingRect convention, main.py:404-409); labels = [ch][cw] (x3 with
+ * sbbseg_set_label_channels(3)).  binarise != 0: otsu_copy of the CROPPED page first (extract_text_regions, main.py:443: the
+ * threshold is the Otsu threshold of the crop's channel 0; *threshold receives it), binarise == 0: textline_contours
+ * (main.py:494).  Upscale, crop and binarisation are index arithmetic in the tile gather: neither the upscaled page nor the
+ * crop is materialised.  Equal to sbbseg_segment_page[_otsu] on the materialised crop of the nearest-resized page.
+ * _dev: page / labels / threshold (may be NULL) are device pointers, work is enqueued on the handle's stream. */
+int sbbseg_segment_crop(sbbseg_ctx* c, const uint8_t* page_hwc, int Hs, int Ws, int Hp, int Wp, int cx, int cy, int cw, int ch,
+                        int binarise, uint8_t* labels_hw, int* threshold);
+int sbbseg_segment_crop_dev(sbbseg_ctx* c, const void* d_page_hwc, int Hs, int Ws, int Hp, int Wp, int cx, int cy, int cw, int ch,
+                            int binarise, void* d_labels_hw, int* d_threshold);
+
 /* ---- seam 1, patches=False (main.py:368-380): nearest-resize page to the model size, one forward,
  * argmax, nearest-resize labels to out_h x out_w (cv2.INTER_NEAREST index rule). */
 int sbbseg_segment_whole(sbbseg_ctx* c, const uint8_t* page_hwc, int Hp, int Wp,

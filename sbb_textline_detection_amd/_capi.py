@@ -23,7 +23,7 @@ EXPORTS = [
     "sbbseg_set_stream", "sbbseg_set_lanes", "sbbseg_set_label_channels", "sbbseg_synchronize", "sbbseg_set_input", "sbbseg_input_form", "sbbseg_add_tensor",
     "sbbseg_add_conv", "sbbseg_add_maxpool", "sbbseg_add_tail", "sbbseg_add_head", "sbbseg_finalize", "sbbseg_model_info",
     "sbbseg_num_ops", "sbbseg_op_info", "sbbseg_op_issued_flops", "sbbseg_device_bytes", "sbbseg_predict", "sbbseg_segment_page",
-    "sbbseg_segment_page_dev", "sbbseg_segment_pages_dev", "sbbseg_segment_page_scaled", "sbbseg_segment_page_otsu", "sbbseg_otsu_dev",
+    "sbbseg_segment_page_dev", "sbbseg_segment_pages_dev", "sbbseg_segment_page_scaled", "sbbseg_segment_page_otsu", "sbbseg_segment_crop", "sbbseg_segment_crop_dev", "sbbseg_otsu_dev",
     "sbbseg_segment_tile_range_bin_dev", "sbbseg_segment_whole", "sbbseg_segment_whole_scaled", "sbbseg_tile_grid", "sbbseg_nearest_map", "sbbseg_segment_tiles_dev",
     "sbbseg_segment_tile_range_dev", "sbbseg_stitch_dev", "sbbseg_debug_ingest", "sbbseg_debug_read_tensor",
     "sbbseg_debug_set_conv_variant", "sbbseg_debug_inject_alloc_failure",
@@ -94,6 +94,8 @@ def load_library(path: Optional[str] = None):
         "sbbseg_segment_pages_dev": [vp, i32, vp, i32, i32, vp],
         "sbbseg_segment_page_scaled": [vp, vp, i32, i32, i32, i32, vp],
         "sbbseg_segment_page_otsu": [vp, vp, i32, i32, i32, i32, vp, C.POINTER(C.c_int)],
+        "sbbseg_segment_crop": [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, C.POINTER(C.c_int)],
+        "sbbseg_segment_crop_dev": [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp],
         "sbbseg_otsu_dev": [vp, vp, i32, i32, vp],
         "sbbseg_segment_tile_range_bin_dev": [vp, vp, i32, i32, i32, i32, vp, vp],
         "sbbseg_segment_whole": [vp, vp, i32, i32, i32, i32, vp],
@@ -320,6 +322,23 @@ class Context:
         check(self.lib.sbbseg_segment_page_otsu(self.h, _ptr(page), page.shape[0], page.shape[1], out_h, out_w, _ptr(out),
                                                 C.byref(thr)), "sbbseg_segment_page_otsu")
         return out, int(thr.value)
+
+    def segment_crop(self, page: np.ndarray, scaled_h: int, scaled_w: int, box, binarise: bool = False, channels: int = 1):
+        """A patch stage on extract_page's cropped page (main.py:2061-2102): ``page`` = the stored image, ``scaled_*`` its size
+        after get_image_and_scales, ``box`` = (x, y, w, h) on the upscaled page.  Returns (labels [h][w] (x3), Otsu threshold or
+        None); ``binarise`` = the layout stage's otsu_copy on the crop."""
+        page = np.ascontiguousarray(page, np.uint8)
+        x, y, w, h = (int(v) for v in box)
+        out = self._label_out(h, w, channels)
+        thr = C.c_int(0)
+        check(self.lib.sbbseg_segment_crop(self.h, _ptr(page), page.shape[0], page.shape[1], int(scaled_h), int(scaled_w), x, y, w, h,
+                                           1 if binarise else 0, _ptr(out), C.byref(thr)), "sbbseg_segment_crop")
+        return out, (int(thr.value) if binarise else None)
+
+    def segment_crop_dev(self, d_page: int, Hs: int, Ws: int, scaled_h: int, scaled_w: int, box, binarise: bool, d_labels: int, d_threshold: int = 0):
+        x, y, w, h = (int(v) for v in box)
+        check(self.lib.sbbseg_segment_crop_dev(self.h, C.c_void_p(d_page), Hs, Ws, int(scaled_h), int(scaled_w), x, y, w, h,
+                                               1 if binarise else 0, C.c_void_p(d_labels), C.c_void_p(d_threshold or None)), "sbbseg_segment_crop_dev")
 
     def otsu_dev(self, d_page: int, Hp: int, Wp: int, d_threshold: int):
         check(self.lib.sbbseg_otsu_dev(self.h, C.c_void_p(d_page), Hp, Wp, C.c_void_p(d_threshold)), "sbbseg_otsu_dev")

@@ -197,6 +197,7 @@ struct sbbseg_ctx {
     int *d_own_x = nullptr, *d_own_y = nullptr; size_t own_cap = 0;
     int own_Hp = -1, own_Wp = -1, own_nyf = 0;
     int *d_map = nullptr; size_t map_cap = 0;
+    int map_key[4] = {0, 0, 0, 0};     // {Hs, Ws, Hp, Wp} the nearest maps in d_map were built for (sbbseg_segment_crop_dev; 0 = none)
     // stage glue scratch (morphology planes, union-find arrays, result words)
     uint8_t *d_morph_a = nullptr, *d_morph_b = nullptr; size_t morph_a_cap = 0, morph_b_cap = 0;
     // pipelined multi-page host path (sbbseg_segment_pages): copy streams, two slots of pinned staging + device buffers
@@ -1839,6 +1840,7 @@ int sbbseg_segment_page_scaled(sbbseg_ctx* c, const uint8_t* page_hwc, int Hs, i
     nearest_map(Hs, Hp, my);               // scaled row -> stored row   (main.py:214 -> 112-113)
     nearest_map(Ws, Wp, mx);
     if (ensure(c, (void**)&c->d_map, &c->map_cap, sizeof(int) * (size_t)(Hp + Wp))) return 1;
+    c->map_key[0] = 0;                     // (d_map is rewritten below: the crop path's cached maps are gone)
     int* d_my = c->d_map; int* d_mx = d_my + Hp;
     HIPCHK(hipStreamSynchronize(c->stream));
     HIPCHK(hipMemcpy(d_my, my.data(), sizeof(int) * Hp, hipMemcpyHostToDevice));
@@ -1893,6 +1895,7 @@ int sbbseg_segment_page_otsu(sbbseg_ctx* c, const uint8_t* page_hwc, int Hs, int
         nearest_map(Hs, Hp, my);           // scaled row -> stored row   (main.py:214 -> 112-113)
         nearest_map(Ws, Wp, mx);
         if (ensure(c, (void**)&c->d_map, &c->map_cap, sizeof(int) * (size_t)(Hp + Wp))) return 1;
+        c->map_key[0] = 0;
         d_my = c->d_map; d_mx = d_my + Hp;
         HIPCHK(hipStreamSynchronize(c->stream));
         HIPCHK(hipMemcpy(d_my, my.data(), sizeof(int) * Hp, hipMemcpyHostToDevice));
@@ -1910,6 +1913,64 @@ int sbbseg_segment_page_otsu(sbbseg_ctx* c, const uint8_t* page_hwc, int Hs, int
     if (labels_to_host(c, labels_hw, pix)) return 1;
     int thr = 0;
     HIPCHK(hipMemcpyAsync(&thr, d_thr, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (threshold) *threshold = thr;
+    return 0;
+    API_END
+}
+
+// The patch stages of run() on the CROPPED page (main.py:2061-2102: extract_page's croped_page goes to extract_text_regions and
+// textline_contours): the crop box lives in the coordinates of the page as upscaled to Hp x Wp, the stored image is Hs x Ws.
+// Rescale, crop and (binarise != 0) otsu_copy are all index arithmetic in the tile gather: row r / column q of the crop read
+// stored row map_y[cy + r] / column map_x[cx + q]; the Otsu histogram is taken over exactly those pixels (channel 0).
+int sbbseg_segment_crop_dev(sbbseg_ctx* c, const void* d_page_hwc, int Hs, int Ws, int Hp, int Wp, int cx, int cy, int cw, int ch,
+                            int binarise, void* d_labels_hw, int* d_threshold)
+{
+    API_BEGIN
+    if (check_ready(c)) return 1;
+    REQUIRE(d_page_hwc && d_labels_hw && Hs > 0 && Ws > 0 && Hp > 0 && Wp > 0, "bad arguments");
+    REQUIRE(cx >= 0 && cy >= 0 && cw > 0 && ch > 0 && cx + cw <= Wp && cy + ch <= Hp, "crop box {%d,%d,%d,%d} leaves the %dx%d page", cx, cy, cw, ch, Hp, Wp);
+    REQUIRE(ch >= c->in_H && cw >= c->in_W, "cropped page %dx%d is smaller than the model input %dx%d (unsupported by the reference too, main.py:278-281)",
+            ch, cw, c->in_H, c->in_W);
+    if (c->map_key[0] != Hs || c->map_key[1] != Ws || c->map_key[2] != Hp || c->map_key[3] != Wp || !c->d_map) {
+        std::vector<int> my, mx;
+        nearest_map(Hs, Hp, my);           // scaled row -> stored row   (main.py:214 -> 112-113); identity when Hs == Hp
+        nearest_map(Ws, Wp, mx);
+        if (ensure(c, (void**)&c->d_map, &c->map_cap, sizeof(int) * (size_t)(Hp + Wp))) return 1;
+        HIPCHK(hipStreamSynchronize(c->stream));
+        HIPCHK(hipMemcpy(c->d_map, my.data(), sizeof(int) * Hp, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(c->d_map + Hp, mx.data(), sizeof(int) * Wp, hipMemcpyHostToDevice));
+        c->map_key[0] = Hs; c->map_key[1] = Ws; c->map_key[2] = Hp; c->map_key[3] = Wp;
+    }
+    const int* d_my = c->d_map + cy;
+    const int* d_mx = c->d_map + Hp + cx;
+    int* d_thr = nullptr;
+    if (binarise) {
+        d_thr = d_threshold ? d_threshold : (int*)(c->d_hist + 256);
+        HIPCHK(launch_otsu((const uint8_t*)d_page_hwc, Ws, ch, cw, d_my, d_mx, c->d_hist, d_thr, c->num_cus, c->stream));
+    }
+    int nx = 0, ny = 0;
+    if (sbbseg_tile_grid(ch, cw, c->in_H, c->in_W, nullptr, 0, &nx, &ny)) return 1;
+    if (ensure(c, (void**)&c->d_tile_labels, &c->tile_labels_cap, (size_t)nx * ny * c->in_H * c->in_W)) return 1;
+    if (tile_range_impl(c, &d_page_hwc, 1, Hs, Ws, d_my, d_mx, ch, cw, 0, nx * ny, c->d_tile_labels, d_thr)) return 1;
+    return sbbseg_stitch_dev(c, c->d_tile_labels, ch, cw, d_labels_hw);
+    API_END
+}
+
+int sbbseg_segment_crop(sbbseg_ctx* c, const uint8_t* page_hwc, int Hs, int Ws, int Hp, int Wp, int cx, int cy, int cw, int ch,
+                        int binarise, uint8_t* labels_hw, int* threshold)
+{
+    API_BEGIN
+    if (check_ready(c)) return 1;
+    REQUIRE(page_hwc && labels_hw && Hs > 0 && Ws > 0 && cw > 0 && ch > 0, "bad arguments");
+    const size_t spix = (size_t)Hs * Ws, pix = (size_t)ch * cw;
+    if (ensure(c, (void**)&c->d_page, &c->page_cap, spix * 3)) return 1;
+    if (ensure(c, (void**)&c->d_page_labels, &c->page_labels_cap, pix + 4)) return 1;
+    HIPCHK(hipMemcpyAsync(c->d_page, page_hwc, spix * 3, hipMemcpyHostToDevice, c->stream));
+    if (sbbseg_segment_crop_dev(c, c->d_page, Hs, Ws, Hp, Wp, cx, cy, cw, ch, binarise, c->d_page_labels, nullptr)) return 1;
+    if (labels_to_host(c, labels_hw, pix)) return 1;
+    int thr = 0;
+    if (binarise) HIPCHK(hipMemcpyAsync(&thr, (int*)(c->d_hist + 256), sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     if (threshold) *threshold = thr;
     return 0;
@@ -1946,6 +2007,7 @@ int sbbseg_segment_whole_scaled(sbbseg_ctx* c, const uint8_t* page_hwc, int Hp, 
     nearest_map(c->in_W, out_w, ox);
     const size_t need = sizeof(int) * (size_t)(c->in_H + c->in_W + out_h + out_w);
     if (ensure(c, (void**)&c->d_map, &c->map_cap, need)) return 1;
+    c->map_key[0] = 0;
     int* d_my = c->d_map; int* d_mx = d_my + c->in_H; int* d_oy = d_mx + c->in_W; int* d_ox = d_oy + out_h;
     HIPCHK(hipStreamSynchronize(c->stream));
     HIPCHK(hipMemcpy(d_my, my.data(), sizeof(int) * c->in_H, hipMemcpyHostToDevice));

@@ -1597,13 +1597,16 @@ __global__ __launch_bounds__(256, 1) void dec_tail_fused_x3(const TailParams p)
         const int y0 = ty * 16, x0 = tx * 16;
         char* lds_src = smem + buf * kT3BufBytes;
         char* lds_img = lds_src + kT3SrcBytes;
-        // src0 halo: 160 pixels x 16 granules (8 hi, 8 lo) = 40 wave-instructions of 4 pixels; pixel hp keeps granule g at slot g ^ (hp & 15)
+        // src0 halo: 160 pixels x 16 granules (8 hi, 8 lo) = 40 wave-instructions of 4 pixels; pixel hp keeps granule g at slot
+        // (g + 2 hp) & 15.  A 16-lane group of ds_read_b128 holds two k-groups (fg = a, a + 1) of eight pixels each whose hp are
+        // eight consecutive residues: rotation by 2 hp sends one k-group to the eight even slots and the other to the eight odd
+        // ones.  (The XOR swizzle g ^ (hp & 15) of round 2 collided two-way in every group: PMC SQ_LDS_BANK_CONFLICT 86 %.)
 #pragma unroll
         for (int j = 0; j < 10; ++j) {
             const int ii = wave + 4 * j;
             const int hp = ii * 4 + (lane >> 4);
             const int r = hp >> 4, c = hp & 15;
-            const int g = (lane & 15) ^ c;
+            const int g = ((lane & 15) - 2 * c) & 15;              // slot s of pixel hp holds granule (s - 2 hp) & 15
             const int Y = (y0 >> 1) - 1 + r, X = (x0 >> 1) - 1 + c;
             const bool ok = ((unsigned)Y < (unsigned)p.PH) & ((unsigned)X < (unsigned)p.PW) & (c < 10);
             uint32_t off = (uint32_t)((n * p.PH + Y) * p.PW + X) * 256u + (uint32_t)(g * 16 + kZeroHeaderBytes);
@@ -1647,8 +1650,8 @@ __global__ __launch_bounds__(256, 1) void dec_tail_fused_x3(const TailParams p)
                 for (int ni = 0; ni < 4; ++ni) {
                     const int hp = src_base[ni] + (ks >> 1) * 16 + (ks & 1);
                     const char* px_ = lds_src + hp * 256;
-                    bh[ni] = *(const bf16x8_t*)(px_ + (((kk * 4 + fg) ^ (hp & 15)) << 4));
-                    bl[ni] = *(const bf16x8_t*)(px_ + (((8 + kk * 4 + fg) ^ (hp & 15)) << 4));
+                    bh[ni] = *(const bf16x8_t*)(px_ + (((kk * 4 + fg + 2 * hp) & 15) << 4));
+                    bl[ni] = *(const bf16x8_t*)(px_ + (((8 + kk * 4 + fg + 2 * hp) & 15) << 4));
                 }
             } else {
                 const int toff = img_toff[(h - 8) >> 1][(h - 8) & 1];
@@ -2190,7 +2193,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_direct(const Direct64Param
 
 // ------------------------------------------------------------------------------------------------
 // conv3x3_c64_direct_x3 -- the same direct conv in the split mode (kF16X3): pixels are [64 hi][64 lo] (256 B, 16 granules,
-// slot = granule ^ (halo row & 15)), the wave's weights are hi + lo fragments (288 VGPRs: one block per CU), three MFMAs per
+// slot = (granule + 2 * halo row) & 15: conflict-free for ds_read_b128's 16-lane groups), the wave's weights are hi + lo fragments (288 VGPRs: one block per CU), three MFMAs per
 // product, outputs split again.  The generic split kernel needs 0.82 ms per 140 patches for each of these layers.
 // ------------------------------------------------------------------------------------------------
 constexpr int kD64x3Instr = 48;                                 // wave-instructions of 4 pixels (192 >= 180)
@@ -2244,7 +2247,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_c64_direct_x3(const Direct64Pa
             const int ii = wave + 4 * j;
             const int hr = ii * 4 + (lane >> 4);                // halo row index = hy * 18 + hx
             const int hy = hr / kD64HaloW, hx = hr - hy * kD64HaloW;
-            const int g = (lane & 15) ^ (hr & 15);
+            const int g = ((lane & 15) - 2 * hr) & 15;          // slot s of halo pixel hr holds granule (s - 2 hr) & 15 (see dec_tail_fused_x3)
             const int Y = ty * 8 - 1 + hy, X = tx * 16 - 1 + hx;
             const bool ok = ((unsigned)Y < (unsigned)p.H) & ((unsigned)X < (unsigned)p.W) & (hr < kD64Rows);
             uint32_t off = (uint32_t)((n * p.H + Y) * p.W + X) * 256u + (uint32_t)(g * 16 + kZeroHeaderBytes);
@@ -2281,8 +2284,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3_c64_direct_x3(const Direct64Pa
                 for (int ni = 0; ni < 4; ++ni) {
                     const int hr = hbase[ni] + toff;
                     const char* px = lds + hr * 256;
-                    const bf16x8_t bh = *(const bf16x8_t*)(px + (((kk * 4 + fg) ^ (hr & 15)) << 4));
-                    const bf16x8_t bl = *(const bf16x8_t*)(px + (((8 + kk * 4 + fg) ^ (hr & 15)) << 4));
+                    const bf16x8_t bh = *(const bf16x8_t*)(px + (((kk * 4 + fg + 2 * hr) & 15) << 4));
+                    const bf16x8_t bl = *(const bf16x8_t*)(px + (((8 + kk * 4 + fg + 2 * hr) & 15) << 4));
 #pragma unroll
                     for (int m = 0; m < 2; ++m) {
                         acc[m][ni] = mfma16<F16>(wlo[t][kk][m], bh, acc[m][ni]);

@@ -207,6 +207,7 @@ class InferenceStages:
             if pixels == 0:
                 raise ValueError("attempt to get argmax of an empty sequence")          # what main.py:401 raises
             x, y, w, h = box
+            self.page_box = (x, y, w, h)
             # crop_image_inside_box (main.py:174-176) on the upscaled page; built here only for the crop
             page = self._scaled_page()
             croped_page, page_coord = page[y:y + h, x:x + w], [y, y + h, x, x + w]
@@ -229,41 +230,79 @@ class InferenceStages:
         finally:
             session.close()
 
-    def extract_text_regions(self, img_u8: Optional[np.ndarray] = None) -> np.ndarray:
+    def extract_text_regions(self, img_u8: Optional[np.ndarray] = None, box=None) -> np.ndarray:
         """main.py:439-454.  On a SegModel the whole wrapper is one library call: histogram, Otsu threshold,
-        binarising tile gather (and, with img_u8=None, the rescale of the stored page), forward, stitch."""
+        binarising tile gather (and, with img_u8=None, the rescale of the stored page), forward, stitch.
+        ``box`` = (x, y, w, h) of extract_page on the upscaled page: the stage runs on that crop (what run() hands it,
+        main.py:2061-2072) without the crop being built."""
         model, session = start_new_session_and_model(self.model_region_dir, **self.kw)
         try:
             if isinstance(model, SegModel):
-                if img_u8 is None:
+                if img_u8 is None and box is not None:
+                    lab, self.otsu_threshold = model.ctx.segment_crop(self.image_stored, self.img_hight_int, self.img_width_int, box,
+                                                                      binarise=True, channels=3)
+                elif img_u8 is None:
                     lab, self.otsu_threshold = model.ctx.segment_page_otsu(self.image_stored, self.img_hight_int, self.img_width_int,
                                                                            channels=3)
                 else:
                     lab, self.otsu_threshold = model.ctx.segment_page_otsu(np.ascontiguousarray(img_u8, np.uint8), channels=3)
                 return lab                                                 # main.py:366 layout: 3 equal channels
-            img = otsu_copy(self._scaled_page() if img_u8 is None else img_u8).astype(np.uint8)   # main.py:443-444
+            if img_u8 is None:
+                img_u8 = self._scaled_page()
+                if box is not None:
+                    img_u8 = img_u8[box[1]:box[1] + box[3], box[0]:box[0] + box[2]]
+            img = otsu_copy(img_u8).astype(np.uint8)                       # main.py:443-444
             return do_prediction(True, img, model)                         # main.py:447
         finally:
             session.close()            # (the reference's gc.collect() after every stage frees TF graphs; nothing to free here)
 
-    def textline_contours(self, img_u8: Optional[np.ndarray] = None) -> np.ndarray:
+    def textline_contours(self, img_u8: Optional[np.ndarray] = None, box=None) -> np.ndarray:
         """main.py:490-503.  With img_u8=None the stored page is segmented through the fused rescale
-        (identical to running on the upscaled page)."""
+        (identical to running on the upscaled page), restricted to ``box`` (extract_page's crop) when one is given."""
         model, session = start_new_session_and_model(self.model_textline_dir, **self.kw)
         try:
             if img_u8 is None and isinstance(model, SegModel):
+                if box is not None:
+                    return model.ctx.segment_crop(self.image_stored, self.img_hight_int, self.img_width_int, box)[0]
                 return model.ctx.segment_page_scaled(self.image_stored, self.img_hight_int, self.img_width_int)
-            img = (self._scaled_page() if img_u8 is None else img_u8).astype(np.uint8)
-            return do_prediction(True, img, model)[:, :, 0]
+            if img_u8 is None:
+                img_u8 = self._scaled_page()
+                if box is not None:
+                    img_u8 = img_u8[box[1]:box[1] + box[3], box[0]:box[0] + box[2]]
+            return do_prediction(True, img_u8.astype(np.uint8), model)[:, :, 0]
         finally:
             session.close()            # (the reference's gc.collect() after every stage frees TF graphs; nothing to free here)
 
+    def page_box_only(self):
+        """extract_page (main.py:384-437) without building the cropped array: (page mask, (x, y, w, h), page_coord).  The mask
+        stays on the device between the border model and the box search; an empty mask raises like main.py:401."""
+        model, session = start_new_session_and_model(self.model_page_dir, **self.kw)
+        try:
+            if isinstance(model, SegModel):
+                mask, box, pixels = model.ctx.extract_page_box(self.image_stored, self.img_hight_int, self.img_width_int, channels=3)
+            else:
+                img = self._scaled_page()
+                mask = do_prediction(False, img, model, full_image_shape=img.shape)
+                box, pixels = host_page_box(mask[:, :, 0])
+            if pixels == 0:
+                raise ValueError("attempt to get argmax of an empty sequence")
+            x, y, w, h = box
+            self.page_mask, self.page_box = mask, (x, y, w, h)
+            page_coord = [y, y + h, x, x + w]
+            self.cont_page = [np.array([[page_coord[2], page_coord[0]], [page_coord[3], page_coord[0]],
+                                        [page_coord[3], page_coord[1]], [page_coord[2], page_coord[1]]])]
+            return mask, self.page_box, page_coord
+        finally:
+            session.close()
+
     def run(self, image_u8: np.ndarray):
-        """border -> (full-page box) -> layout -> textline; returns the three label maps."""
+        """The model-running part of run() (main.py:2056-2107) with its chaining: border model -> page box -> the layout
+        and textline models on the CROPPED page (main.py:2061, 2072, 2102), text regions cleaned by erode x 3 / dilate x 4
+        (main.py:2074-2075).  Returns (page mask [Hs,Ws,3], cleaned regions [h,w,3], text lines [h,w], page_coord) with
+        h x w = extract_page's box; the crop itself is never built on a SegModel."""
         self.get_image_and_scales(image_u8)
-        page_mask = self.extract_page_mask()
-        # box = whole image (main.py:417-419 fallback): both patch stages read the stored page through
-        # the fused rescale, the upscaled page is never built
-        regions = self.extract_text_regions()
-        textlines = self.textline_contours()
-        return page_mask, regions, textlines
+        page_mask, box, page_coord = self.page_box_only()
+        regions = self.extract_text_regions(box=box)
+        regions = self.clean_text_regions(regions)
+        textlines = self.textline_contours(box=box)
+        return page_mask, regions, textlines, page_coord

@@ -359,38 +359,94 @@ def test_three_model_pipeline(tmp_path):
         models[name] = (cfg, w)
     st = stages.InferenceStages(*[str(tmp_path / (n + ".h5")) for n in specs], model_kwargs={"max_batch": 16})
     page = synthetic_page(520, 400, seed=9)                                   # < 2500 high -> upscaled to 2800 x 2153
-    mask, regions, lines = st.run(page)
+    mask, regions, lines, page_coord = st.run(page)
     hs, ws = stages.scaled_size(520, 400)
-    assert mask.shape == (hs, ws, 3) and regions.shape == (hs, ws, 3) and lines.shape == (hs, ws)
+    bx, by, bw, bh = st.page_box
+    assert page_coord == [by, by + bh, bx, bx + bw] and bw >= 224 and bh >= 224
+    assert mask.shape == (hs, ws, 3) and regions.shape == (bh, bw, 3) and lines.shape == (bh, bw)
     assert mask.dtype == regions.dtype == lines.dtype == np.uint8
     assert regions.max() <= 3 and lines.max() <= 1 and mask.max() <= 1
-    # fused-rescale textline path == the same stage on the materialised upscaled page
-    lines2 = st.textline_contours(None)
-    assert np.array_equal(lines, lines2)
-    # the fused layout stage (device histogram + Otsu + binarising gather through the rescale) ==
-    # the reference's sequence on materialised arrays: resize -> otsu_copy -> astype(uint8) -> do_prediction
+    # The chaining of run() (main.py:2061-2102): both patch stages see the CROPPED upscaled page.  The fused path (rescale +
+    # crop + Otsu in the tile gather, nothing materialised) == the reference's sequence on materialised arrays:
+    # resize -> crop_image_inside_box -> otsu_copy -> astype(uint8) -> do_prediction -> erode x 3 / dilate x 4
     from oracle import stage_glue
+    from sbb_textline_detection_amd.model import load_model
     from sbb_textline_detection_amd.predict import resize_nearest
     up = resize_nearest(page, hs, ws)
-    ots = stage_glue.otsu_copy(up).astype(np.uint8)
-    assert st.otsu_threshold == stage_glue.otsu_threshold(up[:, :, 0])
-    from sbb_textline_detection_amd.model import load_model
-    regions2 = predict.do_prediction(True, ots, load_model(str(tmp_path / "model_strukturerkennung.h5"), max_batch=16))
-    assert np.array_equal(regions, regions2)
-    # spot-check the layout stage against the oracle on a crop of the upscaled, Otsu'd page
+    pbox, ppix = stage_glue.page_box(mask)
+    assert tuple(pbox) == (bx, by, bw, bh)                                   # device box == oracle box of the same mask
+    crop, coord = stage_glue.crop_image_inside_box((bx, by, bw, bh), up)
+    assert coord == page_coord
+    ots = stage_glue.otsu_copy(crop).astype(np.uint8)
+    assert st.otsu_threshold == stage_glue.otsu_threshold(crop[:, :, 0])
+    layout = load_model(str(tmp_path / "model_strukturerkennung.h5"), max_batch=16)          # default precision: label-exact f16x3
+    regions2 = predict.do_prediction(True, ots, layout)
+    assert np.array_equal(regions, stage_glue.region_cleanup(regions2))
+    lines2 = predict.do_prediction(True, crop, load_model(str(tmp_path / "model_textline_new.h5"), max_batch=16))[:, :, 0]
+    assert np.array_equal(lines, lines2)
+    # the un-cropped forms still equal their materialised twins
+    assert np.array_equal(st.textline_contours(None), predict.do_prediction(True, up, load_model(str(tmp_path / "model_textline_new.h5"), max_batch=16))[:, :, 0])
+    # label-exact: probabilities of three tiles of the Otsu'd crop against the oracle, labels equal outside EXACT_MARGIN
     cfg, w = models["model_strukturerkennung"]
     om = kf.OracleModel(cfg, w)
-    crop = ots[:448, :448]
-    ref = tiling.do_prediction(True, crop, om)[:, :, 0]
-    layout = load_model(str(tmp_path / "model_strukturerkennung.h5"), max_batch=16)          # default precision: label-exact f16x3
-    got = predict.do_prediction(True, crop, layout)[:, :, 0]
-    # label-exact: probabilities of three tiles of the Otsu'd page against the oracle, labels equal outside EXACT_MARGIN
-    xs = np.stack([ots[y0:y0 + 224, x0:x0 + 224] for (y0, x0) in ((0, 0), (300, 500), (1000, 800))]).astype(np.float32) / np.float32(255.0)
+    ys, xs_ = (0, (bh - 224) // 2, bh - 224), (0, (bw - 224) // 2, bw - 224)
+    xs = np.stack([ots[y0:y0 + 224, x0:x0 + 224] for (y0, x0) in zip(ys, xs_)]).astype(np.float32) / np.float32(255.0)
     pref, pgot = om.predict(xs), layout.predict(xs)
     assert float(np.abs(pref - pgot).max()) < TOL_SOFTMAX["f16x3"]
     total, outside = exact_label_check(pref, pgot)
     assert outside == 0 and total <= 1e-3 * pref[..., 0].size
-    assert (ref != got).mean() <= 1e-3
+    clear_session()
+
+
+def test_full_size_three_model_pipeline_config3(tmp_path):
+    """BASELINE configs[2] at FULL size: border (448x448, 2 classes, whole image) + layout (448x448, 4 classes, Otsu'd crop) +
+    textline (448x448, 2 classes) on one 3500x2500 page -> upscaled to 4200x3000 (main.py:205-207) -> up to 1 + 108 + 108
+    forwards.  Label-exact default mode; the layout and textline maps are checked against the oracle on sampled tiles of the
+    cropped page (owned pixels, outside EXACT_MARGIN), the glue against the oracle's restatements."""
+    from oracle import stage_glue
+    from sbb_textline_detection_amd import clear_session, stages
+    from sbb_textline_detection_amd.predict import resize_nearest
+    from sbb_textline_detection_amd.weights import save_sbbw
+    from tools.synth_model import calibrated_model
+    specs = {"model_page_mixed_best": (2, 21), "model_strukturerkennung": (4, 22), "model_textline_new": (2, 23)}      # main.py:58-60
+    models = {}
+    for name, (classes, seed) in specs.items():
+        cfg, w = calibrated_model(classes, 448, 448, seed=seed)
+        save_sbbw(str(tmp_path / (name + ".sbbw")), cfg, w)
+        models[name] = (cfg, w)
+    st = stages.InferenceStages(*[str(tmp_path / (n + ".h5")) for n in specs], model_kwargs={"max_batch": 108})
+    page = synthetic_page(3500, 2500, seed=33)
+    st.get_image_and_scales(page)
+    assert (st.img_hight_int, st.img_width_int) == (4200, 3000)
+    mask, box, page_coord = st.page_box_only()
+    bx, by, bw, bh = box
+    assert mask.shape == (4200, 3000, 3) and tuple(stage_glue.page_box(mask)[0]) == box and bw >= 448 and bh >= 448
+    regions_raw = st.extract_text_regions(box=box)
+    lines = st.textline_contours(box=box)
+    assert regions_raw.shape == (bh, bw, 3) and lines.shape == (bh, bw) and regions_raw.max() <= 3 and lines.max() <= 1
+    regions = st.clean_text_regions(regions_raw)
+    assert np.array_equal(regions, stage_glue.region_cleanup(regions_raw))                       # main.py:2074-2075
+    up = resize_nearest(page, 4200, 3000)
+    crop = up[by:by + bh, bx:bx + bw]
+    assert st.otsu_threshold == stage_glue.otsu_threshold(crop[:, :, 0])
+    ots = stage_glue.otsu_copy(crop).astype(np.uint8)
+    tiles, nxf, nyf = tiling.tile_grid(bh, bw, 448, 448)
+    own = tiling.owner_map(bh, bw, 448, 448)
+    print(f"[config 3, full size] box {box}: {len(tiles)} tiles per patch stage, {1 + 2 * len(tiles)} forwards")
+    picks = sorted({0, len(tiles) // 2, len(tiles) - 1})
+    for name, src_img, got in (("model_strukturerkennung", ots, regions_raw[:, :, 0]), ("model_textline_new", crop, lines)):
+        cfg, w = models[name]
+        for k in picks[:3] if name == "model_strukturerkennung" else picks[:2]:
+            t = tiles[k]
+            x = (src_img[t["y0"]:t["y0"] + 448, t["x0"]:t["x0"] + 448][None] / 255.0).astype(np.float32)
+            ref = kf.forward_config(cfg, w, x)[0]
+            sl = (slice(t["y0"] + t["ylo"], t["y0"] + t["yhi"]), slice(t["x0"] + t["xlo"], t["x0"] + t["xhi"]))
+            r = ref[t["ylo"]:t["yhi"], t["xlo"]:t["xhi"]]
+            srt = np.sort(r, axis=-1)
+            mism = (got[sl] != r.argmax(-1)) & (own[sl] == k)
+            bad = mism & ((srt[..., -1] - srt[..., -2]) > EXACT_MARGIN)
+            assert not bad.any(), (name, k, int(bad.sum()))
+            assert mism.mean() < 1e-3, (name, k, float(mism.mean()))
     clear_session()
 
 
