@@ -270,6 +270,22 @@ int sbbseg_deskew_profiles_dev(sbbseg_ctx* c, const void* d_mask_hw, int H, int 
 int sbbseg_deskew_profiles(sbbseg_ctx* c, const uint8_t* mask_hw, int H, int W, const double* matrices, const double* angles_deg,
                            int n_angles, int32_t* counts);
 
+/* ---- multi-GPU: one process per GPU, one handle per process; tiles (sbbseg_segment_tile_range_dev) or whole
+ * pages (sbbseg_segment_pages_dev) are sharded by the caller, and the ONE data-path collective -- the all-gather of the u8
+ * label maps -- runs on RCCL inside the library, on the handle's stream, so an integrator needs neither PyTorch nor an MPI:
+ *   rank 0:     sbbseg_comm_unique_id(id)  -> ship the 128 bytes to every rank by any means (file, socket, env)
+ *   every rank: sbbseg_comm_init(ctx, rank, world, id)            (collective: returns when all ranks have joined)
+ *               ... sbbseg_segment_tile_range_dev(...) into my slice ...
+ *               sbbseg_allgather_labels_dev(ctx, d_my_slice, bytes_per_rank, d_all)      (d_all = world x bytes_per_rank)
+ *               sbbseg_stitch_dev(ctx, d_all, Hp, Wp, d_page_mask)
+ * librccl is loaded with dlopen on first use (no link-time dependency: the library loads on machines without it).
+ * The reference has no counterpart: main.py:259-288 is a serial loop; tiles and pages are independent there. */
+int sbbseg_comm_unique_id(char* id128);
+int sbbseg_comm_init(sbbseg_ctx* c, int rank, int world, const char* id128);
+int sbbseg_comm_info(sbbseg_ctx* c, int* rank, int* world);       /* world = 0: no communicator */
+int sbbseg_comm_destroy(sbbseg_ctx* c);
+int sbbseg_allgather_labels_dev(sbbseg_ctx* c, const void* d_send, size_t bytes_per_rank, void* d_recv);
+
 /* ---- building blocks (multi-GPU sharding, tests).  tile_xy: host int32 [n][2] = (x0, y0) origins.
  * d_tile_labels: device uint8 [n][H][W]. */
 int sbbseg_tile_grid(int Hp, int Wp, int H, int W, int32_t* tile_xy, int capacity, int* nxf, int* nyf);

@@ -23,7 +23,7 @@ EXPORTS = [
     "sbbseg_set_stream", "sbbseg_set_lanes", "sbbseg_set_label_channels", "sbbseg_synchronize", "sbbseg_set_input", "sbbseg_input_form", "sbbseg_add_tensor",
     "sbbseg_add_conv", "sbbseg_add_maxpool", "sbbseg_add_tail", "sbbseg_add_head", "sbbseg_finalize", "sbbseg_model_info",
     "sbbseg_num_ops", "sbbseg_op_info", "sbbseg_op_issued_flops", "sbbseg_device_bytes", "sbbseg_predict", "sbbseg_segment_page",
-    "sbbseg_segment_page_dev", "sbbseg_segment_pages_dev", "sbbseg_segment_page_scaled", "sbbseg_segment_page_otsu", "sbbseg_segment_crop", "sbbseg_segment_crop_dev", "sbbseg_otsu_dev",
+    "sbbseg_segment_page_dev", "sbbseg_segment_pages_dev", "sbbseg_segment_page_scaled", "sbbseg_segment_page_otsu", "sbbseg_segment_crop", "sbbseg_segment_crop_dev", "sbbseg_comm_unique_id", "sbbseg_comm_init", "sbbseg_comm_info", "sbbseg_comm_destroy", "sbbseg_allgather_labels_dev", "sbbseg_otsu_dev",
     "sbbseg_segment_tile_range_bin_dev", "sbbseg_segment_whole", "sbbseg_segment_whole_scaled", "sbbseg_tile_grid", "sbbseg_nearest_map", "sbbseg_segment_tiles_dev",
     "sbbseg_segment_tile_range_dev", "sbbseg_stitch_dev", "sbbseg_debug_ingest", "sbbseg_debug_read_tensor",
     "sbbseg_debug_set_conv_variant", "sbbseg_debug_inject_alloc_failure",
@@ -94,6 +94,11 @@ def load_library(path: Optional[str] = None):
         "sbbseg_segment_pages_dev": [vp, i32, vp, i32, i32, vp],
         "sbbseg_segment_page_scaled": [vp, vp, i32, i32, i32, i32, vp],
         "sbbseg_segment_page_otsu": [vp, vp, i32, i32, i32, i32, vp, C.POINTER(C.c_int)],
+        "sbbseg_comm_unique_id": [C.c_char_p],
+        "sbbseg_comm_init": [vp, i32, i32, C.c_char_p],
+        "sbbseg_comm_info": [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)],
+        "sbbseg_comm_destroy": [vp],
+        "sbbseg_allgather_labels_dev": [vp, vp, C.c_size_t, vp],
         "sbbseg_segment_crop": [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, C.POINTER(C.c_int)],
         "sbbseg_segment_crop_dev": [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp],
         "sbbseg_otsu_dev": [vp, vp, i32, i32, vp],
@@ -340,6 +345,25 @@ class Context:
         check(self.lib.sbbseg_segment_crop_dev(self.h, C.c_void_p(d_page), Hs, Ws, int(scaled_h), int(scaled_w), x, y, w, h,
                                                1 if binarise else 0, C.c_void_p(d_labels), C.c_void_p(d_threshold or None)), "sbbseg_segment_crop_dev")
 
+    # -- the sharded path's collective on RCCL, inside the library (no torch.distributed needed) ------------------
+    def comm_init(self, rank: int, world: int, unique_id: bytes):
+        """Join the communicator `unique_id` (from :func:`comm_unique_id` on rank 0) as `rank` of `world`; collective."""
+        if len(unique_id) != 128:
+            raise ValueError("unique_id must be the 128 bytes of comm_unique_id()")
+        check(self.lib.sbbseg_comm_init(self.h, int(rank), int(world), C.create_string_buffer(bytes(unique_id), 128)), "sbbseg_comm_init")
+
+    def comm_info(self):
+        r, w = C.c_int(0), C.c_int(0)
+        check(self.lib.sbbseg_comm_info(self.h, C.byref(r), C.byref(w)), "sbbseg_comm_info")
+        return int(r.value), int(w.value)
+
+    def comm_destroy(self):
+        check(self.lib.sbbseg_comm_destroy(self.h), "sbbseg_comm_destroy")
+
+    def allgather_labels_dev(self, d_send: int, bytes_per_rank: int, d_recv: int):
+        """All-gather of u8 label maps over RCCL on the handle's stream: d_recv = [world][bytes_per_rank]."""
+        check(self.lib.sbbseg_allgather_labels_dev(self.h, C.c_void_p(d_send), int(bytes_per_rank), C.c_void_p(d_recv)), "sbbseg_allgather_labels_dev")
+
     def otsu_dev(self, d_page: int, Hp: int, Wp: int, d_threshold: int):
         check(self.lib.sbbseg_otsu_dev(self.h, C.c_void_p(d_page), Hp, Wp, C.c_void_p(d_threshold)), "sbbseg_otsu_dev")
 
@@ -481,6 +505,13 @@ class Context:
             op.update(total_ms=ms.value, launches=ln.value, patches=pt.value)
             out.append(op)
         return out
+
+
+def comm_unique_id() -> bytes:
+    """128 opaque bytes naming a new RCCL communicator (rank 0 calls this and ships them to every rank)."""
+    buf = C.create_string_buffer(128)
+    check(load_library().sbbseg_comm_unique_id(buf), "sbbseg_comm_unique_id")
+    return buf.raw
 
 
 def tile_grid(Hp: int, Wp: int, H: int, W: int):

@@ -16,6 +16,8 @@
 #include <vector>
 
 #include "../../include/sbbseg.h"
+#include <dlfcn.h>
+
 #include "internal.h"
 
 using namespace sbbseg;
@@ -142,6 +144,7 @@ struct TailOp {
 struct BlockOp {
     int x_tensor = -1, out_tensor = -1, cin = 0, proj = 0, H = 0, W = 0;
     uint16_t *d_w1 = nullptr, *d_w3 = nullptr;
+    float wmul[3] = {1.f, 1.f, 1.f};      // split mode: 2^-s of the three convs' weight pre-scales
 };
 
 struct Op {
@@ -208,6 +211,9 @@ struct sbbseg_ctx {
     size_t pp_in_cap = 0, pp_out_cap = 0, pp_out3_cap = 0;        // device buffers (bytes each)
     size_t pp_hin_cap = 0, pp_hout_cap = 0;                       // pinned host staging (bytes each)
     bool pp_ready = false;                                        // streams + events of the page pipeline exist
+    // RCCL communicator of the sharded path (sbbseg_comm_init; librccl is dlopen'ed on first use)
+    void* comm = nullptr;
+    int comm_rank = 0, comm_world = 1;
     void* d_deskew = nullptr; size_t deskew_cap = 0;      // inverse maps | bicubic table | row counts of sbbseg_deskew_profiles
     int *d_cc_parent = nullptr, *d_cc_count = nullptr; size_t cc_parent_cap = 0, cc_count_cap = 0;
     unsigned long long* d_cc_small = nullptr;      // [0] best key, [1..2] box (4 ints)
@@ -346,7 +352,9 @@ int launch_op(sbbseg_ctx* c, Op& op, int n, uint8_t* d_labels, float* d_probs)
             bp.s2 = op.parts[1].conv.d_scale; bp.b2 = op.parts[1].conv.d_shift;
             bp.s3 = op.parts[2].conv.d_scale; bp.b3 = op.parts[2].conv.d_shift;
             bp.out = c->tensors[bo.out_tensor].data();
-            HIPCHK(launch_bottleneck(bp, c->precision, c->num_cus, c->stream));
+            bp.wmul1 = bo.wmul[0]; bp.wmul2 = bo.wmul[1]; bp.wmul3 = bo.wmul[2];
+            if (c->precision == kF16X3) HIPCHK(launch_block_x3(bp, c->num_cus, c->stream));
+            else HIPCHK(launch_bottleneck(bp, c->precision, c->num_cus, c->stream));
         } else if (op.type == kConv) {
             const ConvOp& co = op.conv;
             ConvParams p;
@@ -379,7 +387,8 @@ int launch_op(sbbseg_ctx* c, Op& op, int n, uint8_t* d_labels, float* d_probs)
             p.variant_flags = ((c->conv_variant & 64) ? 1 : 0) | ((c->conv_variant & 128) ? 2 : 0) | (c->ph8 ? 4 : 0);
             // XCD-grouped walk for single-class layers: measured neutral-to-slower (it removes the n_ct-fold
             // re-fetch of the pixel operand, but those layers are not bound by fetch bytes) -> opt-in, bit 5
-            p.tile_map = ((c->conv_variant & 32) && !(c->conv_variant & 8) && (c->conv_variant & 4) == 0 && co.d.cout > conv_tile_bc(co.d.cout) && p.M >= 256 * 128 &&
+            // (split mode: on by default -- twice the pixel bytes; +0.7 % page throughput in two runs, profiles/r03_experiments.md)
+            p.tile_map = (((c->conv_variant & 32) || c->precision == kF16X3) && !(c->conv_variant & 8) && (c->conv_variant & 4) == 0 && co.d.cout > conv_tile_bc(co.d.cout) && p.M >= 256 * 128 &&
                           (size_t)co.cout_pad * co.Ktot * c->elem <= ((size_t)2 << 20)) ? 1 : 0;
             if (p.tile_map == 1 && co.n_cls == 1 && co.Ktot <= c->contig_max_k) p.tile_map = 2;
             p.w = co.d_w; p.Ktot = co.Ktot; p.total_ksteps = co.total_ksteps;
@@ -510,6 +519,52 @@ int labels_to_host(sbbseg_ctx* c, void* host, size_t pix)
     return 0;
 }
 
+// ---- RCCL, loaded at run time: libsbbseg has no link-time dependency on librccl (it must load on a box without it, and
+// on the CPU-only build container); the sharded path's one collective is the all-gather of u8 label maps
+struct RcclUniqueId { char internal[128]; };                  // = ncclUniqueId (rccl.h: NCCL_UNIQUE_ID_BYTES 128)
+struct RcclApi {
+    void* lib = nullptr;
+    int (*GetUniqueId)(RcclUniqueId*) = nullptr;
+    int (*CommInitRank)(void**, int, RcclUniqueId, int) = nullptr;
+    int (*CommDestroy)(void*) = nullptr;
+    int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+};
+RcclApi g_rccl;
+int rccl_load()
+{
+    if (g_rccl.lib) return 0;
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    void* h = nullptr;
+    for (const char* n : names)
+        if ((h = dlopen(n, RTLD_NOW | RTLD_LOCAL))) break;
+    REQUIRE(h, "librccl not found (tried librccl.so.1, librccl.so, /opt/rocm/lib/librccl.so.1): %s", dlerror());
+    RcclApi a;
+    a.GetUniqueId = (int (*)(RcclUniqueId*))dlsym(h, "ncclGetUniqueId");
+    a.CommInitRank = (int (*)(void**, int, RcclUniqueId, int))dlsym(h, "ncclCommInitRank");
+    a.CommDestroy = (int (*)(void*))dlsym(h, "ncclCommDestroy");
+    a.AllGather = (int (*)(const void*, void*, size_t, int, void*, hipStream_t))dlsym(h, "ncclAllGather");
+    a.GetErrorString = (const char* (*)(int))dlsym(h, "ncclGetErrorString");
+    if (!a.GetUniqueId || !a.CommInitRank || !a.CommDestroy || !a.AllGather || !a.GetErrorString) {
+        dlclose(h);
+        return fail("librccl lacks an expected symbol (ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy / ncclAllGather)");
+    }
+    a.lib = h;
+    g_rccl = a;
+    return 0;
+}
+#define RCCLCHK(expr)                                                                              \
+    do {                                                                                           \
+        const int r_ = (expr);                                                                     \
+        if (r_ != 0) return fail("%s failed: %s", #expr, g_rccl.GetErrorString(r_));              \
+    } while (0)
+
+void comm_release(sbbseg_ctx* c)
+{
+    if (c->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(c->comm);
+    c->comm = nullptr; c->comm_rank = 0; c->comm_world = 1;
+}
+
 int check_ready(sbbseg_ctx* c)
 {
     REQUIRE(c != nullptr, "null handle");
@@ -613,6 +668,7 @@ int sbbseg_destroy(sbbseg_ctx* c)
         if (c->pp_comp[k]) (void)hipEventDestroy(c->pp_comp[k]);
         if (c->pp_out[k]) (void)hipEventDestroy(c->pp_out[k]);
     }
+    comm_release(c);
     if (c->copy_in) (void)hipStreamDestroy(c->copy_in);
     if (c->copy_out) (void)hipStreamDestroy(c->copy_out);
     (void)hipFree(c->d_morph_a); (void)hipFree(c->d_morph_b); (void)hipFree(c->d_cc_parent); (void)hipFree(c->d_cc_count); (void)hipFree(c->d_cc_small);
@@ -1049,7 +1105,7 @@ int sbbseg_add_conv(sbbseg_ctx* c, const sbbseg_conv_desc* d, const float* w_src
             op.name = "direct_" + op.name;
         }
         // small pointwise convs keep their weights on the host until sbbseg_finalize: candidates for bottleneck fusion
-        bool pw = plain16 && d->head_classes == 0 && d->raw_out_tensor < 0 && (d->cout == 64 || d->cout == 256) && d->out_stride_y == 1 &&
+        bool pw = (plain16 || split) && d->head_classes == 0 && d->raw_out_tensor < 0 && (d->cout == 64 || d->cout == 256) && d->out_stride_y == 1 &&
                   d->out_stride_x == 1 && d->out_off_y == 0 && d->out_off_x == 0 && TH == d->out_h && TW == d->out_w;
         for (int s2 = 0; pw && s2 < d->n_src; ++s2) {
             const sbbseg_conv_src& q = d->src[s2];
@@ -1315,7 +1371,8 @@ static int build_fast_gather_tables(sbbseg_ctx* c)
 static int fuse_bottlenecks(sbbseg_ctx* c)
 {
     const char* env = getenv("SBBSEG_FUSE_BLOCKS");
-    if ((env && env[0] == '0') || !(c->precision == kF16 || c->precision == kBF16)) return 0;
+    const bool split = c->precision == kF16X3;
+    if ((env && env[0] == '0') || !(c->precision == kF16 || c->precision == kBF16 || split)) return 0;
     auto readers = [&](int tensor) {
         int nrd = 0;
         for (const Op& o : c->ops) {
@@ -1346,7 +1403,7 @@ static int fuse_bottlenecks(sbbseg_ctx* c)
             proj = 1;
             b_src = C.d.src[0].tensor == T2 ? 0 : 1;
         }
-        if (proj < 0) continue;
+        if (proj < 0 || (split && proj != 0)) continue;        // (split mode: identity blocks only -- block_x3_identity)
         const Tensor& xt = c->tensors[X];
         Op blk;
         blk.type = kBlock;
@@ -1369,6 +1426,32 @@ static int fuse_bottlenecks(sbbseg_ctx* c)
                     for (int e = 0; e < 8; ++e)
                         f3[((((size_t)kk * 16 + mi) * 64) + l) * 8 + e] = half(wsrc[(size_t)((kk & 1) * 32 + (l >> 4) * 8 + e) * 256 + o]);
                 }
+        if (split) {
+            // hi | lo fragments of the pre-scaled weights (each conv's own power of two, ConvOp::wmul_cls[0] = 2^-s), interleaved per
+            // fragment: W1 [8 kk][4 mi][hi | lo][64 lanes][8], W3 [2 kk][16 mi][hi | lo][64 lanes][8]
+            auto put = [&](std::vector<uint16_t>& dst, size_t frag, int l, int e, float v, float wpre) {
+                const float sv = v * wpre;                       // exact (power of two)
+                const uint16_t hb = f32_to_f16_rne(sv);
+                dst[((frag * 2 + 0) * 64 + l) * 8 + e] = hb;
+                dst[((frag * 2 + 1) * 64 + l) * 8 + e] = f32_to_f16_rne(sv - (float)__builtin_bit_cast(_Float16, hb));
+            };
+            const float pre1 = 1.f / A.wmul_cls[0], pre3 = 1.f / C.wmul_cls[0];
+            f1.assign((size_t)8 * 4 * 2 * 64 * 8, 0);
+            f3.assign((size_t)2 * 16 * 2 * 64 * 8, 0);
+            for (int kk = 0; kk < 8; ++kk)
+                for (int mi = 0; mi < 4; ++mi)
+                    for (int l = 0; l < 64; ++l) {
+                        const int o = conv_row_channel(mi * 16 + (l & 15), 64);
+                        for (int e = 0; e < 8; ++e) put(f1, (size_t)kk * 4 + mi, l, e, A.h_w[0][(size_t)(kk * 32 + (l >> 4) * 8 + e) * 64 + o], pre1);
+                    }
+            for (int kk = 0; kk < 2; ++kk)
+                for (int mi = 0; mi < 16; ++mi)
+                    for (int l = 0; l < 64; ++l) {
+                        const int o = conv_row_channel(mi * 16 + (l & 15), 256);
+                        for (int e = 0; e < 8; ++e) put(f3, (size_t)kk * 16 + mi, l, e, C.h_w[0][(size_t)(kk * 32 + (l >> 4) * 8 + e) * 256 + o], pre3);
+                    }
+            blk.block.wmul[0] = A.wmul_cls[0]; blk.block.wmul[1] = B.wmul_cls[0]; blk.block.wmul[2] = C.wmul_cls[0];
+        }
         if (upload(c, &blk.block.d_w1, f1.data(), f1.size()) || upload(c, &blk.block.d_w3, f3.data(), f3.size())) return 1;
         char nm[96];
         snprintf(nm, sizeof(nm), "block%s_c%dto64to256_%dx%d", proj ? "_proj" : "", cin, xt.H, xt.W);
@@ -1377,7 +1460,7 @@ static int fuse_bottlenecks(sbbseg_ctx* c)
             blk.flops += c->ops[i + k].flops;
             blk.issued_flops += c->ops[i + k].issued_flops;
         }
-        blk.min_bytes = (double)xt.H * xt.W * (cin + 256) * c->elem;        // x read once, y written once
+        blk.min_bytes = (double)xt.H * xt.W * (cin + 256) * c->elem * c->planes;        // x read once, y written once
         blk.parts.assign(c->ops.begin() + i, c->ops.begin() + i + 3);
         c->ops.erase(c->ops.begin() + i, c->ops.begin() + i + 3);
         c->ops.insert(c->ops.begin() + i, std::move(blk));
@@ -2261,6 +2344,65 @@ int sbbseg_debug_inject_alloc_failure(int nth_check)
     API_BEGIN
     REQUIRE(nth_check >= 0, "nth_check must be >= 0 (0 disarms)");
     g_alloc_fail_countdown = nth_check;
+    return 0;
+    API_END
+}
+
+// ------------------------------------------------------------------------------ multi-GPU: the one collective, on RCCL
+int sbbseg_comm_unique_id(char* id128)
+{
+    API_BEGIN
+    REQUIRE(id128, "bad arguments");
+    if (rccl_load()) return 1;
+    RcclUniqueId id;
+    RCCLCHK(g_rccl.GetUniqueId(&id));
+    memcpy(id128, id.internal, sizeof(id.internal));
+    return 0;
+    API_END
+}
+
+int sbbseg_comm_init(sbbseg_ctx* c, int rank, int world, const char* id128)
+{
+    API_BEGIN
+    REQUIRE(c && id128 && world >= 1 && rank >= 0 && rank < world, "bad arguments (rank %d of %d)", rank, world);
+    HIPCHK(hipSetDevice(c->device));
+    if (rccl_load()) return 1;
+    comm_release(c);
+    RcclUniqueId id;
+    memcpy(id.internal, id128, sizeof(id.internal));
+    void* comm = nullptr;
+    RCCLCHK(g_rccl.CommInitRank(&comm, world, id, rank));
+    c->comm = comm; c->comm_rank = rank; c->comm_world = world;
+    return 0;
+    API_END
+}
+
+int sbbseg_comm_info(sbbseg_ctx* c, int* rank, int* world)
+{
+    API_BEGIN
+    REQUIRE(c && rank && world, "bad arguments");
+    *rank = c->comm_rank; *world = c->comm ? c->comm_world : 0;
+    return 0;
+    API_END
+}
+
+int sbbseg_comm_destroy(sbbseg_ctx* c)
+{
+    API_BEGIN
+    REQUIRE(c, "null handle");
+    comm_release(c);
+    return 0;
+    API_END
+}
+
+int sbbseg_allgather_labels_dev(sbbseg_ctx* c, const void* d_send, size_t bytes_per_rank, void* d_recv)
+{
+    API_BEGIN
+    REQUIRE(c && d_send && d_recv, "bad arguments");
+    REQUIRE(c->comm, "no communicator: call sbbseg_comm_init first");
+    HIPCHK(hipSetDevice(c->device));
+    if (bytes_per_rank == 0) return 0;
+    RCCLCHK(g_rccl.AllGather(d_send, d_recv, bytes_per_rank, /* ncclUint8 */ 1, c->comm, c->stream));
     return 0;
     API_END
 }

@@ -1,0 +1,336 @@
+// block_x3.hip -- a whole identity ResNet bottleneck block (stage 2 of the sbb nets: 256 -> 64 -> 64 -> 256 channels at 111 x 111)
+// per launch in the split-fp16 mode (kF16X3: every activation and weight is hi + lo fp16, three MFMAs per product).
+//
+//   a = ReLU(BN(conv1x1(x, 256 -> 64)))              phase A, on the 6 x 18 halo of a 4 x 16 output tile
+//   b = ReLU(BN(conv3x3(a, 64 -> 64)))               phase B, from the halo tile in LDS
+//   y = ReLU(BN(conv1x1(b, 64 -> 256)) + x)          phase C
+//
+// Run as three launches in the split mode these layers move 4 bytes per element of the 256-channel tensor four times per
+// block (2.0 ms per 140 patches, 4.0-4.3 TB/s); fused, x is read once (+ the halo overlap, from L2) and y written once.
+// The 16-bit kernel (bottleneck_fused, kernels.hip) does not carry over: doubled operands do not fit its LDS / register
+// budget.  What changes here:
+//   * tile 4 x 16 output pixels (halo 6 x 18 = 108 pixels): inner x (the residual) is 64 VGPRs per lane
+//   * W1 and W3 (hi + lo: 64 KB each) fill the LDS; a (halo, 112 rows x 256 B) and b (64 rows x 256 B) SHARE one 28 KB region:
+//     phase B keeps its results in registers until every wave has finished reading a
+//   * x arrives straight in MFMA B-fragment registers (pixel = lane & 15, 8 channels per lane, hi and lo), the inner
+//     pixels' fragments double as phase C's residual.  The NEXT tile's x is requested into the same registers as soon as the
+//     current tile has spent them: the border pixels right after phase A (in flight across phases B and C), the inner pixels
+//     K-step by K-step inside phase C, right after the residual add that reads them (a second inner buffer would not fit:
+//     x 128 + 3x3 weights 144 VGPRs are live throughout)
+//   * the wave's 3x3 weights (hi + lo fragments of its 16 output channels) live in 144 VGPRs
+//   * pixel rows in LDS are 256 B = [64 hi][64 lo] in 16 granule slots, slot = (granule + 2 * row) & 15: conflict-free for
+//     the 16-lane groups of ds_read_b128 (two k-groups x eight consecutive rows -> the even and the odd slots)
+// One block of four waves per CU (up to 512 VGPRs per lane).  Wave w owns inner row w and border tile w (11 of the 44 border
+// pixels) in phases A and C, and the 16 output channels of MFMA row block w in phase B.
+#include "internal.h"
+
+namespace sbbseg {
+
+typedef __attribute__((ext_vector_type(8))) _Float16 h8_t;
+typedef __attribute__((ext_vector_type(4))) float f4_t;
+template <int N> struct IC { static constexpr int value = N; };
+
+namespace {
+
+constexpr int kHaloW = 18, kHaloRows = 6 * kHaloW;              // 108 halo pixels
+constexpr int kW1Bytes = 8 * 4 * 2 * 1024;                      // [8 kk][4 mi][hi | lo][64 lanes x 16 B]
+constexpr int kW3Bytes = 2 * 16 * 2 * 1024;                     // [2 kk][16 mi][hi | lo][64 lanes x 16 B]
+constexpr int kABBytes = 112 * 256;                             // a: 108 halo rows + 4 dump rows; b: rows 0..63
+constexpr int kCstBytes = (4 * 64 + 2 * 256) * 4;
+constexpr int kBlockX3LdsBytes = kW1Bytes + kW3Bytes + kABBytes + kCstBytes;      // 162 816 <= 163 840
+
+__device__ inline f4_t mma(h8_t a, h8_t b, f4_t c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+// w * x with both operands split: small terms first
+__device__ inline f4_t mma3(h8_t wh, h8_t wl, h8_t xh, h8_t xl, f4_t c) { return mma(wh, xh, mma(wh, xl, mma(wl, xh, c))); }
+
+__device__ inline void split8(const float (&y)[8], h8_t& hi, h8_t& lo)
+{
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const float v = fminf(fmaxf(y[q], -65504.f), 65504.f);
+        const _Float16 h = (_Float16)v;
+        hi[q] = h;
+        lo[q] = (_Float16)(v - (float)h);
+    }
+}
+
+}  // namespace
+
+__global__ __launch_bounds__(256, 1) void block_x3_identity(const BlockParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* lds_w1 = smem;
+    char* lds_w3 = lds_w1 + kW1Bytes;
+    char* lds_ab = lds_w3 + kW3Bytes;
+    float* cst = (float*)(lds_ab + kABBytes);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int frow = lane & 15, fg = lane >> 4;
+    const int tiles_x = (p.W + 15) / 16, tiles_y = (p.H + 3) / 4;
+    const int tiles_per_patch = tiles_x * tiles_y;
+    const int n_tiles = p.n * tiles_per_patch;
+    // XCD-contiguous walk: XCD x = block % 8 owns tiles [x * per_xcd, (x + 1) * per_xcd) -- vertical halo neighbours share an L2
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, GX = gridDim.x >> 3;
+    const int per_xcd = (n_tiles + 7) >> 3;
+    const int xcd_lo = xcd * per_xcd, xcd_hi = min(n_tiles, xcd_lo + per_xcd);
+    const int my_tiles = xcd_lo + slot < xcd_hi ? (xcd_hi - xcd_lo - slot + GX - 1) / GX : 0;
+    if (my_tiles <= 0) return;
+    auto tile_at = [&](int it) __attribute__((always_inline)) -> int { return xcd_lo + slot + it * GX; };
+
+    // ---- one-time: weights and constants to LDS, this wave's 3x3 fragments to registers
+    for (int i = tid; i < kW1Bytes / 16; i += 256) ((uint4*)lds_w1)[i] = ((const uint4*)p.w1)[i];
+    for (int i = tid; i < kW3Bytes / 16; i += 256) ((uint4*)lds_w3)[i] = ((const uint4*)p.w3)[i];
+    if (tid < 64) {
+        cst[tid] = p.s1[tid] * p.wmul1; cst[64 + tid] = p.b1[tid]; cst[128 + tid] = p.s2[tid] * p.wmul2; cst[192 + tid] = p.b2[tid];
+    }
+    cst[256 + tid] = p.s3[tid] * p.wmul3; cst[512 + tid] = p.b3[tid];
+    h8_t wfh[9][2], wfl[9][2];                                  // [tap][kk] of MFMA row block `wave`; w2 = [hi | lo][9][2][4 mi][64 lanes]
+    {
+        const uint4* src = (const uint4*)p.w2 + lane;
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const size_t f = (size_t)((t * 2 + kk) * 4 + wave) * 64;
+                wfh[t][kk] = __builtin_bit_cast(h8_t, src[f]);
+                wfl[t][kk] = __builtin_bit_cast(h8_t, src[(size_t)9 * 2 * 4 * 64 + f]);
+            }
+    }
+
+    // ---- this lane's two halo pixels: j = 0 inner pixel (row `wave`, column frow), j = 1 border pixel wave * 11 + frow (frow < 11)
+    int hy[2], hx[2], hr[2];
+    hy[0] = wave + 1; hx[0] = frow + 1; hr[0] = hy[0] * kHaloW + hx[0];
+    {
+        const int bi = wave * 11 + frow;
+        int y, x;
+        if (frow >= 11) { y = 6; x = frow - 11; }               // dummies: dump rows 108.., never inside the image
+        else if (bi < 18) { y = 0; x = bi; }
+        else if (bi < 36) { y = 5; x = bi - 18; }
+        else if (bi < 40) { y = 1 + (bi - 36); x = 0; }
+        else { y = 1 + (bi - 40); x = 17; }
+        hy[1] = y; hx[1] = x; hr[1] = frow >= 11 ? 108 + ((frow - 11) & 3) : y * kHaloW + x;
+    }
+
+    bool inimg[2];
+    uint32_t xoff[2];
+    auto locate = [&](int tile, bool (&in)[2], uint32_t (&off)[2]) __attribute__((always_inline)) {
+        const int n = tile / tiles_per_patch;
+        const int rem = tile - n * tiles_per_patch;
+        const int ty = rem / tiles_x, tx = rem - ty * tiles_x;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int Y = ty * 4 - 1 + hy[j], X = tx * 16 - 1 + hx[j];
+            in[j] = ((unsigned)Y < (unsigned)p.H) & ((unsigned)X < (unsigned)p.W) & (hy[j] < 6);
+            // stored pixel = [256 hi][256 lo] halves (1 KB); outside the image: the zero header
+            off[j] = in[j] ? (uint32_t)((n * p.H + Y) * p.W + X) * 1024u + (uint32_t)(kZeroHeaderBytes + fg * 16) : 0u;
+        }
+    };
+    h8_t xih[8], xil[8], xbh[8], xbl[8];                        // inner pixel, border pixel: [K-step] fragments, hi and lo
+    auto fetch = [&](uint32_t off, h8_t (&dh)[8], h8_t (&dl)[8]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
+            dh[kk] = *(const h8_t*)(p.x + off + kk * 64);
+            dl[kk] = *(const h8_t*)(p.x + off + 512 + kk * 64);
+        }
+    };
+
+    locate(tile_at(0), inimg, xoff);
+    fetch(xoff[0], xih, xil);
+    fetch(xoff[1], xbh, xbl);
+    __syncthreads();                                            // weights / constants visible
+
+    for (int it = 0; it < my_tiles; ++it) {
+        const int tile = tile_at(it);
+        const bool more = it + 1 < my_tiles;
+        bool in_next[2] = {false, false};
+        uint32_t off_next[2] = {0u, 0u};
+        if (more) locate(tile_at(it + 1), in_next, off_next);
+
+        // ---- phase A: a[halo pixel][64] = ReLU(s1 * (W1 . x) + b1), zero outside the image
+        {
+            f4_t acc[4][2];
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[mi][j] = (f4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) {
+                h8_t wh[4], wl[4];
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi) {
+                    wh[mi] = *(const h8_t*)(lds_w1 + ((kk * 4 + mi) * 2 + 0) * 1024 + lane * 16);
+                    wl[mi] = *(const h8_t*)(lds_w1 + ((kk * 4 + mi) * 2 + 1) * 1024 + lane * 16);
+                }
+                // three sweeps over the eight accumulators (small terms first): MFMAs on one accumulator stay 8 instructions apart
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi) { acc[mi][0] = mma(wl[mi], xih[kk], acc[mi][0]); acc[mi][1] = mma(wl[mi], xbh[kk], acc[mi][1]); }
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi) { acc[mi][0] = mma(wh[mi], xil[kk], acc[mi][0]); acc[mi][1] = mma(wh[mi], xbl[kk], acc[mi][1]); }
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi) { acc[mi][0] = mma(wh[mi], xih[kk], acc[mi][0]); acc[mi][1] = mma(wh[mi], xbh[kk], acc[mi][1]); }
+                __builtin_amdgcn_sched_barrier(0);              // (keeps the scheduler from hoisting all 64 weight fragments at once)
+            }
+            if (more) fetch(off_next[1], xbh, xbl);             // border x is spent: its registers take the next tile's
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const int c0 = s2 * 32 + fg * 8;
+                float sc[8], sh[8];
+                *(float4*)&sc[0] = *(const float4*)(cst + c0); *(float4*)&sc[4] = *(const float4*)(cst + c0 + 4);
+                *(float4*)&sh[0] = *(const float4*)(cst + 64 + c0); *(float4*)&sh[4] = *(const float4*)(cst + 64 + c0 + 4);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    float y[8];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        y[q] = fmaxf(acc[2 * s2][j][q] * sc[q] + sh[q], 0.f);
+                        y[4 + q] = fmaxf(acc[2 * s2 + 1][j][q] * sc[4 + q] + sh[4 + q], 0.f);
+                    }
+                    h8_t vh, vl;
+                    split8(y, vh, vl);
+                    if (!inimg[j]) { vh = (h8_t){0, 0, 0, 0, 0, 0, 0, 0}; vl = vh; }
+                    char* row = lds_ab + hr[j] * 256;
+                    *(h8_t*)(row + (((s2 * 4 + fg + 2 * hr[j]) & 15) << 4)) = vh;
+                    *(h8_t*)(row + (((8 + s2 * 4 + fg + 2 * hr[j]) & 15) << 4)) = vl;
+                }
+            }
+        }
+        __syncthreads();
+
+        // ---- phase B: b[pixel][16 channels of row block `wave`] = ReLU(s2 * conv3x3(a) + b2); kept in registers until a is dead
+        f4_t bacc[4];
+        {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) bacc[i] = (f4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    h8_t bh[4], bl[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int row = (i + t / 3) * kHaloW + frow + t % 3;
+                        const char* px = lds_ab + row * 256;
+                        bh[i] = *(const h8_t*)(px + (((kk * 4 + fg + 2 * row) & 15) << 4));
+                        bl[i] = *(const h8_t*)(px + (((8 + kk * 4 + fg + 2 * row) & 15) << 4));
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) bacc[i] = mma(wfl[t][kk], bh[i], bacc[i]);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) bacc[i] = mma(wfh[t][kk], bl[i], bacc[i]);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) bacc[i] = mma(wfh[t][kk], bh[i], bacc[i]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        __syncthreads();                                        // every wave has read a: b may overwrite it
+        {
+            const int sB = wave >> 1, half = wave & 1;
+            const int cB = sB * 32 + fg * 8 + half * 4;
+            const float4 sc = *(const float4*)(cst + 128 + cB), sh = *(const float4*)(cst + 192 + cB);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = i * 16 + frow;
+                const float v[4] = {fmaxf(bacc[i][0] * sc.x + sh.x, 0.f), fmaxf(bacc[i][1] * sc.y + sh.y, 0.f),
+                                    fmaxf(bacc[i][2] * sc.z + sh.z, 0.f), fmaxf(bacc[i][3] * sc.w + sh.w, 0.f)};
+                typedef __attribute__((ext_vector_type(4))) _Float16 h4_t;
+                h4_t vh, vl;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float c = fminf(v[q], 65504.f);
+                    const _Float16 h = (_Float16)c;
+                    vh[q] = h;
+                    vl[q] = (_Float16)(c - (float)h);
+                }
+                char* px = lds_ab + row * 256;
+                *(h4_t*)(px + (((sB * 4 + fg + 2 * row) & 15) << 4) + half * 8) = vh;
+                *(h4_t*)(px + (((8 + sB * 4 + fg + 2 * row) & 15) << 4) + half * 8) = vl;
+            }
+        }
+        __syncthreads();
+
+        // ---- phase C: y[inner row `wave`][256] = ReLU(s3 * (W3 . b) + b3 + x), 32 channels at a time
+        {
+            const int n = tile / tiles_per_patch;
+            const int rem = tile - n * tiles_per_patch;
+            const int ty = rem / tiles_x, tx = rem - ty * tiles_x;
+            const int oy = ty * 4 + wave, ox = tx * 16 + frow;
+            const bool live = oy < p.H && ox < p.W;
+            h8_t bh[2], bl[2];
+            {
+                const int row = wave * 16 + frow;
+                const char* px = lds_ab + row * 256;
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    bh[kk] = *(const h8_t*)(px + (((kk * 4 + fg + 2 * row) & 15) << 4));
+                    bl[kk] = *(const h8_t*)(px + (((8 + kk * 4 + fg + 2 * row) & 15) << 4));
+                }
+            }
+            __syncthreads();                                    // b is in registers everywhere: the next tile's phase A may write a
+            uint16_t* orow = (uint16_t*)p.out + (((size_t)n * p.H + oy) * p.W + ox) * 512;
+#pragma unroll
+            for (int s3 = 0; s3 < 8; ++s3) {
+                f4_t acc[2] = {(f4_t){0.f, 0.f, 0.f, 0.f}, (f4_t){0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    h8_t wh[2], wl[2];
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) {
+                        wh[m] = *(const h8_t*)(lds_w3 + ((kk * 16 + 2 * s3 + m) * 2 + 0) * 1024 + lane * 16);
+                        wl[m] = *(const h8_t*)(lds_w3 + ((kk * 16 + 2 * s3 + m) * 2 + 1) * 1024 + lane * 16);
+                    }
+                    acc[0] = mma(wl[0], bh[kk], acc[0]); acc[1] = mma(wl[1], bh[kk], acc[1]);
+                    acc[0] = mma(wh[0], bl[kk], acc[0]); acc[1] = mma(wh[1], bl[kk], acc[1]);
+                    acc[0] = mma(wh[0], bh[kk], acc[0]); acc[1] = mma(wh[1], bh[kk], acc[1]);
+                }
+                const int c0 = s3 * 32 + fg * 8;
+                float sc[8], sh[8], y[8];
+                *(float4*)&sc[0] = *(const float4*)(cst + 256 + c0); *(float4*)&sc[4] = *(const float4*)(cst + 256 + c0 + 4);
+                *(float4*)&sh[0] = *(const float4*)(cst + 512 + c0); *(float4*)&sh[4] = *(const float4*)(cst + 512 + c0 + 4);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    y[q] = acc[0][q] * sc[q] + sh[q];
+                    y[4 + q] = acc[1][q] * sc[4 + q] + sh[4 + q];
+                }
+                // the residual: this lane's x fragment of K-step s3 = channels c0 .. c0 + 7 of its inner pixel (hi + lo is exact in fp32)
+#pragma unroll
+                for (int q = 0; q < 8; ++q) y[q] = fmaxf(y[q] + ((float)xih[s3][q] + (float)xil[s3][q]), 0.f);
+                if (more) {                                     // this K-step's x is spent: its registers take the next tile's
+                    xih[s3] = *(const h8_t*)(p.x + off_next[0] + s3 * 64);
+                    xil[s3] = *(const h8_t*)(p.x + off_next[0] + 512 + s3 * 64);
+                }
+                h8_t vh, vl;
+                split8(y, vh, vl);
+                if (live) {
+                    *(h8_t*)(orow + c0) = vh;
+                    *(h8_t*)(orow + 256 + c0) = vl;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+
+        inimg[0] = in_next[0]; inimg[1] = in_next[1];
+    }
+}
+
+hipError_t launch_block_x3(const BlockParams& p, int num_cus, hipStream_t s)
+{
+    const int n_tiles = p.n * ((p.H + 3) / 4) * ((p.W + 15) / 16);
+    int grid = n_tiles < num_cus ? n_tiles : num_cus;
+    grid = (grid + 7) & ~7;                                     // the XCD-contiguous walk needs a multiple of 8 blocks
+    static bool attr_done[64] = {};
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (!attr_done[dev & 63]) {
+        e = hipFuncSetAttribute((const void*)block_x3_identity, hipFuncAttributeMaxDynamicSharedMemorySize, kBlockX3LdsBytes);
+        if (e != hipSuccess) return e;
+        attr_done[dev & 63] = true;
+    }
+    hipLaunchKernelGGL(block_x3_identity, dim3(grid), dim3(256), kBlockX3LdsBytes, s, p);
+    return hipGetLastError();
+}
+
+}  // namespace sbbseg

@@ -164,6 +164,9 @@ struct BlockParams {
     const float *s2, *b2;     // [64]  ... after the 3x3
     const float *s3, *b3;     // [256] ... after the last 1x1 (before the residual add)
     void* out;                // data pointer [n][H][W][256]
+    // split mode (block_x3_identity, block_x3.hip): w1 = [8 kk][4 mi][hi | lo][64 lanes] x 16 B, w3 = [2 kk][16 mi][hi | lo][64 lanes] x 16 B,
+    // w2 = [hi | lo][9][2][4 mi][64 lanes] x 16 B, every conv's weights pre-scaled by a power of two; wmulN = 2^-s undoes it in sN
+    float wmul1 = 1.f, wmul2 = 1.f, wmul3 = 1.f;
 };
 
 struct HeadParams {
@@ -233,6 +236,7 @@ hipError_t launch_to_f32(const void* src, float* dst, size_t n, int precision, h
 hipError_t launch_deskew_profiles(const uint8_t* mask, int H, int W, int S, int top, int left, const double* minv, const float* cubic,
                                   int n_angles, int* counts, hipStream_t s);
 hipError_t launch_bottleneck(const BlockParams& p, int precision, int num_cus, hipStream_t s);
+hipError_t launch_block_x3(const BlockParams& p, int num_cus, hipStream_t s);      // split mode, identity blocks (block_x3.hip)
 hipError_t launch_split_to_f32(const void* src, float* dst, size_t npix, int C, hipStream_t s);   // [pix][C hi][C lo] -> [pix][C]
 
 int conv_row_channel(int row, int cout);   // packed weight row -> output channel (16-bit modes)

@@ -501,8 +501,10 @@ void conv_igemm_mfma(const ConvParams p)
 
     // residual tile of the tile being finished: requested BEFORE its last K-step's MFMAs so the HBM
     // round trip hides under them
-    constexpr bool kPrefetchRes = !X3 && (T::kMI / 2) * T::kNI <= 8;      // big wave tiles (and the split mode's hi+lo pairs) cannot spare the registers
+    // (big wave tiles cannot spare the registers; the split mode's hi + lo pairs fit beside the 128x128 tile's 187 registers only)
+    constexpr bool kPrefetchRes = (T::kMI / 2) * T::kNI <= 8 && (!X3 || (BP == 128 && BC == 128));
     uint4 res[kPrefetchRes ? T::kMI / 2 : 1][kPrefetchRes ? T::kNI : 1];
+    uint4 res_lo[kPrefetchRes && X3 ? T::kMI / 2 : 1][kPrefetchRes && X3 ? T::kNI : 1];      // split mode: the lo halves
     auto prefetch_residual = [&](int tile) __attribute__((always_inline)) {
         int ctile, cls, ptile;
         decode(tile, ctile, cls, ptile);
@@ -514,8 +516,10 @@ void conv_igemm_mfma(const ConvParams p)
             for (int s2 = 0; s2 < T::kMI / 2; ++s2) {
                 const int c0 = ctile * BC + wc * T::kWCH + s2 * 32 + fg * 8;
                 if constexpr (kPrefetchRes) {
-                    if (c0 < p.cout && m < p.M)
-                        res[s2][ni] = *(const uint4*)((const uint16_t*)p.residual + (size_t)opix * p.cout + c0);
+                    if (c0 < p.cout && m < p.M) {
+                        res[s2][ni] = *(const uint4*)((const uint16_t*)p.residual + (size_t)opix * (p.cout * PL) + c0);
+                        if constexpr (X3) res_lo[s2][ni] = *(const uint4*)((const uint16_t*)p.residual + (size_t)opix * (p.cout * PL) + p.cout + c0);
+                    }
                 }
             }
         }
@@ -692,7 +696,11 @@ void conv_igemm_mfma(const ConvParams p)
                             }
                         }
                         if (p.residual) {
-                            if constexpr (X3) add_split8((const uint16_t*)p.residual + o, p.cout, y);
+                            if constexpr (X3 && kPrefetchRes) {
+                                const f16x8_t h = __builtin_bit_cast(f16x8_t, res[s2][ni]), l = __builtin_bit_cast(f16x8_t, res_lo[s2][ni]);
+#pragma unroll
+                                for (int q = 0; q < 8; ++q) y[q] += (float)h[q] + (float)l[q];      // (as add_split8: hi + lo is exact in fp32)
+                            } else if constexpr (X3) add_split8((const uint16_t*)p.residual + o, p.cout, y);
                             else {
                                 uint4 rr;
                                 if constexpr (kPrefetchRes) rr = res[s2][ni];

@@ -138,6 +138,50 @@ def test_fused_bottleneck_blocks_match_their_three_convs(precision, hw):
     model.release()
 
 
+@pytest.mark.parametrize("hw", [(64, 96), (224, 256)])
+def test_fused_x3_identity_blocks_match_their_three_convs(hw):
+    """Split mode: the two IDENTITY blocks of stage 2 run as one block_x3_identity launch each (csrc/block_x3.hip); the projection
+    block stays three convs.  Fused vs unfused (conv variant bit 18) on every tensor the fused plan still writes: the same MFMA
+    K order and the same epilogue formulas -> bit-identical; block outputs against the fp32 oracle within the layer tolerance."""
+    h, wd = hw
+    cfg, w, g, model = make_model(2, h, wd, seed=5, precision="f16x3", max_batch=4, calib_hw=min(160, max(h, wd)))
+    names = [o["name"] for o in model.ctx.ops()]
+    blocks = [n for n in names if n.startswith("block")]
+    assert len(blocks) == 2 and not any("proj" in n for n in blocks), names
+    x = (patches_from_page(h, wd, 3, seed=8) / 255.0).astype(np.float32)
+    taps = {name: None for name in model.plan.layer_tensor}
+    ref = kf.forward(g, w, x, taps=taps)
+
+    def read_all():
+        out = {}
+        for name, tid in model.plan.layer_tensor.items():
+            t = model.plan.tensors[tid]
+            out[name] = model.ctx.debug_read_tensor(tid, 3, (t.H, t.W, t.C))
+        return out
+    got_fused = model.predict(x)
+    t_fused = read_all()
+    model.ctx.set_conv_variant(1 << 18)
+    got_parts = model.predict(x)
+    t_parts = read_all()
+    model.ctx.set_conv_variant(0)
+    stage2 = max(model.plan.tensors[tid].H for tid in model.plan.layer_tensor.values() if model.plan.tensors[tid].C == 256)
+    checked = 0
+    for name, tid in model.plan.layer_tensor.items():
+        t = model.plan.tensors[tid]
+        if t.C == 256 and t.H == stage2:
+            a, b, r = t_fused[name], t_parts[name], taps[name]
+            assert np.array_equal(a, b), (name, float(np.abs(a - b).max()))
+            rel = float(np.abs(a - r).max() / (np.abs(r).max() + 1e-6))
+            assert rel < TOL_LAYER_REL["f16x3"], (name, rel)
+            checked += 1
+    assert checked >= 3
+    assert np.array_equal(got_fused, got_parts)
+    d = float(np.abs(got_fused - ref).max())
+    print(f"[fused x3 blocks {h}x{wd}] max|dsoftmax| vs oracle {d:.2e}")
+    assert d < TOL_SOFTMAX["f16x3"] and exact_label_check(ref, got_fused)[1] == 0
+    model.release()
+
+
 def test_conv_tile_families_agree():
     """4-wave/2-stage and 8-wave/3-stage conv tiles, persistent or one block per tile, compute the same sums."""
     cfg, w, g, model = make_model(2, 224, 224, seed=3, precision="f16", max_batch=6)
@@ -1005,3 +1049,35 @@ def test_full_size_pages_do_not_depend_on_chunking():
         assert hist[0] > 0 and hist[1] > 0                      # a non-trivial label map
         m.release()
     assert len(set(crcs.values())) == 1, crcs
+
+
+def test_c_abi_rccl_collective_world1(torch_cuda, stitch_model):
+    """The sharded path's collective inside the C ABI (sbbseg_comm_* / sbbseg_allgather_labels_dev: RCCL, dlopen'ed): a world of
+    one on this box -- unique id, communicator, all-gather of a tile-label slice on the handle's stream, stitch -- equals the
+    single-call fused path.  (World sizes > 1 need one GPU per rank: covered by the driver's multi-GPU run, not here.)"""
+    torch = torch_cuda
+    m = stitch_model
+    ctx = m.ctx
+    uid = _capi.comm_unique_id()
+    assert len(uid) == 128 and any(uid)
+    ctx.comm_init(0, 1, uid)
+    assert ctx.comm_info() == (0, 1)
+    page = synthetic_page(900, 800, seed=12)
+    xy = _capi.tile_grid(900, 800, 448, 448)[0]
+    n = xy.shape[0]
+    d_page = torch.from_numpy(page).cuda()
+    mine = torch.empty((n, 448, 448), dtype=torch.uint8, device="cuda")
+    everything = torch.zeros_like(mine)
+    out = torch.empty((900, 800), dtype=torch.uint8, device="cuda")
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    ctx.segment_tile_range_dev(d_page.data_ptr(), 900, 800, 0, n, mine.data_ptr())
+    ctx.allgather_labels_dev(mine.data_ptr(), mine.numel(), everything.data_ptr())
+    ctx.stitch_dev(everything.data_ptr(), 900, 800, out.data_ptr())
+    torch.cuda.synchronize()
+    assert torch.equal(mine, everything)
+    assert np.array_equal(out.cpu().numpy(), m.segment_page(page))
+    ctx.comm_destroy()
+    assert ctx.comm_info() == (0, 0)
+    with pytest.raises(RuntimeError, match="no communicator"):
+        ctx.allgather_labels_dev(mine.data_ptr(), mine.numel(), everything.data_ptr())
+    ctx.set_stream(-1)
