@@ -56,6 +56,9 @@ __device__ inline void split8(const float (&y)[8], h8_t& hi, h8_t& lo)
 
 }  // namespace
 
+// FULL: the next tile's inner x has its own registers and is requested before phase A (in flight across all three phases);
+// !FULL: it is requested K-step by K-step inside phase C into the registers the residual add has just released
+template <bool FULL>
 __global__ __launch_bounds__(256, 1) void block_x3_identity(const BlockParams p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -113,6 +116,15 @@ __global__ __launch_bounds__(256, 1) void block_x3_identity(const BlockParams p)
         hy[1] = y; hx[1] = x; hr[1] = frow >= 11 ? 108 + ((frow - 11) & 3) : y * kHaloW + x;
     }
 
+    // tile-invariant LDS read offsets of phases B and C (no address arithmetic per fragment read): row = frow + rc with rc known at
+    // compile time, slot of granule G = (G + 2 row) & 15 = (s0 + D) & 15, s0 = (fg + 2 frow) & 15, D = kk * 4 + 8 * lo + (2 rc & 15)
+    const char* rb[8];
+    {
+        const int s0 = (fg + 2 * frow) & 15;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) rb[e] = lds_ab + frow * 256 + (((s0 + 2 * e) & 15) << 4);
+    }
+
     bool inimg[2];
     uint32_t xoff[2];
     auto locate = [&](int tile, bool (&in)[2], uint32_t (&off)[2]) __attribute__((always_inline)) {
@@ -128,6 +140,7 @@ __global__ __launch_bounds__(256, 1) void block_x3_identity(const BlockParams p)
         }
     };
     h8_t xih[8], xil[8], xbh[8], xbl[8];                        // inner pixel, border pixel: [K-step] fragments, hi and lo
+    h8_t nih[FULL ? 8 : 1], nil[FULL ? 8 : 1];                  // FULL: the next tile's inner pixel
     auto fetch = [&](uint32_t off, h8_t (&dh)[8], h8_t (&dl)[8]) __attribute__((always_inline)) {
 #pragma unroll
         for (int kk = 0; kk < 8; ++kk) {
@@ -146,7 +159,16 @@ __global__ __launch_bounds__(256, 1) void block_x3_identity(const BlockParams p)
         const bool more = it + 1 < my_tiles;
         bool in_next[2] = {false, false};
         uint32_t off_next[2] = {0u, 0u};
-        if (more) locate(tile_at(it + 1), in_next, off_next);
+        if (more) {
+            locate(tile_at(it + 1), in_next, off_next);
+            if constexpr (FULL) {
+#pragma unroll
+                for (int kk = 0; kk < 8; ++kk) {
+                    nih[kk] = *(const h8_t*)(p.x + off_next[0] + kk * 64);
+                    nil[kk] = *(const h8_t*)(p.x + off_next[0] + 512 + kk * 64);
+                }
+            }
+        }
 
         // ---- phase A: a[halo pixel][64] = ReLU(s1 * (W1 . x) + b1), zero outside the image
         {
@@ -184,8 +206,8 @@ __global__ __launch_bounds__(256, 1) void block_x3_identity(const BlockParams p)
                     float y[8];
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        y[q] = fmaxf(acc[2 * s2][j][q] * sc[q] + sh[q], 0.f);
-                        y[4 + q] = fmaxf(acc[2 * s2 + 1][j][q] * sc[4 + q] + sh[4 + q], 0.f);
+                        y[q] = fmaxf(__builtin_fmaf(acc[2 * s2][j][q], sc[q], sh[q]), 0.f);
+                        y[4 + q] = fmaxf(__builtin_fmaf(acc[2 * s2 + 1][j][q], sc[4 + q], sh[4 + q]), 0.f);
                     }
                     h8_t vh, vl;
                     split8(y, vh, vl);
@@ -210,10 +232,10 @@ __global__ __launch_bounds__(256, 1) void block_x3_identity(const BlockParams p)
                     h8_t bh[4], bl[4];
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        const int row = (i + t / 3) * kHaloW + frow + t % 3;
-                        const char* px = lds_ab + row * 256;
-                        bh[i] = *(const h8_t*)(px + (((kk * 4 + fg + 2 * row) & 15) << 4));
-                        bl[i] = *(const h8_t*)(px + (((8 + kk * 4 + fg + 2 * row) & 15) << 4));
+                        const int rc = (i + t / 3) * kHaloW + t % 3;
+                        const int dh = (kk * 4 + 2 * rc) & 15, dl = (8 + kk * 4 + 2 * rc) & 15;
+                        bh[i] = *(const h8_t*)(rb[dh >> 1] + rc * 256);
+                        bl[i] = *(const h8_t*)(rb[dl >> 1] + rc * 256);
                     }
 #pragma unroll
                     for (int i = 0; i < 4; ++i) bacc[i] = mma(wfl[t][kk], bh[i], bacc[i]);
@@ -233,8 +255,8 @@ __global__ __launch_bounds__(256, 1) void block_x3_identity(const BlockParams p)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int row = i * 16 + frow;
-                const float v[4] = {fmaxf(bacc[i][0] * sc.x + sh.x, 0.f), fmaxf(bacc[i][1] * sc.y + sh.y, 0.f),
-                                    fmaxf(bacc[i][2] * sc.z + sh.z, 0.f), fmaxf(bacc[i][3] * sc.w + sh.w, 0.f)};
+                const float v[4] = {fmaxf(__builtin_fmaf(bacc[i][0], sc.x, sh.x), 0.f), fmaxf(__builtin_fmaf(bacc[i][1], sc.y, sh.y), 0.f),
+                                    fmaxf(__builtin_fmaf(bacc[i][2], sc.z, sh.z), 0.f), fmaxf(__builtin_fmaf(bacc[i][3], sc.w, sh.w), 0.f)};
                 typedef __attribute__((ext_vector_type(4))) _Float16 h4_t;
                 h4_t vh, vl;
 #pragma unroll
@@ -259,14 +281,10 @@ __global__ __launch_bounds__(256, 1) void block_x3_identity(const BlockParams p)
             const int oy = ty * 4 + wave, ox = tx * 16 + frow;
             const bool live = oy < p.H && ox < p.W;
             h8_t bh[2], bl[2];
-            {
-                const int row = wave * 16 + frow;
-                const char* px = lds_ab + row * 256;
 #pragma unroll
-                for (int kk = 0; kk < 2; ++kk) {
-                    bh[kk] = *(const h8_t*)(px + (((kk * 4 + fg + 2 * row) & 15) << 4));
-                    bl[kk] = *(const h8_t*)(px + (((8 + kk * 4 + fg + 2 * row) & 15) << 4));
-                }
+            for (int kk = 0; kk < 2; ++kk) {                    // row = wave * 16 + frow: 2 * 16 * wave = 0 mod 16
+                bh[kk] = *(const h8_t*)(rb[(kk * 4) >> 1] + wave * 16 * 256);
+                bl[kk] = *(const h8_t*)(rb[(8 + kk * 4) >> 1] + wave * 16 * 256);
             }
             __syncthreads();                                    // b is in registers everywhere: the next tile's phase A may write a
             uint16_t* orow = (uint16_t*)p.out + (((size_t)n * p.H + oy) * p.W + ox) * 512;
@@ -291,15 +309,17 @@ __global__ __launch_bounds__(256, 1) void block_x3_identity(const BlockParams p)
                 *(float4*)&sh[0] = *(const float4*)(cst + 512 + c0); *(float4*)&sh[4] = *(const float4*)(cst + 512 + c0 + 4);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    y[q] = acc[0][q] * sc[q] + sh[q];
-                    y[4 + q] = acc[1][q] * sc[4 + q] + sh[4 + q];
+                    y[q] = __builtin_fmaf(acc[0][q], sc[q], sh[q]);
+                    y[4 + q] = __builtin_fmaf(acc[1][q], sc[4 + q], sh[4 + q]);
                 }
                 // the residual: this lane's x fragment of K-step s3 = channels c0 .. c0 + 7 of its inner pixel (hi + lo is exact in fp32)
 #pragma unroll
-                for (int q = 0; q < 8; ++q) y[q] = fmaxf(y[q] + ((float)xih[s3][q] + (float)xil[s3][q]), 0.f);
-                if (more) {                                     // this K-step's x is spent: its registers take the next tile's
-                    xih[s3] = *(const h8_t*)(p.x + off_next[0] + s3 * 64);
-                    xil[s3] = *(const h8_t*)(p.x + off_next[0] + 512 + s3 * 64);
+                for (int q = 0; q < 8; ++q) y[q] = fmaxf(__fadd_rn(y[q], __fadd_rn((float)xih[s3][q], (float)xil[s3][q])), 0.f);      // (= add_split8, kernels.hip)
+                if constexpr (!FULL) {
+                    if (more) {                                 // this K-step's x is spent: its registers take the next tile's
+                        xih[s3] = *(const h8_t*)(p.x + off_next[0] + s3 * 64);
+                        xil[s3] = *(const h8_t*)(p.x + off_next[0] + 512 + s3 * 64);
+                    }
                 }
                 h8_t vh, vl;
                 split8(y, vh, vl);
@@ -312,6 +332,12 @@ __global__ __launch_bounds__(256, 1) void block_x3_identity(const BlockParams p)
         }
 
         inimg[0] = in_next[0]; inimg[1] = in_next[1];
+        if constexpr (FULL) {
+            if (more) {
+#pragma unroll
+                for (int kk = 0; kk < 8; ++kk) { xih[kk] = nih[kk]; xil[kk] = nil[kk]; }
+            }
+        }
     }
 }
 
@@ -325,11 +351,14 @@ hipError_t launch_block_x3(const BlockParams& p, int num_cus, hipStream_t s)
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
     if (!attr_done[dev & 63]) {
-        e = hipFuncSetAttribute((const void*)block_x3_identity, hipFuncAttributeMaxDynamicSharedMemorySize, kBlockX3LdsBytes);
+        e = hipFuncSetAttribute((const void*)block_x3_identity<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kBlockX3LdsBytes);
+        if (e != hipSuccess) return e;
+        e = hipFuncSetAttribute((const void*)block_x3_identity<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kBlockX3LdsBytes);
         if (e != hipSuccess) return e;
         attr_done[dev & 63] = true;
     }
-    hipLaunchKernelGGL(block_x3_identity, dim3(grid), dim3(256), kBlockX3LdsBytes, s, p);
+    if (p.pq) hipLaunchKernelGGL(block_x3_identity<true>, dim3(grid), dim3(256), kBlockX3LdsBytes, s, p);      // (conv variant bit 20 clears pq)
+    else hipLaunchKernelGGL(block_x3_identity<false>, dim3(grid), dim3(256), kBlockX3LdsBytes, s, p);
     return hipGetLastError();
 }
 

@@ -95,7 +95,7 @@ __device__ inline void add_split8(const uint16_t* src, int plane, float (&y)[8])
 {
     const f16x8_t h = *(const f16x8_t*)src, l = *(const f16x8_t*)(src + plane);
 #pragma unroll
-    for (int q = 0; q < 8; ++q) y[q] += (float)h[q] + (float)l[q];      // hi + lo is exact in fp32
+    for (int q = 0; q < 8; ++q) y[q] = __fadd_rn(y[q], __fadd_rn((float)h[q], (float)l[q]));      // hi + lo is exact in fp32; one rounding, never fused
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -603,8 +603,8 @@ void conv_igemm_mfma(const ConvParams p)
                             float y[8];
 #pragma unroll
                             for (int q = 0; q < 4; ++q) {
-                                y[q] = acc[2 * s2][ni][q] * sc[h][q] + sh[h][q];
-                                y[4 + q] = acc[2 * s2 + 1][ni][q] * sc[h][4 + q] + sh[h][4 + q];
+                                y[q] = __builtin_fmaf(acc[2 * s2][ni][q], sc[h][q], sh[h][q]);
+                                y[4 + q] = __builtin_fmaf(acc[2 * s2 + 1][ni][q], sc[h][4 + q], sh[h][4 + q]);
                             }
                             if (p.residual) {
                                 uint4 rr;
@@ -679,7 +679,7 @@ void conv_igemm_mfma(const ConvParams p)
 #pragma unroll
                     for (int q = 0; q < 4; ++q) { v[q] = acc[2 * s2][ni][q]; v[4 + q] = acc[2 * s2 + 1][ni][q]; }
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) y[q] = v[q] * sc[q] + sh[q];
+                    for (int q = 0; q < 8; ++q) y[q] = __builtin_fmaf(v[q], sc[q], sh[q]);
                     // element offset of the pixel's channel group; the split mode stores [C hi][C lo] per pixel
                     const size_t o = (size_t)(opix[ni] < 0 ? 0 : opix[ni]) * (p.cout * PL) + c0;
                     if (opix[ni] >= 0) {
@@ -699,7 +699,7 @@ void conv_igemm_mfma(const ConvParams p)
                             if constexpr (X3 && kPrefetchRes) {
                                 const f16x8_t h = __builtin_bit_cast(f16x8_t, res[s2][ni]), l = __builtin_bit_cast(f16x8_t, res_lo[s2][ni]);
 #pragma unroll
-                                for (int q = 0; q < 8; ++q) y[q] += (float)h[q] + (float)l[q];      // (as add_split8: hi + lo is exact in fp32)
+                                for (int q = 0; q < 8; ++q) y[q] = __fadd_rn(y[q], __fadd_rn((float)h[q], (float)l[q]));      // (= add_split8)
                             } else if constexpr (X3) add_split8((const uint16_t*)p.residual + o, p.cout, y);
                             else {
                                 uint4 rr;
@@ -1581,21 +1581,26 @@ __global__ __launch_bounds__(256, 1) void dec_tail_fused_x3(const TailParams p)
 #pragma unroll
     for (int c = 0; c < NC; ++c) { hsc[c] = c < p.classes ? p.head_scale[c] : 0.f; hsh[c] = c < p.classes ? p.head_shift[c] : 0.f; }
 
-    int src_base[4], img_base[4];
+    // Tile-invariant LDS read offsets, so that a fragment read costs no address arithmetic (the round-2 form spent ~7 integer ops
+    // per ds_read_b128: 664 of the kernel's 1 643 vector instructions per tile).  Pixel block ni of this lane sits at
+    //   src0:  hp = hp0 + ni * 32 (+ tap: (ks >> 1) * 16 + (ks & 1)),  slot of granule G = (G + 2 hp) & 15 = (s0 + D) & 15 with
+    //          s0 = (fg + 2 hp0) & 15 per lane and D = kk * 4 + 8 * lo + 2 * (ks & 1) known at compile time (even: 8 table entries);
+    //   image: pixel ib0 + ni * 128 (+ tap offset of this lane's k-group).
+    // Everything that depends on ni / ks is a multiple of 256 (32) bytes and rides in the instruction's immediate offset.
+    const int hp0 = ((frow >> 3) + py) * 16 + (frow & 7) + px;
+    const int s0 = (fg + 2 * hp0) & 15;
+    int src_t[8];
 #pragma unroll
-    for (int ni = 0; ni < 4; ++ni) {
-        const int i = ni * 16 + frow;
-        const int sy = i >> 3, sx = i & 7;
-        src_base[ni] = (sy + py) * 16 + (sx + px);
-        img_base[ni] = (2 * sy + py) * 32 + (2 * sx + px);
-    }
-    int img_toff[2][2];
+    for (int e = 0; e < 8; ++e) src_t[e] = hp0 * 256 + (((s0 + 2 * e) & 15) << 4);
+    const int ib0 = (2 * (frow >> 3) + py) * 32 + 2 * (frow & 7) + px;
+    int img_t[2][2];                                           // byte offset of (pixel block 0, this lane's tap) per image half-step
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             const int t = s2 * 8 + kk * 4 + fg;
-            img_toff[s2][kk] = t < 9 ? (t / 3) * 32 + (t % 3) : -1;
+            // taps 9..15 do not exist: their weights are zero (api.hip packs them so), any finite pixel will do -> tap 0
+            img_t[s2][kk] = (ib0 + (t < 9 ? (t / 3) * 32 + (t % 3) : 0)) * 32;
         }
 
     auto issue_tile = [&](int tile, int buf) __attribute__((always_inline)) {
@@ -1651,23 +1656,25 @@ __global__ __launch_bounds__(256, 1) void dec_tail_fused_x3(const TailParams p)
 #pragma unroll
             for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
+        const char* sb[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) sb[e] = lds_src + src_t[e];
         auto load_b = [&](int h, bf16x8_t (&bh)[4], bf16x8_t (&bl)[4]) __attribute__((always_inline)) {
             if (h < 8) {
                 const int ks = h >> 1, kk = h & 1;
+                const int dh = (kk * 4 + 2 * (ks & 1)) & 15, dl = (8 + kk * 4 + 2 * (ks & 1)) & 15;
 #pragma unroll
                 for (int ni = 0; ni < 4; ++ni) {
-                    const int hp = src_base[ni] + (ks >> 1) * 16 + (ks & 1);
-                    const char* px_ = lds_src + hp * 256;
-                    bh[ni] = *(const bf16x8_t*)(px_ + (((kk * 4 + fg + 2 * hp) & 15) << 4));
-                    bl[ni] = *(const bf16x8_t*)(px_ + (((8 + kk * 4 + fg + 2 * hp) & 15) << 4));
+                    const int k = (ni * 32 + (ks >> 1) * 16 + (ks & 1)) * 256;      // immediate offset
+                    bh[ni] = *(const bf16x8_t*)(sb[dh >> 1] + k);
+                    bl[ni] = *(const bf16x8_t*)(sb[dl >> 1] + k);
                 }
             } else {
-                const int toff = img_toff[(h - 8) >> 1][(h - 8) & 1];
+                const char* a = lds_img + img_t[(h - 8) >> 1][(h - 8) & 1];
 #pragma unroll
                 for (int ni = 0; ni < 4; ++ni) {
-                    const char* a = toff >= 0 ? lds_img + (img_base[ni] + toff) * 32 : zero_gran;
-                    bh[ni] = *(const bf16x8_t*)a;
-                    bl[ni] = *(const bf16x8_t*)(toff >= 0 ? a + 16 : zero_gran);
+                    bh[ni] = *(const bf16x8_t*)(a + ni * 128 * 32);
+                    bl[ni] = *(const bf16x8_t*)(a + ni * 128 * 32 + 16);
                 }
             }
         };
@@ -2264,9 +2271,12 @@ __global__ __launch_bounds__(256, 1) void conv3x3_c64_direct_x3(const Direct64Pa
         }
     };
 
-    int hbase[4];
+    // tile-invariant read offsets (as dec_tail_fused_x3): halo row hr = wp * 72 + frow + rc with rc = (ni + t / 3) * 18 + t % 3 known at
+    // compile time, slot of granule G = (G + 2 hr) & 15 = (s0 + D) & 15, s0 = (fg + 2 frow) & 15, D = kk * 4 + 8 * lo + (2 rc & 15)
+    const int s0 = (fg + 2 * frow) & 15;
+    int rd_t[8];
 #pragma unroll
-    for (int ni = 0; ni < 4; ++ni) hbase[ni] = (wp * 4 + ni) * kD64HaloW + frow;
+    for (int e = 0; e < 8; ++e) rd_t[e] = (wp * 4 * kD64HaloW + frow) * 256 + (((s0 + 2 * e) & 15) << 4);
 
     issue_tile(tile_at(0), 0);
     for (int it = 0; it < my_tiles; ++it) {
@@ -2276,24 +2286,24 @@ __global__ __launch_bounds__(256, 1) void conv3x3_c64_direct_x3(const Direct64Pa
         if (it + 1 < my_tiles) issue_tile(tile_at(it + 1), (it + 1) & 1);
 
         const char* lds = smem + (it & 1) * kD64x3BufBytes;
+        const char* rb[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) rb[e] = lds + rd_t[e];
         f32x4_t acc[2][4];
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
             for (int ni = 0; ni < 4; ++ni) acc[m][ni] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-        int zero;
-        asm volatile("v_mov_b32 %0, 0" : "=v"(zero));           // (keeps the 72 tile-invariant fragment addresses out of registers)
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
-            const int toff = (t / 3) * kD64HaloW + (t % 3) + zero;
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
 #pragma unroll
                 for (int ni = 0; ni < 4; ++ni) {
-                    const int hr = hbase[ni] + toff;
-                    const char* px = lds + hr * 256;
-                    const bf16x8_t bh = *(const bf16x8_t*)(px + (((kk * 4 + fg + 2 * hr) & 15) << 4));
-                    const bf16x8_t bl = *(const bf16x8_t*)(px + (((8 + kk * 4 + fg + 2 * hr) & 15) << 4));
+                    const int rc = (ni + t / 3) * kD64HaloW + t % 3;
+                    const int dh = (kk * 4 + 2 * rc) & 15, dl = (8 + kk * 4 + 2 * rc) & 15;
+                    const bf16x8_t bh = *(const bf16x8_t*)(rb[dh >> 1] + rc * 256);
+                    const bf16x8_t bl = *(const bf16x8_t*)(rb[dl >> 1] + rc * 256);
 #pragma unroll
                     for (int m = 0; m < 2; ++m) {
                         acc[m][ni] = mfma16<F16>(wlo[t][kk][m], bh, acc[m][ni]);
@@ -2322,8 +2332,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3_c64_direct_x3(const Direct64Pa
             float y[8];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                y[q] = acc[0][ni][q] * sc[q] + sh[q];
-                y[4 + q] = acc[1][ni][q] * sc[4 + q] + sh[4 + q];
+                y[q] = __builtin_fmaf(acc[0][ni][q], sc[q], sh[q]);
+                y[4 + q] = __builtin_fmaf(acc[1][ni][q], sc[4 + q], sh[4 + q]);
             }
             if (p.relu) {
 #pragma unroll
