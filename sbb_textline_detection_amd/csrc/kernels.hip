@@ -1529,6 +1529,7 @@ constexpr int kT3SrcBytes = 10 * 16 * 256;              // 40 KB: 10 rows x 16 p
 constexpr int kT3ImgBytes = 18 * 32 * 32;               // 18 KB: 18 rows x 32 pixels (18 used) x 32 B
 constexpr int kT3BufBytes = kT3SrcBytes + kT3ImgBytes;
 constexpr int kT3LdsBytes = 2 * kT3BufBytes + 256 + 64 + kTailConstBytes;
+constexpr int kT3PartBytes = 4 * 64 * 4 * 4;              // dec_tail_fused_x3w8: partial logits [4 parities][64 pixels][<= 4 classes]
 
 template <int NC>
 __global__ __launch_bounds__(256, 1) void dec_tail_fused_x3(const TailParams p)
@@ -1771,6 +1772,273 @@ __global__ __launch_bounds__(256, 1) void dec_tail_fused_x3(const TailParams p)
     }
 }
 
+// dec_tail_fused_x3w8 -- the same tile with EIGHT waves (two per SIMD): wave = (parity class, half of the 32 output channels).
+// With one wave per SIMD (dec_tail_fused_x3) the tile loop is issue-bound on its own instruction stream -- ~2 200 vector / scalar /
+// LDS instructions per tile and wave around 288 MFMAs; PMC: 46 % of the wave cycles issuing, 33 % parked, MFMA pipe 31 % busy -- and
+// nothing fills the parked cycles.  Here every wave issues half the MFMAs and half the epilogue, and its partner on the SIMD
+// runs while it waits (the weights halve too: 96 VGPRs, which is what lets two waves share a SIMD's register file).  The head's
+// 32-channel contraction is finished through LDS: the upper-half waves hand their partial logits to the lower-half waves.
+template <int NC>
+__global__ __launch_bounds__(512, 2) void dec_tail_fused_x3w8(const TailParams p)
+{
+    constexpr bool F16 = true;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* lbl_tile = smem + 2 * kT3BufBytes;                   // [16][16] u8
+    char* zero_gran = lbl_tile + 256;                          // 16 zero bytes (unused here; keeps the layout of dec_tail_fused_x3)
+    float* cst = (float*)(zero_gran + 64);                     // [32 channels][CR]: scale, shift, head_w
+    float* part = (float*)((char*)cst + kTailConstBytes);      // [4 parities][64 pixels][NC]: partial logits of the upper channel half
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int par = wave & 3, mh = wave >> 2;                  // parity class, MFMA row block (channels fg * 8 + mh * 4 + 0..3)
+    const int py = par >> 1, px = par & 1;
+    const int frow = lane & 15, fg = lane >> 4;
+
+    const int H = 2 * p.PH, W = 2 * p.PW;
+    const int tiles_x = W / 16, tiles_y = H / 16;
+    const int tiles_per_patch = tiles_x * tiles_y;
+    const int n_tiles = p.n * tiles_per_patch;
+    // XCD-contiguous walk (grid = a multiple of 8 blocks): XCD x = block % 8 owns tiles [x * per_xcd, (x + 1) * per_xcd), so the
+    // halo pixels neighbouring tiles share are fetched into one L2 once instead of once per XCD (a round-robin walk
+    // re-fetched them from HBM: 1.8x the input bytes, L2 hit rate 2 %)
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, GX = gridDim.x >> 3;
+    const int per_xcd = (n_tiles + 7) >> 3;
+    const int xcd_lo = xcd * per_xcd, xcd_hi = min(n_tiles, xcd_lo + per_xcd);
+    const int my_tiles = xcd_lo + slot < xcd_hi ? (xcd_hi - xcd_lo - slot + GX - 1) / GX : 0;
+    if (my_tiles <= 0) return;
+    auto tile_at = [&](int it) __attribute__((always_inline)) -> int { return xcd_lo + slot + it * GX; };
+    if (tid < 4) ((uint32_t*)zero_gran)[tid] = 0u;
+    constexpr int CR = NC <= 2 ? 4 : 8;
+    if (tid < 32) {
+        float* row = cst + ((tid & 7) * 4 + (tid >> 3)) * CR;
+        row[0] = p.scale[tid];
+        row[1] = p.shift[tid];
+        for (int c = 0; c < CR - 2; ++c) row[2 + c] = c < p.classes ? p.head_w[tid * p.classes + c] : 0.f;
+    }
+
+    // ---- this wave's weights: [plane hi|lo][half-K-step 12] fragments of row block mh (wfrag = per class [hi | lo][12][mi 2])
+    bf16x8_t whi[kTailKSteps * 2], wlo[kTailKSteps * 2];
+    {
+        const uint4* src = (const uint4*)p.wfrag + (size_t)(par * 2 * kTailKSteps * 4) * 64 + lane;
+#pragma unroll
+        for (int h = 0; h < kTailKSteps * 2; ++h) {
+            whi[h] = __builtin_bit_cast(bf16x8_t, src[(size_t)(h * 2 + mh) * 64]);
+            wlo[h] = __builtin_bit_cast(bf16x8_t, src[(size_t)(kTailKSteps * 4 + h * 2 + mh) * 64]);
+        }
+    }
+    float hsc[NC], hsh[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) { hsc[c] = c < p.classes ? p.head_scale[c] : 0.f; hsh[c] = c < p.classes ? p.head_shift[c] : 0.f; }
+
+    // Tile-invariant LDS read offsets, so that a fragment read costs no address arithmetic (the round-2 form spent ~7 integer ops
+    // per ds_read_b128: 664 of the kernel's 1 643 vector instructions per tile).  Pixel block ni of this lane sits at
+    //   src0:  hp = hp0 + ni * 32 (+ tap: (ks >> 1) * 16 + (ks & 1)),  slot of granule G = (G + 2 hp) & 15 = (s0 + D) & 15 with
+    //          s0 = (fg + 2 hp0) & 15 per lane and D = kk * 4 + 8 * lo + 2 * (ks & 1) known at compile time (even: 8 table entries);
+    //   image: pixel ib0 + ni * 128 (+ tap offset of this lane's k-group).
+    // Everything that depends on ni / ks is a multiple of 256 (32) bytes and rides in the instruction's immediate offset.
+    const int hp0 = ((frow >> 3) + py) * 16 + (frow & 7) + px;
+    const int s0 = (fg + 2 * hp0) & 15;
+    int src_t[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) src_t[e] = hp0 * 256 + (((s0 + 2 * e) & 15) << 4);
+    // Image tile: row y = 64 units of 16 B; pixel x = 2 m + b, plane lo: unit 4 m + b + 2 lo, the low four bits rotated by y
+    // (inside each 256-byte group).  The 16 lanes of a ds_read_b128 group are two taps (k-groups a, a + 1) x eight pixels
+    // {(y0, x0 + 2 i), (y0 + 2, x0 + 8 + 2 i)}: with this order they land on 16 different slots whether the second tap is the
+    // right-hand neighbour (b flips: slot class +- 1) or the first tap of the next kernel row (y + 1: rotation + 1).  The plain
+    // [pixel][hi | lo] rows of dec_tail_fused_x3 collide four-way here.
+    int img_t[2][2][4][2];                                     // [image half-step][kk][pixel block][hi | lo] byte offsets
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int t0 = s2 * 8 + kk * 4 + fg;
+            const int t = t0 < 9 ? t0 : 0;                     // taps 9..15 do not exist: zero weights, any finite pixel will do
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+                const int y = 4 * ni + 2 * (frow >> 3) + py + t / 3, x = 2 * (frow & 7) + px + t % 3;
+                const int m = x >> 1, b = x & 1;
+#pragma unroll
+                for (int lo = 0; lo < 2; ++lo)
+                    img_t[s2][kk][ni][lo] = y * 1024 + (m >> 2) * 256 + (((4 * (m & 3) + b + 2 * lo + y) & 15) << 4);
+            }
+        }
+
+    auto issue_tile = [&](int tile, int buf) __attribute__((always_inline)) {
+        const int n = tile / tiles_per_patch;
+        const int rem = tile - n * tiles_per_patch;
+        const int ty = rem / tiles_x, tx = rem - ty * tiles_x;
+        const int y0 = ty * 16, x0 = tx * 16;
+        char* lds_src = smem + buf * kT3BufBytes;
+        char* lds_img = lds_src + kT3SrcBytes;
+        // src0 halo: 160 pixels x 16 granules (8 hi, 8 lo) = 40 wave-instructions of 4 pixels; pixel hp keeps granule g at slot
+        // (g + 2 hp) & 15.  A 16-lane group of ds_read_b128 holds two k-groups (fg = a, a + 1) of eight pixels each whose hp are
+        // eight consecutive residues: rotation by 2 hp sends one k-group to the eight even slots and the other to the eight odd
+        // ones.  (The XOR swizzle g ^ (hp & 15) of round 2 collided two-way in every group: PMC SQ_LDS_BANK_CONFLICT 86 %.)
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            const int ii = wave + 8 * j;
+            const int hp = ii * 4 + (lane >> 4);
+            const int r = hp >> 4, c = hp & 15;
+            const int g = ((lane & 15) - 2 * c) & 15;              // slot s of pixel hp holds granule (s - 2 hp) & 15
+            const int Y = (y0 >> 1) - 1 + r, X = (x0 >> 1) - 1 + c;
+            const bool ok = ((unsigned)Y < (unsigned)p.PH) & ((unsigned)X < (unsigned)p.PW) & (c < 10);
+            uint32_t off = (uint32_t)((n * p.PH + Y) * p.PW + X) * 256u + (uint32_t)(g * 16 + kZeroHeaderBytes);
+            off = ok ? off : 0u;
+            __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(p.src0 + off), (LDS_AS void*)(lds_src + ii * 1024), 16, 0, 0);
+        }
+        // image halo: 18 rows x 32 pixels x (hi 16 B, lo 16 B) = 18 wave-instructions of one row; lane l fills physical unit l of
+        // the row and fetches the (pixel, plane) the rotated order puts there
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int ii = wave + 8 * j;
+            if (ii < 18) {
+                const int low = ((lane & 15) - ii) & 15;
+                const int c = 2 * (4 * (lane >> 4) + (low >> 2)) + (low & 1), lo = (low >> 1) & 1;
+                const int Y = y0 - 1 + ii, X = x0 - 1 + c;
+                const bool ok = ((unsigned)Y < (unsigned)H) & ((unsigned)X < (unsigned)W) & (c < 18);
+                uint32_t off = (uint32_t)((n * H + Y) * W + X) * 32u + (uint32_t)(lo * 16 + kZeroHeaderBytes);
+                off = ok ? off : 0u;
+                __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(p.img + off), (LDS_AS void*)(lds_img + ii * 1024), 16, 0, 0);
+            }
+        }
+    };
+
+    issue_tile(tile_at(0), 0);
+    for (int it = 0; it < my_tiles; ++it) {
+        const int tile = tile_at(it);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (it + 1 < my_tiles) issue_tile(tile_at(it + 1), (it + 1) & 1);
+
+        const char* lds_src = smem + (it & 1) * kT3BufBytes;
+        const char* lds_img = lds_src + kT3SrcBytes;
+        f32x4_t acc[4];
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) acc[ni] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+        const char* sb[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) sb[e] = lds_src + src_t[e];
+        auto load_b = [&](int h, bf16x8_t (&bh)[4], bf16x8_t (&bl)[4]) __attribute__((always_inline)) {
+            if (h < 8) {
+                const int ks = h >> 1, kk = h & 1;
+                const int dh = (kk * 4 + 2 * (ks & 1)) & 15, dl = (8 + kk * 4 + 2 * (ks & 1)) & 15;
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) {
+                    const int k = (ni * 32 + (ks >> 1) * 16 + (ks & 1)) * 256;      // immediate offset
+                    bh[ni] = *(const bf16x8_t*)(sb[dh >> 1] + k);
+                    bl[ni] = *(const bf16x8_t*)(sb[dl >> 1] + k);
+                }
+            } else {
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) {
+                    bh[ni] = *(const bf16x8_t*)(lds_img + img_t[(h - 8) >> 1][(h - 8) & 1][ni][0]);
+                    bl[ni] = *(const bf16x8_t*)(lds_img + img_t[(h - 8) >> 1][(h - 8) & 1][ni][1]);
+                }
+            }
+        };
+        auto mac = [&](int h, const bf16x8_t (&bh)[4], const bf16x8_t (&bl)[4]) __attribute__((always_inline)) {
+            // three sweeps over the four accumulators (small terms first)
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) acc[ni] = mfma16<F16>(wlo[h], bh[ni], acc[ni]);
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) acc[ni] = mfma16<F16>(whi[h], bl[ni], acc[ni]);
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) acc[ni] = mfma16<F16>(whi[h], bh[ni], acc[ni]);
+        };
+        bf16x8_t b0h[4], b0l[4], b1h[4], b1l[4];
+        load_b(0, b0h, b0l);
+#pragma unroll
+        for (int h = 0; h < 12; h += 2) {
+            load_b(h + 1, b1h, b1l);
+            mac(h, b0h, b0l);
+            if (h + 2 < 12) load_b(h + 2, b0h, b0l);
+            mac(h + 1, b1h, b1l);
+        }
+
+        // ---- epilogue: BN/ReLU, head, softmax, argmax (as dec_tail_fused)
+        const int n = tile / tiles_per_patch;
+        const int rem = tile - n * tiles_per_patch;
+        const int tyy = rem / tiles_x, txx = rem - tyy * tiles_x;
+        // (channel constants are read once per tile -- q outer, the four pixel blocks inner -- not once per pixel block)
+        float lg[4][NC];
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+            for (int c = 0; c < NC; ++c) lg[ni][c] = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float* row = cst + ((mh * 4 + q) * 4 + fg) * CR;                // channel fg * 8 + mh * 4 + q
+            const float4 c0 = *(const float4*)row;                                // scale, shift, hw0, hw1
+            float2 c1 = make_float2(0.f, 0.f);
+            if constexpr (NC > 2) c1 = *(const float2*)(row + 4);                 // hw2, hw3
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+                const float yq = fmaxf(acc[ni][q] * c0.x + c0.y, 0.f);
+                lg[ni][0] = fmaf(yq, c0.z, lg[ni][0]);
+                if constexpr (NC > 1) lg[ni][1] = fmaf(yq, c0.w, lg[ni][1]);
+                if constexpr (NC > 2) {
+                    lg[ni][2] = fmaf(yq, c1.x, lg[ni][2]);
+                    lg[ni][3] = fmaf(yq, c1.y, lg[ni][3]);
+                }
+            }
+        }
+        // this wave's 16 channels: the four k-groups of a pixel add up; the upper half hands its sums to the lower half
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                float a = lg[ni][c];
+                a += __shfl_xor(a, 16);
+                a += __shfl_xor(a, 32);
+                lg[ni][c] = a;
+            }
+        if (mh == 1 && fg == 0) {
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                for (int c = 0; c < NC; ++c) part[(par * 64 + ni * 16 + frow) * NC + c] = lg[ni][c];
+        }
+        __syncthreads();
+        if (mh == 0 && fg == 0) {
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+                float logit[NC];
+#pragma unroll
+                for (int c = 0; c < NC; ++c) logit[c] = (lg[ni][c] + part[(par * 64 + ni * 16 + frow) * NC + c]) * hsc[c] + hsh[c];
+                float mx = -3.0e38f;
+#pragma unroll
+                for (int c = 0; c < NC; ++c)
+                    if (c < p.classes) mx = fmaxf(mx, logit[c]);
+                float pr[NC], sum = 0.f;
+#pragma unroll
+                for (int c = 0; c < NC; ++c) { pr[c] = c < p.classes ? expf(logit[c] - mx) : 0.f; sum += pr[c]; }
+                int best = 0;
+                float bestp = -1.f;
+#pragma unroll
+                for (int c = 0; c < NC; ++c)
+                    if (c < p.classes) {
+                        pr[c] = pr[c] / sum;
+                        if (pr[c] > bestp) { bestp = pr[c]; best = c; }
+                    }
+                const int i = ni * 16 + frow;
+                const int oy = 2 * (i >> 3) + py, ox = 2 * (i & 7) + px;
+                lbl_tile[oy * 16 + ox] = (char)best;
+                if (p.probs) {
+                    float* dst = p.probs + ((size_t)(n * H + tyy * 16 + oy) * W + txx * 16 + ox) * p.classes;
+#pragma unroll
+                    for (int c = 0; c < NC; ++c)
+                        if (c < p.classes) dst[c] = pr[c];
+                }
+            }
+        }
+        __syncthreads();
+        if (tid < 16)
+            *(uint4*)(p.labels + (size_t)(n * H + tyy * 16 + tid) * W + txx * 16) = *(const uint4*)(lbl_tile + tid * 16);
+    }
+}
+
 hipError_t launch_tail(const TailParams& p, int precision, int num_cus, hipStream_t s)
 {
     const int n_tiles = p.n * (p.PH / 8) * (p.PW / 8);
@@ -1790,7 +2058,18 @@ hipError_t launch_tail(const TailParams& p, int precision, int num_cus, hipStrea
             hipLaunchKernelGGL(kern, dim3(grid3), dim3(256), kT3LdsBytes, s, p);
             return hipSuccess;
         };
-        e = p.classes <= 2 ? go3(dec_tail_fused_x3<2>) : go3(dec_tail_fused_x3<4>);
+        static const bool w8 = !(getenv("SBBSEG_TAIL_X3_W8") && getenv("SBBSEG_TAIL_X3_W8")[0] == '0');      // A/B: 0 = one wave per SIMD
+        if (w8) {
+            auto go8 = [&](auto kern) -> hipError_t {
+                hipError_t e8 = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, kT3LdsBytes + kT3PartBytes);
+                if (e8 != hipSuccess) return e8;
+                hipLaunchKernelGGL(kern, dim3(grid3), dim3(512), kT3LdsBytes + kT3PartBytes, s, p);
+                return hipSuccess;
+            };
+            e = p.classes <= 2 ? go8(dec_tail_fused_x3w8<2>) : go8(dec_tail_fused_x3w8<4>);
+        } else {
+            e = p.classes <= 2 ? go3(dec_tail_fused_x3<2>) : go3(dec_tail_fused_x3<4>);
+        }
         if (e != hipSuccess) return e;
         return hipGetLastError();
     }
