@@ -240,11 +240,15 @@ int sbbseg_segment_whole_scaled(sbbseg_ctx* c, const uint8_t* page_hwc, int Hp, 
 #define SBBSEG_MORPH_DILATE 1
 int sbbseg_morph_dev(sbbseg_ctx* c, const void* d_src_hw, int H, int W, int op, int ksize, int iterations, void* d_dst_hw);
 int sbbseg_morph(sbbseg_ctx* c, const uint8_t* src_hw, int H, int W, int op, int ksize, int iterations, uint8_t* dst_hw);
-/* extract_page's box (main.py:394-404): mask > 0 -> dilate 5x5 x 6 -> largest 8-connected component -> its bounding box
- * {x, y, w, h} (cv2.boundingRect convention) and pixel count; {0,0,0,0} / 0 when the mask is empty.  [EXT, unpinned]: the
- * reference ranks cv2.findContours contours by cv2.contourArea (polygon area of the traced border) and breaks ties by
- * contour order; here components are ranked by PIXEL COUNT, ties by first pixel in raster order.  Both pick the same blob
- * unless two components are nearly equal in size or the largest one is mostly holes. */
+/* extract_page's box (main.py:394-404): mask > 0 -> dilate 5x5 x 6 -> the component whose OUTER CONTOUR has the largest
+ * cv2.contourArea (contours[np.argmax([cv2.contourArea(c) ...])]; a hole's contour lies inside its component's and never wins)
+ * -> its bounding box {x, y, w, h} (cv2.boundingRect convention) and pixel count; {0,0,0,0} / 0 when the mask is empty.
+ * The contour area of a component = area of the polygon through its boundary pixels' centres = (2x2 pixel cells fully inside)
+ * + (cells with three pixels inside) / 2, counted over the component with its holes filled.  The device ranks the components
+ * by that sum over the component as it is (a lower bound) and checks the winner against every other component's bounding-box
+ * bound; a ring- or frame-shaped blob beside a solid one can leave that undecided, and only then the dilated mask is copied
+ * back and the contours are traced on the host (Moore border following + shoelace: exact).  [EXT, unpinned]: equal areas are
+ * broken by raster order of the components' first pixels; in the reference OpenCV's contour order decides. */
 int sbbseg_page_box_dev(sbbseg_ctx* c, const void* d_mask_hw, int H, int W, int32_t* box_xywh, int64_t* pixels);
 /* extract_page's model + glue in one call: border model on the page as upscaled to Hs x Ws (sbbseg_segment_whole_scaled),
  * then sbbseg_page_box_dev on the label plane while it is still on the device.  mask_out: Hs x Ws labels (x3 with
@@ -317,8 +321,12 @@ int sbbseg_debug_read_tensor(sbbseg_ctx* c, int tensor_id, int n, float* out, si
  * bit 17 = plain gather (per-load address arithmetic) instead of the fast gather on every layer;
  * bit 18 = fused bottleneck blocks run as the three convs they replace; bit 19 = grouped (parity-class) launches walk
  * XCD-contiguous tile ranges; bit 20 = fused bottleneck blocks run bottleneck_fused (one group of four waves per tile)
- * instead of bottleneck_fused_pq (producer / consumer wave groups) */
+ * instead of bottleneck_fused_pq (producer / consumer wave groups); bit 21 = sbbseg_page_box_dev always ranks on the host */
 int sbbseg_debug_set_conv_variant(sbbseg_ctx* c, int variant);
+/* the exact host-side contour ranking of sbbseg_page_box_dev on a host mask that is ALREADY dilated (no GPU needed; tests) */
+int sbbseg_debug_largest_contour(const uint8_t* mask_hw, int H, int W, int32_t* box_xywh, int64_t* pixels);
+/* counters: which 0 = how often sbbseg_page_box_dev had to fall back to the host ranking on this handle */
+int sbbseg_debug_counter(sbbseg_ctx* c, int which, int64_t* value);
 /* Test hook for the no-abort guarantee: the nth_check-th next internal host-allocation checkpoint throws
  * std::bad_alloc, which every entry point turns into a non-zero status + sbbseg_last_error() instead of
  * terminating the process (main.py:2061-2157 relies on ordinary exceptions).  0 disarms.  Process-global. */

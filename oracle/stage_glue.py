@@ -110,16 +110,59 @@ def region_cleanup(text_regions: np.ndarray) -> np.ndarray:
     return morph(morph(text_regions, "erode", 5, 3), "dilate", 5, 4)
 
 
+_DX8 = (1, 1, 0, -1, -1, -1, 0, 1)          # E, SE, S, SW, W, NW, N, NE: clockwise with y pointing down
+_DY8 = (0, 1, 1, 1, 0, -1, -1, -1)
+
+
+def outer_contour_area2(comp: np.ndarray) -> int:
+    """TWICE the area cv2.contourArea gives for the OUTER contour cv2.findContours traces around the 8-connected component
+    ``comp`` (bool [H,W], exactly one component) [EXT: OpenCV's border following visits the component's boundary pixels in
+    order; contourArea is the shoelace sum over that closed chain of pixel centres; CHAIN_APPROX_SIMPLE only drops collinear
+    points].  Moore neighbour tracing from the first pixel in raster order (its west neighbour is background), stopped when
+    the start pixel is left again in the first direction."""
+    H, W = comp.shape
+    ys, xs = np.nonzero(comp)
+    sy, sx = int(ys[0]), int(xs[0])                      # np.nonzero is row-major: the first pixel in raster order
+
+    def inside(y, x):
+        return 0 <= y < H and 0 <= x < W and bool(comp[y, x])
+    cy, cx, back, first, area2 = sy, sx, 4, None, 0
+    for _ in range(4 * H * W + 8):
+        d = None
+        for k in range(1, 9):
+            dd = (back + k) & 7
+            if inside(cy + _DY8[dd], cx + _DX8[dd]):
+                d = dd
+                break
+        if d is None:
+            return 0                                     # a single pixel
+        if (cy, cx) == (sy, sx):
+            if first is None:
+                first = d
+            elif d == first:
+                break
+        ny, nx = cy + _DY8[d], cx + _DX8[d]
+        area2 += cx * ny - nx * cy
+        cy, cx = ny, nx
+        back = (d + (5 if d & 1 else 6)) & 7             # the background neighbour examined just before, seen from the new pixel
+    return abs(area2)
+
+
 def largest_component_box(mask: np.ndarray):
-    """((x, y, w, h), pixels) of the 8-connected component of mask > 0 with the most pixels; ((0,0,0,0), 0) if none."""
+    """((x, y, w, h), pixels) of the 8-connected component of mask > 0 whose OUTER CONTOUR has the largest cv2.contourArea
+    (main.py:398-404: contours[np.argmax([cv2.contourArea(c) ...])], cv2.boundingRect) -- a hole's contour never wins, it lies
+    inside its component's outer contour; ((0,0,0,0), 0) if the mask is empty.  Ties: the first component in raster order
+    [EXT, unpinned: OpenCV's own contour order decides in the reference]."""
     from scipy import ndimage
     lab, n = ndimage.label(np.asarray(mask) > 0, structure=np.ones((3, 3), int))
     if n == 0:
         return (0, 0, 0, 0), 0
-    counts = np.bincount(lab.reshape(-1))[1:]
-    best = int(np.argmax(counts)) + 1                    # scipy numbers components in raster order of their first pixel: ties -> first
-    ys, xs = np.nonzero(lab == best)
-    return (int(xs.min()), int(ys.min()), int(xs.max() - xs.min() + 1), int(ys.max() - ys.min() + 1)), int(counts[best - 1])
+    slices = ndimage.find_objects(lab)
+    areas = [outer_contour_area2(lab[sl] == k + 1) for k, sl in enumerate(slices)]
+    best = int(np.argmax(areas))                         # scipy numbers components in raster order of their first pixel: ties -> first
+    sl = slices[best]
+    pixels = int((lab[sl] == best + 1).sum())
+    return (int(sl[1].start), int(sl[0].start), int(sl[1].stop - sl[1].start), int(sl[0].stop - sl[0].start)), pixels
 
 
 def page_box(img_page_prediction: np.ndarray):
@@ -128,7 +171,7 @@ def page_box(img_page_prediction: np.ndarray):
     gray = img_page_prediction[:, :, 0] if img_page_prediction.ndim == 3 else img_page_prediction
     thresh = np.where(gray > 0, 255, 0).astype(np.uint8)             # main.py:394-395
     thresh = morph(thresh, "dilate", 5, 6)                           # main.py:397
-    return largest_component_box(thresh)                             # main.py:398-404 (see [EXT] note above)
+    return largest_component_box(thresh)                             # main.py:398-404 (see [EXT] notes there)
 
 
 def crop_image_inside_box(box, img):

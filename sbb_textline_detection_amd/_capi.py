@@ -23,7 +23,7 @@ EXPORTS = [
     "sbbseg_set_stream", "sbbseg_set_lanes", "sbbseg_set_label_channels", "sbbseg_synchronize", "sbbseg_set_input", "sbbseg_input_form", "sbbseg_add_tensor",
     "sbbseg_add_conv", "sbbseg_add_maxpool", "sbbseg_add_tail", "sbbseg_add_head", "sbbseg_finalize", "sbbseg_model_info",
     "sbbseg_num_ops", "sbbseg_op_info", "sbbseg_op_issued_flops", "sbbseg_device_bytes", "sbbseg_predict", "sbbseg_segment_page",
-    "sbbseg_segment_page_dev", "sbbseg_segment_pages_dev", "sbbseg_segment_page_scaled", "sbbseg_segment_page_otsu", "sbbseg_segment_crop", "sbbseg_segment_crop_dev", "sbbseg_comm_unique_id", "sbbseg_comm_init", "sbbseg_comm_info", "sbbseg_comm_destroy", "sbbseg_allgather_labels_dev", "sbbseg_otsu_dev",
+    "sbbseg_segment_page_dev", "sbbseg_segment_pages_dev", "sbbseg_segment_page_scaled", "sbbseg_segment_page_otsu", "sbbseg_segment_crop", "sbbseg_segment_crop_dev", "sbbseg_debug_largest_contour", "sbbseg_debug_counter", "sbbseg_comm_unique_id", "sbbseg_comm_init", "sbbseg_comm_info", "sbbseg_comm_destroy", "sbbseg_allgather_labels_dev", "sbbseg_otsu_dev",
     "sbbseg_segment_tile_range_bin_dev", "sbbseg_segment_whole", "sbbseg_segment_whole_scaled", "sbbseg_tile_grid", "sbbseg_nearest_map", "sbbseg_segment_tiles_dev",
     "sbbseg_segment_tile_range_dev", "sbbseg_stitch_dev", "sbbseg_debug_ingest", "sbbseg_debug_read_tensor",
     "sbbseg_debug_set_conv_variant", "sbbseg_debug_inject_alloc_failure",
@@ -94,6 +94,8 @@ def load_library(path: Optional[str] = None):
         "sbbseg_segment_pages_dev": [vp, i32, vp, i32, i32, vp],
         "sbbseg_segment_page_scaled": [vp, vp, i32, i32, i32, i32, vp],
         "sbbseg_segment_page_otsu": [vp, vp, i32, i32, i32, i32, vp, C.POINTER(C.c_int)],
+        "sbbseg_debug_largest_contour": [vp, i32, i32, vp, C.POINTER(C.c_int64)],
+        "sbbseg_debug_counter": [vp, i32, C.POINTER(C.c_int64)],
         "sbbseg_comm_unique_id": [C.c_char_p],
         "sbbseg_comm_init": [vp, i32, i32, C.c_char_p],
         "sbbseg_comm_info": [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)],
@@ -447,6 +449,11 @@ class Context:
         check(self.lib.sbbseg_page_box_dev(self.h, C.c_void_p(d_mask), H, W, _ptr(box), C.byref(px)), "sbbseg_page_box_dev")
         return tuple(int(v) for v in box), int(px.value)
 
+    def host_contour_calls(self) -> int:
+        v = C.c_int64(0)
+        check(self.lib.sbbseg_debug_counter(self.h, 0, C.byref(v)), "sbbseg_debug_counter")
+        return int(v.value)
+
     def extract_page_box(self, page: np.ndarray, scaled_h: int, scaled_w: int, channels: int = 1):
         """Border model on the page as upscaled to scaled_h x scaled_w + the page box, one call: (mask, (x, y, w, h), pixels)."""
         page = np.ascontiguousarray(page, np.uint8)
@@ -505,6 +512,15 @@ class Context:
             op.update(total_ms=ms.value, launches=ln.value, patches=pt.value)
             out.append(op)
         return out
+
+
+def host_largest_contour(mask: np.ndarray):
+    """((x, y, w, h), pixels) by the library's exact HOST ranking (contour tracing) on an already dilated u8 mask; no GPU."""
+    mask = np.ascontiguousarray(mask, np.uint8)
+    box = np.zeros(4, np.int32)
+    px = C.c_int64(0)
+    check(load_library().sbbseg_debug_largest_contour(_ptr(mask), mask.shape[0], mask.shape[1], _ptr(box), C.byref(px)), "sbbseg_debug_largest_contour")
+    return tuple(int(v) for v in box), int(px.value)
 
 
 def comm_unique_id() -> bytes:

@@ -216,6 +216,9 @@ struct sbbseg_ctx {
     int comm_rank = 0, comm_world = 1;
     void* d_deskew = nullptr; size_t deskew_cap = 0;      // inverse maps | bicubic table | row counts of sbbseg_deskew_profiles
     int *d_cc_parent = nullptr, *d_cc_count = nullptr; size_t cc_parent_cap = 0, cc_count_cap = 0;
+    bool force_host_contours = false;     // test hook (conv variant bit 21): always take the exact host ranking
+    int host_contour_calls = 0;           // how often the exact host ranking ran (sbbseg_debug_counter)
+    int* d_cc_aux = nullptr; size_t cc_aux_cap = 0;      // five int planes: doubled cell area + bounding boxes per root (sbbseg_page_box_dev)
     unsigned long long* d_cc_small = nullptr;      // [0] best key, [1..2] box (4 ints)
     // profiling
     bool profiling = false;
@@ -565,6 +568,71 @@ void comm_release(sbbseg_ctx* c)
     c->comm = nullptr; c->comm_rank = 0; c->comm_world = 1;
 }
 
+// ---- extract_page's ranking, exact, on the host (main.py:398-404): cv2.findContours(RETR_TREE) + cv2.contourArea + np.argmax.
+// Only the OUTER contour of a component can win (a hole's contour lies inside it), so: label the 8-connected components, trace
+// each one's outer border through its boundary pixels (Moore neighbour tracing from the first pixel in raster order, whose
+// west / north neighbours are background; stop when the start pixel is re-entered in the start direction), shoelace area of
+// that closed chain (CHAIN_APPROX_SIMPLE drops collinear points only: same area).  Ties: first component in raster order
+// [EXT: OpenCV's contour order is not pinned].  Returns {x0, y0, x1, y1, pixels}; false for an empty mask.
+bool host_largest_contour(const uint8_t* m, int H, int W, int (&out)[5])
+{
+    const long n = (long)H * W;
+    std::vector<int> lab(n, -1);
+    std::vector<long> stack;
+    static const int dx8[8] = {1, 1, 0, -1, -1, -1, 0, 1}, dy8[8] = {0, 1, 1, 1, 0, -1, -1, -1};      // E, SE, S, SW, W, NW, N, NE (clockwise, y down)
+    long long best_area2 = -1;
+    int n_comp = 0;
+    for (long s = 0; s < n; ++s) {
+        if (!m[s] || lab[s] >= 0) continue;
+        // flood the component; box and pixel count on the way
+        const int id = n_comp++;
+        int x0 = W, y0 = H, x1 = -1, y1 = -1, cnt = 0;
+        stack.clear();
+        stack.push_back(s);
+        lab[s] = id;
+        while (!stack.empty()) {
+            const long i = stack.back();
+            stack.pop_back();
+            const int y = (int)(i / W), x = (int)(i - (long)y * W);
+            ++cnt;
+            x0 = x < x0 ? x : x0; x1 = x > x1 ? x : x1; y0 = y < y0 ? y : y0; y1 = y > y1 ? y : y1;
+            for (int d = 0; d < 8; ++d) {
+                const int yy = y + dy8[d], xx = x + dx8[d];
+                if ((unsigned)yy >= (unsigned)H || (unsigned)xx >= (unsigned)W) continue;
+                const long j = (long)yy * W + xx;
+                if (m[j] && lab[j] < 0) { lab[j] = id; stack.push_back(j); }
+            }
+        }
+        // outer border from s (first pixel in raster order): the walk enters s "from the west"
+        auto inside = [&](int y, int x) { return (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W && lab[(long)y * W + x] == id; };
+        const int sy = (int)(s / W), sx = (int)(s - (long)sy * W);
+        long long area2 = 0;
+        int cy = sy, cx = sx, back = 4;                          // direction pointing at the (background) pixel the walk came from: W
+        int first_dir = -1;
+        for (long guard = 0; guard < 4 * n + 8; ++guard) {
+            int d = -1;
+            for (int k = 1; k <= 8; ++k) {                       // clockwise from the backtrack direction
+                const int dd = (back + k) & 7;
+                if (inside(cy + dy8[dd], cx + dx8[dd])) { d = dd; break; }
+            }
+            if (d < 0) break;                                    // isolated pixel: area 0
+            if (cy == sy && cx == sx) {
+                if (first_dir < 0) first_dir = d;
+                else if (d == first_dir) break;                  // back at the start, leaving the same way: closed
+            }
+            const int ny = cy + dy8[d], nx = cx + dx8[d];
+            area2 += (long long)cx * ny - (long long)nx * cy;
+            cy = ny; cx = nx;
+            // the neighbour examined just before (direction d - 1 from the old pixel) is background; seen from the new pixel it
+            // lies in direction d + 6 (axis step) or d + 5 (diagonal step): the next search resumes right after it
+            back = (d + ((d & 1) ? 5 : 6)) & 7;
+        }
+        if (area2 < 0) area2 = -area2;
+        if (area2 > best_area2) { best_area2 = area2; out[0] = x0; out[1] = y0; out[2] = x1; out[3] = y1; out[4] = cnt; }
+    }
+    return n_comp > 0;
+}
+
 int check_ready(sbbseg_ctx* c)
 {
     REQUIRE(c != nullptr, "null handle");
@@ -671,7 +739,7 @@ int sbbseg_destroy(sbbseg_ctx* c)
     comm_release(c);
     if (c->copy_in) (void)hipStreamDestroy(c->copy_in);
     if (c->copy_out) (void)hipStreamDestroy(c->copy_out);
-    (void)hipFree(c->d_morph_a); (void)hipFree(c->d_morph_b); (void)hipFree(c->d_cc_parent); (void)hipFree(c->d_cc_count); (void)hipFree(c->d_cc_small);
+    (void)hipFree(c->d_morph_a); (void)hipFree(c->d_morph_b); (void)hipFree(c->d_cc_parent); (void)hipFree(c->d_cc_count); (void)hipFree(c->d_cc_aux); (void)hipFree(c->d_cc_small);
     for (auto& pe : c->pending) { (void)hipEventDestroy(pe.a); (void)hipEventDestroy(pe.b); }
     for (auto e : c->free_events) (void)hipEventDestroy(e);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -2149,18 +2217,31 @@ int sbbseg_page_box_dev(sbbseg_ctx* c, const void* d_mask_hw, int H, int W, int3
     const size_t pix = (size_t)H * W;
     if (ensure(c, (void**)&c->d_morph_a, &c->morph_a_cap, pix) || ensure(c, (void**)&c->d_morph_b, &c->morph_b_cap, pix)) return 1;
     if (ensure(c, (void**)&c->d_cc_parent, &c->cc_parent_cap, pix * sizeof(int)) || ensure(c, (void**)&c->d_cc_count, &c->cc_count_cap, pix * sizeof(int))) return 1;
+    if (ensure(c, (void**)&c->d_cc_aux, &c->cc_aux_cap, 5 * pix * sizeof(int))) return 1;
     if (!c->d_cc_small && dmalloc(c, (void**)&c->d_cc_small, 4 * sizeof(unsigned long long))) return 1;
     // main.py:394-398: gray > 0 -> 255, dilate with the 5x5 kernel of ones, 6 iterations (= one clipped 25x25 maximum)
     HIPCHK(launch_morph((const uint8_t*)d_mask_hw, c->d_morph_a, c->d_morph_b, H, W, 12, 1, 1, c->stream));
-    int* d_box = (int*)(c->d_cc_small + 1);
-    HIPCHK(launch_largest_component(c->d_morph_b, H, W, c->d_cc_parent, c->d_cc_count, c->d_cc_small, d_box, c->stream));
-    unsigned long long best = 0;
-    int box[4] = {0, 0, 0, 0};
-    HIPCHK(hipMemcpyAsync(&best, c->d_cc_small, sizeof(best), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipMemcpyAsync(box, d_box, sizeof(box), hipMemcpyDeviceToHost, c->stream));
+    // main.py:398-404: the contour with the largest cv2.contourArea.  The device ranks the components by a lower bound of
+    // their outer contour's area and checks it against every other component's upper bound (launch_largest_contour)...
+    int* d_out = (int*)(c->d_cc_small + 1);
+    int* aux = c->d_cc_aux;
+    HIPCHK(launch_largest_contour(c->d_morph_b, H, W, c->d_cc_parent, c->d_cc_count, aux, aux + pix, aux + 2 * pix, aux + 3 * pix, aux + 4 * pix,
+                                  c->d_cc_small, d_out, c->stream));
+    int out[6] = {0, 0, 0, 0, 0, 0};
+    HIPCHK(hipMemcpyAsync(out, d_out, sizeof(out), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
-    if (pixels) *pixels = (int64_t)(best >> 32);
-    if (best == 0) {                                   // empty mask: the reference's np.argmax of an empty list raises (main.py:399-401)
+    int box[5] = {out[0], out[1], out[2], out[3], out[4]};
+    bool any = out[2] >= 0;
+    if (any && (out[5] || c->force_host_contours)) {
+        // ... and when that does not decide it (a ring- or frame-shaped blob beside a solid one), the host traces the contours
+        alloc_check();
+        std::vector<uint8_t> hm(pix);
+        HIPCHK(hipMemcpy(hm.data(), c->d_morph_b, pix, hipMemcpyDeviceToHost));
+        any = host_largest_contour(hm.data(), H, W, box);
+        c->host_contour_calls += 1;
+    }
+    if (pixels) *pixels = any ? (int64_t)box[4] : 0;
+    if (!any) {                                        // empty mask: the reference's np.argmax of an empty list raises (main.py:399-401)
         box_xywh[0] = box_xywh[1] = box_xywh[2] = box_xywh[3] = 0;
         return 0;
     }
@@ -2407,16 +2488,40 @@ int sbbseg_allgather_labels_dev(sbbseg_ctx* c, const void* d_send, size_t bytes_
     API_END
 }
 
+int sbbseg_debug_largest_contour(const uint8_t* mask_hw, int H, int W, int32_t* box_xywh, int64_t* pixels)
+{
+    API_BEGIN
+    REQUIRE(mask_hw && box_xywh && H > 0 && W > 0 && (size_t)H * W < ((size_t)1 << 31), "bad arguments");
+    alloc_check();
+    int out[5] = {0, 0, 0, 0, 0};
+    const bool any = host_largest_contour(mask_hw, H, W, out);
+    if (pixels) *pixels = any ? out[4] : 0;
+    box_xywh[0] = any ? out[0] : 0; box_xywh[1] = any ? out[1] : 0;
+    box_xywh[2] = any ? out[2] - out[0] + 1 : 0; box_xywh[3] = any ? out[3] - out[1] + 1 : 0;
+    return 0;
+    API_END
+}
+
+int sbbseg_debug_counter(sbbseg_ctx* c, int which, int64_t* value)
+{
+    API_BEGIN
+    REQUIRE(c && value && which == 0, "unknown counter %d", which);
+    *value = c->host_contour_calls;
+    return 0;
+    API_END
+}
+
 int sbbseg_debug_set_conv_variant(sbbseg_ctx* c, int variant)
 {
     API_BEGIN
-    REQUIRE(c && variant >= 0 && variant <= 0x1fffff, "variant: bits 0-1 = 0 auto | 1 4-wave/2-stage | 2 8-wave/3-stage; bit 2 = one block per tile (non-persistent); bit 3 = no XCD-grouped tile walk; bit 4 = half-K-step stages; bit 5 = XCD-grouped walk on single-class layers; bit 6 = drain epilogue stores; bit 7 = half-line epilogue stores; bits 8-15 = contiguous-run K limit / 64; bit 16 = 8-phase schedule on the 256x256 tile; bit 17 = plain gather everywhere; bit 18 = fused bottleneck blocks run as their three convs; bit 19 = XCD-contiguous walk for grouped launches; bit 20 = one-group form of the fused block kernel");
+    REQUIRE(c && variant >= 0 && variant <= 0x3fffff, "variant: bits 0-1 = 0 auto | 1 4-wave/2-stage | 2 8-wave/3-stage; bit 2 = one block per tile (non-persistent); bit 3 = no XCD-grouped tile walk; bit 4 = half-K-step stages; bit 5 = XCD-grouped walk on single-class layers; bit 6 = drain epilogue stores; bit 7 = half-line epilogue stores; bits 8-15 = contiguous-run K limit / 64; bit 16 = 8-phase schedule on the 256x256 tile; bit 17 = plain gather everywhere; bit 18 = fused bottleneck blocks run as their three convs; bit 19 = XCD-contiguous walk for grouped launches; bit 20 = one-group form of the fused block kernel; bit 21 = extract_page ranks contours on the host always");
     c->conv_variant = variant & 0xff;
     c->ph8 = (variant >> 16) & 1;
     c->plain_gather = (variant >> 17) & 1;
     c->unfuse_blocks = (variant >> 18) & 1;
     c->ranged_walk = (variant >> 19) & 1;
     c->block_pq = !((variant >> 20) & 1);
+    c->force_host_contours = (variant >> 21) & 1;
     if ((variant >> 8) & 0xff) c->contig_max_k = ((variant >> 8) & 0xff) * 64;
     return 0;
     API_END

@@ -1245,8 +1245,10 @@ static hipError_t launch_conv_x3(const ConvParams& p, hipStream_t s)
     if (p.variant == 0 && bc == 128 && !p.residual) {          // the long-K decoder launches: same 8-wave tiles as the plain modes
         const long t256 = (long)p.n_cls * ((p.M + 255) / 256) * (p.cout / 256);
         const long t512 = (long)p.n_cls * ((p.M + 511) / 512) * ((p.cout + 127) / 128);
-        if (p.cout % 256 == 0 && p.Ktot >= 1024 && t256 >= 200) return launch_conv_t<256, 256, 2, 4, 2, true, 8, false, true>(p, s);
-        if (p.Ktot >= 2048 && t512 >= 200) return launch_conv_t<512, 128, 4, 2, 2, true, 8, false, true>(p, s);
+        static const int k512 = getenv("SBBSEG_X3_T512_MINK") ? atoi(getenv("SBBSEG_X3_T512_MINK")) : 2048;      // A/B knobs
+        static const int k256 = getenv("SBBSEG_X3_T256_MINK") ? atoi(getenv("SBBSEG_X3_T256_MINK")) : 1024;
+        if (p.cout % 256 == 0 && p.Ktot >= k256 && t256 >= 200) return launch_conv_t<256, 256, 2, 4, 2, true, 8, false, true>(p, s);
+        if (p.Ktot >= k512 && t512 >= 200) return launch_conv_t<512, 128, 4, 2, 2, true, 8, false, true>(p, s);
     }
     if (bc == 128) return launch_conv_t<128, 128, 2, 2, 2, true, 8, false, true>(p, s);
     if (bc == 64) return launch_conv_t<256, 64, 4, 1, 2, true, 8, false, true>(p, s);
@@ -3816,55 +3818,105 @@ __global__ __launch_bounds__(256) void cc_count_kernel(int* parent, int* count, 
     }
     if (cur >= 0) atomicAdd(&count[cur], run);
 }
-// best = max over roots of (count, then smallest root index); key = count << 32 | ~root
-__global__ __launch_bounds__(256) void cc_best_kernel(const int* parent, const int* count, long n, unsigned long long* best)
+// ---- ranking by cv2.contourArea (main.py:399-401).  The outer contour cv2.findContours traces runs through the centres of the
+// component's boundary pixels (8-connected steps); its polygon area is, for the component with its holes filled, the number of
+// 2 x 2 pixel cells that are completely inside plus half the number of cells with exactly three pixels inside (a diagonal
+// step cuts such a cell in half).  Counted over the component AS IT IS (holes not filled) that sum is a LOWER bound of the
+// contour area, and (w - 1)(h - 1) of the bounding box an UPPER bound: the device picks the component with the largest lower
+// bound and reports whether any other component's upper bound could beat it; only then does the host trace contours.
+// Areas are kept doubled (integers).  Two set pixels of one 2 x 2 cell are 8-neighbours, i.e. of one component.
+__global__ __launch_bounds__(256) void cc_cell_area_kernel(const int* parent, int* area2, int H, int W)
+{
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)(H - 1) * (W - 1)) return;
+    const int y = (int)(idx / (W - 1)), x = (int)(idx - (long)y * (W - 1));
+    const long i = (long)y * W + x;
+    const int a = parent[i], b = parent[i + 1], c2 = parent[i + W], d = parent[i + W + 1];
+    const int k = (a >= 0) + (b >= 0) + (c2 >= 0) + (d >= 0);
+    if (k < 3) return;
+    const int root = a >= 0 ? a : b;                            // (parent[] is flat after cc_count_kernel)
+    atomicAdd(&area2[root], k == 4 ? 2 : 1);
+}
+// bounding box per root: {min x, min y, max x, max y} in four arrays indexed by root (initialised by cc_box_init_kernel)
+__global__ __launch_bounds__(256) void cc_box_init_kernel(const int* parent, int* area2, int* bx0, int* by0, int* bx1, int* by1, long n)
+{
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    area2[i] = 0;
+    if (parent[i] == (int)i) { bx0[i] = 1 << 30; by0[i] = 1 << 30; bx1[i] = -1; by1[i] = -1; }
+}
+__global__ __launch_bounds__(256) void cc_box_kernel(const int* parent, int* bx0, int* by0, int* bx1, int* by1, int H, int W)
+{
+    // one thread per 64-pixel strip of a row: a run of equal roots costs four atomics
+    const long strips_per_row = (W + 63) / 64;
+    const long s = (long)blockIdx.x * 256 + threadIdx.x;
+    if (s >= strips_per_row * H) return;
+    const int y = (int)(s / strips_per_row), xs = (int)(s - (long)y * strips_per_row) * 64;
+    int cur = -1, lo = 0, hi = 0;
+    for (int x = xs; x < xs + 64 && x < W; ++x) {
+        const int r = parent[(long)y * W + x];
+        if (r != cur) {
+            if (cur >= 0) { atomicMin(&bx0[cur], lo); atomicMax(&bx1[cur], hi); atomicMin(&by0[cur], y); atomicMax(&by1[cur], y); }
+            cur = r; lo = x;
+        }
+        hi = x;
+    }
+    if (cur >= 0) { atomicMin(&bx0[cur], lo); atomicMax(&bx1[cur], hi); atomicMin(&by0[cur], y); atomicMax(&by1[cur], y); }
+}
+// best = max over roots of (area2 lower bound, then smallest root index); key = area2 << 32 | ~root
+__global__ __launch_bounds__(256) void cc_best_area_kernel(const int* parent, const int* area2, long n, unsigned long long* best)
 {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     unsigned long long key = 0;
-    if (i < n && parent[i] == (int)i) key = ((unsigned long long)(unsigned)count[i] << 32) | (0xffffffffu - (unsigned)i);
-    // wave maximum, one atomic per wave
+    if (i < n && parent[i] == (int)i) key = ((unsigned long long)(unsigned)area2[i] << 32) | (0xffffffffu - (unsigned)i);
     for (int off = 32; off > 0; off >>= 1) {
         const unsigned long long o = __shfl_xor(key, off);
         key = o > key ? o : key;
     }
     if ((threadIdx.x & 63) == 0 && key) atomicMax(best, key);
 }
-__global__ __launch_bounds__(256) void cc_bbox_kernel(const int* parent, int H, int W, const unsigned long long* best, int* box)
+// out[0..3] = bounding box of the best root, out[4] = its pixel count, out[5] = 1 when another root's upper bound
+// 2 (w - 1)(h - 1) exceeds the best lower bound (or ties it with a smaller index): the ranking is then not decided here
+__global__ __launch_bounds__(256) void cc_decide_kernel(const int* parent, const int* count, const int* bx0, const int* by0, const int* bx1,
+                                                        const int* by1, long n, const unsigned long long* best, int* out)
 {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     const unsigned long long key = *best;
-    const int root = key ? (int)(0xffffffffu - (unsigned)(key & 0xffffffffu)) : -2;
-    int x0 = 1 << 30, y0 = 1 << 30, x1 = -1, y1 = -1;
-    if (i < (long)H * W && parent[i] == root) {
-        const int y = (int)(i / W), x = (int)(i - (long)y * W);
-        x0 = x1 = x; y0 = y1 = y;
+    if (!key || i >= n || parent[i] != (int)i) return;
+    const int root = (int)(0xffffffffu - (unsigned)(key & 0xffffffffu));
+    const long long best_lo = (long long)(key >> 32);
+    if ((int)i == root) {
+        out[0] = bx0[i]; out[1] = by0[i]; out[2] = bx1[i]; out[3] = by1[i]; out[4] = count[i];
+        return;
     }
-    for (int off = 32; off > 0; off >>= 1) {
-        x0 = min(x0, __shfl_xor(x0, off)); y0 = min(y0, __shfl_xor(y0, off));
-        x1 = max(x1, __shfl_xor(x1, off)); y1 = max(y1, __shfl_xor(y1, off));
-    }
-    if ((threadIdx.x & 63) == 0 && x1 >= 0) {
-        atomicMin(&box[0], x0); atomicMin(&box[1], y0); atomicMax(&box[2], x1); atomicMax(&box[3], y1);
-    }
+    const long long hi2 = 2ll * (bx1[i] - bx0[i]) * (by1[i] - by0[i]);
+    if (hi2 > best_lo || (hi2 == best_lo && (int)i < root)) atomicOr(&out[5], 1);
 }
 
-// d_box: int[4] = {min x, min y, max x, max y} of the largest component (untouched sentinel {2^30, 2^30, -1, -1} if none);
-// d_best: its (pixel count << 32 | ~root) key
-hipError_t launch_largest_component(const uint8_t* mask, int H, int W, int* parent, int* count, unsigned long long* d_best, int* d_box,
-                                    hipStream_t s)
+// d_out: int[6] = {min x, min y, max x, max y, pixels, undecided} of the component with the largest contour-area lower bound
+// ({2^30, 2^30, -1, -1, 0, 0} if the mask is empty); d_best: its (area2 << 32 | ~root) key.  scratch: five int arrays of H * W.
+hipError_t launch_largest_contour(const uint8_t* mask, int H, int W, int* parent, int* count, int* area2, int* bx0, int* by0, int* bx1,
+                                  int* by1, unsigned long long* d_best, int* d_out, hipStream_t s)
 {
     const long n = (long)H * W;
-    static const int init_box[4] = {1 << 30, 1 << 30, -1, -1};
+    static const int init_out[6] = {1 << 30, 1 << 30, -1, -1, 0, 0};
     hipError_t e = hipMemsetAsync(d_best, 0, sizeof(unsigned long long), s);
     if (e != hipSuccess) return e;
-    e = hipMemcpyAsync(d_box, init_box, sizeof(init_box), hipMemcpyHostToDevice, s);
+    e = hipMemcpyAsync(d_out, init_out, sizeof(init_out), hipMemcpyHostToDevice, s);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(cc_rows_kernel, dim3((unsigned)((H + 63) / 64)), dim3(64), 0, s, mask, parent, count, H, W);
     hipLaunchKernelGGL(cc_link_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, mask, parent, H, W);
     hipLaunchKernelGGL(cc_count_kernel, dim3((unsigned)((n + 256 * 64 - 1) / (256 * 64))), dim3(256), 0, s, parent, count, n);
-    hipLaunchKernelGGL(cc_best_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const int*)parent, (const int*)count, n, d_best);
-    hipLaunchKernelGGL(cc_bbox_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const int*)parent, H, W,
-                       (const unsigned long long*)d_best, d_box);
+    hipLaunchKernelGGL(cc_box_init_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const int*)parent, area2, bx0, by0, bx1, by1, n);
+    if (H > 1 && W > 1) {
+        const long cells = (long)(H - 1) * (W - 1);
+        hipLaunchKernelGGL(cc_cell_area_kernel, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, s, (const int*)parent, area2, H, W);
+    }
+    const long strips = (long)((W + 63) / 64) * H;
+    hipLaunchKernelGGL(cc_box_kernel, dim3((unsigned)((strips + 255) / 256)), dim3(256), 0, s, (const int*)parent, bx0, by0, bx1, by1, H, W);
+    hipLaunchKernelGGL(cc_best_area_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const int*)parent, (const int*)area2, n, d_best);
+    hipLaunchKernelGGL(cc_decide_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const int*)parent, (const int*)count, (const int*)bx0,
+                       (const int*)by0, (const int*)bx1, (const int*)by1, n, (const unsigned long long*)d_best, d_out);
     return hipGetLastError();
 }
 

@@ -87,16 +87,11 @@ def host_morph(plane: np.ndarray, is_max: bool, ksize: int, iterations: int) -> 
 
 
 def host_page_box(mask: np.ndarray):
-    """Host mirror of sbbseg_page_box_dev (foreign model objects only)."""
-    from scipy import ndimage
+    """Host mirror of sbbseg_page_box_dev (foreign model objects only): dilate x 6, then the component whose outer contour has
+    the largest cv2.contourArea, traced by the library's host code (``sbbseg_debug_largest_contour``: no GPU involved)."""
+    from . import _capi
     d = host_morph(np.where(np.asarray(mask) > 0, 255, 0).astype(np.uint8), True, 5, 6)
-    lab, n = ndimage.label(d > 0, structure=np.ones((3, 3), int))
-    if n == 0:
-        return (0, 0, 0, 0), 0
-    counts = np.bincount(lab.reshape(-1))[1:]
-    best = int(np.argmax(counts)) + 1
-    ys, xs = np.nonzero(lab == best)
-    return (int(xs.min()), int(ys.min()), int(xs.max() - xs.min() + 1), int(ys.max() - ys.min() + 1)), int(counts[best - 1])
+    return _capi.host_largest_contour(d)
 
 
 def _profile_statistics(y: np.ndarray, sigma: float, multiplier: float):

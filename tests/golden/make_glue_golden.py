@@ -93,7 +93,11 @@ def install_cv2_stubs(cv2, pages_by_name):
         lab, n = ndimage.label(mask > 0, structure=np.ones((3, 3), int))
         return [Blob(*np.nonzero(lab == k)) for k in range(1, n + 1)], None
     cv2.findContours = find_contours
-    cv2.contourArea = lambda b: float(len(b.ys))          # [EXT] ranking stand-in: pixel count (the oracle's documented choice)
+    def contour_area(b):                                  # [EXT] the oracle's restatement: shoelace area of the traced outer border
+        comp = np.zeros((int(b.ys.max()) + 1, int(b.xs.max()) + 1), bool)
+        comp[b.ys, b.xs] = True
+        return sg.outer_contour_area2(comp) / 2.0
+    cv2.contourArea = contour_area
     cv2.boundingRect = lambda b: (int(b.xs.min()), int(b.ys.min()), int(b.xs.max() - b.xs.min() + 1), int(b.ys.max() - b.ys.min() + 1))
 
 
