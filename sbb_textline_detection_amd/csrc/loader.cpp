@@ -15,6 +15,7 @@
 #include <stdarg.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -326,6 +327,14 @@ Graph read_graph(const JVal& mc)
             const GNode& prev = need_input();
             if (prev.op != "zeropad" || prev.pad[0] != 1 || prev.pad[1] != 1 || prev.pad[2] != 1 || prev.pad[3] != 1)
                 fail("layer %s: Lambda not recognised as one_side_pad crop", n.name.c_str());
+            // (the body is opaque marshalled bytecode: what can be checked is -- an anonymous lambda without bound arguments;
+            // SBBSEG_STRICT_LAMBDA=1 refuses Lambda layers altogether, as keras_graph.py does)
+            const JVal* ft = lc.get("function_type");
+            const JVal* args = lc.get("arguments");
+            if ((ft && ft->t == JVal::Str && ft->s != "lambda") || (args && ((args->t == JVal::Obj && !args->o.empty()) || (args->t == JVal::Arr && !args->a.empty()))))
+                fail("layer %s: Lambda with a named function / bound arguments is not the one_side_pad crop", n.name.c_str());
+            if (const char* strict = getenv("SBBSEG_STRICT_LAMBDA"))
+                if (strict[0] && strict[0] != '0') fail("layer %s: Lambda layers are refused (SBBSEG_STRICT_LAMBDA); its bytecode cannot be inspected", n.name.c_str());
             n.op = "crop_last";
             n.H = prev.H - 1; n.W = prev.W - 1; n.C = prev.C;
         } else if (lc_cls == "Dropout" || lc_cls == "SpatialDropout2D") {

@@ -20,6 +20,8 @@ layer by layer, unfused) and by the planner (``planner.py``, fused for HIP).
 from __future__ import annotations
 
 import json
+import os
+import warnings
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Sequence, Tuple
 
@@ -389,9 +391,20 @@ def parse_model_config(model_config) -> Graph:
         elif cls == "Lambda":
             # Upstream's only Lambda is one_side_pad's crop  x[:, :-1, :-1, :]  right after
             # ZeroPadding2D((1,1)).  Match that structure; refuse anything else (never unmarshal).
+            # The function body itself is opaque (marshalled CPython bytecode of the training interpreter): a foreign model whose
+            # Lambda does something ELSE of the same shape (crops the FIRST row / column, flips, ...) would be lowered wrongly
+            # and silently.  What can be checked is checked: position (straight after ZeroPadding2D((1,1))), an anonymous
+            # lambda without bound arguments, and a warning that names the layer; SBBSEG_STRICT_LAMBDA=1 refuses instead.
             prev = next(n for n in nodes if n.name == ins[0])
             if prev.op != "zeropad" or prev.attrs["pad"] != (1, 1, 1, 1):
                 raise ValueError(f"layer {name}: Lambda not recognised as one_side_pad crop")
+            if lc.get("function_type", "lambda") != "lambda" or lc.get("arguments"):
+                raise ValueError(f"layer {name}: Lambda with function_type {lc.get('function_type')!r} / arguments {lc.get('arguments')!r} "
+                                 f"is not the one_side_pad crop")
+            if os.environ.get("SBBSEG_STRICT_LAMBDA", "0") not in ("", "0"):
+                raise ValueError(f"layer {name}: Lambda layers are refused (SBBSEG_STRICT_LAMBDA); its bytecode cannot be inspected")
+            warnings.warn(f"layer {name}: Lambda after ZeroPadding2D((1,1)) lowered as one_side_pad's crop x[:, :-1, :-1, :] (its bytecode "
+                          f"is not inspected; set SBBSEG_STRICT_LAMBDA=1 to refuse)", stacklevel=2)
             node = Node(name, "crop_last", ins, {}, (ish[0] - 1, ish[1] - 1, ish[2]))
         elif cls in ("Dropout", "SpatialDropout2D"):
             node = Node(name, "act", ins, {"kind": "linear"}, ish)     # identity at inference

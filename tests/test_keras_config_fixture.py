@@ -116,3 +116,25 @@ def test_batchnorm_without_scale_or_center(cfg):
     q = forward_torch(g, w, x, torch.float64)
     lab, pr, _ = run_plan(build_plan(g, w), x)
     assert np.abs(p - q).max() < 1e-4 and np.abs(pr - p).max() < 5e-4
+
+
+def test_lambda_lowering_warns_and_can_be_refused(cfg, monkeypatch):
+    """A Lambda's body is opaque bytecode: the parser lowers the one after ZeroPadding2D((1,1)) as upstream's one_side_pad crop, says
+    so in a warning that names the layer, refuses named functions / bound arguments, and refuses everything in strict mode."""
+    import warnings
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        parse_model_config(cfg)
+    assert any("lambda_1" in str(w.message) and "one_side_pad" in str(w.message) for w in rec)
+    bad = copy.deepcopy(cfg)
+    lam = next(l for l in bad["config"]["layers"] if l["class_name"] == "Lambda")
+    lam["config"]["function_type"] = "function"
+    with pytest.raises(ValueError, match="not the one_side_pad crop"):
+        parse_model_config(bad)
+    lam["config"]["function_type"] = "lambda"
+    lam["config"]["arguments"] = {"k": 1}
+    with pytest.raises(ValueError, match="not the one_side_pad crop"):
+        parse_model_config(bad)
+    monkeypatch.setenv("SBBSEG_STRICT_LAMBDA", "1")
+    with pytest.raises(ValueError, match="SBBSEG_STRICT_LAMBDA"):
+        parse_model_config(cfg)
