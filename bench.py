@@ -259,27 +259,38 @@ def main():
         return step, tpp * NPAGES, desc, "strong", (gather if world > 1 else None), world * block * BH * BW, step_local, tpp * count
 
     def build_pipeline3(m):
+        """BASELINE configs[2] as textline_detector.run() chains it (main.py:2056-2107): get_image_and_scales (3500x2500 -> 4200x3000,
+        fused into the gathers), border model on the whole page + page box, then the layout model (Otsu'd) and the textline model
+        on the CROPPED page, text regions cleaned by erode x 3 / dilate x 4.  Models resident; the page starts in host memory for
+        the border stage (as in the reference) and is resident in HBM for the two patch stages."""
+        from sbb_textline_detection_amd.stages import scaled_size
         cfg_b, w_b = calibrated_model(2, MODEL_HW, MODEL_HW, seed=11)
         cfg_l, w_l = calibrated_model(4, MODEL_HW, MODEL_HW, seed=12)
+        Hs, Ws = scaled_size(PAGE_H, PAGE_W)
+        n_full = _capi.tile_grid(Hs, Ws, MODEL_HW, MODEL_HW)[0].shape[0]
         m_border = make_model(m.precision, (cfg_b, w_b), max_batch=1)
-        m_layout = make_model(m.precision, (cfg_l, w_l))
+        m_layout = make_model(m.precision, (cfg_l, w_l), max_batch=n_full)
+        m_text = make_model(m.precision, None, max_batch=n_full) if m.max_batch < n_full else m
         d_page = torch.from_numpy(page0).cuda()
-        d_labels = torch.empty((PAGE_H, PAGE_W), dtype=torch.uint8, device="cuda")
-        d_thr = torch.zeros(1, dtype=torch.int32, device="cuda")
-        d_tiles2 = torch.empty((tiles_per_page, MODEL_HW, MODEL_HW), dtype=torch.uint8, device="cuda")
-        d_lab2 = torch.empty((PAGE_H, PAGE_W), dtype=torch.uint8, device="cuda")
+        _, box, pixels = m_border.ctx.extract_page_box(page0, Hs, Ws)
+        if pixels == 0 or box[2] < MODEL_HW or box[3] < MODEL_HW:
+            box = (0, 0, Ws, Hs)                                                    # main.py:417-419: fall back to the whole page
+        bw, bh = box[2], box[3]
+        tiles_crop = _capi.tile_grid(bh, bw, MODEL_HW, MODEL_HW)[0].shape[0]
+        d_regions = torch.empty((bh, bw), dtype=torch.uint8, device="cuda")
+        d_clean = torch.empty((bh, bw), dtype=torch.uint8, device="cuda")
+        d_lines = torch.empty((bh, bw), dtype=torch.uint8, device="cuda")
 
         def step():
-            m_border.segment_whole(page0, PAGE_H, PAGE_W)                       # host page in / host mask out (1 forward)
-            # layout stage = otsu_copy + do_prediction (main.py:443-447): histogram, threshold and the
-            # binarising gather all run on the device inside the timed step
-            m_layout.ctx.otsu_dev(d_page.data_ptr(), PAGE_H, PAGE_W, d_thr.data_ptr())
-            m_layout.ctx.segment_tile_range_bin_dev(d_page.data_ptr(), PAGE_H, PAGE_W, 0, tiles_per_page, d_thr.data_ptr(), d_tiles2.data_ptr())
-            m_layout.ctx.stitch_dev(d_tiles2.data_ptr(), PAGE_H, PAGE_W, d_lab2.data_ptr())
-            m.ctx.segment_page_dev(d_page.data_ptr(), PAGE_H, PAGE_W, d_labels.data_ptr())
-        desc = (f"BASELINE configs[2]: three-model pipeline on one {PAGE_H}x{PAGE_W} page per GPU: border (whole image, 1 forward) + layout "
-                f"(device Otsu + binarising gather, 4 classes, {tiles_per_page} tiles) + textline ({tiles_per_page} tiles); models resident")
-        return step, (1 + 2 * tiles_per_page) * world, desc, "weak", None, 0, None, 1 + 2 * tiles_per_page
+            m_border.ctx.extract_page_box(page0, Hs, Ws)                            # border model + dilate x 6 + largest contour + box
+            m_layout.ctx.segment_crop_dev(d_page.data_ptr(), PAGE_H, PAGE_W, Hs, Ws, box, True, d_regions.data_ptr())
+            m_layout.ctx.morph_dev(d_regions.data_ptr(), bh, bw, 0, 5, 3, d_clean.data_ptr())      # main.py:2074-2075
+            m_layout.ctx.morph_dev(d_clean.data_ptr(), bh, bw, 1, 5, 4, d_clean.data_ptr())
+            m_text.ctx.segment_crop_dev(d_page.data_ptr(), PAGE_H, PAGE_W, Hs, Ws, box, False, d_lines.data_ptr())
+        desc = (f"BASELINE configs[2]: three-model pipeline on one {PAGE_H}x{PAGE_W} page per GPU, chained as main.py:2056-2107: upscale to "
+                f"{Hs}x{Ws} (fused), border (whole image, 1 forward) + page box {box}, layout (Otsu'd crop, 4 classes, {tiles_crop} tiles) + "
+                f"erode x 3 / dilate x 4, textline (crop, {tiles_crop} tiles); models resident")
+        return step, (1 + 2 * tiles_crop) * world, desc, "weak", None, 0, None, 1 + 2 * tiles_crop
 
     builders = {"page": build_page, "batch64": build_batch64, "pipeline3": build_pipeline3}
 
