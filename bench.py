@@ -210,6 +210,7 @@ def main():
     tiles_per_page = _capi.tile_grid(PAGE_H, PAGE_W, MODEL_HW, MODEL_HW)[0].shape[0]
     page0 = synthetic_page(PAGE_H, PAGE_W, seed=rank)
 
+    fallbacks_of_pipeline3 = lambda: 0
     # ---- workloads: build(model) -> (step(), tiles per step, description, scaling, gather() or None, bytes gathered)
     def build_page(m):
         P = max(1, args.pages_per_step)
@@ -280,6 +281,10 @@ def main():
         d_regions = torch.empty((bh, bw), dtype=torch.uint8, device="cuda")
         d_clean = torch.empty((bh, bw), dtype=torch.uint8, device="cuda")
         d_lines = torch.empty((bh, bw), dtype=torch.uint8, device="cuda")
+
+        c0 = m_border.ctx.host_contour_calls()
+        nonlocal fallbacks_of_pipeline3
+        fallbacks_of_pipeline3 = lambda: m_border.ctx.host_contour_calls() - c0      # how often the box needed the exact host ranking
 
         def step():
             m_border.ctx.extract_page_box(page0, Hs, Ws)                            # border model + dilate x 6 + largest contour + box
@@ -576,6 +581,7 @@ def main():
             extras["pipeline3_forwards_per_page"] = tps3
             extras["pipeline3_patches_per_s"] = round(tps3 * n3 / d3, 1)
             extras["pipeline3_what"] = desc3
+            extras["pipeline3_host_contour_fallbacks_per_page"] = round(fallbacks_of_pipeline3() / float(n3 + 2), 2)
         except Exception as e:                                         # never lose the headline over a side measurement
             extras["pipeline3_error"] = repr(e)
 

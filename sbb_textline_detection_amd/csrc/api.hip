@@ -218,6 +218,7 @@ struct sbbseg_ctx {
     int *d_cc_parent = nullptr, *d_cc_count = nullptr; size_t cc_parent_cap = 0, cc_count_cap = 0;
     bool force_host_contours = false;     // test hook (conv variant bit 21): always take the exact host ranking
     int host_contour_calls = 0;           // how often the exact host ranking ran (sbbseg_debug_counter)
+    int* d_cc_list = nullptr;             // [6 + kCcMaxRivals]: launch_largest_contour's result record
     int* d_cc_aux = nullptr; size_t cc_aux_cap = 0;      // five int planes: doubled cell area + bounding boxes per root (sbbseg_page_box_dev)
     unsigned long long* d_cc_small = nullptr;      // [0] best key, [1..2] box (4 ints)
     // profiling
@@ -574,12 +575,45 @@ void comm_release(sbbseg_ctx* c)
 // west / north neighbours are background; stop when the start pixel is re-entered in the start direction), shoelace area of
 // that closed chain (CHAIN_APPROX_SIMPLE drops collinear points only: same area).  Ties: first component in raster order
 // [EXT: OpenCV's contour order is not pinned].  Returns {x0, y0, x1, y1, pixels}; false for an empty mask.
+// Doubled shoelace area of the outer border of the component `inside` describes, walked from its first pixel in raster order
+// (sy, sx) -- whose west / north neighbours are background -- by Moore neighbour tracing, clockwise with y pointing down; stops
+// when the start pixel is left again in the first direction.  box = {x0, y0, x1, y1} of the border (= of the component).
+template <typename Inside>
+long long trace_outer_area2(Inside inside, int sy, int sx, long n_pixels, int (&box)[4])
+{
+    static const int dx8[8] = {1, 1, 0, -1, -1, -1, 0, 1}, dy8[8] = {0, 1, 1, 1, 0, -1, -1, -1};      // E, SE, S, SW, W, NW, N, NE
+    long long area2 = 0;
+    int cy = sy, cx = sx, back = 4, first_dir = -1;              // back: direction of the background pixel the search resumes after (W)
+    box[0] = box[2] = sx; box[1] = box[3] = sy;
+    for (long guard = 0; guard < 4 * n_pixels + 8; ++guard) {
+        int d = -1;
+        for (int k = 1; k <= 8; ++k) {                           // clockwise from the backtrack direction
+            const int dd = (back + k) & 7;
+            if (inside(cy + dy8[dd], cx + dx8[dd])) { d = dd; break; }
+        }
+        if (d < 0) break;                                        // isolated pixel: area 0
+        if (cy == sy && cx == sx) {
+            if (first_dir < 0) first_dir = d;
+            else if (d == first_dir) break;                      // back at the start, leaving the same way: closed
+        }
+        const int ny = cy + dy8[d], nx = cx + dx8[d];
+        area2 += (long long)cx * ny - (long long)nx * cy;
+        cy = ny; cx = nx;
+        box[0] = cx < box[0] ? cx : box[0]; box[2] = cx > box[2] ? cx : box[2];
+        box[1] = cy < box[1] ? cy : box[1]; box[3] = cy > box[3] ? cy : box[3];
+        // the neighbour examined just before (direction d - 1 from the old pixel) is background; seen from the new pixel it
+        // lies in direction d + 6 (axis step) or d + 5 (diagonal step): the next search resumes right after it
+        back = (d + ((d & 1) ? 5 : 6)) & 7;
+    }
+    return area2 < 0 ? -area2 : area2;
+}
+
 bool host_largest_contour(const uint8_t* m, int H, int W, int (&out)[5])
 {
     const long n = (long)H * W;
     std::vector<int> lab(n, -1);
     std::vector<long> stack;
-    static const int dx8[8] = {1, 1, 0, -1, -1, -1, 0, 1}, dy8[8] = {0, 1, 1, 1, 0, -1, -1, -1};      // E, SE, S, SW, W, NW, N, NE (clockwise, y down)
+    static const int dx8[8] = {1, 1, 0, -1, -1, -1, 0, 1}, dy8[8] = {0, 1, 1, 1, 0, -1, -1, -1};
     long long best_area2 = -1;
     int n_comp = 0;
     for (long s = 0; s < n; ++s) {
@@ -603,31 +637,9 @@ bool host_largest_contour(const uint8_t* m, int H, int W, int (&out)[5])
                 if (m[j] && lab[j] < 0) { lab[j] = id; stack.push_back(j); }
             }
         }
-        // outer border from s (first pixel in raster order): the walk enters s "from the west"
         auto inside = [&](int y, int x) { return (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W && lab[(long)y * W + x] == id; };
-        const int sy = (int)(s / W), sx = (int)(s - (long)sy * W);
-        long long area2 = 0;
-        int cy = sy, cx = sx, back = 4;                          // direction pointing at the (background) pixel the walk came from: W
-        int first_dir = -1;
-        for (long guard = 0; guard < 4 * n + 8; ++guard) {
-            int d = -1;
-            for (int k = 1; k <= 8; ++k) {                       // clockwise from the backtrack direction
-                const int dd = (back + k) & 7;
-                if (inside(cy + dy8[dd], cx + dx8[dd])) { d = dd; break; }
-            }
-            if (d < 0) break;                                    // isolated pixel: area 0
-            if (cy == sy && cx == sx) {
-                if (first_dir < 0) first_dir = d;
-                else if (d == first_dir) break;                  // back at the start, leaving the same way: closed
-            }
-            const int ny = cy + dy8[d], nx = cx + dx8[d];
-            area2 += (long long)cx * ny - (long long)nx * cy;
-            cy = ny; cx = nx;
-            // the neighbour examined just before (direction d - 1 from the old pixel) is background; seen from the new pixel it
-            // lies in direction d + 6 (axis step) or d + 5 (diagonal step): the next search resumes right after it
-            back = (d + ((d & 1) ? 5 : 6)) & 7;
-        }
-        if (area2 < 0) area2 = -area2;
+        int tb[4];
+        const long long area2 = trace_outer_area2(inside, (int)(s / W), (int)(s - (long)(s / W) * W), n, tb);
         if (area2 > best_area2) { best_area2 = area2; out[0] = x0; out[1] = y0; out[2] = x1; out[3] = y1; out[4] = cnt; }
     }
     return n_comp > 0;
@@ -739,7 +751,7 @@ int sbbseg_destroy(sbbseg_ctx* c)
     comm_release(c);
     if (c->copy_in) (void)hipStreamDestroy(c->copy_in);
     if (c->copy_out) (void)hipStreamDestroy(c->copy_out);
-    (void)hipFree(c->d_morph_a); (void)hipFree(c->d_morph_b); (void)hipFree(c->d_cc_parent); (void)hipFree(c->d_cc_count); (void)hipFree(c->d_cc_aux); (void)hipFree(c->d_cc_small);
+    (void)hipFree(c->d_morph_a); (void)hipFree(c->d_morph_b); (void)hipFree(c->d_cc_parent); (void)hipFree(c->d_cc_count); (void)hipFree(c->d_cc_aux); (void)hipFree(c->d_cc_list); (void)hipFree(c->d_cc_small);
     for (auto& pe : c->pending) { (void)hipEventDestroy(pe.a); (void)hipEventDestroy(pe.b); }
     for (auto e : c->free_events) (void)hipEventDestroy(e);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -2219,25 +2231,47 @@ int sbbseg_page_box_dev(sbbseg_ctx* c, const void* d_mask_hw, int H, int W, int3
     if (ensure(c, (void**)&c->d_cc_parent, &c->cc_parent_cap, pix * sizeof(int)) || ensure(c, (void**)&c->d_cc_count, &c->cc_count_cap, pix * sizeof(int))) return 1;
     if (ensure(c, (void**)&c->d_cc_aux, &c->cc_aux_cap, 5 * pix * sizeof(int))) return 1;
     if (!c->d_cc_small && dmalloc(c, (void**)&c->d_cc_small, 4 * sizeof(unsigned long long))) return 1;
+    if (!c->d_cc_list && dmalloc(c, (void**)&c->d_cc_list, (6 + kCcMaxRivals) * sizeof(int))) return 1;
     // main.py:394-398: gray > 0 -> 255, dilate with the 5x5 kernel of ones, 6 iterations (= one clipped 25x25 maximum)
     HIPCHK(launch_morph((const uint8_t*)d_mask_hw, c->d_morph_a, c->d_morph_b, H, W, 12, 1, 1, c->stream));
     // main.py:398-404: the contour with the largest cv2.contourArea.  The device ranks the components by a lower bound of
     // their outer contour's area and checks it against every other component's upper bound (launch_largest_contour)...
-    int* d_out = (int*)(c->d_cc_small + 1);
+    int* d_out = c->d_cc_list;
     int* aux = c->d_cc_aux;
     HIPCHK(launch_largest_contour(c->d_morph_b, H, W, c->d_cc_parent, c->d_cc_count, aux, aux + pix, aux + 2 * pix, aux + 3 * pix, aux + 4 * pix,
                                   c->d_cc_small, d_out, c->stream));
-    int out[6] = {0, 0, 0, 0, 0, 0};
+    int out[6 + kCcMaxRivals];
+    unsigned long long key = 0;
     HIPCHK(hipMemcpyAsync(out, d_out, sizeof(out), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(&key, c->d_cc_small, sizeof(key), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     int box[5] = {out[0], out[1], out[2], out[3], out[4]};
-    bool any = out[2] >= 0;
-    if (any && (out[5] || c->force_host_contours)) {
-        // ... and when that does not decide it (a ring- or frame-shaped blob beside a solid one), the host traces the contours
+    const bool any = out[2] >= 0;
+    if (any && (out[5] > 0 || c->force_host_contours)) {
+        // ... and when that does not decide it (a ring- or frame-shaped blob beside a solid one), the host walks the outer
+        // borders of the candidates on the device's label plane (parent[i] = root = the component's first pixel in raster
+        // order): cost = 4 bytes per pixel of D2H + the candidates' perimeters
         alloc_check();
-        std::vector<uint8_t> hm(pix);
-        HIPCHK(hipMemcpy(hm.data(), c->d_morph_b, pix, hipMemcpyDeviceToHost));
-        any = host_largest_contour(hm.data(), H, W, box);
+        std::vector<int> lab(pix);
+        HIPCHK(hipMemcpy(lab.data(), c->d_cc_parent, pix * sizeof(int), hipMemcpyDeviceToHost));
+        std::vector<int> cand;
+        cand.push_back((int)(0xffffffffu - (unsigned)(key & 0xffffffffu)));
+        if (out[5] <= kCcMaxRivals && !c->force_host_contours) cand.insert(cand.end(), out + 6, out + 6 + out[5]);
+        else
+            for (size_t i = 0; i < pix; ++i)
+                if (lab[i] == (int)i && (int)i != cand[0]) cand.push_back((int)i);          // every root
+        long long best_area2 = -1;
+        int best_root = -1;
+        for (int root : cand) {
+            auto inside = [&](int y, int x) { return (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W && lab[(size_t)y * W + x] == root; };
+            int tb[4];
+            const long long a2 = trace_outer_area2(inside, root / W, root % W, (long)pix, tb);
+            if (a2 > best_area2 || (a2 == best_area2 && root < best_root)) {
+                best_area2 = a2; best_root = root;
+                box[0] = tb[0]; box[1] = tb[1]; box[2] = tb[2]; box[3] = tb[3];
+            }
+        }
+        HIPCHK(hipMemcpy(&box[4], c->d_cc_count + best_root, sizeof(int), hipMemcpyDeviceToHost));
         c->host_contour_calls += 1;
     }
     if (pixels) *pixels = any ? (int64_t)box[4] : 0;

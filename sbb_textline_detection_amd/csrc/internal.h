@@ -229,6 +229,7 @@ hipError_t launch_resize_labels(const uint8_t* labels, int H, int W, const int* 
                                 int out_h, int out_w, uint8_t* out, hipStream_t s);
 // stage glue: iterated 5x5 erode / dilate as one separable clipped min / max filter; largest 8-connected component
 hipError_t launch_morph(const uint8_t* src, uint8_t* tmp, uint8_t* dst, int H, int W, int radius, int is_max, int binarize, hipStream_t s);
+constexpr int kCcMaxRivals = 250;    // rival roots sbbseg_page_box_dev gets back from the device (more: the host scans the label plane)
 hipError_t launch_largest_contour(const uint8_t* mask, int H, int W, int* parent, int* count, int* area2, int* bx0, int* by0, int* bx1,
                                   int* by1, unsigned long long* d_best, int* d_out, hipStream_t s);
 hipError_t launch_replicate3(const uint8_t* src, uint8_t* dst, size_t n, hipStream_t s);

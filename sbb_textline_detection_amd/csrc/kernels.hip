@@ -3769,6 +3769,38 @@ __device__ inline void cc_union(int* parent, int a, int b)
         b = old;                                            // b had been linked meanwhile: go on from its parent
     }
 }
+// Wave-aggregated atomics: a page mask is mostly ONE component, so nearly every lane of a wave targets the same root -- 11 M
+// single-address atomics took 125 ms before the lanes of a wave were combined (one atomic per wave and distinct root).
+__device__ inline void wave_add_by_root(int* dst, int root, int val)
+{
+    bool pending = root >= 0 && val != 0;
+    while (__builtin_amdgcn_ballot_w64(pending)) {
+        const unsigned long long live = __builtin_amdgcn_ballot_w64(pending);
+        const int leader = __builtin_ctzll(live);
+        const int r = __builtin_amdgcn_readlane(root, leader);
+        const bool mine = pending && root == r;
+        int v = mine ? val : 0;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+        if ((int)(threadIdx.x & 63) == leader) atomicAdd(&dst[r], v);
+        pending = pending && !mine;
+    }
+}
+__device__ inline void wave_minmax_by_root(int* dmin, int* dmax, int root, int lo, int hi)
+{
+    bool pending = root >= 0;
+    while (__builtin_amdgcn_ballot_w64(pending)) {
+        const unsigned long long live = __builtin_amdgcn_ballot_w64(pending);
+        const int leader = __builtin_ctzll(live);
+        const int r = __builtin_amdgcn_readlane(root, leader);
+        const bool mine = pending && root == r;
+        int a = mine ? lo : (1 << 30), b = mine ? hi : -1;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { a = min(a, __shfl_xor(a, off)); b = max(b, __shfl_xor(b, off)); }
+        if ((int)(threadIdx.x & 63) == leader) { atomicMin(&dmin[r], a); atomicMax(&dmax[r], b); }
+        pending = pending && !mine;
+    }
+}
 // one thread per row: parent = first pixel of the horizontal run (keeps the union-find trees flat)
 __global__ __launch_bounds__(64) void cc_rows_kernel(const uint8_t* mask, int* parent, int* count, int H, int W)
 {
@@ -3800,23 +3832,24 @@ __global__ __launch_bounds__(256) void cc_link_kernel(const uint8_t* mask, int* 
     if (x > 0 && mask[up - 1]) cc_union(parent, (int)idx, (int)(up - 1));
     if (x + 1 < W && mask[up + 1]) cc_union(parent, (int)idx, (int)(up + 1));
 }
-// flatten + pixel count per root (runs of equal root inside a 64-pixel strip are added with one atomic)
+// flatten + pixel count per root (runs of equal root inside a 64-pixel strip are merged by the thread, equal roots across the
+// lanes of a wave by wave_add_by_root: one atomic per wave and distinct root)
 __global__ __launch_bounds__(256) void cc_count_kernel(int* parent, int* count, long n)
 {
     const long base = ((long)blockIdx.x * 256 + threadIdx.x) * 64;
     int cur = -1, run = 0;
-    for (int k = 0; k < 64 && base + k < n; ++k) {
+    for (int k = 0; k < 64; ++k) {
         const long i = base + k;
         int r = -1;
-        if (parent[i] >= 0) { r = cc_find(parent, (int)i); parent[i] = r; }
-        if (r != cur) {
-            if (cur >= 0) atomicAdd(&count[cur], run);
-            cur = r;
-            run = 0;
+        if (i < n && parent[i] >= 0) { r = cc_find(parent, (int)i); parent[i] = r; }
+        if (__builtin_amdgcn_ballot_w64(r != cur)) {               // wave-uniform branch: some lane's run ends
+            const bool flush = r != cur;
+            wave_add_by_root(count, flush ? cur : -1, run);
+            if (flush) { cur = r; run = 0; }
         }
         ++run;
     }
-    if (cur >= 0) atomicAdd(&count[cur], run);
+    wave_add_by_root(count, cur, run);
 }
 // ---- ranking by cv2.contourArea (main.py:399-401).  The outer contour cv2.findContours traces runs through the centres of the
 // component's boundary pixels (8-connected steps); its polygon area is, for the component with its holes filled, the number of
@@ -3828,14 +3861,15 @@ __global__ __launch_bounds__(256) void cc_count_kernel(int* parent, int* count, 
 __global__ __launch_bounds__(256) void cc_cell_area_kernel(const int* parent, int* area2, int H, int W)
 {
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= (long)(H - 1) * (W - 1)) return;
-    const int y = (int)(idx / (W - 1)), x = (int)(idx - (long)y * (W - 1));
-    const long i = (long)y * W + x;
-    const int a = parent[i], b = parent[i + 1], c2 = parent[i + W], d = parent[i + W + 1];
-    const int k = (a >= 0) + (b >= 0) + (c2 >= 0) + (d >= 0);
-    if (k < 3) return;
-    const int root = a >= 0 ? a : b;                            // (parent[] is flat after cc_count_kernel)
-    atomicAdd(&area2[root], k == 4 ? 2 : 1);
+    int root = -1, val = 0;
+    if (idx < (long)(H - 1) * (W - 1)) {
+        const int y = (int)(idx / (W - 1)), x = (int)(idx - (long)y * (W - 1));
+        const long i = (long)y * W + x;
+        const int a = parent[i], b = parent[i + 1], c2 = parent[i + W], d = parent[i + W + 1];
+        const int k = (a >= 0) + (b >= 0) + (c2 >= 0) + (d >= 0);
+        if (k >= 3) { root = a >= 0 ? a : b; val = k == 4 ? 2 : 1; }      // (parent[] is flat after cc_count_kernel)
+    }
+    wave_add_by_root(area2, root, val);
 }
 // bounding box per root: {min x, min y, max x, max y} in four arrays indexed by root (initialised by cc_box_init_kernel)
 __global__ __launch_bounds__(256) void cc_box_init_kernel(const int* parent, int* area2, int* bx0, int* by0, int* bx1, int* by1, long n)
@@ -3847,21 +3881,26 @@ __global__ __launch_bounds__(256) void cc_box_init_kernel(const int* parent, int
 }
 __global__ __launch_bounds__(256) void cc_box_kernel(const int* parent, int* bx0, int* by0, int* bx1, int* by1, int H, int W)
 {
-    // one thread per 64-pixel strip of a row: a run of equal roots costs four atomics
+    // one thread per 64-pixel strip of a row; runs of equal roots inside the strip are merged by the thread, equal roots across
+    // the lanes of a wave by wave_minmax_by_root
     const long strips_per_row = (W + 63) / 64;
     const long s = (long)blockIdx.x * 256 + threadIdx.x;
-    if (s >= strips_per_row * H) return;
-    const int y = (int)(s / strips_per_row), xs = (int)(s - (long)y * strips_per_row) * 64;
+    const bool live = s < strips_per_row * H;
+    const int y = live ? (int)(s / strips_per_row) : 0, xs = live ? (int)(s - (long)y * strips_per_row) * 64 : 0;
     int cur = -1, lo = 0, hi = 0;
-    for (int x = xs; x < xs + 64 && x < W; ++x) {
-        const int r = parent[(long)y * W + x];
-        if (r != cur) {
-            if (cur >= 0) { atomicMin(&bx0[cur], lo); atomicMax(&bx1[cur], hi); atomicMin(&by0[cur], y); atomicMax(&by1[cur], y); }
-            cur = r; lo = x;
+    for (int k = 0; k < 64; ++k) {
+        const int x = xs + k;
+        const int r = (live && x < W) ? parent[(long)y * W + x] : -1;
+        if (__builtin_amdgcn_ballot_w64(r != cur)) {               // some lane's run ends here: flush those runs (wave-uniform branch)
+            const bool flush = r != cur;
+            wave_minmax_by_root(bx0, bx1, flush ? cur : -1, lo, hi);
+            wave_minmax_by_root(by0, by1, flush ? cur : -1, y, y);
+            if (flush) { cur = r; lo = x; }
         }
         hi = x;
     }
-    if (cur >= 0) { atomicMin(&bx0[cur], lo); atomicMax(&bx1[cur], hi); atomicMin(&by0[cur], y); atomicMax(&by1[cur], y); }
+    wave_minmax_by_root(bx0, bx1, cur, lo, hi);
+    wave_minmax_by_root(by0, by1, cur, y, y);
 }
 // best = max over roots of (area2 lower bound, then smallest root index); key = area2 << 32 | ~root
 __global__ __launch_bounds__(256) void cc_best_area_kernel(const int* parent, const int* area2, long n, unsigned long long* best)
@@ -3875,8 +3914,9 @@ __global__ __launch_bounds__(256) void cc_best_area_kernel(const int* parent, co
     }
     if ((threadIdx.x & 63) == 0 && key) atomicMax(best, key);
 }
-// out[0..3] = bounding box of the best root, out[4] = its pixel count, out[5] = 1 when another root's upper bound
-// 2 (w - 1)(h - 1) exceeds the best lower bound (or ties it with a smaller index): the ranking is then not decided here
+// out[0..3] = bounding box of the best root, out[4] = its pixel count, out[5] = number of RIVALS -- other roots whose upper bound
+// 2 (w - 1)(h - 1) exceeds the best lower bound (or ties it with a smaller index) -- and out[6..] the first kCcMaxRivals of them:
+// with rivals the ranking is not decided here
 __global__ __launch_bounds__(256) void cc_decide_kernel(const int* parent, const int* count, const int* bx0, const int* by0, const int* bx1,
                                                         const int* by1, long n, const unsigned long long* best, int* out)
 {
@@ -3890,11 +3930,14 @@ __global__ __launch_bounds__(256) void cc_decide_kernel(const int* parent, const
         return;
     }
     const long long hi2 = 2ll * (bx1[i] - bx0[i]) * (by1[i] - by0[i]);
-    if (hi2 > best_lo || (hi2 == best_lo && (int)i < root)) atomicOr(&out[5], 1);
+    if (hi2 > best_lo || (hi2 == best_lo && (int)i < root)) {
+        const int k = atomicAdd(&out[5], 1);                     // out[5] = number of undecided rivals, out[6 + k] = their roots
+        if (k < kCcMaxRivals) out[6 + k] = (int)i;
+    }
 }
 
-// d_out: int[6] = {min x, min y, max x, max y, pixels, undecided} of the component with the largest contour-area lower bound
-// ({2^30, 2^30, -1, -1, 0, 0} if the mask is empty); d_best: its (area2 << 32 | ~root) key.  scratch: five int arrays of H * W.
+// d_out: int[6 + kCcMaxRivals] = {min x, min y, max x, max y, pixels, rivals, rival roots...} of the component with the largest
+// contour-area lower bound ({2^30, 2^30, -1, -1, 0, 0} if the mask is empty); d_best: its (area2 << 32 | ~root) key.  scratch: five int arrays of H * W.
 hipError_t launch_largest_contour(const uint8_t* mask, int H, int W, int* parent, int* count, int* area2, int* bx0, int* by0, int* bx1,
                                   int* by1, unsigned long long* d_best, int* d_out, hipStream_t s)
 {
