@@ -373,7 +373,7 @@ int launch_op(sbbseg_ctx* c, Op& op, int n, uint8_t* d_labels, float* d_probs)
                 sd.base = t.buf;
                 sd.PH = t.H; sd.PW = t.W;
                 sd.pix_bytes = t.C * c->elem * c->planes;
-                sd.lo_off = c->planes == 2 ? t.C * c->elem : 64;
+                sd.lo_off = c->planes == 2 ? split_group(t.C) * c->elem : 64;       // split mode: hi -> lo inside a channel group
                 sd.shift = co.d.src[s].up_shift;
                 sd.lim_y = t.H << sd.shift; sd.lim_x = t.W << sd.shift;
                 sd.ksteps = co.ksteps[s];
@@ -938,7 +938,9 @@ int sbbseg_add_conv(sbbseg_ctx* c, const sbbseg_conv_desc* d, const float* w_src
                         KTabEntry e;
                         e.dy = (int16_t)(ky - cs.pad_top - cs.off_y);
                         e.dx = (int16_t)(kx - cs.pad_left - cs.off_x);
-                        e.coff = g * 8 * c->elem;
+                        // byte offset of the granule's 8 channels inside the stored pixel (split mode: of their hi halves, in the
+                        // interleaved [group hi | group lo] layout, internal.h)
+                        e.coff = split ? split_hi_elem(c->tensors[cs.tensor].C, g * 8) * c->elem : g * 8 * c->elem;
                         lin.push_back(e);
                         lref.push_back({s, ky, kx, g * 8});
                         ++granules;
@@ -967,7 +969,7 @@ int sbbseg_add_conv(sbbseg_ctx* c, const sbbseg_conv_desc* d, const float* w_src
             kref[ki] = lref[li];
             if (split && g >= 4) {
                 kpart[ki] = 1;
-                if (lref[li].s >= 0) ktab[ki].coff += c->tensors[d->src[lref[li].s].tensor].C * c->elem;      // the pixel's lo plane
+                if (lref[li].s >= 0) ktab[ki].coff += split_group(c->tensors[d->src[lref[li].s].tensor].C) * c->elem;      // the group's lo halves
             }
         }
 
@@ -1055,7 +1057,7 @@ int sbbseg_add_conv(sbbseg_ctx* c, const sbbseg_conv_desc* d, const float* w_src
             int want = e[0].coff + 16 * g;
             if (split) {
                 const KRef& r0 = kref[(size_t)t * kGranulesPerStep];
-                const int lo_off = r0.s >= 0 ? c->tensors[d->src[r0.s].tensor].C * c->elem : 0;
+                const int lo_off = r0.s >= 0 ? split_group(c->tensors[d->src[r0.s].tensor].C) * c->elem : 0;
                 want = e[0].coff + 16 * (g & 3) + (g >> 2) * lo_off;
                 if (r0.s < 0 || kref[(size_t)t * kGranulesPerStep + g].s != r0.s) r.irregular = 1;
             }

@@ -135,7 +135,7 @@ __global__ __launch_bounds__(256, 1) void block_x3_identity(const BlockParams p)
         for (int j = 0; j < 2; ++j) {
             const int Y = ty * 4 - 1 + hy[j], X = tx * 16 - 1 + hx[j];
             in[j] = ((unsigned)Y < (unsigned)p.H) & ((unsigned)X < (unsigned)p.W) & (hy[j] < 6);
-            // stored pixel = [256 hi][256 lo] halves (1 KB); outside the image: the zero header
+            // stored pixel = 8 channel groups of [32 hi][32 lo] halves (1 KB); outside the image: the zero header
             off[j] = in[j] ? (uint32_t)((n * p.H + Y) * p.W + X) * 1024u + (uint32_t)(kZeroHeaderBytes + fg * 16) : 0u;
         }
     };
@@ -144,8 +144,8 @@ __global__ __launch_bounds__(256, 1) void block_x3_identity(const BlockParams p)
     auto fetch = [&](uint32_t off, h8_t (&dh)[8], h8_t (&dl)[8]) __attribute__((always_inline)) {
 #pragma unroll
         for (int kk = 0; kk < 8; ++kk) {
-            dh[kk] = *(const h8_t*)(p.x + off + kk * 64);
-            dl[kk] = *(const h8_t*)(p.x + off + 512 + kk * 64);
+            dh[kk] = *(const h8_t*)(p.x + off + kk * 128);          // stored pixel = 8 groups of [32 hi][32 lo]: one 128-byte line per K-step
+            dl[kk] = *(const h8_t*)(p.x + off + kk * 128 + 64);
         }
     };
 
@@ -164,8 +164,8 @@ __global__ __launch_bounds__(256, 1) void block_x3_identity(const BlockParams p)
             if constexpr (FULL) {
 #pragma unroll
                 for (int kk = 0; kk < 8; ++kk) {
-                    nih[kk] = *(const h8_t*)(p.x + off_next[0] + kk * 64);
-                    nil[kk] = *(const h8_t*)(p.x + off_next[0] + 512 + kk * 64);
+                    nih[kk] = *(const h8_t*)(p.x + off_next[0] + kk * 128);
+                    nil[kk] = *(const h8_t*)(p.x + off_next[0] + kk * 128 + 64);
                 }
             }
         }
@@ -317,15 +317,15 @@ __global__ __launch_bounds__(256, 1) void block_x3_identity(const BlockParams p)
                 for (int q = 0; q < 8; ++q) y[q] = fmaxf(__fadd_rn(y[q], __fadd_rn((float)xih[s3][q], (float)xil[s3][q])), 0.f);      // (= add_split8, kernels.hip)
                 if constexpr (!FULL) {
                     if (more) {                                 // this K-step's x is spent: its registers take the next tile's
-                        xih[s3] = *(const h8_t*)(p.x + off_next[0] + s3 * 64);
-                        xil[s3] = *(const h8_t*)(p.x + off_next[0] + 512 + s3 * 64);
+                        xih[s3] = *(const h8_t*)(p.x + off_next[0] + s3 * 128);
+                        xil[s3] = *(const h8_t*)(p.x + off_next[0] + s3 * 128 + 64);
                     }
                 }
                 h8_t vh, vl;
                 split8(y, vh, vl);
                 if (live) {
-                    *(h8_t*)(orow + c0) = vh;
-                    *(h8_t*)(orow + 256 + c0) = vl;
+                    *(h8_t*)(orow + s3 * 64 + fg * 8) = vh;             // channel group s3: [32 hi][32 lo]
+                    *(h8_t*)(orow + s3 * 64 + 32 + fg * 8) = vl;
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }

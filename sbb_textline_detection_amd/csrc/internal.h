@@ -151,6 +151,22 @@ struct Direct64Params {
     void* out;                // data pointer [n][H][W][64] (split mode: [64 hi][64 lo] per pixel)
 };
 
+// Split mode (kF16X3) pixel layout (round 3): a stored pixel of C channels is a sequence of channel GROUPS of G = min(C, 32)
+// channels, each group = [G hi halves][G lo halves] -- for C >= 32 one 128-byte line per group, which is exactly what a split K-step
+// (32 channels of one tap, hi and lo) reads.  (Round 2 stored [C hi][C lo]: a K-step then touched two half-used lines per pixel,
+// doubling the L2 footprint of every gather and fetching every line twice -- PMC: 2-6x the unique bytes on the decoder launches.)
+#if defined(__HIPCC__)
+#define SBBSEG_HD __host__ __device__
+#else
+#define SBBSEG_HD
+#endif
+SBBSEG_HD inline int split_group(int C) { return C < 32 ? C : 32; }                      // channels per group = distance (in halves) hi -> lo
+SBBSEG_HD inline int split_hi_elem(int C, int ch)                                         // index (in halves) of channel ch's hi half inside the pixel
+{
+    const int G = split_group(C);
+    return (ch / G) * 2 * G + (ch % G);
+}
+
 // One ResNet bottleneck block at 64 internal channels (1x1 -> 3x3 -> 1x1 + shortcut) as ONE launch.  See bottleneck_fused.
 struct BlockParams {
     const char* x;            // buffer start (zero header), [n][H][W][CIN] 16-bit; CIN = 256 (identity) | 64 (projection)

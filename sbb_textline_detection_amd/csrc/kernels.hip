@@ -517,8 +517,9 @@ void conv_igemm_mfma(const ConvParams p)
                 const int c0 = ctile * BC + wc * T::kWCH + s2 * 32 + fg * 8;
                 if constexpr (kPrefetchRes) {
                     if (c0 < p.cout && m < p.M) {
-                        res[s2][ni] = *(const uint4*)((const uint16_t*)p.residual + (size_t)opix * (p.cout * PL) + c0);
-                        if constexpr (X3) res_lo[s2][ni] = *(const uint4*)((const uint16_t*)p.residual + (size_t)opix * (p.cout * PL) + p.cout + c0);
+                        const uint16_t* rp = (const uint16_t*)p.residual + (size_t)opix * (p.cout * PL) + (X3 ? split_hi_elem(p.cout, c0) : c0);
+                        res[s2][ni] = *(const uint4*)rp;
+                        if constexpr (X3) res_lo[s2][ni] = *(const uint4*)(rp + split_group(p.cout));
                     }
                 }
             }
@@ -681,13 +682,14 @@ void conv_igemm_mfma(const ConvParams p)
 #pragma unroll
                     for (int q = 0; q < 8; ++q) y[q] = __builtin_fmaf(v[q], sc[q], sh[q]);
                     // element offset of the pixel's channel group; the split mode stores [C hi][C lo] per pixel
-                    const size_t o = (size_t)(opix[ni] < 0 ? 0 : opix[ni]) * (p.cout * PL) + c0;
+                    const size_t o = (size_t)(opix[ni] < 0 ? 0 : opix[ni]) * (p.cout * PL) + (X3 ? split_hi_elem(p.cout, c0) : c0);
+                    const int lo_d = split_group(p.cout);                  // (split mode: halves from a group's hi to its lo part)
                     if (opix[ni] >= 0) {
                         if (p.raw_out) {
                             float rv[8];
 #pragma unroll
                             for (int q = 0; q < 8; ++q) rv[q] = v[q] * rsc[q] + rsh[q];
-                            if constexpr (X3) store_split8((uint16_t*)p.raw_out + o, p.cout, rv);
+                            if constexpr (X3) store_split8((uint16_t*)p.raw_out + o, lo_d, rv);
                             else {
                                 uint4 r;
                                 r.x = pack2<F16>(rv[0], rv[1]); r.y = pack2<F16>(rv[2], rv[3]);
@@ -700,7 +702,7 @@ void conv_igemm_mfma(const ConvParams p)
                                 const f16x8_t h = __builtin_bit_cast(f16x8_t, res[s2][ni]), l = __builtin_bit_cast(f16x8_t, res_lo[s2][ni]);
 #pragma unroll
                                 for (int q = 0; q < 8; ++q) y[q] = __fadd_rn(y[q], __fadd_rn((float)h[q], (float)l[q]));      // (= add_split8)
-                            } else if constexpr (X3) add_split8((const uint16_t*)p.residual + o, p.cout, y);
+                            } else if constexpr (X3) add_split8((const uint16_t*)p.residual + o, lo_d, y);
                             else {
                                 uint4 rr;
                                 if constexpr (kPrefetchRes) rr = res[s2][ni];
@@ -717,7 +719,7 @@ void conv_igemm_mfma(const ConvParams p)
                         for (int q = 0; q < 8; ++q) y[q] = fmaxf(y[q], 0.f);
                     }
                     if (p.out && opix[ni] >= 0) {
-                        if constexpr (X3) store_split8((uint16_t*)p.out + o, p.cout, y);
+                        if constexpr (X3) store_split8((uint16_t*)p.out + o, lo_d, y);
                         else {
                             uint4 r;
                             r.x = pack2<F16>(y[0], y[1]); r.y = pack2<F16>(y[2], y[3]);
@@ -1522,7 +1524,7 @@ __global__ __launch_bounds__(256, 2) void dec_tail_fused(const TailParams p)
 }
 
 // ------------------------------------------------------------------------------------------------
-// dec_tail_fused_x3 -- the same tail in the split mode (kF16X3): src0 pixels are [64 hi][64 lo] (256 B), image pixels
+// dec_tail_fused_x3 -- the same tail in the split mode (kF16X3): src0 pixels are [32 hi][32 lo][32 hi][32 lo] (256 B), image pixels
 // [8 hi][8 lo] (32 B), the wave's weights are hi + lo fragments (192 VGPRs), three MFMAs per product (lo*hi, hi*lo, hi*hi),
 // everything after the accumulators as in dec_tail_fused.  One block per CU (up to 512 registers per lane).  The generic
 // kernel needs 5.1 ms per 140 patches for this layer (32 output channels: 24 MFMAs per 288 staged rows).
@@ -1665,7 +1667,7 @@ __global__ __launch_bounds__(256, 1) void dec_tail_fused_x3(const TailParams p)
         auto load_b = [&](int h, bf16x8_t (&bh)[4], bf16x8_t (&bl)[4]) __attribute__((always_inline)) {
             if (h < 8) {
                 const int ks = h >> 1, kk = h & 1;
-                const int dh = (kk * 4 + 2 * (ks & 1)) & 15, dl = (8 + kk * 4 + 2 * (ks & 1)) & 15;
+                const int dh = (kk * 8 + 2 * (ks & 1)) & 15, dl = (kk * 8 + 4 + 2 * (ks & 1)) & 15;      // src0 pixel: [32 hi][32 lo][32 hi][32 lo]
 #pragma unroll
                 for (int ni = 0; ni < 4; ++ni) {
                     const int k = (ni * 32 + (ks >> 1) * 16 + (ks & 1)) * 256;      // immediate offset
@@ -1925,7 +1927,7 @@ __global__ __launch_bounds__(512, 2) void dec_tail_fused_x3w8(const TailParams p
         auto load_b = [&](int h, bf16x8_t (&bh)[4], bf16x8_t (&bl)[4]) __attribute__((always_inline)) {
             if (h < 8) {
                 const int ks = h >> 1, kk = h & 1;
-                const int dh = (kk * 4 + 2 * (ks & 1)) & 15, dl = (8 + kk * 4 + 2 * (ks & 1)) & 15;
+                const int dh = (kk * 8 + 2 * (ks & 1)) & 15, dl = (kk * 8 + 4 + 2 * (ks & 1)) & 15;      // src0 pixel: [32 hi][32 lo][32 hi][32 lo]
 #pragma unroll
                 for (int ni = 0; ni < 4; ++ni) {
                     const int k = (ni * 32 + (ks >> 1) * 16 + (ks & 1)) * 256;      // immediate offset
@@ -2324,7 +2326,7 @@ __global__ __launch_bounds__(256, 1) void stem_conv_pairs_x3(const StemParams p)
 #pragma unroll
                     for (int q = 0; q < 8; ++q) y[q] = fmaxf(y[q], 0.f);
                 }
-                store_split8((uint16_t*)p.out + pix * 128 + c0, 64, y);
+                store_split8((uint16_t*)p.out + pix * 128 + split_hi_elem(64, c0), 32, y);
             }
         }
     }
@@ -2488,7 +2490,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_direct(const Direct64Param
 }
 
 // ------------------------------------------------------------------------------------------------
-// conv3x3_c64_direct_x3 -- the same direct conv in the split mode (kF16X3): pixels are [64 hi][64 lo] (256 B, 16 granules,
+// conv3x3_c64_direct_x3 -- the same direct conv in the split mode (kF16X3): pixels are [32 hi][32 lo][32 hi][32 lo] (256 B, 16 granules,
 // slot = (granule + 2 * halo row) & 15: conflict-free for ds_read_b128's 16-lane groups), the wave's weights are hi + lo fragments (288 VGPRs: one block per CU), three MFMAs per
 // product, outputs split again.  The generic split kernel needs 0.82 ms per 140 patches for each of these layers.
 // ------------------------------------------------------------------------------------------------
@@ -2582,7 +2584,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_c64_direct_x3(const Direct64Pa
 #pragma unroll
                 for (int ni = 0; ni < 4; ++ni) {
                     const int rc = (ni + t / 3) * kD64HaloW + t % 3;
-                    const int dh = (kk * 4 + 2 * rc) & 15, dl = (8 + kk * 4 + 2 * rc) & 15;
+                    const int dh = (kk * 8 + 2 * rc) & 15, dl = (kk * 8 + 4 + 2 * rc) & 15;      // stored pixel: [32 hi][32 lo][32 hi][32 lo]
                     const bf16x8_t bh = *(const bf16x8_t*)(rb[dh >> 1] + rc * 256);
                     const bf16x8_t bl = *(const bf16x8_t*)(rb[dl >> 1] + rc * 256);
 #pragma unroll
@@ -2621,7 +2623,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_c64_direct_x3(const Direct64Pa
                 for (int q = 0; q < 8; ++q) y[q] = fmaxf(y[q], 0.f);
             }
             if (oy < p.H && ox < p.W)
-                store_split8((uint16_t*)p.out + (((size_t)n * p.H + oy) * p.W + ox) * 128 + c0, 64, y);
+                store_split8((uint16_t*)p.out + (((size_t)n * p.H + oy) * p.W + ox) * 128 + split_hi_elem(64, c0), 32, y);
         }
     }
 }
@@ -3477,7 +3479,7 @@ hipError_t launch_ingest_f32(const float* x, int n, int H, int W, void* c8, void
 // ------------------------------------------------------------------------------------------------
 // optional per-channel affine + ReLU applied to every input element before the max: lets the stem
 // write only its pre-BN tensor (the f1 skip) and the pool apply bn_conv1 + relu on the fly
-// SPLIT (kF16X3): pixels are [C hi][C lo]; values are re-assembled in fp32 (exact), the maximum is split again
+// SPLIT (kF16X3): pixels are channel groups [G hi][G lo] (internal.h); values are re-assembled in fp32 (exact), the maximum is split again
 template <typename E, bool SPLIT = false>
 __global__ __launch_bounds__(256) void maxpool_kernel(const E* src, E* dst, int n, int H, int W, int C,
                                                       int k, int stride, int Ho, int Wo,
@@ -3517,12 +3519,12 @@ __global__ __launch_bounds__(256) void maxpool_kernel(const E* src, E* dst, int 
         // the ResNet stem pool, full strip: all 27 loads are independent -> issue them back to back
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky) {
-            const E* row = src + (((size_t)b * H + oy * 2 + ky) * W + ox0 * 2) * CS + g * 8;
+            const E* row = src + (((size_t)b * H + oy * 2 + ky) * W + ox0 * 2) * CS + (SPLIT ? split_hi_elem(C, g * 8) : g * 8);
             Vec8<E> v[9], vl[SPLIT ? 9 : 1];
 #pragma unroll
             for (int c = 0; c < 9; ++c) {
                 v[c] = *(const Vec8<E>*)(row + (size_t)c * CS);
-                if constexpr (SPLIT) vl[c] = *(const Vec8<E>*)(row + (size_t)c * CS + C);
+                if constexpr (SPLIT) vl[c] = *(const Vec8<E>*)(row + (size_t)c * CS + split_group(C));
             }
 #pragma unroll
             for (int c = 0; c < 9; ++c) {
@@ -3545,14 +3547,14 @@ __global__ __launch_bounds__(256) void maxpool_kernel(const E* src, E* dst, int 
         }
     } else
     for (int ky = 0; ky < k; ++ky) {
-        const E* row = src + (((size_t)b * H + oy * stride + ky) * W + ox0 * stride) * CS + g * 8;
+        const E* row = src + (((size_t)b * H + oy * stride + ky) * W + ox0 * stride) * CS + (SPLIT ? split_hi_elem(C, g * 8) : g * 8);
         for (int c = 0; c < ncol; ++c) {
             const Vec8<E> v = *(const Vec8<E>*)(row + (size_t)c * CS);
             float x[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 float xv = from_elem<E>(v.v[i]);
-                if constexpr (SPLIT) xv += from_elem<E>((*(const Vec8<E>*)(row + (size_t)c * CS + C)).v[i]);
+                if constexpr (SPLIT) xv += from_elem<E>((*(const Vec8<E>*)(row + (size_t)c * CS + split_group(C))).v[i]);
                 x[i] = xv * ps[i] + pb[i];
                 if (pre_relu) x[i] = fmaxf(x[i], 0.f);
             }
@@ -3569,8 +3571,8 @@ __global__ __launch_bounds__(256) void maxpool_kernel(const E* src, E* dst, int 
 #pragma unroll
     for (int o = 0; o < OX; ++o) {
         if (o < nout) {
-            E* dp = dst + (((size_t)b * Ho + oy) * Wo + ox0 + o) * CS + g * 8;
-            if constexpr (SPLIT) store_split8((uint16_t*)dp, C, m[o]);
+            E* dp = dst + (((size_t)b * Ho + oy) * Wo + ox0 + o) * CS + (SPLIT ? split_hi_elem(C, g * 8) : g * 8);
+            if constexpr (SPLIT) store_split8((uint16_t*)dp, split_group(C), m[o]);
             else {
                 Vec8<E> r;
 #pragma unroll
@@ -3617,9 +3619,10 @@ __global__ __launch_bounds__(256) void head_kernel(const HeadParams p)
     for (int c = 0; c < 8; ++c) logit[c] = 0.f;
     const E* src = (const E*)p.src + (size_t)m * p.cin * (SPLIT ? 2 : 1);
     for (int g = 0; g < p.cin / 8; ++g) {
-        const Vec8<E> v = *(const Vec8<E>*)(src + g * 8);
+        const int e0 = SPLIT ? split_hi_elem(p.cin, g * 8) : g * 8;
+        const Vec8<E> v = *(const Vec8<E>*)(src + e0);
         Vec8<E> vl;
-        if constexpr (SPLIT) vl = *(const Vec8<E>*)(src + p.cin + g * 8);
+        if constexpr (SPLIT) vl = *(const Vec8<E>*)(src + e0 + split_group(p.cin));
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             float xv = from_elem<E>(v.v[i]);
@@ -4049,7 +4052,8 @@ __global__ __launch_bounds__(256) void split_to_f32_kernel(const _Float16* src, 
     if (i >= n) return;
     const size_t pix = i / C;
     const int ch = (int)(i - pix * C);
-    dst[i] = (float)src[pix * 2 * C + ch] + (float)src[pix * 2 * C + C + ch];
+    const size_t e0 = pix * 2 * C + split_hi_elem(C, ch);           // channel groups [G hi][G lo] (internal.h)
+    dst[i] = (float)src[e0] + (float)src[e0 + split_group(C)];
 }
 
 hipError_t launch_split_to_f32(const void* src, float* dst, size_t npix, int C, hipStream_t s)
