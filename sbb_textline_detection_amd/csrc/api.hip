@@ -1421,7 +1421,9 @@ static int build_fast_gather_tables(sbbseg_ctx* c)
                         co.d.src[s].pad_top == 0 && co.d.src[s].pad_left == 0 && co.d.src[s].off_y == 0 && co.d.src[s].off_x == 0;
         co.fg_pointwise = pointwise;
         const int min_ksteps = pointwise ? c->fg_pointwise_min_ksteps : c->fg_min_ksteps;
-        static const bool x3_small = getenv("SBBSEG_FG_X3_SMALL") != nullptr;       // experiment knob: fast gather on the split mode's 64-channel tiles too
+        // fast gather on the split mode's 64-channel tiles too: +13 % time under round 2's [C hi][C lo] layout, -11 % (dec4 3.25 ->
+        // 2.89 ms) with the interleaved groups of round 3; SBBSEG_FG_X3_SMALL=0 turns it off (A/B)
+        static const bool x3_small = !(getenv("SBBSEG_FG_X3_SMALL") && getenv("SBBSEG_FG_X3_SMALL")[0] == '0');
         if (!co.fg_ok || c->precision == kF32 || co.total_ksteps < min_ksteps || (c->precision == kF16X3 && co.d.cout < 128 && !x3_small)) continue;
         bool ok = true;
         for (int s = 0; s < co.d.n_src; ++s)
