@@ -1487,7 +1487,7 @@ static int fuse_bottlenecks(sbbseg_ctx* c)
             proj = 1;
             b_src = C.d.src[0].tensor == T2 ? 0 : 1;
         }
-        if (proj < 0 || (split && proj != 0)) continue;        // (split mode: identity blocks only -- block_x3_identity)
+        if (proj < 0) continue;
         const Tensor& xt = c->tensors[X];
         Op blk;
         blk.type = kBlock;
@@ -1520,21 +1520,24 @@ static int fuse_bottlenecks(sbbseg_ctx* c)
                 dst[((frag * 2 + 1) * 64 + l) * 8 + e] = f32_to_f16_rne(sv - (float)__builtin_bit_cast(_Float16, hb));
             };
             const float pre1 = 1.f / A.wmul_cls[0], pre3 = 1.f / C.wmul_cls[0];
-            f1.assign((size_t)8 * 4 * 2 * 64 * 8, 0);
-            f3.assign((size_t)2 * 16 * 2 * 64 * 8, 0);
-            for (int kk = 0; kk < 8; ++kk)
+            const int ka = cin / 32, kc = proj ? 4 : 2;
+            f1.assign((size_t)ka * 4 * 2 * 64 * 8, 0);
+            f3.assign((size_t)kc * 16 * 2 * 64 * 8, 0);
+            for (int kk = 0; kk < ka; ++kk)
                 for (int mi = 0; mi < 4; ++mi)
                     for (int l = 0; l < 64; ++l) {
                         const int o = conv_row_channel(mi * 16 + (l & 15), 64);
                         for (int e = 0; e < 8; ++e) put(f1, (size_t)kk * 4 + mi, l, e, A.h_w[0][(size_t)(kk * 32 + (l >> 4) * 8 + e) * 64 + o], pre1);
                     }
-            for (int kk = 0; kk < 2; ++kk)
+            for (int kk = 0; kk < kc; ++kk)                        // the conv's own K order: source 0, then source 1 (block_x3 adds up the same way)
                 for (int mi = 0; mi < 16; ++mi)
                     for (int l = 0; l < 64; ++l) {
                         const int o = conv_row_channel(mi * 16 + (l & 15), 256);
-                        for (int e = 0; e < 8; ++e) put(f3, (size_t)kk * 16 + mi, l, e, C.h_w[0][(size_t)(kk * 32 + (l >> 4) * 8 + e) * 256 + o], pre3);
+                        const std::vector<float>& wsrc = C.h_w[kk < 2 ? 0 : 1];
+                        for (int e = 0; e < 8; ++e) put(f3, (size_t)kk * 16 + mi, l, e, wsrc[(size_t)((kk & 1) * 32 + (l >> 4) * 8 + e) * 256 + o], pre3);
                     }
             blk.block.wmul[0] = A.wmul_cls[0]; blk.block.wmul[1] = B.wmul_cls[0]; blk.block.wmul[2] = C.wmul_cls[0];
+            if (proj) blk.block.proj = b_src == 0 ? 1 : 2;         // 1: K order [b, x]; 2: [x, b]
         }
         if (upload(c, &blk.block.d_w1, f1.data(), f1.size()) || upload(c, &blk.block.d_w3, f3.data(), f3.size())) return 1;
         char nm[96];

@@ -58,13 +58,21 @@ __device__ inline void split8(const float (&y)[8], h8_t& hi, h8_t& lo)
 
 // FULL: the next tile's inner x has its own registers and is requested before phase A (in flight across all three phases);
 // !FULL: it is requested K-step by K-step inside phase C into the registers the residual add has just released
-template <bool FULL>
-__global__ __launch_bounds__(256, 1) void block_x3_identity(const BlockParams p)
+// PROJ: the projection block at the head of the stage (64 -> 64 -> 64 -> 256 channels; the planner has folded the shortcut conv into
+// the last contraction: y = ReLU(BN(W3' . [b, x]))).  x is 64 channels (2 K-steps): W1 moves to 64 VGPRs, W3' (K = 128: 128 KB as
+// hi | lo fragments) takes the whole weight region of the LDS, phase C contracts b (LDS) and the inner x fragments (registers),
+// and there is no residual add.
+template <bool FULL, bool PROJ>
+__global__ __launch_bounds__(256, 1) void block_x3(const BlockParams p)
 {
+    static_assert(FULL || !PROJ, "the projection block keeps its inner x for the whole of phase C: full next-tile buffer only");
+    constexpr int KA = PROJ ? 2 : 8;                            // K-steps (32 channels) of phase A
+    constexpr int KC = PROJ ? 4 : 2;                            // K-steps of phase C
+    constexpr int PIXB = KA * 128;                              // bytes per stored x pixel (channel groups of [32 hi][32 lo])
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* lds_w1 = smem;
-    char* lds_w3 = lds_w1 + kW1Bytes;
-    char* lds_ab = lds_w3 + kW3Bytes;
+    char* lds_w1 = smem;                                        // (identity block only)
+    char* lds_w3 = PROJ ? smem : lds_w1 + kW1Bytes;
+    char* lds_ab = smem + kW1Bytes + kW3Bytes;                  // (PROJ: W3' fills kW1Bytes + kW3Bytes = 128 KB)
     float* cst = (float*)(lds_ab + kABBytes);
 
     const int tid = threadIdx.x;
@@ -83,8 +91,20 @@ __global__ __launch_bounds__(256, 1) void block_x3_identity(const BlockParams p)
     auto tile_at = [&](int it) __attribute__((always_inline)) -> int { return xcd_lo + slot + it * GX; };
 
     // ---- one-time: weights and constants to LDS, this wave's 3x3 fragments to registers
-    for (int i = tid; i < kW1Bytes / 16; i += 256) ((uint4*)lds_w1)[i] = ((const uint4*)p.w1)[i];
-    for (int i = tid; i < kW3Bytes / 16; i += 256) ((uint4*)lds_w3)[i] = ((const uint4*)p.w3)[i];
+    if constexpr (!PROJ)
+        for (int i = tid; i < kW1Bytes / 16; i += 256) ((uint4*)lds_w1)[i] = ((const uint4*)p.w1)[i];
+    for (int i = tid; i < KC * 16 * 2 * 64; i += 256) ((uint4*)lds_w3)[i] = ((const uint4*)p.w3)[i];
+    h8_t w1h[PROJ ? KA : 1][PROJ ? 4 : 1], w1l[PROJ ? KA : 1][PROJ ? 4 : 1];      // PROJ: W1 in registers, [kk][mi]
+    if constexpr (PROJ) {
+        const uint4* src = (const uint4*)p.w1 + lane;
+#pragma unroll
+        for (int kk = 0; kk < KA; ++kk)
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) {
+                w1h[kk][mi] = __builtin_bit_cast(h8_t, src[(size_t)((kk * 4 + mi) * 2 + 0) * 64]);
+                w1l[kk][mi] = __builtin_bit_cast(h8_t, src[(size_t)((kk * 4 + mi) * 2 + 1) * 64]);
+            }
+    }
     if (tid < 64) {
         cst[tid] = p.s1[tid] * p.wmul1; cst[64 + tid] = p.b1[tid]; cst[128 + tid] = p.s2[tid] * p.wmul2; cst[192 + tid] = p.b2[tid];
     }
@@ -136,14 +156,14 @@ __global__ __launch_bounds__(256, 1) void block_x3_identity(const BlockParams p)
             const int Y = ty * 4 - 1 + hy[j], X = tx * 16 - 1 + hx[j];
             in[j] = ((unsigned)Y < (unsigned)p.H) & ((unsigned)X < (unsigned)p.W) & (hy[j] < 6);
             // stored pixel = 8 channel groups of [32 hi][32 lo] halves (1 KB); outside the image: the zero header
-            off[j] = in[j] ? (uint32_t)((n * p.H + Y) * p.W + X) * 1024u + (uint32_t)(kZeroHeaderBytes + fg * 16) : 0u;
+            off[j] = in[j] ? (uint32_t)((n * p.H + Y) * p.W + X) * (uint32_t)PIXB + (uint32_t)(kZeroHeaderBytes + fg * 16) : 0u;
         }
     };
-    h8_t xih[8], xil[8], xbh[8], xbl[8];                        // inner pixel, border pixel: [K-step] fragments, hi and lo
-    h8_t nih[FULL ? 8 : 1], nil[FULL ? 8 : 1];                  // FULL: the next tile's inner pixel
-    auto fetch = [&](uint32_t off, h8_t (&dh)[8], h8_t (&dl)[8]) __attribute__((always_inline)) {
+    h8_t xih[KA], xil[KA], xbh[KA], xbl[KA];                    // inner pixel, border pixel: [K-step] fragments, hi and lo
+    h8_t nih[FULL ? KA : 1], nil[FULL ? KA : 1];                // FULL: the next tile's inner pixel
+    auto fetch = [&](uint32_t off, h8_t (&dh)[KA], h8_t (&dl)[KA]) __attribute__((always_inline)) {
 #pragma unroll
-        for (int kk = 0; kk < 8; ++kk) {
+        for (int kk = 0; kk < KA; ++kk) {
             dh[kk] = *(const h8_t*)(p.x + off + kk * 128);          // stored pixel = 8 groups of [32 hi][32 lo]: one 128-byte line per K-step
             dl[kk] = *(const h8_t*)(p.x + off + kk * 128 + 64);
         }
@@ -163,7 +183,7 @@ __global__ __launch_bounds__(256, 1) void block_x3_identity(const BlockParams p)
             locate(tile_at(it + 1), in_next, off_next);
             if constexpr (FULL) {
 #pragma unroll
-                for (int kk = 0; kk < 8; ++kk) {
+                for (int kk = 0; kk < KA; ++kk) {
                     nih[kk] = *(const h8_t*)(p.x + off_next[0] + kk * 128);
                     nil[kk] = *(const h8_t*)(p.x + off_next[0] + kk * 128 + 64);
                 }
@@ -177,22 +197,33 @@ __global__ __launch_bounds__(256, 1) void block_x3_identity(const BlockParams p)
             for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[mi][j] = (f4_t){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int kk = 0; kk < 8; ++kk) {
-                h8_t wh[4], wl[4];
+            // W1 fragments of K-step kk + 1 are requested before the MFMAs of K-step kk (register double buffer): with one wave per
+            // SIMD nothing else covers the LDS round trip
+            h8_t wh[2][4], wl[2][4];
+            auto load_w1 = [&](int kk, h8_t (&dh)[4], h8_t (&dl)[4]) __attribute__((always_inline)) {
 #pragma unroll
                 for (int mi = 0; mi < 4; ++mi) {
-                    wh[mi] = *(const h8_t*)(lds_w1 + ((kk * 4 + mi) * 2 + 0) * 1024 + lane * 16);
-                    wl[mi] = *(const h8_t*)(lds_w1 + ((kk * 4 + mi) * 2 + 1) * 1024 + lane * 16);
+                    if constexpr (PROJ) { dh[mi] = w1h[kk][mi]; dl[mi] = w1l[kk][mi]; }
+                    else {
+                        dh[mi] = *(const h8_t*)(lds_w1 + ((kk * 4 + mi) * 2 + 0) * 1024 + lane * 16);
+                        dl[mi] = *(const h8_t*)(lds_w1 + ((kk * 4 + mi) * 2 + 1) * 1024 + lane * 16);
+                    }
                 }
+            };
+            load_w1(0, wh[0], wl[0]);
+#pragma unroll
+            for (int kk = 0; kk < KA; ++kk) {
+                if (kk + 1 < KA) load_w1(kk + 1, wh[(kk + 1) & 1], wl[(kk + 1) & 1]);
+                const h8_t (&ch)[4] = wh[kk & 1];
+                const h8_t (&cl)[4] = wl[kk & 1];
                 // three sweeps over the eight accumulators (small terms first): MFMAs on one accumulator stay 8 instructions apart
 #pragma unroll
-                for (int mi = 0; mi < 4; ++mi) { acc[mi][0] = mma(wl[mi], xih[kk], acc[mi][0]); acc[mi][1] = mma(wl[mi], xbh[kk], acc[mi][1]); }
+                for (int mi = 0; mi < 4; ++mi) { acc[mi][0] = mma(cl[mi], xih[kk], acc[mi][0]); acc[mi][1] = mma(cl[mi], xbh[kk], acc[mi][1]); }
 #pragma unroll
-                for (int mi = 0; mi < 4; ++mi) { acc[mi][0] = mma(wh[mi], xil[kk], acc[mi][0]); acc[mi][1] = mma(wh[mi], xbl[kk], acc[mi][1]); }
+                for (int mi = 0; mi < 4; ++mi) { acc[mi][0] = mma(ch[mi], xil[kk], acc[mi][0]); acc[mi][1] = mma(ch[mi], xbl[kk], acc[mi][1]); }
 #pragma unroll
-                for (int mi = 0; mi < 4; ++mi) { acc[mi][0] = mma(wh[mi], xih[kk], acc[mi][0]); acc[mi][1] = mma(wh[mi], xbh[kk], acc[mi][1]); }
-                __builtin_amdgcn_sched_barrier(0);              // (keeps the scheduler from hoisting all 64 weight fragments at once)
+                for (int mi = 0; mi < 4; ++mi) { acc[mi][0] = mma(ch[mi], xih[kk], acc[mi][0]); acc[mi][1] = mma(ch[mi], xbh[kk], acc[mi][1]); }
+                __builtin_amdgcn_sched_barrier(0);
             }
             if (more) fetch(off_next[1], xbh, xbl);             // border x is spent: its registers take the next tile's
 #pragma unroll
@@ -225,25 +256,30 @@ __global__ __launch_bounds__(256, 1) void block_x3_identity(const BlockParams p)
         {
 #pragma unroll
             for (int i = 0; i < 4; ++i) bacc[i] = (f4_t){0.f, 0.f, 0.f, 0.f};
+            h8_t fh[2][4], fl[2][4];
+            auto load_a = [&](int step, h8_t (&dh)[4], h8_t (&dl)[4]) __attribute__((always_inline)) {
+                const int t = step >> 1, kk = step & 1;
 #pragma unroll
-            for (int t = 0; t < 9; ++t) {
-#pragma unroll
-                for (int kk = 0; kk < 2; ++kk) {
-                    h8_t bh[4], bl[4];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const int rc = (i + t / 3) * kHaloW + t % 3;
-                        const int dh = (kk * 4 + 2 * rc) & 15, dl = (8 + kk * 4 + 2 * rc) & 15;
-                        bh[i] = *(const h8_t*)(rb[dh >> 1] + rc * 256);
-                        bl[i] = *(const h8_t*)(rb[dl >> 1] + rc * 256);
-                    }
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) bacc[i] = mma(wfl[t][kk], bh[i], bacc[i]);
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) bacc[i] = mma(wfh[t][kk], bl[i], bacc[i]);
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) bacc[i] = mma(wfh[t][kk], bh[i], bacc[i]);
+                for (int i = 0; i < 4; ++i) {
+                    const int rc = (i + t / 3) * kHaloW + t % 3;
+                    const int eh = (kk * 4 + 2 * rc) & 15, el = (8 + kk * 4 + 2 * rc) & 15;
+                    dh[i] = *(const h8_t*)(rb[eh >> 1] + rc * 256);
+                    dl[i] = *(const h8_t*)(rb[el >> 1] + rc * 256);
                 }
+            };
+            load_a(0, fh[0], fl[0]);
+#pragma unroll
+            for (int step = 0; step < 18; ++step) {             // (tap, K-step): fragments of step + 1 are in flight during step's MFMAs
+                const int t = step >> 1, kk = step & 1;
+                if (step + 1 < 18) load_a(step + 1, fh[(step + 1) & 1], fl[(step + 1) & 1]);
+                const h8_t (&bh)[4] = fh[step & 1];
+                const h8_t (&bl)[4] = fl[step & 1];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) bacc[i] = mma(wfl[t][kk], bh[i], bacc[i]);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) bacc[i] = mma(wfh[t][kk], bl[i], bacc[i]);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) bacc[i] = mma(wfh[t][kk], bh[i], bacc[i]);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -288,37 +324,59 @@ __global__ __launch_bounds__(256, 1) void block_x3_identity(const BlockParams p)
             }
             __syncthreads();                                    // b is in registers everywhere: the next tile's phase A may write a
             uint16_t* orow = (uint16_t*)p.out + (((size_t)n * p.H + oy) * p.W + ox) * 512;
+            // channel group s3 + 1's weight fragments and constants are requested before group s3's MFMAs and epilogue
+            h8_t w3h[2][KC][2], w3l[2][KC][2];
+            float4 kc[2][4];                                    // scale[c0..c0+7], shift[c0..c0+7]
+            auto load_c = [&](int s3, h8_t (&dh)[KC][2], h8_t (&dl)[KC][2], float4 (&dk)[4]) __attribute__((always_inline)) {
 #pragma unroll
-            for (int s3 = 0; s3 < 8; ++s3) {
-                f4_t acc[2] = {(f4_t){0.f, 0.f, 0.f, 0.f}, (f4_t){0.f, 0.f, 0.f, 0.f}};
-#pragma unroll
-                for (int kk = 0; kk < 2; ++kk) {
-                    h8_t wh[2], wl[2];
+                for (int kk = 0; kk < KC; ++kk)
 #pragma unroll
                     for (int m = 0; m < 2; ++m) {
-                        wh[m] = *(const h8_t*)(lds_w3 + ((kk * 16 + 2 * s3 + m) * 2 + 0) * 1024 + lane * 16);
-                        wl[m] = *(const h8_t*)(lds_w3 + ((kk * 16 + 2 * s3 + m) * 2 + 1) * 1024 + lane * 16);
+                        dh[kk][m] = *(const h8_t*)(lds_w3 + ((kk * 16 + 2 * s3 + m) * 2 + 0) * 1024 + lane * 16);
+                        dl[kk][m] = *(const h8_t*)(lds_w3 + ((kk * 16 + 2 * s3 + m) * 2 + 1) * 1024 + lane * 16);
                     }
-                    acc[0] = mma(wl[0], bh[kk], acc[0]); acc[1] = mma(wl[1], bh[kk], acc[1]);
-                    acc[0] = mma(wh[0], bl[kk], acc[0]); acc[1] = mma(wh[1], bl[kk], acc[1]);
-                    acc[0] = mma(wh[0], bh[kk], acc[0]); acc[1] = mma(wh[1], bh[kk], acc[1]);
-                }
                 const int c0 = s3 * 32 + fg * 8;
+                dk[0] = *(const float4*)(cst + 256 + c0); dk[1] = *(const float4*)(cst + 256 + c0 + 4);
+                dk[2] = *(const float4*)(cst + 512 + c0); dk[3] = *(const float4*)(cst + 512 + c0 + 4);
+            };
+            load_c(0, w3h[0], w3l[0], kc[0]);
+#pragma unroll
+            for (int s3 = 0; s3 < 8; ++s3) {
+                if (s3 + 1 < 8) load_c(s3 + 1, w3h[(s3 + 1) & 1], w3l[(s3 + 1) & 1], kc[(s3 + 1) & 1]);
+                f4_t acc[2] = {(f4_t){0.f, 0.f, 0.f, 0.f}, (f4_t){0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+                for (int kk = 0; kk < KC; ++kk) {
+                    const h8_t (&wh)[2] = w3h[s3 & 1][kk];
+                    const h8_t (&wl)[2] = w3l[s3 & 1][kk];
+                    // identity block: two K-steps over b.  Projection block: four K-steps in the SOURCE ORDER of the conv it replaces
+                    // (p.proj == 1: [b, x]; 2: [x, b]) -- the same accumulation order, hence the same bits
+                    const bool from_b = !PROJ || ((kk < 2) != (p.proj == 2));
+                    const h8_t qh = from_b ? bh[kk & 1] : xih[(kk & 1) % KA], ql = from_b ? bl[kk & 1] : xil[(kk & 1) % KA];
+                    acc[0] = mma(wl[0], qh, acc[0]); acc[1] = mma(wl[1], qh, acc[1]);
+                    acc[0] = mma(wh[0], ql, acc[0]); acc[1] = mma(wh[1], ql, acc[1]);
+                    acc[0] = mma(wh[0], qh, acc[0]); acc[1] = mma(wh[1], qh, acc[1]);
+                }
                 float sc[8], sh[8], y[8];
-                *(float4*)&sc[0] = *(const float4*)(cst + 256 + c0); *(float4*)&sc[4] = *(const float4*)(cst + 256 + c0 + 4);
-                *(float4*)&sh[0] = *(const float4*)(cst + 512 + c0); *(float4*)&sh[4] = *(const float4*)(cst + 512 + c0 + 4);
+                *(float4*)&sc[0] = kc[s3 & 1][0]; *(float4*)&sc[4] = kc[s3 & 1][1];
+                *(float4*)&sh[0] = kc[s3 & 1][2]; *(float4*)&sh[4] = kc[s3 & 1][3];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     y[q] = __builtin_fmaf(acc[0][q], sc[q], sh[q]);
                     y[4 + q] = __builtin_fmaf(acc[1][q], sc[4 + q], sh[4 + q]);
                 }
-                // the residual: this lane's x fragment of K-step s3 = channels c0 .. c0 + 7 of its inner pixel (hi + lo is exact in fp32)
+                if constexpr (PROJ) {
 #pragma unroll
-                for (int q = 0; q < 8; ++q) y[q] = fmaxf(__fadd_rn(y[q], __fadd_rn((float)xih[s3][q], (float)xil[s3][q])), 0.f);      // (= add_split8, kernels.hip)
+                    for (int q = 0; q < 8; ++q) y[q] = fmaxf(y[q], 0.f);
+                } else {
+                    // the residual: this lane's x fragment of K-step s3 = channels c0 .. c0 + 7 of its inner pixel (hi + lo is exact in fp32)
+#pragma unroll
+                    for (int q = 0; q < 8; ++q)
+                        y[q] = fmaxf(__fadd_rn(y[q], __fadd_rn((float)xih[s3 % KA][q], (float)xil[s3 % KA][q])), 0.f);      // (= add_split8, kernels.hip)
+                }
                 if constexpr (!FULL) {
                     if (more) {                                 // this K-step's x is spent: its registers take the next tile's
-                        xih[s3] = *(const h8_t*)(p.x + off_next[0] + s3 * 128);
-                        xil[s3] = *(const h8_t*)(p.x + off_next[0] + s3 * 128 + 64);
+                        xih[s3 % KA] = *(const h8_t*)(p.x + off_next[0] + s3 * 128);
+                        xil[s3 % KA] = *(const h8_t*)(p.x + off_next[0] + s3 * 128 + 64);
                     }
                 }
                 h8_t vh, vl;
@@ -335,7 +393,7 @@ __global__ __launch_bounds__(256, 1) void block_x3_identity(const BlockParams p)
         if constexpr (FULL) {
             if (more) {
 #pragma unroll
-                for (int kk = 0; kk < 8; ++kk) { xih[kk] = nih[kk]; xil[kk] = nil[kk]; }
+                for (int kk = 0; kk < KA; ++kk) { xih[kk] = nih[kk]; xil[kk] = nil[kk]; }
             }
         }
     }
@@ -351,14 +409,19 @@ hipError_t launch_block_x3(const BlockParams& p, int num_cus, hipStream_t s)
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
     if (!attr_done[dev & 63]) {
-        e = hipFuncSetAttribute((const void*)block_x3_identity<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kBlockX3LdsBytes);
+        e = hipFuncSetAttribute((const void*)block_x3<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kBlockX3LdsBytes);
         if (e != hipSuccess) return e;
-        e = hipFuncSetAttribute((const void*)block_x3_identity<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kBlockX3LdsBytes);
+        e = hipFuncSetAttribute((const void*)block_x3<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kBlockX3LdsBytes);
+        if (e != hipSuccess) return e;
+        e = hipFuncSetAttribute((const void*)block_x3<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kBlockX3LdsBytes);
         if (e != hipSuccess) return e;
         attr_done[dev & 63] = true;
     }
-    if (p.pq) hipLaunchKernelGGL(block_x3_identity<true>, dim3(grid), dim3(256), kBlockX3LdsBytes, s, p);      // (conv variant bit 20 clears pq)
-    else hipLaunchKernelGGL(block_x3_identity<false>, dim3(grid), dim3(256), kBlockX3LdsBytes, s, p);
+    if (p.proj) hipLaunchKernelGGL((block_x3<true, true>), dim3(grid), dim3(256), kBlockX3LdsBytes, s, p);
+    // identity blocks: the in-place x prefetch is the default (the software-pipelined phases need the 64 registers a full
+    // next-tile buffer would take: that form spills); conv variant bit 20 (pq cleared) selects the full buffer for A/B
+    else if (p.pq) hipLaunchKernelGGL((block_x3<false, false>), dim3(grid), dim3(256), kBlockX3LdsBytes, s, p);
+    else hipLaunchKernelGGL((block_x3<true, false>), dim3(grid), dim3(256), kBlockX3LdsBytes, s, p);
     return hipGetLastError();
 }
 
