@@ -931,9 +931,20 @@ int sbbseg_add_conv(sbbseg_ctx* c, const sbbseg_conv_desc* d, const float* w_src
         const sbbseg_conv_src& cs = d->src[s];
         const int g8 = (cs.channels + 7) / 8;
         int granules = 0;
+        // Tap order inside a channel group.  A 3x3 stride-2 source (the skip tensor of a parity-split decoder conv) is walked parity
+        // set by parity set -- (0,0) (0,2) (2,0) (2,2) | (0,1) (2,1) | (1,0) (1,2) | (1,1): taps of one set read the SAME source pixels
+        // (shifted by one output step), so their K-steps, now adjacent, find the lines of the previous step in L2; in row-major
+        // order the next touch of a line came 2 or 6 K-steps later, after 4-12 MB of other gathers had passed through the XCD's
+        // 4 MB L2 (PMC: dec4 fetched 4.4x its input).  SBBSEG_TAP_ORDER=0: row-major (A/B).  Only the order of the sum changes.
+        std::vector<int> tap_order;
+        static const bool grouped_taps = !(getenv("SBBSEG_TAP_ORDER") && getenv("SBBSEG_TAP_ORDER")[0] == '0');
+        if (grouped_taps && cs.kh == 3 && cs.kw == 3 && cs.stride_y == 2 && cs.stride_x == 2) tap_order = {0, 2, 6, 8, 1, 7, 3, 5, 4};
+        else
+            for (int t = 0; t < cs.kh * cs.kw; ++t) tap_order.push_back(t);
         for (int cg = 0; cg < g8; cg += gps)
-            for (int ky = 0; ky < cs.kh; ++ky)
-                for (int kx = 0; kx < cs.kw; ++kx)
+            for (int ti = 0; ti < cs.kh * cs.kw; ++ti)
+                {
+                    const int ky = tap_order[ti] / cs.kw, kx = tap_order[ti] % cs.kw;
                     for (int g = cg; g < g8 && g < cg + gps; ++g) {
                         KTabEntry e;
                         e.dy = (int16_t)(ky - cs.pad_top - cs.off_y);
@@ -945,6 +956,7 @@ int sbbseg_add_conv(sbbseg_ctx* c, const sbbseg_conv_desc* d, const float* w_src
                         lref.push_back({s, ky, kx, g * 8});
                         ++granules;
                     }
+                }
         const int ks = (granules + gps - 1) / gps;
         for (int g = granules; g < ks * gps; ++g) {
             KTabEntry e;
