@@ -18,6 +18,8 @@
 #include "../../include/sbbseg.h"
 #include <dlfcn.h>
 
+#include <mutex>
+
 #include "internal.h"
 
 using namespace sbbseg;
@@ -535,8 +537,10 @@ struct RcclApi {
     const char* (*GetErrorString)(int) = nullptr;
 };
 RcclApi g_rccl;
+std::mutex g_rccl_mutex;                                      // (handles on distinct devices may be driven from distinct threads)
 int rccl_load()
 {
+    std::lock_guard<std::mutex> lock(g_rccl_mutex);
     if (g_rccl.lib) return 0;
     const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
     void* h = nullptr;

@@ -1343,23 +1343,24 @@ __global__ __launch_bounds__(256, 2) void dec_tail_fused(const TailParams p)
 #pragma unroll
     for (int c = 0; c < NC; ++c) { hsc[c] = c < p.classes ? p.head_scale[c] : 0.f; hsh[c] = c < p.classes ? p.head_shift[c] : 0.f; }
 
-    // ---- LDS read addresses (per lane, tile independent)
-    int src_base[4], img_base[4];
+    // ---- LDS read offsets (per lane, tile independent): a fragment read then costs no address arithmetic (the kernel is VALU-issue
+    // bound at two blocks per CU: 353 of its 858 vector instructions per tile were these).  Pixel block ni of this lane sits at
+    //   src0:  hp = hp0 + ni * 32 (+ tap: (ks >> 1) * 16 + (ks & 1)); slot of granule kk * 4 + fg = (kk * 4 + fg) ^ ((hp0 + (ks & 1)) & 7)
+    //   image: pixel ib0 + ni * 128 (+ tap offset of this lane's k-group; taps 9..15 carry zero weights: any finite pixel will do)
+    const int hp0 = ((frow >> 3) + py) * kTailSrcRowPx + (frow & 7) + px;
+    int src_t[2][2];                                           // [kk][ks & 1]
 #pragma unroll
-    for (int ni = 0; ni < 4; ++ni) {
-        const int i = ni * 16 + frow;                          // pixel of the wave's 8x8 sub-grid
-        const int sy = i >> 3, sx = i & 7;
-        src_base[ni] = (sy + py) * kTailSrcRowPx + (sx + px);                  // + ty*16 + tx
-        img_base[ni] = (2 * sy + py) * kTailImgRowPx + (2 * sx + px);          // + ky*32 + kx
-    }
-    // image taps of this lane's k-chunk: K-step A: tap = kk*4+fg (0..7), K-step B: tap 8 + kk*4+fg (only 8 real)
-    int img_toff[2][2];
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) src_t[kk][e] = hp0 * 128 + (((kk * 4 + fg) ^ ((hp0 + e) & 7)) << 4);
+    const int ib0 = (2 * (frow >> 3) + py) * kTailImgRowPx + 2 * (frow & 7) + px;
+    int img_t[2][2];
 #pragma unroll
     for (int s = 0; s < 2; ++s)
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             const int t = s * 8 + kk * 4 + fg;
-            img_toff[s][kk] = t < 9 ? (t / 3) * kTailImgRowPx + (t % 3) : -1;
+            img_t[s][kk] = (ib0 + (t < 9 ? (t / 3) * kTailImgRowPx + (t % 3) : 0)) * 16;
         }
 
     auto issue_tile = [&](int tile, int buf) __attribute__((always_inline)) {
@@ -1418,18 +1419,13 @@ __global__ __launch_bounds__(256, 2) void dec_tail_fused(const TailParams p)
         auto load_b = [&](int h, bf16x8_t (&b)[4]) __attribute__((always_inline)) {
             if (h < 8) {
                 const int ks = h >> 1, kk = h & 1;
+                const char* a = lds_src + src_t[kk][ks & 1];
 #pragma unroll
-                for (int ni = 0; ni < 4; ++ni) {
-                    const int hp = src_base[ni] + (ks >> 1) * kTailSrcRowPx + (ks & 1);
-                    b[ni] = *(const bf16x8_t*)(lds_src + hp * 128 + (((kk * 4 + fg) ^ (hp & 7)) << 4));
-                }
+                for (int ni = 0; ni < 4; ++ni) b[ni] = *(const bf16x8_t*)(a + (ni * 32 + (ks >> 1) * kTailSrcRowPx + (ks & 1)) * 128);
             } else {
-                const int toff = img_toff[(h - 8) >> 1][(h - 8) & 1];
+                const char* a = lds_img + img_t[(h - 8) >> 1][(h - 8) & 1];
 #pragma unroll
-                for (int ni = 0; ni < 4; ++ni) {
-                    const char* a = toff >= 0 ? lds_img + (img_base[ni] + toff) * 16 : zero_gran;
-                    b[ni] = *(const bf16x8_t*)a;
-                }
+                for (int ni = 0; ni < 4; ++ni) b[ni] = *(const bf16x8_t*)(a + ni * 128 * 16);
             }
         };
         bf16x8_t b0[4], b1[4];

@@ -1081,3 +1081,23 @@ def test_c_abi_rccl_collective_world1(torch_cuda, stitch_model):
     with pytest.raises(RuntimeError, match="no communicator"):
         ctx.allgather_labels_dev(mine.data_ptr(), mine.numel(), everything.data_ptr())
     ctx.set_stream(-1)
+
+
+def test_bench_batch64_workload_on_one_gpu():
+    """`bench.py --workload batch64` (BASELINE configs[3]: pages of 4000x3000 sharded as whole pages, the N > 1 default) on ONE GPU,
+    cut down to two pages: the JSON line must be complete and consistent (a world of one: no exchange, every tile counted)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--workload", "batch64", "--batch-pages", "2", "--steps", "2",
+                          "--warmup", "1", "--repeats", "1", "--no-cpu-baseline", "--no-second-mode", "--no-extras"],
+                         capture_output=True, text=True, env=env, timeout=900, cwd=root)
+    assert res.returncode == 0, res.stderr[-2000:]
+    d = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 1 and d["dtype"] == "f16x3" and d["scaling"] == "strong" and d["unit"] == "patches/s"
+    assert d["config"]["workload_id"] == "batch64" and d["config"]["tiles_per_step"] == 2 * 108 and d["config"]["max_batch"] == 216
+    assert d["value"] > 500 and abs(d["value"] - d["config"]["tiles_per_step"] * d["steps"] / (d["ms_per_step"] * d["steps"] / 1e3)) < 0.01 * d["value"]
+    assert d["exchange"] is None and d["ranks_seen"] is None
+    r = d["roofline"]
+    assert r["bound"] == "mfma" and 0 < r["frac"] < 1 and r["peak"] == 2500.0 and "frac_of_split_peak" in r
