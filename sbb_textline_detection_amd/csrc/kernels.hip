@@ -2039,6 +2039,283 @@ __global__ __launch_bounds__(512, 2) void dec_tail_fused_x3w8(const TailParams p
     }
 }
 
+// dec_tail_fused_x3ps -- the eight-wave tile with the two waves of every SIMD half a tile out of phase.
+// In dec_tail_fused_x3w8 all eight waves load, multiply and run the epilogue at the same moments, and the three parts simply add up
+// (tools/probes/tail_probe.hip, 140 patches: tile loads alone 0.64 ms, MFMAs alone 1.23, epilogue alone 0.83; all of it 2.48).
+// Here the group A = waves 0-3 (channel half 0) does   main loop(t) -> BN / ReLU / partial logits(t) -> part[t & 1] -> tile loads(t+1),
+// and the group B = waves 4-7 (channel half 1) does    label store(t-2), epilogue(t-1) incl. softmax, main loop(t)
+// between two consecutive block barriers.  Wave w and wave w + 4 share a SIMD (waves go to SIMDs round-robin), so while A's wave
+// keeps the MFMA pipe busy B's wave issues the address arithmetic, the DMA loads and the epilogue VALU work, and the other way
+// round in the second half of the step.  B finishes the pixels (A's partial logits come through LDS, written one step earlier).
+// The k-group reduction is a two-step butterfly that leaves ONE pixel per lane (pixel block ni = fg), so the softmax runs once on
+// 64 lanes instead of four times on 16; the fp32 sums associate exactly as in dec_tail_fused_x3w8 (bit-identical outputs).
+constexpr int kT3PsPartBytes = 2 * 4 * 64 * 4 * 4;        // [step parity][4 pixel parities][64 lanes][<= 4 classes] partial logits
+constexpr int kT3PsLdsBytes = 2 * kT3BufBytes + 2 * 256 + kTailConstBytes + kT3PsPartBytes;
+
+template <int NC>
+__global__ __launch_bounds__(512, 2) void dec_tail_fused_x3ps(const TailParams p)
+{
+    constexpr bool F16 = true;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* lbl_tile = smem + 2 * kT3BufBytes;                   // [2][16][16] u8
+    float* cst = (float*)(lbl_tile + 2 * 256);                 // [32 channels][CR]: scale, shift, head_w
+    float* part = (float*)((char*)cst + kTailConstBytes);      // [2][4 parities][64 lanes][NC]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int par = wave & 3, mh = wave >> 2;                  // parity class; channel half = wave group (A = 0, B = 1)
+    const int py = par >> 1, px = par & 1;
+    const int frow = lane & 15, fg = lane >> 4;
+
+    const int H = 2 * p.PH, W = 2 * p.PW;
+    const int tiles_x = W / 16, tiles_y = H / 16;
+    const int tiles_per_patch = tiles_x * tiles_y;
+    const int n_tiles = p.n * tiles_per_patch;
+    // XCD-contiguous walk, as in the other tail kernels
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, GX = gridDim.x >> 3;
+    const int per_xcd = (n_tiles + 7) >> 3;
+    const int xcd_lo = xcd * per_xcd, xcd_hi = min(n_tiles, xcd_lo + per_xcd);
+    const int my_tiles = xcd_lo + slot < xcd_hi ? (xcd_hi - xcd_lo - slot + GX - 1) / GX : 0;
+    if (my_tiles <= 0) return;
+    auto tile_at = [&](int it) __attribute__((always_inline)) -> int { return xcd_lo + slot + it * GX; };
+    constexpr int CR = NC <= 2 ? 4 : 8;
+    if (tid < 32) {
+        float* row = cst + ((tid & 7) * 4 + (tid >> 3)) * CR;
+        row[0] = p.scale[tid];
+        row[1] = p.shift[tid];
+        for (int c = 0; c < CR - 2; ++c) row[2 + c] = c < p.classes ? p.head_w[tid * p.classes + c] : 0.f;
+    }
+
+    // ---- this wave's weights: [plane hi|lo][half-K-step 12] fragments of row block mh (wfrag = per class [hi | lo][12][mi 2])
+    bf16x8_t whi[kTailKSteps * 2], wlo[kTailKSteps * 2];
+    {
+        const uint4* src = (const uint4*)p.wfrag + (size_t)(par * 2 * kTailKSteps * 4) * 64 + lane;
+#pragma unroll
+        for (int h = 0; h < kTailKSteps * 2; ++h) {
+            whi[h] = __builtin_bit_cast(bf16x8_t, src[(size_t)(h * 2 + mh) * 64]);
+            wlo[h] = __builtin_bit_cast(bf16x8_t, src[(size_t)(kTailKSteps * 4 + h * 2 + mh) * 64]);
+        }
+    }
+    float hsc[NC], hsh[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) { hsc[c] = c < p.classes ? p.head_scale[c] : 0.f; hsh[c] = c < p.classes ? p.head_shift[c] : 0.f; }
+
+    // tile-invariant LDS read offsets (see dec_tail_fused_x3w8)
+    const int hp0 = ((frow >> 3) + py) * 16 + (frow & 7) + px;
+    const int s0 = (fg + 2 * hp0) & 15;
+    int src_t[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) src_t[e] = hp0 * 256 + (((s0 + 2 * e) & 15) << 4);
+    int img_t[2][2][4][2];                                     // [image half-step][kk][pixel block][hi | lo] byte offsets
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int t0 = s2 * 8 + kk * 4 + fg;
+            const int t = t0 < 9 ? t0 : 0;                     // taps 9..15 do not exist: zero weights, any finite pixel will do
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+                const int y = 4 * ni + 2 * (frow >> 3) + py + t / 3, x = 2 * (frow & 7) + px + t % 3;
+                const int m = x >> 1, b = x & 1;
+#pragma unroll
+                for (int lo = 0; lo < 2; ++lo)
+                    img_t[s2][kk][ni][lo] = y * 1024 + (m >> 2) * 256 + (((4 * (m & 3) + b + 2 * lo + y) & 15) << 4);
+            }
+        }
+
+    // all 58 wave-instructions of a tile's halo, spread over the four waves w4 = 0..3 that call this
+    auto issue_tile = [&](int tile, int buf, int w4) __attribute__((always_inline)) {
+        const int n = tile / tiles_per_patch;
+        const int rem = tile - n * tiles_per_patch;
+        const int ty = rem / tiles_x, tx = rem - ty * tiles_x;
+        const int y0 = ty * 16, x0 = tx * 16;
+        char* lds_src = smem + buf * kT3BufBytes;
+        char* lds_img = lds_src + kT3SrcBytes;
+#pragma unroll
+        for (int j = 0; j < 10; ++j) {
+            const int ii = w4 + 4 * j;
+            const int hp = ii * 4 + (lane >> 4);
+            const int r = hp >> 4, c = hp & 15;
+            const int g = ((lane & 15) - 2 * c) & 15;              // slot s of pixel hp holds granule (s - 2 hp) & 15
+            const int Y = (y0 >> 1) - 1 + r, X = (x0 >> 1) - 1 + c;
+            const bool ok = ((unsigned)Y < (unsigned)p.PH) & ((unsigned)X < (unsigned)p.PW) & (c < 10);
+            uint32_t off = (uint32_t)((n * p.PH + Y) * p.PW + X) * 256u + (uint32_t)(g * 16 + kZeroHeaderBytes);
+            off = ok ? off : 0u;
+            __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(p.src0 + off), (LDS_AS void*)(lds_src + ii * 1024), 16, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            const int ii = w4 + 4 * j;
+            if (ii < 18) {
+                const int low = ((lane & 15) - ii) & 15;
+                const int c = 2 * (4 * (lane >> 4) + (low >> 2)) + (low & 1), lo = (low >> 1) & 1;
+                const int Y = y0 - 1 + ii, X = x0 - 1 + c;
+                const bool ok = ((unsigned)Y < (unsigned)H) & ((unsigned)X < (unsigned)W) & (c < 18);
+                uint32_t off = (uint32_t)((n * H + Y) * W + X) * 32u + (uint32_t)(lo * 16 + kZeroHeaderBytes);
+                off = ok ? off : 0u;
+                __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(p.img + off), (LDS_AS void*)(lds_img + ii * 1024), 16, 0, 0);
+            }
+        }
+    };
+
+    f32x4_t acc[4];
+    auto main_loop = [&](int it) __attribute__((always_inline)) {
+        const char* lds_src = smem + (it & 1) * kT3BufBytes;
+        const char* lds_img = lds_src + kT3SrcBytes;
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) acc[ni] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        const char* sb[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) sb[e] = lds_src + src_t[e];
+        auto load_b = [&](int h, bf16x8_t (&bh)[4], bf16x8_t (&bl)[4]) __attribute__((always_inline)) {
+            if (h < 8) {
+                const int ks = h >> 1, kk = h & 1;
+                const int dh = (kk * 8 + 2 * (ks & 1)) & 15, dl = (kk * 8 + 4 + 2 * (ks & 1)) & 15;      // src0 pixel: [32 hi][32 lo][32 hi][32 lo]
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) {
+                    const int k = (ni * 32 + (ks >> 1) * 16 + (ks & 1)) * 256;      // immediate offset
+                    bh[ni] = *(const bf16x8_t*)(sb[dh >> 1] + k);
+                    bl[ni] = *(const bf16x8_t*)(sb[dl >> 1] + k);
+                }
+            } else {
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) {
+                    bh[ni] = *(const bf16x8_t*)(lds_img + img_t[(h - 8) >> 1][(h - 8) & 1][ni][0]);
+                    bl[ni] = *(const bf16x8_t*)(lds_img + img_t[(h - 8) >> 1][(h - 8) & 1][ni][1]);
+                }
+            }
+        };
+        auto mac = [&](int h, const bf16x8_t (&bh)[4], const bf16x8_t (&bl)[4]) __attribute__((always_inline)) {
+            // three sweeps over the four accumulators (small terms first)
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) acc[ni] = mfma16<F16>(wlo[h], bh[ni], acc[ni]);
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) acc[ni] = mfma16<F16>(whi[h], bl[ni], acc[ni]);
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) acc[ni] = mfma16<F16>(whi[h], bh[ni], acc[ni]);
+        };
+        bf16x8_t b0h[4], b0l[4], b1h[4], b1l[4];
+        load_b(0, b0h, b0l);
+#pragma unroll
+        for (int h = 0; h < 12; h += 2) {
+            load_b(h + 1, b1h, b1l);
+            mac(h, b0h, b0l);
+            if (h + 2 < 12) load_b(h + 2, b0h, b0l);
+            mac(h + 1, b1h, b1l);
+        }
+    };
+    // BN / ReLU / head on this wave's 16 channels, then the k-group butterfly: lane (frow, fg) ends up with the partial logits of
+    // pixel block ni = fg, pixel frow
+    auto partial_logits = [&](float (&tot)[NC]) __attribute__((always_inline)) {
+        float lg[4][NC];
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+            for (int c = 0; c < NC; ++c) lg[ni][c] = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float* row = cst + ((mh * 4 + q) * 4 + fg) * CR;                // channel fg * 8 + mh * 4 + q
+            const float4 c0 = *(const float4*)row;                                // scale, shift, hw0, hw1
+            float2 c1 = make_float2(0.f, 0.f);
+            if constexpr (NC > 2) c1 = *(const float2*)(row + 4);                 // hw2, hw3
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+                const float yq = fmaxf(acc[ni][q] * c0.x + c0.y, 0.f);
+                lg[ni][0] = fmaf(yq, c0.z, lg[ni][0]);
+                if constexpr (NC > 1) lg[ni][1] = fmaf(yq, c0.w, lg[ni][1]);
+                if constexpr (NC > 2) {
+                    lg[ni][2] = fmaf(yq, c1.x, lg[ni][2]);
+                    lg[ni][3] = fmaf(yq, c1.y, lg[ni][3]);
+                }
+            }
+        }
+        const bool o1 = fg & 1, o2 = fg & 2;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            // step 1 (partner fg ^ 1): keep the pixel blocks of this lane's parity, hand over the other two
+            const float k0 = (o1 ? lg[1][c] : lg[0][c]) + __shfl_xor(o1 ? lg[0][c] : lg[1][c], 16);      // block 0 + (fg & 1)
+            const float k1 = (o1 ? lg[3][c] : lg[2][c]) + __shfl_xor(o1 ? lg[2][c] : lg[3][c], 16);      // block 2 + (fg & 1)
+            // step 2 (partner fg ^ 2)
+            tot[c] = (o2 ? k1 : k0) + __shfl_xor(o2 ? k0 : k1, 32);
+        }
+    };
+    auto tile_coords = [&](int tile, int& n, int& tyy, int& txx) __attribute__((always_inline)) {
+        n = tile / tiles_per_patch;
+        const int rem = tile - n * tiles_per_patch;
+        tyy = rem / tiles_x;
+        txx = rem - tyy * tiles_x;
+    };
+    // group B: finish tile `it` (its accumulators are still in this wave's registers; A's half came through part[it & 1])
+    auto finish = [&](int it) __attribute__((always_inline)) {
+        float tot[NC];
+        partial_logits(tot);
+        const float* pa = part + (((it & 1) * 4 + par) * 64 + lane) * NC;
+        float logit[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) logit[c] = (pa[c] + tot[c]) * hsc[c] + hsh[c];
+        float mx = -3.0e38f;
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+            if (c < p.classes) mx = fmaxf(mx, logit[c]);
+        float pr[NC], sum = 0.f;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) { pr[c] = c < p.classes ? expf(logit[c] - mx) : 0.f; sum += pr[c]; }
+        int best = 0;
+        float bestp = -1.f;
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+            if (c < p.classes) {
+                pr[c] = pr[c] / sum;
+                if (pr[c] > bestp) { bestp = pr[c]; best = c; }
+            }
+        const int i = fg * 16 + frow;
+        const int oy = 2 * (i >> 3) + py, ox = 2 * (i & 7) + px;
+        lbl_tile[(it & 1) * 256 + oy * 16 + ox] = (char)best;
+        if (p.probs) {
+            int n, tyy, txx;
+            tile_coords(tile_at(it), n, tyy, txx);
+            float* dst = p.probs + ((size_t)(n * H + tyy * 16 + oy) * W + txx * 16 + ox) * p.classes;
+#pragma unroll
+            for (int c = 0; c < NC; ++c)
+                if (c < p.classes) dst[c] = pr[c];
+        }
+    };
+    auto store_labels = [&](int it) __attribute__((always_inline)) {       // (wave 4, after the barrier that follows finish(it))
+        if (wave == 4 && lane < 16) {
+            int n, tyy, txx;
+            tile_coords(tile_at(it), n, tyy, txx);
+            *(uint4*)(p.labels + (size_t)(n * H + tyy * 16 + lane) * W + txx * 16) = *(const uint4*)(lbl_tile + (it & 1) * 256 + lane * 16);
+        }
+    };
+
+    if (mh == 0) issue_tile(tile_at(0), 0, par);
+    for (int it = 0; it < my_tiles; ++it) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (mh == 1) {
+            if (it >= 2) store_labels(it - 2);
+            if (it >= 1) finish(it - 1);
+        }
+        main_loop(it);
+        if (mh == 0) {
+            float tot[NC];
+            partial_logits(tot);
+            float* pa = part + (((it & 1) * 4 + par) * 64 + lane) * NC;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) pa[c] = tot[c];
+        }
+        if (mh == 0 && it + 1 < my_tiles) issue_tile(tile_at(it + 1), (it + 1) & 1, par);
+    }
+    __syncthreads();
+    if (mh == 1) {
+        if (my_tiles >= 2) store_labels(my_tiles - 2);
+        finish(my_tiles - 1);
+    }
+    __syncthreads();
+    if (mh == 1) store_labels(my_tiles - 1);
+}
+
 hipError_t launch_tail(const TailParams& p, int precision, int num_cus, hipStream_t s)
 {
     const int n_tiles = p.n * (p.PH / 8) * (p.PW / 8);
@@ -2059,7 +2336,16 @@ hipError_t launch_tail(const TailParams& p, int precision, int num_cus, hipStrea
             return hipSuccess;
         };
         static const bool w8 = !(getenv("SBBSEG_TAIL_X3_W8") && getenv("SBBSEG_TAIL_X3_W8")[0] == '0');      // A/B: 0 = one wave per SIMD
-        if (w8) {
+        static const bool ps = !(getenv("SBBSEG_TAIL_X3_PS") && getenv("SBBSEG_TAIL_X3_PS")[0] == '0');      // A/B: 0 = the lock-step eight-wave kernel
+        if (ps && w8) {
+            auto gops = [&](auto kern) -> hipError_t {
+                hipError_t e8 = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, kT3PsLdsBytes);
+                if (e8 != hipSuccess) return e8;
+                hipLaunchKernelGGL(kern, dim3(grid3), dim3(512), kT3PsLdsBytes, s, p);
+                return hipSuccess;
+            };
+            e = p.classes <= 2 ? gops(dec_tail_fused_x3ps<2>) : gops(dec_tail_fused_x3ps<4>);
+        } else if (w8) {
             auto go8 = [&](auto kern) -> hipError_t {
                 hipError_t e8 = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, kT3LdsBytes + kT3PartBytes);
                 if (e8 != hipSuccess) return e8;
