@@ -2124,37 +2124,43 @@ __global__ __launch_bounds__(512, 2) void dec_tail_fused_x3ps(const TailParams p
             }
         }
 
-    // all 58 wave-instructions of a tile's halo, spread over the four waves w4 = 0..3 that call this
-    auto issue_tile = [&](int tile, int buf, int w4) __attribute__((always_inline)) {
+    // Halo loads (group A): wave `par` issues the src0 pieces ii = par + 4 j (j = 0..9: halo row j, halo columns 4 par .. 4 par + 3) and
+    // the image rows ii = par + 4 j (< 18).  `buffer_load ... lds` with a per-tile resource (this patch's image, one pixel of
+    // bias so that the lane part is never negative): the lane offset of a src0 piece does not depend on j or on the tile, the row
+    // rides in the scalar offset, and anything outside the image sets bit 31 of the lane offset (past num_records: the hardware
+    // writes zeros).  ~3 vector instructions per piece instead of the ~20 of per-lane global addresses.
+    const int c_src = par * 4 + (lane >> 4);                   // halo column of this lane's src0 pixel
+    const uint32_t voff_src = (uint32_t)(c_src * 256 + ((((lane & 15) - 2 * c_src) & 15) << 4));      // slot s of pixel hp holds granule (s - 2 hp) & 15
+    const int low0 = ((lane & 15) - par) & 15;                 // image row ii: physical unit l holds the (pixel, plane) of rotated unit (l - ii) & 15
+    const uint32_t src_img_bytes = (uint32_t)(p.PH * p.PW) * 256u, img_img_bytes = (uint32_t)(H * W) * 32u;
+    auto issue_tile = [&](int tile, int buf) __attribute__((always_inline)) {
         const int n = tile / tiles_per_patch;
         const int rem = tile - n * tiles_per_patch;
         const int ty = rem / tiles_x, tx = rem - ty * tiles_x;
         const int y0 = ty * 16, x0 = tx * 16;
         char* lds_src = smem + buf * kT3BufBytes;
         char* lds_img = lds_src + kT3SrcBytes;
+        const char* sbase = p.src0 + kZeroHeaderBytes - 256 + (size_t)n * src_img_bytes;
+        const uint32_t vs = ((unsigned)((x0 >> 1) - 1 + c_src) < (unsigned)p.PW && c_src < 10) ? voff_src : 0x80000000u;
 #pragma unroll
         for (int j = 0; j < 10; ++j) {
-            const int ii = w4 + 4 * j;
-            const int hp = ii * 4 + (lane >> 4);
-            const int r = hp >> 4, c = hp & 15;
-            const int g = ((lane & 15) - 2 * c) & 15;              // slot s of pixel hp holds granule (s - 2 hp) & 15
-            const int Y = (y0 >> 1) - 1 + r, X = (x0 >> 1) - 1 + c;
-            const bool ok = ((unsigned)Y < (unsigned)p.PH) & ((unsigned)X < (unsigned)p.PW) & (c < 10);
-            uint32_t off = (uint32_t)((n * p.PH + Y) * p.PW + X) * 256u + (uint32_t)(g * 16 + kZeroHeaderBytes);
-            off = ok ? off : 0u;
-            __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(p.src0 + off), (LDS_AS void*)(lds_src + ii * 1024), 16, 0, 0);
+            const int Y = (y0 >> 1) - 1 + j;
+            const bool yok = (unsigned)Y < (unsigned)p.PH;
+            const uint32_t soff = yok ? (uint32_t)(Y * p.PW + (x0 >> 1)) * 256u : 0u;
+            buffer_load_lds16(sbase, src_img_bytes + 256u, (LDS_AS void*)(lds_src + (par + 4 * j) * 1024), yok ? vs : 0x80000000u, soff);
         }
+        const char* ibase = p.img + kZeroHeaderBytes - 32 + (size_t)n * img_img_bytes;
 #pragma unroll
         for (int j = 0; j < 5; ++j) {
-            const int ii = w4 + 4 * j;
+            const int ii = par + 4 * j;
             if (ii < 18) {
-                const int low = ((lane & 15) - ii) & 15;
+                const int low = (low0 - 4 * j) & 15;
                 const int c = 2 * (4 * (lane >> 4) + (low >> 2)) + (low & 1), lo = (low >> 1) & 1;
-                const int Y = y0 - 1 + ii, X = x0 - 1 + c;
-                const bool ok = ((unsigned)Y < (unsigned)H) & ((unsigned)X < (unsigned)W) & (c < 18);
-                uint32_t off = (uint32_t)((n * H + Y) * W + X) * 32u + (uint32_t)(lo * 16 + kZeroHeaderBytes);
-                off = ok ? off : 0u;
-                __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(p.img + off), (LDS_AS void*)(lds_img + ii * 1024), 16, 0, 0);
+                const int Y = y0 - 1 + ii;
+                const bool yok = (unsigned)Y < (unsigned)H;
+                const bool xok = ((unsigned)(x0 - 1 + c) < (unsigned)W) & (c < 18);
+                const uint32_t soff = yok ? (uint32_t)(Y * W + x0) * 32u : 0u;
+                buffer_load_lds16(ibase, img_img_bytes + 32u, (LDS_AS void*)(lds_img + ii * 1024), (xok && yok) ? (uint32_t)(c * 32 + lo * 16) : 0x80000000u, soff);
             }
         }
     };
@@ -2289,7 +2295,7 @@ __global__ __launch_bounds__(512, 2) void dec_tail_fused_x3ps(const TailParams p
         }
     };
 
-    if (mh == 0) issue_tile(tile_at(0), 0, par);
+    if (mh == 0) issue_tile(tile_at(0), 0);
     for (int it = 0; it < my_tiles; ++it) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -2299,13 +2305,13 @@ __global__ __launch_bounds__(512, 2) void dec_tail_fused_x3ps(const TailParams p
         }
         main_loop(it);
         if (mh == 0) {
+            if (it + 1 < my_tiles) issue_tile(tile_at(it + 1), (it + 1) & 1);       // (before the epilogue: more time to land)
             float tot[NC];
             partial_logits(tot);
             float* pa = part + (((it & 1) * 4 + par) * 64 + lane) * NC;
 #pragma unroll
             for (int c = 0; c < NC; ++c) pa[c] = tot[c];
         }
-        if (mh == 0 && it + 1 < my_tiles) issue_tile(tile_at(it + 1), (it + 1) & 1, par);
     }
     __syncthreads();
     if (mh == 1) {

@@ -23,6 +23,7 @@ int main(int argc, char** argv)
     CK(hipMalloc(&src, src_bytes)); CK(hipMalloc(&img, img_bytes)); CK(hipMalloc(&w, w_bytes)); CK(hipMalloc(&cst, 4096)); CK(hipMalloc(&labels, (size_t)n * 4 * PH * PW));
     for (size_t o = 0; o < src_bytes; o += h.size() * 2) CK(hipMemcpy(src + o, h.data(), std::min(h.size() * 2, src_bytes - o), hipMemcpyHostToDevice));
     for (size_t o = 0; o < img_bytes; o += h.size() * 2) CK(hipMemcpy(img + o, h.data(), std::min(h.size() * 2, img_bytes - o), hipMemcpyHostToDevice));
+    CK(hipMemset(src, 0, kZeroHeaderBytes)); CK(hipMemset(img, 0, kZeroHeaderBytes));      // (the buffers start with a zero header)
     CK(hipMemcpy(w, h.data(), w_bytes, hipMemcpyHostToDevice));
     std::vector<float> c(1024, 0.5f);
     for (auto& v : c) v = (float)(rand() % 2001 - 1000) * 1e-3f;
