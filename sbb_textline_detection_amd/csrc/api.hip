@@ -1314,16 +1314,19 @@ int sbbseg_add_tail(sbbseg_ctx* c, int src0_tensor, int img_c8_tensor, const flo
     const int C0 = 64, CO = 32;
     // pre-summed fp32 weights in fragment order first; then 16-bit (plain modes) or hi | lo after the power-of-two pre-scale
     // (split mode: per class [hi fragments][lo fragments], scale divided by the pre-scale, see sbbseg_add_conv)
-    std::vector<float> fragf((size_t)4 * kTailKSteps * 4 * 64 * 8, 0.f);
+    // (split mode: the image taps are packed two to a k-group -- [tap 2g: ch 0..3][tap 2g + 1: ch 0..3] -- and take ONE K-step,
+    // see dec_tail_fused_x3ps; the plain modes keep one tap per k-group, two K-steps)
+    const int KS = split ? 5 : kTailKSteps;
+    std::vector<float> fragf((size_t)4 * KS * 4 * 64 * 8, 0.f);
     for (int q = 0; q < 4; ++q) {
         const int py = q >> 1, px = q & 1;
-        for (int ks = 0; ks < kTailKSteps; ++ks)
+        for (int ks = 0; ks < KS; ++ks)
             for (int kk = 0; kk < 2; ++kk)
                 for (int mi = 0; mi < 2; ++mi)
                     for (int l = 0; l < 64; ++l) {
                         const int o = conv_row_channel(mi * 16 + (l & 15), CO);
                         const int gidx = kk * 4 + (l >> 4);
-                        float* dst = &fragf[((((size_t)q * kTailKSteps + ks) * 4 + kk * 2 + mi) * 64 + l) * 8];
+                        float* dst = &fragf[((((size_t)q * KS + ks) * 4 + kk * 2 + mi) * 64 + l) * 8];
                         for (int e = 0; e < 8; ++e) {
                             float v = 0.f;
                             if (ks < 4) {
@@ -1331,6 +1334,9 @@ int sbbseg_add_tail(sbbseg_ctx* c, int src0_tensor, int img_c8_tensor, const flo
                                 for (int ky = taps[py][ty][0]; ky <= taps[py][ty][1]; ++ky)
                                     for (int kx = taps[px][tx][0]; kx <= taps[px][tx][1]; ++kx)
                                         v += w_src0[((size_t)(ky * 3 + kx) * C0 + ch) * CO + o];
+                            } else if (split) {
+                                const int t = kk * 8 + 2 * (l >> 4) + (e >> 2), ch = e & 3;
+                                if (t < 9 && ch < 3) v = w_img[((size_t)t * 3 + ch) * CO + o];
                             } else {
                                 const int t = (ks - 4) * 8 + gidx;
                                 if (t < 9 && e < 3) v = w_img[((size_t)t * 3 + e) * CO + o];
@@ -1339,7 +1345,7 @@ int sbbseg_add_tail(sbbseg_ctx* c, int src0_tensor, int img_c8_tensor, const flo
                         }
                     }
     }
-    const size_t per_class = (size_t)kTailKSteps * 4 * 64 * 8;
+    const size_t per_class = (size_t)KS * 4 * 64 * 8;
     std::vector<uint16_t> frag(fragf.size() * (split ? 2 : 1), 0);
     std::vector<float> scale_v(scale, scale + CO);
     if (!split) {
@@ -1377,7 +1383,7 @@ int sbbseg_add_tail(sbbseg_ctx* c, int src0_tensor, int img_c8_tensor, const flo
     snprintf(nm, sizeof(nm), "tail_conv3x3_c67to32_up_cat_head%d_%dx%d", classes, c->in_H, c->in_W);
     op.name = nm;
     op.flops = 2.0 * (algorithmic_macs > 0 ? algorithmic_macs : (double)c->in_H * c->in_W * CO * (9.0 * 67 + classes));
-    op.issued_flops = 2.0 * c->in_H * c->in_W * CO * (double)(kTailKSteps * kBK) * (split ? 3 : 1);
+    op.issued_flops = 2.0 * c->in_H * c->in_W * CO * (double)(KS * kBK) * (split ? 3 : 1);
     op.min_bytes = (double)s0.H * s0.W * 64 * c->elem * c->planes + (double)c->in_H * c->in_W * (8 * c->elem * c->planes + 1);
     c->classes = classes;
     c->ops.push_back(op);
@@ -2453,6 +2459,9 @@ int sbbseg_debug_ingest(sbbseg_ctx* c, const uint8_t* page_hwc, int Hp, int Wp, 
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     (void)hipFree(d_tmp);
     HIPCHK(e);
+    if (c->planes == 2 && form == SBBSEG_INPUT_C8)      // (the hi plane's slots 4..6 repeat lo(ch 0..2) for the fused tail: not channels)
+        for (size_t i = 0; i < n; i += 8)
+            for (int ch = 3; ch < 8; ++ch) out[i + ch] = 0.f;
     return 0;
     API_END
 }
@@ -2473,6 +2482,9 @@ int sbbseg_debug_read_tensor(sbbseg_ctx* c, int tensor_id, int n, float* out, si
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     (void)hipFree(d_tmp);
     HIPCHK(e);
+    if (c->planes == 2 && t.is_input_form && t.form == SBBSEG_INPUT_C8)      // (see sbbseg_debug_ingest)
+        for (size_t i = 0; i < cnt; i += 8)
+            for (int ch = 3; ch < 8; ++ch) out[i + ch] = 0.f;
     return 0;
     API_END
 }

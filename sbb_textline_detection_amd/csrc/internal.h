@@ -107,10 +107,11 @@ struct ConvParams {
 // probabilities) written.  See dec_tail_fused in kernels.hip.
 struct TailParams {
     const char* src0;         // buffer start (zero header), [n][PH][PW][64] 16-bit
-    const char* img;          // buffer start (zero header), C8 form [n][2PH][2PW][8]
+    const char* img;          // buffer start (zero header), C8 form [n][2PH][2PW][8] (split mode: hi slots 4..6 repeat lo 0..2)
     int PH, PW;               // src0 size; output is 2PH x 2PW
     int n;                    // patches
-    const void* wfrag;        // [4 parities][6 K-steps][2 kk][2 mi][64 lanes] x 16 bytes, MFMA A-fragment order
+    const void* wfrag;        // [4 parities][6 K-steps][2 kk][2 mi][64 lanes] x 16 bytes, MFMA A-fragment order (split mode: per parity
+                              // [hi | lo][5 K-steps][2 kk][2 mi][64 lanes], the image taps packed two to a k-group: sbbseg_add_tail)
     const float* scale;       // [32]
     const float* shift;
     int classes;              // <= 4

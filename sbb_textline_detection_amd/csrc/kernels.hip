@@ -1520,537 +1520,40 @@ __global__ __launch_bounds__(256, 2) void dec_tail_fused(const TailParams p)
 }
 
 // ------------------------------------------------------------------------------------------------
-// dec_tail_fused_x3 -- the same tail in the split mode (kF16X3): src0 pixels are [32 hi][32 lo][32 hi][32 lo] (256 B), image pixels
-// [8 hi][8 lo] (32 B), the wave's weights are hi + lo fragments (192 VGPRs), three MFMAs per product (lo*hi, hi*lo, hi*hi),
-// everything after the accumulators as in dec_tail_fused.  One block per CU (up to 512 registers per lane).  The generic
-// kernel needs 5.1 ms per 140 patches for this layer (32 output channels: 24 MFMAs per 288 staged rows).
+// dec_tail_fused_x3ps -- the same tail in the split mode (kF16X3): three MFMAs per product (lo*hi, hi*lo, hi*hi), everything after
+// the accumulators as in dec_tail_fused.  The generic kernel needs 5.1 ms per 140 patches for this layer (32 output channels:
+// 24 MFMAs per 288 staged rows).
+//   * tile = 16 x 16 output pixels, one block of EIGHT waves per CU: wave = (output-parity class, half of the 32 output channels);
+//     its weights are hi + lo fragments in registers (80 VGPRs), two waves share a SIMD
+//   * src0 halo: 10 x 10 pixels (rows of 16) x 256 B ([32 hi][32 lo][32 hi][32 lo]); pixel hp keeps granule g at slot
+//     (g + 2 hp) & 15.  A 16-lane group of ds_read_b128 holds two k-groups (fg = a, a + 1) of eight pixels each whose hp are eight
+//     consecutive residues: the rotation sends one k-group to the eight even slots and the other to the eight odd ones (an XOR
+//     swizzle collided two-way in every group: PMC SQ_LDS_BANK_CONFLICT 86 %)
+//   * image halo: 18 x 18 pixels x 16 B.  In the split mode the C8 input form keeps lo(ch 0..2) a second time in the unused
+//     channel slots 4..6 of its hi plane (write_split_input), so the first granule of a pixel is [h0 h1 h2 0 | l0 l1 l2 0]: one
+//     16-byte load fetches both planes, a k-group of 8 is TWO taps x 4 channel slots, and the nine image taps take 2 half-K-steps
+//     (K = 36 of 64) instead of the 4 of one-tap-per-granule (K = 72 of 128): 120 instead of 144 MFMAs per wave and tile.
+//     LDS row y = 32 units of 16 B; pixel x sits at unit ((x >> 1) + 12 (x & 1) + 16 - 4 (y & 3)) & 31 (brute-forced over this
+//     family: 1.31 LDS cycles per conflict-free cycle on the image reads, which are 12 of 76 reads per wave and tile)
 // ------------------------------------------------------------------------------------------------
 constexpr int kT3SrcBytes = 10 * 16 * 256;              // 40 KB: 10 rows x 16 pixels (10 used) x 256 B
-constexpr int kT3ImgBytes = 18 * 32 * 32;               // 18 KB: 18 rows x 32 pixels (18 used) x 32 B
+constexpr int kT3ImgBytes = 18 * 32 * 16;               // 9 KB: 18 rows x 32 units (18 used) x 16 B
 constexpr int kT3BufBytes = kT3SrcBytes + kT3ImgBytes;
-constexpr int kT3LdsBytes = 2 * kT3BufBytes + 256 + 64 + kTailConstBytes;
-constexpr int kT3PartBytes = 4 * 64 * 4 * 4;              // dec_tail_fused_x3w8: partial logits [4 parities][64 pixels][<= 4 classes]
+constexpr int kT3HalfSteps = 10;                        // 4 taps x 64 channels of src0 = 8 half-K-steps of 32, + 2 for the 9 image taps
 
-template <int NC>
-__global__ __launch_bounds__(256, 1) void dec_tail_fused_x3(const TailParams p)
-{
-    constexpr bool F16 = true;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* lbl_tile = smem + 2 * kT3BufBytes;                   // [16][16] u8
-    char* zero_gran = lbl_tile + 256;                          // 16 zero bytes (image taps 9..15)
-    float* cst = (float*)(zero_gran + 64);                     // [32 channels][CR]: scale, shift, head_w
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int py = wave >> 1, px = wave & 1;
-    const int frow = lane & 15, fg = lane >> 4;
-
-    const int H = 2 * p.PH, W = 2 * p.PW;
-    const int tiles_x = W / 16, tiles_y = H / 16;
-    const int tiles_per_patch = tiles_x * tiles_y;
-    const int n_tiles = p.n * tiles_per_patch;
-    // XCD-contiguous walk (grid = a multiple of 8 blocks): XCD x = block % 8 owns tiles [x * per_xcd, (x + 1) * per_xcd), so the
-    // halo pixels neighbouring tiles share are fetched into one L2 once instead of once per XCD (a round-robin walk
-    // re-fetched them from HBM: 1.8x the input bytes, L2 hit rate 2 %)
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, GX = gridDim.x >> 3;
-    const int per_xcd = (n_tiles + 7) >> 3;
-    const int xcd_lo = xcd * per_xcd, xcd_hi = min(n_tiles, xcd_lo + per_xcd);
-    const int my_tiles = xcd_lo + slot < xcd_hi ? (xcd_hi - xcd_lo - slot + GX - 1) / GX : 0;
-    if (my_tiles <= 0) return;
-    auto tile_at = [&](int it) __attribute__((always_inline)) -> int { return xcd_lo + slot + it * GX; };
-    if (tid < 4) ((uint32_t*)zero_gran)[tid] = 0u;
-    constexpr int CR = NC <= 2 ? 4 : 8;
-    if (tid < 32) {
-        float* row = cst + ((tid & 7) * 4 + (tid >> 3)) * CR;
-        row[0] = p.scale[tid];
-        row[1] = p.shift[tid];
-        for (int c = 0; c < CR - 2; ++c) row[2 + c] = c < p.classes ? p.head_w[tid * p.classes + c] : 0.f;
-    }
-
-    // ---- this wave's weights: [plane hi|lo][half-K-step 12][mi 2] fragments
-    bf16x8_t whi[kTailKSteps * 4], wlo[kTailKSteps * 4];
-    {
-        const uint4* src = (const uint4*)p.wfrag + (size_t)(wave * 2 * kTailKSteps * 4) * 64 + lane;
-#pragma unroll
-        for (int f = 0; f < kTailKSteps * 4; ++f) {
-            whi[f] = __builtin_bit_cast(bf16x8_t, src[(size_t)f * 64]);
-            wlo[f] = __builtin_bit_cast(bf16x8_t, src[(size_t)(kTailKSteps * 4 + f) * 64]);
-        }
-    }
-    float hsc[NC], hsh[NC];
-#pragma unroll
-    for (int c = 0; c < NC; ++c) { hsc[c] = c < p.classes ? p.head_scale[c] : 0.f; hsh[c] = c < p.classes ? p.head_shift[c] : 0.f; }
-
-    // Tile-invariant LDS read offsets, so that a fragment read costs no address arithmetic (the round-2 form spent ~7 integer ops
-    // per ds_read_b128: 664 of the kernel's 1 643 vector instructions per tile).  Pixel block ni of this lane sits at
-    //   src0:  hp = hp0 + ni * 32 (+ tap: (ks >> 1) * 16 + (ks & 1)),  slot of granule G = (G + 2 hp) & 15 = (s0 + D) & 15 with
-    //          s0 = (fg + 2 hp0) & 15 per lane and D = kk * 4 + 8 * lo + 2 * (ks & 1) known at compile time (even: 8 table entries);
-    //   image: pixel ib0 + ni * 128 (+ tap offset of this lane's k-group).
-    // Everything that depends on ni / ks is a multiple of 256 (32) bytes and rides in the instruction's immediate offset.
-    const int hp0 = ((frow >> 3) + py) * 16 + (frow & 7) + px;
-    const int s0 = (fg + 2 * hp0) & 15;
-    int src_t[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) src_t[e] = hp0 * 256 + (((s0 + 2 * e) & 15) << 4);
-    const int ib0 = (2 * (frow >> 3) + py) * 32 + 2 * (frow & 7) + px;
-    int img_t[2][2];                                           // byte offset of (pixel block 0, this lane's tap) per image half-step
-#pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            const int t = s2 * 8 + kk * 4 + fg;
-            // taps 9..15 do not exist: their weights are zero (api.hip packs them so), any finite pixel will do -> tap 0
-            img_t[s2][kk] = (ib0 + (t < 9 ? (t / 3) * 32 + (t % 3) : 0)) * 32;
-        }
-
-    auto issue_tile = [&](int tile, int buf) __attribute__((always_inline)) {
-        const int n = tile / tiles_per_patch;
-        const int rem = tile - n * tiles_per_patch;
-        const int ty = rem / tiles_x, tx = rem - ty * tiles_x;
-        const int y0 = ty * 16, x0 = tx * 16;
-        char* lds_src = smem + buf * kT3BufBytes;
-        char* lds_img = lds_src + kT3SrcBytes;
-        // src0 halo: 160 pixels x 16 granules (8 hi, 8 lo) = 40 wave-instructions of 4 pixels; pixel hp keeps granule g at slot
-        // (g + 2 hp) & 15.  A 16-lane group of ds_read_b128 holds two k-groups (fg = a, a + 1) of eight pixels each whose hp are
-        // eight consecutive residues: rotation by 2 hp sends one k-group to the eight even slots and the other to the eight odd
-        // ones.  (The XOR swizzle g ^ (hp & 15) of round 2 collided two-way in every group: PMC SQ_LDS_BANK_CONFLICT 86 %.)
-#pragma unroll
-        for (int j = 0; j < 10; ++j) {
-            const int ii = wave + 4 * j;
-            const int hp = ii * 4 + (lane >> 4);
-            const int r = hp >> 4, c = hp & 15;
-            const int g = ((lane & 15) - 2 * c) & 15;              // slot s of pixel hp holds granule (s - 2 hp) & 15
-            const int Y = (y0 >> 1) - 1 + r, X = (x0 >> 1) - 1 + c;
-            const bool ok = ((unsigned)Y < (unsigned)p.PH) & ((unsigned)X < (unsigned)p.PW) & (c < 10);
-            uint32_t off = (uint32_t)((n * p.PH + Y) * p.PW + X) * 256u + (uint32_t)(g * 16 + kZeroHeaderBytes);
-            off = ok ? off : 0u;
-            __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(p.src0 + off), (LDS_AS void*)(lds_src + ii * 1024), 16, 0, 0);
-        }
-        // image halo: 18 rows x 32 pixels x (hi 16 B, lo 16 B) = 18 wave-instructions of one row
-#pragma unroll
-        for (int j = 0; j < 5; ++j) {
-            const int ii = wave + 4 * j;
-            if (ii < 18) {
-                const int c = lane >> 1;
-                const int Y = y0 - 1 + ii, X = x0 - 1 + c;
-                const bool ok = ((unsigned)Y < (unsigned)H) & ((unsigned)X < (unsigned)W) & (c < 18);
-                uint32_t off = (uint32_t)((n * H + Y) * W + X) * 32u + (uint32_t)((lane & 1) * 16 + kZeroHeaderBytes);
-                off = ok ? off : 0u;
-                __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(p.img + off), (LDS_AS void*)(lds_img + ii * 1024), 16, 0, 0);
-            }
-        }
-    };
-
-    issue_tile(tile_at(0), 0);
-    for (int it = 0; it < my_tiles; ++it) {
-        const int tile = tile_at(it);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (it + 1 < my_tiles) issue_tile(tile_at(it + 1), (it + 1) & 1);
-
-        const char* lds_src = smem + (it & 1) * kT3BufBytes;
-        const char* lds_img = lds_src + kT3SrcBytes;
-        f32x4_t acc[2][4];
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-
-        const char* sb[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) sb[e] = lds_src + src_t[e];
-        auto load_b = [&](int h, bf16x8_t (&bh)[4], bf16x8_t (&bl)[4]) __attribute__((always_inline)) {
-            if (h < 8) {
-                const int ks = h >> 1, kk = h & 1;
-                const int dh = (kk * 8 + 2 * (ks & 1)) & 15, dl = (kk * 8 + 4 + 2 * (ks & 1)) & 15;      // src0 pixel: [32 hi][32 lo][32 hi][32 lo]
-#pragma unroll
-                for (int ni = 0; ni < 4; ++ni) {
-                    const int k = (ni * 32 + (ks >> 1) * 16 + (ks & 1)) * 256;      // immediate offset
-                    bh[ni] = *(const bf16x8_t*)(sb[dh >> 1] + k);
-                    bl[ni] = *(const bf16x8_t*)(sb[dl >> 1] + k);
-                }
-            } else {
-                const char* a = lds_img + img_t[(h - 8) >> 1][(h - 8) & 1];
-#pragma unroll
-                for (int ni = 0; ni < 4; ++ni) {
-                    bh[ni] = *(const bf16x8_t*)(a + ni * 128 * 32);
-                    bl[ni] = *(const bf16x8_t*)(a + ni * 128 * 32 + 16);
-                }
-            }
-        };
-        auto mac = [&](int h, const bf16x8_t (&bh)[4], const bf16x8_t (&bl)[4]) __attribute__((always_inline)) {
-#pragma unroll
-            for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-                for (int mi = 0; mi < 2; ++mi) {
-                    acc[mi][ni] = mfma16<F16>(wlo[h * 2 + mi], bh[ni], acc[mi][ni]);
-                    acc[mi][ni] = mfma16<F16>(whi[h * 2 + mi], bl[ni], acc[mi][ni]);
-                    acc[mi][ni] = mfma16<F16>(whi[h * 2 + mi], bh[ni], acc[mi][ni]);
-                }
-        };
-        bf16x8_t b0h[4], b0l[4], b1h[4], b1l[4];
-        load_b(0, b0h, b0l);
-#pragma unroll
-        for (int h = 0; h < 12; h += 2) {
-            load_b(h + 1, b1h, b1l);
-            mac(h, b0h, b0l);
-            if (h + 2 < 12) load_b(h + 2, b0h, b0l);
-            mac(h + 1, b1h, b1l);
-        }
-
-        // ---- epilogue: BN/ReLU, head, softmax, argmax (as dec_tail_fused)
-        const int n = tile / tiles_per_patch;
-        const int rem = tile - n * tiles_per_patch;
-        const int tyy = rem / tiles_x, txx = rem - tyy * tiles_x;
-        // (channel constants are read once per tile -- q outer, the four pixel blocks inner -- not once per pixel block)
-        float lg[4][NC];
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-            for (int c = 0; c < NC; ++c) lg[ni][c] = 0.f;
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const float* row = cst + (q * 4 + fg) * CR;
-            const float4 c0 = *(const float4*)row;                                // scale, shift, hw0, hw1
-            float2 c1 = make_float2(0.f, 0.f);
-            if constexpr (NC > 2) c1 = *(const float2*)(row + 4);                 // hw2, hw3
-#pragma unroll
-            for (int ni = 0; ni < 4; ++ni) {
-                const float v = q < 4 ? acc[0][ni][q] : acc[1][ni][q - 4];
-                const float yq = fmaxf(v * c0.x + c0.y, 0.f);
-                lg[ni][0] = fmaf(yq, c0.z, lg[ni][0]);
-                if constexpr (NC > 1) lg[ni][1] = fmaf(yq, c0.w, lg[ni][1]);
-                if constexpr (NC > 2) {
-                    lg[ni][2] = fmaf(yq, c1.x, lg[ni][2]);
-                    lg[ni][3] = fmaf(yq, c1.y, lg[ni][3]);
-                }
-            }
-        }
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni) {
-            float logit[NC];
-#pragma unroll
-            for (int c = 0; c < NC; ++c) logit[c] = lg[ni][c];
-#pragma unroll
-            for (int c = 0; c < NC; ++c) {
-                float a = logit[c];
-                a += __shfl_xor(a, 16);
-                a += __shfl_xor(a, 32);
-                logit[c] = a * hsc[c] + hsh[c];
-            }
-            if (fg == 0) {
-                float mx = -3.0e38f;
-#pragma unroll
-                for (int c = 0; c < NC; ++c)
-                    if (c < p.classes) mx = fmaxf(mx, logit[c]);
-                float pr[NC], sum = 0.f;
-#pragma unroll
-                for (int c = 0; c < NC; ++c) { pr[c] = c < p.classes ? expf(logit[c] - mx) : 0.f; sum += pr[c]; }
-                int best = 0;
-                float bestp = -1.f;
-#pragma unroll
-                for (int c = 0; c < NC; ++c)
-                    if (c < p.classes) {
-                        pr[c] = pr[c] / sum;
-                        if (pr[c] > bestp) { bestp = pr[c]; best = c; }
-                    }
-                const int i = ni * 16 + frow;
-                const int oy = 2 * (i >> 3) + py, ox = 2 * (i & 7) + px;
-                lbl_tile[oy * 16 + ox] = (char)best;
-                if (p.probs) {
-                    float* dst = p.probs + ((size_t)(n * H + tyy * 16 + oy) * W + txx * 16 + ox) * p.classes;
-#pragma unroll
-                    for (int c = 0; c < NC; ++c)
-                        if (c < p.classes) dst[c] = pr[c];
-                }
-            }
-        }
-        __syncthreads();
-        if (tid < 16)
-            *(uint4*)(p.labels + (size_t)(n * H + tyy * 16 + tid) * W + txx * 16) = *(const uint4*)(lbl_tile + tid * 16);
-    }
-}
-
-// dec_tail_fused_x3w8 -- the same tile with EIGHT waves (two per SIMD): wave = (parity class, half of the 32 output channels).
-// With one wave per SIMD (dec_tail_fused_x3) the tile loop is issue-bound on its own instruction stream -- ~2 200 vector / scalar /
-// LDS instructions per tile and wave around 288 MFMAs; PMC: 46 % of the wave cycles issuing, 33 % parked, MFMA pipe 31 % busy -- and
-// nothing fills the parked cycles.  Here every wave issues half the MFMAs and half the epilogue, and its partner on the SIMD
-// runs while it waits (the weights halve too: 96 VGPRs, which is what lets two waves share a SIMD's register file).  The head's
-// 32-channel contraction is finished through LDS: the upper-half waves hand their partial logits to the lower-half waves.
-template <int NC>
-__global__ __launch_bounds__(512, 2) void dec_tail_fused_x3w8(const TailParams p)
-{
-    constexpr bool F16 = true;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* lbl_tile = smem + 2 * kT3BufBytes;                   // [16][16] u8
-    char* zero_gran = lbl_tile + 256;                          // 16 zero bytes (unused here; keeps the layout of dec_tail_fused_x3)
-    float* cst = (float*)(zero_gran + 64);                     // [32 channels][CR]: scale, shift, head_w
-    float* part = (float*)((char*)cst + kTailConstBytes);      // [4 parities][64 pixels][NC]: partial logits of the upper channel half
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int par = wave & 3, mh = wave >> 2;                  // parity class, MFMA row block (channels fg * 8 + mh * 4 + 0..3)
-    const int py = par >> 1, px = par & 1;
-    const int frow = lane & 15, fg = lane >> 4;
-
-    const int H = 2 * p.PH, W = 2 * p.PW;
-    const int tiles_x = W / 16, tiles_y = H / 16;
-    const int tiles_per_patch = tiles_x * tiles_y;
-    const int n_tiles = p.n * tiles_per_patch;
-    // XCD-contiguous walk (grid = a multiple of 8 blocks): XCD x = block % 8 owns tiles [x * per_xcd, (x + 1) * per_xcd), so the
-    // halo pixels neighbouring tiles share are fetched into one L2 once instead of once per XCD (a round-robin walk
-    // re-fetched them from HBM: 1.8x the input bytes, L2 hit rate 2 %)
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, GX = gridDim.x >> 3;
-    const int per_xcd = (n_tiles + 7) >> 3;
-    const int xcd_lo = xcd * per_xcd, xcd_hi = min(n_tiles, xcd_lo + per_xcd);
-    const int my_tiles = xcd_lo + slot < xcd_hi ? (xcd_hi - xcd_lo - slot + GX - 1) / GX : 0;
-    if (my_tiles <= 0) return;
-    auto tile_at = [&](int it) __attribute__((always_inline)) -> int { return xcd_lo + slot + it * GX; };
-    if (tid < 4) ((uint32_t*)zero_gran)[tid] = 0u;
-    constexpr int CR = NC <= 2 ? 4 : 8;
-    if (tid < 32) {
-        float* row = cst + ((tid & 7) * 4 + (tid >> 3)) * CR;
-        row[0] = p.scale[tid];
-        row[1] = p.shift[tid];
-        for (int c = 0; c < CR - 2; ++c) row[2 + c] = c < p.classes ? p.head_w[tid * p.classes + c] : 0.f;
-    }
-
-    // ---- this wave's weights: [plane hi|lo][half-K-step 12] fragments of row block mh (wfrag = per class [hi | lo][12][mi 2])
-    bf16x8_t whi[kTailKSteps * 2], wlo[kTailKSteps * 2];
-    {
-        const uint4* src = (const uint4*)p.wfrag + (size_t)(par * 2 * kTailKSteps * 4) * 64 + lane;
-#pragma unroll
-        for (int h = 0; h < kTailKSteps * 2; ++h) {
-            whi[h] = __builtin_bit_cast(bf16x8_t, src[(size_t)(h * 2 + mh) * 64]);
-            wlo[h] = __builtin_bit_cast(bf16x8_t, src[(size_t)(kTailKSteps * 4 + h * 2 + mh) * 64]);
-        }
-    }
-    float hsc[NC], hsh[NC];
-#pragma unroll
-    for (int c = 0; c < NC; ++c) { hsc[c] = c < p.classes ? p.head_scale[c] : 0.f; hsh[c] = c < p.classes ? p.head_shift[c] : 0.f; }
-
-    // Tile-invariant LDS read offsets, so that a fragment read costs no address arithmetic (the round-2 form spent ~7 integer ops
-    // per ds_read_b128: 664 of the kernel's 1 643 vector instructions per tile).  Pixel block ni of this lane sits at
-    //   src0:  hp = hp0 + ni * 32 (+ tap: (ks >> 1) * 16 + (ks & 1)),  slot of granule G = (G + 2 hp) & 15 = (s0 + D) & 15 with
-    //          s0 = (fg + 2 hp0) & 15 per lane and D = kk * 4 + 8 * lo + 2 * (ks & 1) known at compile time (even: 8 table entries);
-    //   image: pixel ib0 + ni * 128 (+ tap offset of this lane's k-group).
-    // Everything that depends on ni / ks is a multiple of 256 (32) bytes and rides in the instruction's immediate offset.
-    const int hp0 = ((frow >> 3) + py) * 16 + (frow & 7) + px;
-    const int s0 = (fg + 2 * hp0) & 15;
-    int src_t[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) src_t[e] = hp0 * 256 + (((s0 + 2 * e) & 15) << 4);
-    // Image tile: row y = 64 units of 16 B; pixel x = 2 m + b, plane lo: unit 4 m + b + 2 lo, the low four bits rotated by y
-    // (inside each 256-byte group).  The 16 lanes of a ds_read_b128 group are two taps (k-groups a, a + 1) x eight pixels
-    // {(y0, x0 + 2 i), (y0 + 2, x0 + 8 + 2 i)}: with this order they land on 16 different slots whether the second tap is the
-    // right-hand neighbour (b flips: slot class +- 1) or the first tap of the next kernel row (y + 1: rotation + 1).  The plain
-    // [pixel][hi | lo] rows of dec_tail_fused_x3 collide four-way here.
-    int img_t[2][2][4][2];                                     // [image half-step][kk][pixel block][hi | lo] byte offsets
-#pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            const int t0 = s2 * 8 + kk * 4 + fg;
-            const int t = t0 < 9 ? t0 : 0;                     // taps 9..15 do not exist: zero weights, any finite pixel will do
-#pragma unroll
-            for (int ni = 0; ni < 4; ++ni) {
-                const int y = 4 * ni + 2 * (frow >> 3) + py + t / 3, x = 2 * (frow & 7) + px + t % 3;
-                const int m = x >> 1, b = x & 1;
-#pragma unroll
-                for (int lo = 0; lo < 2; ++lo)
-                    img_t[s2][kk][ni][lo] = y * 1024 + (m >> 2) * 256 + (((4 * (m & 3) + b + 2 * lo + y) & 15) << 4);
-            }
-        }
-
-    auto issue_tile = [&](int tile, int buf) __attribute__((always_inline)) {
-        const int n = tile / tiles_per_patch;
-        const int rem = tile - n * tiles_per_patch;
-        const int ty = rem / tiles_x, tx = rem - ty * tiles_x;
-        const int y0 = ty * 16, x0 = tx * 16;
-        char* lds_src = smem + buf * kT3BufBytes;
-        char* lds_img = lds_src + kT3SrcBytes;
-        // src0 halo: 160 pixels x 16 granules (8 hi, 8 lo) = 40 wave-instructions of 4 pixels; pixel hp keeps granule g at slot
-        // (g + 2 hp) & 15.  A 16-lane group of ds_read_b128 holds two k-groups (fg = a, a + 1) of eight pixels each whose hp are
-        // eight consecutive residues: rotation by 2 hp sends one k-group to the eight even slots and the other to the eight odd
-        // ones.  (The XOR swizzle g ^ (hp & 15) of round 2 collided two-way in every group: PMC SQ_LDS_BANK_CONFLICT 86 %.)
-#pragma unroll
-        for (int j = 0; j < 5; ++j) {
-            const int ii = wave + 8 * j;
-            const int hp = ii * 4 + (lane >> 4);
-            const int r = hp >> 4, c = hp & 15;
-            const int g = ((lane & 15) - 2 * c) & 15;              // slot s of pixel hp holds granule (s - 2 hp) & 15
-            const int Y = (y0 >> 1) - 1 + r, X = (x0 >> 1) - 1 + c;
-            const bool ok = ((unsigned)Y < (unsigned)p.PH) & ((unsigned)X < (unsigned)p.PW) & (c < 10);
-            uint32_t off = (uint32_t)((n * p.PH + Y) * p.PW + X) * 256u + (uint32_t)(g * 16 + kZeroHeaderBytes);
-            off = ok ? off : 0u;
-            __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(p.src0 + off), (LDS_AS void*)(lds_src + ii * 1024), 16, 0, 0);
-        }
-        // image halo: 18 rows x 32 pixels x (hi 16 B, lo 16 B) = 18 wave-instructions of one row; lane l fills physical unit l of
-        // the row and fetches the (pixel, plane) the rotated order puts there
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            const int ii = wave + 8 * j;
-            if (ii < 18) {
-                const int low = ((lane & 15) - ii) & 15;
-                const int c = 2 * (4 * (lane >> 4) + (low >> 2)) + (low & 1), lo = (low >> 1) & 1;
-                const int Y = y0 - 1 + ii, X = x0 - 1 + c;
-                const bool ok = ((unsigned)Y < (unsigned)H) & ((unsigned)X < (unsigned)W) & (c < 18);
-                uint32_t off = (uint32_t)((n * H + Y) * W + X) * 32u + (uint32_t)(lo * 16 + kZeroHeaderBytes);
-                off = ok ? off : 0u;
-                __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(p.img + off), (LDS_AS void*)(lds_img + ii * 1024), 16, 0, 0);
-            }
-        }
-    };
-
-    issue_tile(tile_at(0), 0);
-    for (int it = 0; it < my_tiles; ++it) {
-        const int tile = tile_at(it);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (it + 1 < my_tiles) issue_tile(tile_at(it + 1), (it + 1) & 1);
-
-        const char* lds_src = smem + (it & 1) * kT3BufBytes;
-        const char* lds_img = lds_src + kT3SrcBytes;
-        f32x4_t acc[4];
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni) acc[ni] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-
-        const char* sb[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) sb[e] = lds_src + src_t[e];
-        auto load_b = [&](int h, bf16x8_t (&bh)[4], bf16x8_t (&bl)[4]) __attribute__((always_inline)) {
-            if (h < 8) {
-                const int ks = h >> 1, kk = h & 1;
-                const int dh = (kk * 8 + 2 * (ks & 1)) & 15, dl = (kk * 8 + 4 + 2 * (ks & 1)) & 15;      // src0 pixel: [32 hi][32 lo][32 hi][32 lo]
-#pragma unroll
-                for (int ni = 0; ni < 4; ++ni) {
-                    const int k = (ni * 32 + (ks >> 1) * 16 + (ks & 1)) * 256;      // immediate offset
-                    bh[ni] = *(const bf16x8_t*)(sb[dh >> 1] + k);
-                    bl[ni] = *(const bf16x8_t*)(sb[dl >> 1] + k);
-                }
-            } else {
-#pragma unroll
-                for (int ni = 0; ni < 4; ++ni) {
-                    bh[ni] = *(const bf16x8_t*)(lds_img + img_t[(h - 8) >> 1][(h - 8) & 1][ni][0]);
-                    bl[ni] = *(const bf16x8_t*)(lds_img + img_t[(h - 8) >> 1][(h - 8) & 1][ni][1]);
-                }
-            }
-        };
-        auto mac = [&](int h, const bf16x8_t (&bh)[4], const bf16x8_t (&bl)[4]) __attribute__((always_inline)) {
-            // three sweeps over the four accumulators (small terms first)
-#pragma unroll
-            for (int ni = 0; ni < 4; ++ni) acc[ni] = mfma16<F16>(wlo[h], bh[ni], acc[ni]);
-#pragma unroll
-            for (int ni = 0; ni < 4; ++ni) acc[ni] = mfma16<F16>(whi[h], bl[ni], acc[ni]);
-#pragma unroll
-            for (int ni = 0; ni < 4; ++ni) acc[ni] = mfma16<F16>(whi[h], bh[ni], acc[ni]);
-        };
-        bf16x8_t b0h[4], b0l[4], b1h[4], b1l[4];
-        load_b(0, b0h, b0l);
-#pragma unroll
-        for (int h = 0; h < 12; h += 2) {
-            load_b(h + 1, b1h, b1l);
-            mac(h, b0h, b0l);
-            if (h + 2 < 12) load_b(h + 2, b0h, b0l);
-            mac(h + 1, b1h, b1l);
-        }
-
-        // ---- epilogue: BN/ReLU, head, softmax, argmax (as dec_tail_fused)
-        const int n = tile / tiles_per_patch;
-        const int rem = tile - n * tiles_per_patch;
-        const int tyy = rem / tiles_x, txx = rem - tyy * tiles_x;
-        // (channel constants are read once per tile -- q outer, the four pixel blocks inner -- not once per pixel block)
-        float lg[4][NC];
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-            for (int c = 0; c < NC; ++c) lg[ni][c] = 0.f;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const float* row = cst + ((mh * 4 + q) * 4 + fg) * CR;                // channel fg * 8 + mh * 4 + q
-            const float4 c0 = *(const float4*)row;                                // scale, shift, hw0, hw1
-            float2 c1 = make_float2(0.f, 0.f);
-            if constexpr (NC > 2) c1 = *(const float2*)(row + 4);                 // hw2, hw3
-#pragma unroll
-            for (int ni = 0; ni < 4; ++ni) {
-                const float yq = fmaxf(acc[ni][q] * c0.x + c0.y, 0.f);
-                lg[ni][0] = fmaf(yq, c0.z, lg[ni][0]);
-                if constexpr (NC > 1) lg[ni][1] = fmaf(yq, c0.w, lg[ni][1]);
-                if constexpr (NC > 2) {
-                    lg[ni][2] = fmaf(yq, c1.x, lg[ni][2]);
-                    lg[ni][3] = fmaf(yq, c1.y, lg[ni][3]);
-                }
-            }
-        }
-        // this wave's 16 channels: the four k-groups of a pixel add up; the upper half hands its sums to the lower half
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-            for (int c = 0; c < NC; ++c) {
-                float a = lg[ni][c];
-                a += __shfl_xor(a, 16);
-                a += __shfl_xor(a, 32);
-                lg[ni][c] = a;
-            }
-        if (mh == 1 && fg == 0) {
-#pragma unroll
-            for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-                for (int c = 0; c < NC; ++c) part[(par * 64 + ni * 16 + frow) * NC + c] = lg[ni][c];
-        }
-        __syncthreads();
-        if (mh == 0 && fg == 0) {
-#pragma unroll
-            for (int ni = 0; ni < 4; ++ni) {
-                float logit[NC];
-#pragma unroll
-                for (int c = 0; c < NC; ++c) logit[c] = (lg[ni][c] + part[(par * 64 + ni * 16 + frow) * NC + c]) * hsc[c] + hsh[c];
-                float mx = -3.0e38f;
-#pragma unroll
-                for (int c = 0; c < NC; ++c)
-                    if (c < p.classes) mx = fmaxf(mx, logit[c]);
-                float pr[NC], sum = 0.f;
-#pragma unroll
-                for (int c = 0; c < NC; ++c) { pr[c] = c < p.classes ? expf(logit[c] - mx) : 0.f; sum += pr[c]; }
-                int best = 0;
-                float bestp = -1.f;
-#pragma unroll
-                for (int c = 0; c < NC; ++c)
-                    if (c < p.classes) {
-                        pr[c] = pr[c] / sum;
-                        if (pr[c] > bestp) { bestp = pr[c]; best = c; }
-                    }
-                const int i = ni * 16 + frow;
-                const int oy = 2 * (i >> 3) + py, ox = 2 * (i & 7) + px;
-                lbl_tile[oy * 16 + ox] = (char)best;
-                if (p.probs) {
-                    float* dst = p.probs + ((size_t)(n * H + tyy * 16 + oy) * W + txx * 16 + ox) * p.classes;
-#pragma unroll
-                    for (int c = 0; c < NC; ++c)
-                        if (c < p.classes) dst[c] = pr[c];
-                }
-            }
-        }
-        __syncthreads();
-        if (tid < 16)
-            *(uint4*)(p.labels + (size_t)(n * H + tyy * 16 + tid) * W + txx * 16) = *(const uint4*)(lbl_tile + tid * 16);
-    }
-}
-
-// dec_tail_fused_x3ps -- the eight-wave tile with the two waves of every SIMD half a tile out of phase.
-// In dec_tail_fused_x3w8 all eight waves load, multiply and run the epilogue at the same moments, and the three parts simply add up
-// (tools/probes/tail_probe.hip, 140 patches: tile loads alone 0.64 ms, MFMAs alone 1.23, epilogue alone 0.83; all of it 2.48).
+// The two waves of every SIMD run half a tile out of phase.  With all eight waves loading, multiplying and running the epilogue at
+// the same moments (round 3's first eight-wave form) the three parts simply added up (tools/probes/tail_probe.hip, 140 patches:
+// tile loads alone 0.64 ms, MFMAs alone 1.23, epilogue alone 0.83; all of it 2.48).
 // Here the group A = waves 0-3 (channel half 0) does   main loop(t) -> BN / ReLU / partial logits(t) -> part[t & 1] -> tile loads(t+1),
 // and the group B = waves 4-7 (channel half 1) does    label store(t-2), epilogue(t-1) incl. softmax, main loop(t)
 // between two consecutive block barriers.  Wave w and wave w + 4 share a SIMD (waves go to SIMDs round-robin), so while A's wave
 // keeps the MFMA pipe busy B's wave issues the address arithmetic, the DMA loads and the epilogue VALU work, and the other way
 // round in the second half of the step.  B finishes the pixels (A's partial logits come through LDS, written one step earlier).
 // The k-group reduction is a two-step butterfly that leaves ONE pixel per lane (pixel block ni = fg), so the softmax runs once on
-// 64 lanes instead of four times on 16; the fp32 sums associate exactly as in dec_tail_fused_x3w8 (bit-identical outputs).
+// 64 lanes instead of four times on 16.
 constexpr int kT3PsPartBytes = 2 * 4 * 64 * 4 * 4;        // [step parity][4 pixel parities][64 lanes][<= 4 classes] partial logits
 constexpr int kT3PsLdsBytes = 2 * kT3BufBytes + 2 * 256 + kTailConstBytes + kT3PsPartBytes;
+static_assert(kT3PsLdsBytes <= 160 * 1024, "x3 tail: LDS");
 
 template <int NC>
 __global__ __launch_bounds__(512, 2) void dec_tail_fused_x3ps(const TailParams p)
@@ -2087,51 +1590,52 @@ __global__ __launch_bounds__(512, 2) void dec_tail_fused_x3ps(const TailParams p
         for (int c = 0; c < CR - 2; ++c) row[2 + c] = c < p.classes ? p.head_w[tid * p.classes + c] : 0.f;
     }
 
-    // ---- this wave's weights: [plane hi|lo][half-K-step 12] fragments of row block mh (wfrag = per class [hi | lo][12][mi 2])
-    bf16x8_t whi[kTailKSteps * 2], wlo[kTailKSteps * 2];
+    // ---- this wave's weights: [plane hi|lo][half-K-step 10] fragments of row block mh (wfrag = per class [hi | lo][10][mi 2])
+    constexpr int NH = kT3HalfSteps;
+    bf16x8_t whi[NH], wlo[NH];
     {
-        const uint4* src = (const uint4*)p.wfrag + (size_t)(par * 2 * kTailKSteps * 4) * 64 + lane;
+        const uint4* src = (const uint4*)p.wfrag + (size_t)(par * 2 * NH * 2) * 64 + lane;
 #pragma unroll
-        for (int h = 0; h < kTailKSteps * 2; ++h) {
+        for (int h = 0; h < NH; ++h) {
             whi[h] = __builtin_bit_cast(bf16x8_t, src[(size_t)(h * 2 + mh) * 64]);
-            wlo[h] = __builtin_bit_cast(bf16x8_t, src[(size_t)(kTailKSteps * 4 + h * 2 + mh) * 64]);
+            wlo[h] = __builtin_bit_cast(bf16x8_t, src[(size_t)(NH * 2 + h * 2 + mh) * 64]);
         }
     }
     float hsc[NC], hsh[NC];
 #pragma unroll
     for (int c = 0; c < NC; ++c) { hsc[c] = c < p.classes ? p.head_scale[c] : 0.f; hsh[c] = c < p.classes ? p.head_shift[c] : 0.f; }
 
-    // tile-invariant LDS read offsets (see dec_tail_fused_x3w8)
+    // Tile-invariant LDS read offsets, so that a fragment read costs no address arithmetic.  Pixel block ni of this lane sits at
+    //   src0:  hp = hp0 + ni * 32 (+ tap: (ks >> 1) * 16 + (ks & 1)),  slot of granule G = (G + 2 hp) & 15 = (s0 + D) & 15 with
+    //          s0 = (fg + 2 hp0) & 15 per lane and D = kk * 4 + 8 * lo + 2 * (ks & 1) known at compile time (even: 8 table entries);
+    //   image: row 4 ni + yb (the rotation depends on y & 3 only), tap t = 8 s2 + 2 fg + j of image half-step s2, j = 0 / 1.
+    // Everything that depends on ni / ks is a multiple of 256 (2048) bytes and rides in the instruction's immediate offset.
     const int hp0 = ((frow >> 3) + py) * 16 + (frow & 7) + px;
     const int s0 = (fg + 2 * hp0) & 15;
     int src_t[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) src_t[e] = hp0 * 256 + (((s0 + 2 * e) & 15) << 4);
-    int img_t[2][2][4][2];                                     // [image half-step][kk][pixel block][hi | lo] byte offsets
+    int img_t[3];                                              // [s2 = 0: j = 0, 1][s2 = 1: j = 0]
 #pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            const int t0 = s2 * 8 + kk * 4 + fg;
-            const int t = t0 < 9 ? t0 : 0;                     // taps 9..15 do not exist: zero weights, any finite pixel will do
-#pragma unroll
-            for (int ni = 0; ni < 4; ++ni) {
-                const int y = 4 * ni + 2 * (frow >> 3) + py + t / 3, x = 2 * (frow & 7) + px + t % 3;
-                const int m = x >> 1, b = x & 1;
-#pragma unroll
-                for (int lo = 0; lo < 2; ++lo)
-                    img_t[s2][kk][ni][lo] = y * 1024 + (m >> 2) * 256 + (((4 * (m & 3) + b + 2 * lo + y) & 15) << 4);
-            }
-        }
+    for (int e = 0; e < 3; ++e) {
+        const int t0 = (e >> 1) * 8 + 2 * fg + (e & 1);
+        const int t = t0 < 9 ? t0 : 1;                         // taps 9..15 do not exist: zero weights, any finite pixel will do
+        const int yb = 2 * (frow >> 3) + py + t / 3, x = 2 * (frow & 7) + px + t % 3;
+        img_t[e] = yb * 512 + ((((x >> 1) + 12 * (x & 1) + 16 - 4 * (yb & 3)) & 31) << 4);
+    }
 
     // Halo loads (group A): wave `par` issues the src0 pieces ii = par + 4 j (j = 0..9: halo row j, halo columns 4 par .. 4 par + 3) and
-    // the image rows ii = par + 4 j (< 18).  `buffer_load ... lds` with a per-tile resource (this patch's image, one pixel of
+    // the image pieces q = par + 4 j (< 9).  `buffer_load ... lds` with a per-tile resource (this patch's image, one pixel of
     // bias so that the lane part is never negative): the lane offset of a src0 piece does not depend on j or on the tile, the row
     // rides in the scalar offset, and anything outside the image sets bit 31 of the lane offset (past num_records: the hardware
     // writes zeros).  ~3 vector instructions per piece instead of the ~20 of per-lane global addresses.
     const int c_src = par * 4 + (lane >> 4);                   // halo column of this lane's src0 pixel
     const uint32_t voff_src = (uint32_t)(c_src * 256 + ((((lane & 15) - 2 * c_src) & 15) << 4));      // slot s of pixel hp holds granule (s - 2 hp) & 15
-    const int low0 = ((lane & 15) - par) & 15;                 // image row ii: physical unit l holds the (pixel, plane) of rotated unit (l - ii) & 15
+    // image piece q: lane l fills unit l & 31 of halo row 2 q + (l >> 5); (2 q) & 3 = 2 (par & 1) for every piece of this wave
+    const int img_v = ((lane & 31) - (16 - 4 * ((2 * par + (lane >> 5)) & 3))) & 31;
+    const bool img_xok = img_v < 9 || (img_v >= 12 && img_v < 21);
+    const int img_x = img_v < 9 ? 2 * img_v : 2 * (img_v - 12) + 1;
+    const uint32_t voff_img = (uint32_t)(((lane >> 5) * W + img_x) * 32);
     const uint32_t src_img_bytes = (uint32_t)(p.PH * p.PW) * 256u, img_img_bytes = (uint32_t)(H * W) * 32u;
     auto issue_tile = [&](int tile, int buf) __attribute__((always_inline)) {
         const int n = tile / tiles_per_patch;
@@ -2149,18 +1653,16 @@ __global__ __launch_bounds__(512, 2) void dec_tail_fused_x3ps(const TailParams p
             const uint32_t soff = yok ? (uint32_t)(Y * p.PW + (x0 >> 1)) * 256u : 0u;
             buffer_load_lds16(sbase, src_img_bytes + 256u, (LDS_AS void*)(lds_src + (par + 4 * j) * 1024), yok ? vs : 0x80000000u, soff);
         }
-        const char* ibase = p.img + kZeroHeaderBytes - 32 + (size_t)n * img_img_bytes;
+        // image: piece q = par + 4 j (< 9) = halo rows 2 q, 2 q + 1 (32 units each); one row + one pixel of bias
+        const char* ibase = p.img + kZeroHeaderBytes + (size_t)n * img_img_bytes - (size_t)(W + 1) * 32;
+        const uint32_t vi = (img_xok && (unsigned)(x0 - 1 + img_x) < (unsigned)W) ? voff_img : 0x80000000u;
 #pragma unroll
-        for (int j = 0; j < 5; ++j) {
-            const int ii = par + 4 * j;
-            if (ii < 18) {
-                const int low = (low0 - 4 * j) & 15;
-                const int c = 2 * (4 * (lane >> 4) + (low >> 2)) + (low & 1), lo = (low >> 1) & 1;
-                const int Y = y0 - 1 + ii;
-                const bool yok = (unsigned)Y < (unsigned)H;
-                const bool xok = ((unsigned)(x0 - 1 + c) < (unsigned)W) & (c < 18);
-                const uint32_t soff = yok ? (uint32_t)(Y * W + x0) * 32u : 0u;
-                buffer_load_lds16(ibase, img_img_bytes + 32u, (LDS_AS void*)(lds_img + ii * 1024), (xok && yok) ? (uint32_t)(c * 32 + lo * 16) : 0x80000000u, soff);
+        for (int j = 0; j < 3; ++j) {
+            const int q = par + 4 * j;
+            if (q < 9) {
+                const bool yok = (unsigned)(y0 - 1 + 2 * q + (lane >> 5)) < (unsigned)H;
+                buffer_load_lds16(ibase, img_img_bytes + (uint32_t)(W + 1) * 32u, (LDS_AS void*)(lds_img + q * 1024), yok ? vi : 0x80000000u,
+                                  (uint32_t)((y0 + 2 * q) * W + x0) * 32u);
             }
         }
     };
@@ -2185,10 +1687,14 @@ __global__ __launch_bounds__(512, 2) void dec_tail_fused_x3ps(const TailParams p
                     bl[ni] = *(const bf16x8_t*)(sb[dl >> 1] + k);
                 }
             } else {
+                // image pixel = [h0 h1 h2 0 | l0 l1 l2 0]: the k-group is two taps; half-step 9 has tap 8 only (its second tap
+                // multiplies zero weights: the first one's registers do)
 #pragma unroll
                 for (int ni = 0; ni < 4; ++ni) {
-                    bh[ni] = *(const bf16x8_t*)(lds_img + img_t[(h - 8) >> 1][(h - 8) & 1][ni][0]);
-                    bl[ni] = *(const bf16x8_t*)(lds_img + img_t[(h - 8) >> 1][(h - 8) & 1][ni][1]);
+                    const uint4 r0 = *(const uint4*)(lds_img + img_t[(h - 8) * 2] + ni * 2048);
+                    const uint4 r1 = h == 8 ? *(const uint4*)(lds_img + img_t[1] + ni * 2048) : r0;
+                    bh[ni] = __builtin_bit_cast(bf16x8_t, make_uint4(r0.x, r0.y, r1.x, r1.y));
+                    bl[ni] = __builtin_bit_cast(bf16x8_t, make_uint4(r0.z, r0.w, r1.z, r1.w));
                 }
             }
         };
@@ -2204,10 +1710,10 @@ __global__ __launch_bounds__(512, 2) void dec_tail_fused_x3ps(const TailParams p
         bf16x8_t b0h[4], b0l[4], b1h[4], b1l[4];
         load_b(0, b0h, b0l);
 #pragma unroll
-        for (int h = 0; h < 12; h += 2) {
+        for (int h = 0; h < NH; h += 2) {
             load_b(h + 1, b1h, b1l);
             mac(h, b0h, b0l);
-            if (h + 2 < 12) load_b(h + 2, b0h, b0l);
+            if (h + 2 < NH) load_b(h + 2, b0h, b0l);
             mac(h + 1, b1h, b1l);
         }
     };
@@ -2335,33 +1841,13 @@ hipError_t launch_tail(const TailParams& p, int precision, int num_cus, hipStrea
     hipError_t e;
     if (precision == kF16X3) {
         const int grid3 = ((n_tiles < num_cus ? n_tiles : num_cus) + 7) & ~7;
-        auto go3 = [&](auto kern) -> hipError_t {
-            hipError_t e3 = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, kT3LdsBytes);
-            if (e3 != hipSuccess) return e3;
-            hipLaunchKernelGGL(kern, dim3(grid3), dim3(256), kT3LdsBytes, s, p);
+        auto gops = [&](auto kern) -> hipError_t {
+            hipError_t e8 = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, kT3PsLdsBytes);
+            if (e8 != hipSuccess) return e8;
+            hipLaunchKernelGGL(kern, dim3(grid3), dim3(512), kT3PsLdsBytes, s, p);
             return hipSuccess;
         };
-        static const bool w8 = !(getenv("SBBSEG_TAIL_X3_W8") && getenv("SBBSEG_TAIL_X3_W8")[0] == '0');      // A/B: 0 = one wave per SIMD
-        static const bool ps = !(getenv("SBBSEG_TAIL_X3_PS") && getenv("SBBSEG_TAIL_X3_PS")[0] == '0');      // A/B: 0 = the lock-step eight-wave kernel
-        if (ps && w8) {
-            auto gops = [&](auto kern) -> hipError_t {
-                hipError_t e8 = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, kT3PsLdsBytes);
-                if (e8 != hipSuccess) return e8;
-                hipLaunchKernelGGL(kern, dim3(grid3), dim3(512), kT3PsLdsBytes, s, p);
-                return hipSuccess;
-            };
-            e = p.classes <= 2 ? gops(dec_tail_fused_x3ps<2>) : gops(dec_tail_fused_x3ps<4>);
-        } else if (w8) {
-            auto go8 = [&](auto kern) -> hipError_t {
-                hipError_t e8 = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, kT3LdsBytes + kT3PartBytes);
-                if (e8 != hipSuccess) return e8;
-                hipLaunchKernelGGL(kern, dim3(grid3), dim3(512), kT3LdsBytes + kT3PartBytes, s, p);
-                return hipSuccess;
-            };
-            e = p.classes <= 2 ? go8(dec_tail_fused_x3w8<2>) : go8(dec_tail_fused_x3w8<4>);
-        } else {
-            e = p.classes <= 2 ? go3(dec_tail_fused_x3<2>) : go3(dec_tail_fused_x3<4>);
-        }
+        e = p.classes <= 2 ? gops(dec_tail_fused_x3ps<2>) : gops(dec_tail_fused_x3ps<4>);
         if (e != hipSuccess) return e;
         return hipGetLastError();
     }
@@ -3552,6 +3038,10 @@ __device__ inline void write_split_input(const float (&f)[3], void* c8, void* pa
     Vec8<_Float16> oh, ol;
 #pragma unroll
     for (int i = 0; i < 8; ++i) { oh.v[i] = i < 3 ? hi[i] : z; ol.v[i] = i < 3 ? lo[i] : z; }
+    // The channel slots 4..6 of the hi plane repeat lo(ch 0..2): every kernel that treats the form as an 8-channel tensor multiplies
+    // them by zero weights (channels 3..7 do not exist), dec_tail_fused_x3ps reads the first granule as [h0 h1 h2 0 | l0 l1 l2 0]
+#pragma unroll
+    for (int i = 0; i < 3; ++i) oh.v[4 + i] = lo[i];
     ((Vec8<_Float16>*)c8)[2 * idx] = oh;
     ((Vec8<_Float16>*)c8)[2 * idx + 1] = ol;
     if (pairs) {
@@ -3570,7 +3060,7 @@ __device__ inline void write_split_input(const float (&f)[3], void* c8, void* pa
 // ingest: u8 page -> normalised network input in both forms (main.py:239 `img / 255.0`, 285 slice)
 // one thread per (tile, y, x)
 // ------------------------------------------------------------------------------------------------
-// SPLIT (kF16X3): every stored element is an fp16 (hi, lo) pair -- C8 pixel = [8 hi][8 lo] (32 bytes), PAIRS
+// SPLIT (kF16X3): every stored element is an fp16 (hi, lo) pair -- C8 pixel = [8 hi][8 lo] (32 bytes; hi slots 4..6 = lo 0..2), PAIRS
 // granule = [2 px x 4 hi][2 px x 4 lo] (32 bytes); f32(v / 255.0) is carried to ~22 bits
 template <typename E, bool SPLIT = false>
 __global__ __launch_bounds__(256) void ingest_u8_kernel(const IngestParams p)
