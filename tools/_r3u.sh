@@ -1,2 +1,1 @@
-tools/probes/bin/tail_probe 140 3 0
-tools/probes/bin/tail_probe 140 3 0
+for k in 0 64 0 64; do timeout 120 tools/probes/bin/block_probe_$k; done
