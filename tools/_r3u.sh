@@ -1,1 +1,4 @@
-for k in 0 64 0 64; do timeout 120 tools/probes/bin/block_probe_$k; done
+tools/probes/bin/tail_probe 20 3 0
+tools/probes/bin/tail_probe 20 3 0
+tools/probes/bin/tail_probe 20 2 0
+tools/probes/bin/tail_probe 20 2 0

@@ -42,6 +42,16 @@ int main(int argc, char** argv)
     for (int i = 0; i < reps; ++i) CK(launch_tail(tp, prec, 256, 0));
     CK(hipEventRecord(b, 0)); CK(hipEventSynchronize(b));
     float ms; CK(hipEventElapsedTime(&ms, a, b));
+    {   // run-to-run determinism inside this process: the labels of two more launches must be identical
+        std::vector<uint8_t> l0((size_t)n * 4 * PH * PW), l1(l0.size());
+        CK(hipMemset(labels, 9, l0.size())); CK(launch_tail(tp, prec, 256, 0)); CK(hipDeviceSynchronize());
+        CK(hipMemcpy(l0.data(), labels, l0.size(), hipMemcpyDeviceToHost));
+        CK(hipMemset(labels, 7, l0.size())); CK(launch_tail(tp, prec, 256, 0)); CK(hipDeviceSynchronize());
+        CK(hipMemcpy(l1.data(), labels, l1.size(), hipMemcpyDeviceToHost));
+        size_t diff = 0, unwritten = 0;
+        for (size_t i = 0; i < l0.size(); ++i) { diff += l0[i] != l1[i]; unwritten += l1[i] == 7; }
+        printf("determinism: %zu of %zu labels differ between two launches, %zu never written\n", diff, l0.size(), unwritten);
+    }
     std::vector<uint8_t> l((size_t)n * 4 * PH * PW);
     CK(hipMemcpy(l.data(), labels, l.size(), hipMemcpyDeviceToHost));
     unsigned long sum = 0; unsigned long long hsh = 1469598103934665603ull;
