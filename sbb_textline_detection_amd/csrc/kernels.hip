@@ -977,7 +977,14 @@ void conv_igemm_mfma(const ConvParams p)
             if (kPrefetchConst) prefetch_consts(tile_at(c_q));
             if (kPrefetchRes && p.residual) prefetch_residual(tile_at(c_q));
         }
-        if (issued < total) issue(nxt);
+        // 512 x 128 split tiles: waves NW/2.. (the SIMD partners of waves 0..NW/2-1) issue the next stage's loads in the MIDDLE of the
+        // K-step, after their first half's MFMAs -- a stage's DMA issue costs a wave several hundred cycles in which it feeds no
+        // MFMAs; issued by all eight waves right after the barrier those cycles coincided on every SIMD.  dec3 and the 128 -> 128
+        // 3x3 convs: -8 % time; the 256 x 256 tiles (12 loads per wave and stage instead of 10, K-steps twice as long) +1 %: not
+        // there.  (variant flag bit 3 = off)
+        constexpr bool kSplitIssue = X3 && NW == 8 && BP == 512;
+        const bool late_issue = kSplitIssue && wave >= NW / 2 && !(p.variant_flags & 8);
+        if (!late_issue && issued < total) issue(nxt);
         const char* sb = smem + cur * T::kStageBytes;
         if constexpr (X3) {
             // split mode: slots 0-3 hold the hi halves of the stage's 32 channels, slots 4-7 the lo halves (rd_k0 / rd_k1
@@ -1012,6 +1019,9 @@ void conv_igemm_mfma(const ConvParams p)
                 for (int mi = 0; mi < T::kMI; ++mi)
 #pragma unroll
                     for (int q = 0; q < NIH; ++q) acc[mi][h * NIH + q] = mfma16<true>(ah[mi], bh[q], acc[mi][h * NIH + q]);
+                if constexpr (kSplitIssue) {
+                    if (h == 0 && late_issue && issued < total) issue(nxt);
+                }
             }
         } else {
             // The K-step's MFMAs run in phases of (k-half kk, group of <= 4 pixel blocks); the LDS
@@ -1241,8 +1251,11 @@ static hipError_t launch_conv_16(const ConvParams& p, hipStream_t s)
 
 // split mode: the 4-wave tiles at 2 blocks per CU (3 MFMAs per product for the same LDS bytes: the matrix pipe, not the
 // staging path, is what fills first here)
-static hipError_t launch_conv_x3(const ConvParams& p, hipStream_t s)
+static hipError_t launch_conv_x3(const ConvParams& p0, hipStream_t s)
 {
+    static const bool split_issue = !(getenv("SBBSEG_X3_SPLIT_ISSUE") && getenv("SBBSEG_X3_SPLIT_ISSUE")[0] == '0');      // A/B
+    ConvParams p = p0;
+    if (!split_issue) p.variant_flags |= 8;
     const int bc = conv_tile_bc(p.cout);
     if (p.variant == 0 && bc == 128 && !p.residual) {          // the long-K decoder launches: same 8-wave tiles as the plain modes
         const long t256 = (long)p.n_cls * ((p.M + 255) / 256) * (p.cout / 256);
