@@ -977,12 +977,12 @@ void conv_igemm_mfma(const ConvParams p)
             if (kPrefetchConst) prefetch_consts(tile_at(c_q));
             if (kPrefetchRes && p.residual) prefetch_residual(tile_at(c_q));
         }
-        // 512 x 128 split tiles: waves NW/2.. (the SIMD partners of waves 0..NW/2-1) issue the next stage's loads in the MIDDLE of the
+        // 512 x 128 tiles (all 16-bit modes): waves NW/2.. (the SIMD partners of waves 0..NW/2-1) issue the next stage's loads in the MIDDLE of the
         // K-step, after their first half's MFMAs -- a stage's DMA issue costs a wave several hundred cycles in which it feeds no
         // MFMAs; issued by all eight waves right after the barrier those cycles coincided on every SIMD.  dec3 and the 128 -> 128
         // 3x3 convs: -8 % time; the 256 x 256 tiles (12 loads per wave and stage instead of 10, K-steps twice as long) +1 %: not
-        // there.  (variant flag bit 3 = off)
-        constexpr bool kSplitIssue = X3 && NW == 8 && BP == 512;
+        // there.  f16: dec3 -8.6 %, 128 -> 128 3x3 -6 %.  (variant flag bit 3 = off)
+        constexpr bool kSplitIssue = NW == 8 && BP == 512 && !PH8 && NS == 2;
         const bool late_issue = kSplitIssue && wave >= NW / 2 && !(p.variant_flags & 8);
         if (!late_issue && issued < total) issue(nxt);
         const char* sb = smem + cur * T::kStageBytes;
@@ -1057,6 +1057,9 @@ void conv_igemm_mfma(const ConvParams p)
 #pragma unroll
                     for (int q = 0; q < NIH; ++q)
                         acc[mi][h * NIH + q] = mfma16<F16>(a[kk & 1][mi], b[ph & 1][q], acc[mi][h * NIH + q]);
+                if constexpr (kSplitIssue) {
+                    if (ph == NP / 2 - 1 && late_issue && issued < total) issue(nxt);
+                }
             }
         }
         bool tile_done = false, counted = false;
@@ -1270,9 +1273,12 @@ static hipError_t launch_conv_x3(const ConvParams& p0, hipStream_t s)
     return launch_conv_t<256, 32, 4, 1, 2, true, 8, false, true>(p, s);
 }
 
-hipError_t launch_conv(const ConvParams& p, int precision, hipStream_t s)
+hipError_t launch_conv(const ConvParams& p0, int precision, hipStream_t s)
 {
-    if (precision == kF16X3) return launch_conv_x3(p, s);
+    if (precision == kF16X3) return launch_conv_x3(p0, s);
+    static const bool split_issue = !(getenv("SBBSEG_X3_SPLIT_ISSUE") && getenv("SBBSEG_X3_SPLIT_ISSUE")[0] == '0');      // A/B (all 16-bit modes)
+    ConvParams p = p0;
+    if (!split_issue) p.variant_flags |= 8;
     if (precision == kF32) {
         const long total = (long)p.M * (p.cout / 4);
         hipLaunchKernelGGL(conv_naive_f32, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, p);
