@@ -977,13 +977,13 @@ void conv_igemm_mfma(const ConvParams p)
             if (kPrefetchConst) prefetch_consts(tile_at(c_q));
             if (kPrefetchRes && p.residual) prefetch_residual(tile_at(c_q));
         }
-        // 512 x 128 tiles (all 16-bit modes): waves NW/2.. (the SIMD partners of waves 0..NW/2-1) issue the next stage's loads in the MIDDLE of the
+        // 8-wave tiles (split mode: the 512 x 128 ones only): waves NW/2.. (the SIMD partners of waves 0..NW/2-1) issue the next stage's loads in the MIDDLE of the
         // K-step, after their first half's MFMAs -- a stage's DMA issue costs a wave several hundred cycles in which it feeds no
         // MFMAs; issued by all eight waves right after the barrier those cycles coincided on every SIMD.  dec3 and the 128 -> 128
         // 3x3 convs: -8 % time; the 256 x 256 tiles (12 loads per wave and stage instead of 10, K-steps twice as long) +1 %: not
-        // there.  f16: dec3 -8.6 %, 128 -> 128 3x3 -6 %.  (variant flag bit 3 = off)
-        constexpr bool kSplitIssue = NW == 8 && BP == 512 && !PH8 && NS == 2;
-        const bool late_issue = kSplitIssue && wave >= NW / 2 && !(p.variant_flags & 8);
+        // there.  f16: dec3 -8.6 %, 128 -> 128 3x3 -6 %, dec1 / dec2 on 256 x 256 tiles -1.5 % (+0.75 % throughput).  (variant flag bit 3 = off)
+        constexpr bool kSplitIssue = NW == 8 && !PH8 && NS == 2;
+        const bool late_issue = kSplitIssue && (BP == 512 || !X3) && wave >= NW / 2 && !(p.variant_flags & 8);
         if (!late_issue && issued < total) issue(nxt);
         const char* sb = smem + cur * T::kStageBytes;
         if constexpr (X3) {
