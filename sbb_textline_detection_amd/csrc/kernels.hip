@@ -1563,7 +1563,7 @@ constexpr int kT3HalfSteps = 10;                        // 4 taps x 64 channels 
 // The two waves of every SIMD run half a tile out of phase.  With all eight waves loading, multiplying and running the epilogue at
 // the same moments (round 3's first eight-wave form) the three parts simply added up (tools/probes/tail_probe.hip, 140 patches:
 // tile loads alone 0.64 ms, MFMAs alone 1.23, epilogue alone 0.83; all of it 2.48).
-// Here the group A = waves 0-3 (channel half 0) does   main loop(t) -> BN / ReLU / partial logits(t) -> part[t & 1] -> tile loads(t+1),
+// Here the group A = waves 0-3 (channel half 0) does   main loop(t) -> tile loads(t+1) -> BN / ReLU / partial logits(t) -> part[t & 1],
 // and the group B = waves 4-7 (channel half 1) does    label store(t-2), epilogue(t-1) incl. softmax, main loop(t)
 // between two consecutive block barriers.  Wave w and wave w + 4 share a SIMD (waves go to SIMDs round-robin), so while A's wave
 // keeps the MFMA pipe busy B's wave issues the address arithmetic, the DMA loads and the epilogue VALU work, and the other way
@@ -1620,6 +1620,16 @@ __global__ __launch_bounds__(512, 2) void dec_tail_fused_x3ps(const TailParams p
             wlo[h] = __builtin_bit_cast(bf16x8_t, src[(size_t)(NH * 2 + h * 2 + mh) * 64]);
         }
     }
+    __syncthreads();                                           // (cst written)
+    float4 kc0[4];                                             // this wave's channel constants: [q] = scale, shift, hw0, hw1 of channel fg * 8 + mh * 4 + q
+    float2 kc1[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float* row = cst + ((mh * 4 + q) * 4 + fg) * CR;
+        kc0[q] = *(const float4*)row;
+        kc1[q] = make_float2(0.f, 0.f);
+        if constexpr (NC > 2) kc1[q] = *(const float2*)(row + 4);
+    }
     float hsc[NC], hsh[NC];
 #pragma unroll
     for (int c = 0; c < NC; ++c) { hsc[c] = c < p.classes ? p.head_scale[c] : 0.f; hsh[c] = c < p.classes ? p.head_shift[c] : 0.f; }
@@ -1656,13 +1666,12 @@ __global__ __launch_bounds__(512, 2) void dec_tail_fused_x3ps(const TailParams p
     const int img_x = img_v < 9 ? 2 * img_v : 2 * (img_v - 12) + 1;
     const uint32_t voff_img = (uint32_t)(((lane >> 5) * W + img_x) * 32);
     const uint32_t src_img_bytes = (uint32_t)(p.PH * p.PW) * 256u, img_img_bytes = (uint32_t)(H * W) * 32u;
-    auto issue_tile = [&](int tile, int buf) __attribute__((always_inline)) {
+    auto issue_src = [&](int tile, int buf) __attribute__((always_inline)) {           // group A: ten pieces per wave
         const int n = tile / tiles_per_patch;
         const int rem = tile - n * tiles_per_patch;
         const int ty = rem / tiles_x, tx = rem - ty * tiles_x;
         const int y0 = ty * 16, x0 = tx * 16;
         char* lds_src = smem + buf * kT3BufBytes;
-        char* lds_img = lds_src + kT3SrcBytes;
         const char* sbase = p.src0 + kZeroHeaderBytes - 256 + (size_t)n * src_img_bytes;
         const uint32_t vs = ((unsigned)((x0 >> 1) - 1 + c_src) < (unsigned)p.PW && c_src < 10) ? voff_src : 0x80000000u;
 #pragma unroll
@@ -1672,6 +1681,13 @@ __global__ __launch_bounds__(512, 2) void dec_tail_fused_x3ps(const TailParams p
             const uint32_t soff = yok ? (uint32_t)(Y * p.PW + (x0 >> 1)) * 256u : 0u;
             buffer_load_lds16(sbase, src_img_bytes + 256u, (LDS_AS void*)(lds_src + (par + 4 * j) * 1024), yok ? vs : 0x80000000u, soff);
         }
+    };
+    auto issue_img = [&](int tile, int buf) __attribute__((always_inline)) {           // group B: two or three pieces per wave
+        const int n = tile / tiles_per_patch;
+        const int rem = tile - n * tiles_per_patch;
+        const int ty = rem / tiles_x, tx = rem - ty * tiles_x;
+        const int y0 = ty * 16, x0 = tx * 16;
+        char* lds_img = smem + buf * kT3BufBytes + kT3SrcBytes;
         // image: piece q = par + 4 j (< 9) = halo rows 2 q, 2 q + 1 (32 units each); one row + one pixel of bias
         const char* ibase = p.img + kZeroHeaderBytes + (size_t)n * img_img_bytes - (size_t)(W + 1) * 32;
         const uint32_t vi = (img_xok && (unsigned)(x0 - 1 + img_x) < (unsigned)W) ? voff_img : 0x80000000u;
@@ -1746,10 +1762,8 @@ __global__ __launch_bounds__(512, 2) void dec_tail_fused_x3ps(const TailParams p
             for (int c = 0; c < NC; ++c) lg[ni][c] = 0.f;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const float* row = cst + ((mh * 4 + q) * 4 + fg) * CR;                // channel fg * 8 + mh * 4 + q
-            const float4 c0 = *(const float4*)row;                                // scale, shift, hw0, hw1
-            float2 c1 = make_float2(0.f, 0.f);
-            if constexpr (NC > 2) c1 = *(const float2*)(row + 4);                 // hw2, hw3
+            const float4 c0 = kc0[q];                                             // scale, shift, hw0, hw1
+            const float2 c1 = kc1[q];                                             // hw2, hw3
 #pragma unroll
             for (int ni = 0; ni < 4; ++ni) {
                 const float yq = fmaxf(acc[ni][q] * c0.x + c0.y, 0.f);
@@ -1820,7 +1834,7 @@ __global__ __launch_bounds__(512, 2) void dec_tail_fused_x3ps(const TailParams p
         }
     };
 
-    if (mh == 0) issue_tile(tile_at(0), 0);
+    if (mh == 0) { issue_src(tile_at(0), 0); issue_img(tile_at(0), 0); }
     for (int it = 0; it < my_tiles; ++it) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -1830,7 +1844,9 @@ __global__ __launch_bounds__(512, 2) void dec_tail_fused_x3ps(const TailParams p
         }
         main_loop(it);
         if (mh == 0) {
-            if (it + 1 < my_tiles) issue_tile(tile_at(it + 1), (it + 1) & 1);       // (before the epilogue: more time to land)
+            // all of the next tile's halo pieces (before the epilogue: more time to land).  Moving the image pieces to group B --
+            // before or after its epilogue -- made B the longer group: a piece costs its wave 200-400 cycles there
+            if (it + 1 < my_tiles) { issue_src(tile_at(it + 1), (it + 1) & 1); issue_img(tile_at(it + 1), (it + 1) & 1); }
             float tot[NC];
             partial_logits(tot);
             float* pa = part + (((it & 1) * 4 + par) * 64 + lane) * NC;
