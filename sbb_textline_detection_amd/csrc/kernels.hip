@@ -977,13 +977,14 @@ void conv_igemm_mfma(const ConvParams p)
             if (kPrefetchConst) prefetch_consts(tile_at(c_q));
             if (kPrefetchRes && p.residual) prefetch_residual(tile_at(c_q));
         }
-        // 8-wave tiles (split mode: the 512 x 128 ones only): waves NW/2.. (the SIMD partners of waves 0..NW/2-1) issue the next stage's loads in the MIDDLE of the
-        // K-step, after their first half's MFMAs -- a stage's DMA issue costs a wave several hundred cycles in which it feeds no
-        // MFMAs; issued by all eight waves right after the barrier those cycles coincided on every SIMD.  dec3 and the 128 -> 128
-        // 3x3 convs: -8 % time; the 256 x 256 tiles (12 loads per wave and stage instead of 10, K-steps twice as long) +1 %: not
-        // there.  f16: dec3 -8.6 %, 128 -> 128 3x3 -6 %, dec1 / dec2 on 256 x 256 tiles -1.5 % (+0.75 % throughput).  (variant flag bit 3 = off)
-        constexpr bool kSplitIssue = NW == 8 && !PH8 && NS == 2;
-        const bool late_issue = kSplitIssue && (BP == 512 || !X3) && wave >= NW / 2 && !(p.variant_flags & 8);
+        // 8-wave tiles of the plain 16-bit modes: waves NW/2.. (the SIMD partners of waves 0..NW/2-1) issue the next stage's loads in
+        // the MIDDLE of the K-step, after their first half's MFMAs -- a stage's DMA issue costs a wave several hundred cycles in which
+        // it feeds no MFMAs; issued by all eight waves right after the barrier those cycles coincided on every SIMD.  f16: dec3 -8.6 %,
+        // 128 -> 128 3x3 -6 %, dec1 / dec2 on 256 x 256 tiles -1.5 % (+1.1 % and +0.75 % throughput).  The split mode's 512 x 128 tile
+        // gains the same 8 % per launch but has no register left for the second call site (one VGPR spilled) and its 256 x 256 tile
+        // loses 1-3 %: plain modes only.  (variant flag bit 3 = off)
+        constexpr bool kSplitIssue = !X3 && NW == 8 && !PH8 && NS == 2;
+        const bool late_issue = kSplitIssue && wave >= NW / 2 && !(p.variant_flags & 8);
         if (!late_issue && issued < total) issue(nxt);
         const char* sb = smem + cur * T::kStageBytes;
         if constexpr (X3) {
@@ -1019,9 +1020,6 @@ void conv_igemm_mfma(const ConvParams p)
                 for (int mi = 0; mi < T::kMI; ++mi)
 #pragma unroll
                     for (int q = 0; q < NIH; ++q) acc[mi][h * NIH + q] = mfma16<true>(ah[mi], bh[q], acc[mi][h * NIH + q]);
-                if constexpr (kSplitIssue) {
-                    if (h == 0 && late_issue && issued < total) issue(nxt);
-                }
             }
         } else {
             // The K-step's MFMAs run in phases of (k-half kk, group of <= 4 pixel blocks); the LDS
@@ -1254,11 +1252,8 @@ static hipError_t launch_conv_16(const ConvParams& p, hipStream_t s)
 
 // split mode: the 4-wave tiles at 2 blocks per CU (3 MFMAs per product for the same LDS bytes: the matrix pipe, not the
 // staging path, is what fills first here)
-static hipError_t launch_conv_x3(const ConvParams& p0, hipStream_t s)
+static hipError_t launch_conv_x3(const ConvParams& p, hipStream_t s)
 {
-    static const bool split_issue = !(getenv("SBBSEG_X3_SPLIT_ISSUE") && getenv("SBBSEG_X3_SPLIT_ISSUE")[0] == '0');      // A/B
-    ConvParams p = p0;
-    if (!split_issue) p.variant_flags |= 8;
     const int bc = conv_tile_bc(p.cout);
     if (p.variant == 0 && bc == 128 && !p.residual) {          // the long-K decoder launches: same 8-wave tiles as the plain modes
         const long t256 = (long)p.n_cls * ((p.M + 255) / 256) * (p.cout / 256);
@@ -1276,7 +1271,7 @@ static hipError_t launch_conv_x3(const ConvParams& p0, hipStream_t s)
 hipError_t launch_conv(const ConvParams& p0, int precision, hipStream_t s)
 {
     if (precision == kF16X3) return launch_conv_x3(p0, s);
-    static const bool split_issue = !(getenv("SBBSEG_X3_SPLIT_ISSUE") && getenv("SBBSEG_X3_SPLIT_ISSUE")[0] == '0');      // A/B (all 16-bit modes)
+    static const bool split_issue = !(getenv("SBBSEG_SPLIT_ISSUE") && getenv("SBBSEG_SPLIT_ISSUE")[0] == '0');      // A/B (plain 16-bit modes)
     ConvParams p = p0;
     if (!split_issue) p.variant_flags |= 8;
     if (precision == kF32) {
