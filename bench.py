@@ -10,9 +10,14 @@ of 448x448 per page; a step is `--pages-per-step` (16) such pages back to back, 
 seconds, not a fraction of one (the clocks settle).  value = tiles / time, the median of `--repeats` (3) timed
 regions of exactly K steps each (all repeats are reported).
 
-N > 1: BASELINE.json configs[3] -- 64 pages of 4000x3000 (108 tiles each) sharded as whole pages over the ranks,
-one RCCL all-gather of the u8 masks per step (the "stitch" exchange north_star names); strong scaling.
-`--workload page` keeps the weak-scaling page workload.  One rank per GPU: either launched by
+N > 1 (round 4: like for like with N = 1): the SAME page workload on every rank -- 16 such pages per GPU per step -- plus one RCCL
+all-gather of the u8 masks per step (the "stitch" exchange north_star names); `scaling` = "weak" at every N, so value(N) / value(1)
+is a scaling efficiency of one workload.  BASELINE.json configs[3] -- 64 pages of 4000x3000 (108 tiles each) sharded as whole pages
+over the ranks, one all-gather of the masks per step, strong scaling -- is measured in the same run at EVERY N (N = 1 included:
+the base of its curve) and reported under `batch64`; `--workload batch64` makes it the headline instead.
+`SBBSEG_BENCH_COLLECTIVE=capi` routes the all-gather through the C ABI's own RCCL communicator (sbbseg_comm_* /
+sbbseg_allgather_labels_dev: the path an integrator without torch uses) instead of torch.distributed.
+One rank per GPU: either launched by
 `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...` (RANK / LOCAL_RANK / WORLD_SIZE in the
 environment) or as plain `python bench.py --gpus N`, which re-executes itself under torch.distributed.run on
 127.0.0.1 and relays the ranks' output.  The N > 1 line carries `ranks_seen` (world size and device of every rank, read
@@ -91,6 +96,29 @@ def _ranks_seen(dist, world, rank, local_rank, device_name):
     return {"world_size": dist.get_world_size(), "backend": dist.get_backend(), "ranks": everyone}
 
 
+def _collective_choice():
+    """SBBSEG_BENCH_COLLECTIVE: "torch" (default: torch.distributed all_gather_into_tensor, backend nccl = RCCL) or "capi" (the
+    all-gather inside the C ABI: sbbseg_comm_init + sbbseg_allgather_labels_dev on the handle's stream, librccl dlopen'ed)."""
+    v = os.environ.get("SBBSEG_BENCH_COLLECTIVE", "torch").lower()
+    if v not in ("torch", "capi"):
+        raise SystemExit(f"SBBSEG_BENCH_COLLECTIVE={v}: expected 'torch' or 'capi'")
+    return v
+
+
+def _default_workload(world):
+    """`--workload auto`: the page workload (BASELINE configs[1]) at EVERY N, so that the driver's 1/2/4/8 sweep compares one
+    workload with itself (weak scaling); configs[3] rides along under `batch64` at every N."""
+    return "page"
+
+
+def _broadcast_unique_id(dist, rank, make):
+    """Rank 0 makes the 128-byte RCCL communicator id (`make()`), every rank returns the same bytes (shipped over the process group
+    that torchrun's rendezvous built -- an integrator without torch ships them over its own channel)."""
+    box = [make() if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0)
+    return bytes(box[0])
+
+
 def _plumbing_check(args):
     """Launch + rendezvous + collective only (no GPU, no model): gloo on CPU.  Exercised by the CPU tests at world 2 and 4 so
     that the round-end multi-GPU run cannot die in argument / launcher / process-group plumbing."""
@@ -105,9 +133,21 @@ def _plumbing_check(args):
     everything = torch.empty((world * block, 4), dtype=torch.uint8)
     dist.all_gather_into_tensor(everything.view(-1), mine.view(-1))
     ok = all(int(everything[r * block, 0]) == r for r in range(world))
+    # SBBSEG_BENCH_COLLECTIVE=capi: rank 0's 128-byte communicator id must reach every rank unchanged (here a stand-in id: the real
+    # one needs RCCL and a GPU); every rank reports the digest of what it received
+    collective = _collective_choice()
+    uid_ok = None
+    if collective == "capi":
+        import hashlib
+        uid = _broadcast_unique_id(dist, rank, lambda: bytes((7 * k + 1) & 0xFF for k in range(128)))
+        digests = [None] * world
+        dist.all_gather_object(digests, hashlib.sha1(uid).hexdigest())
+        uid_ok = len(uid) == 128 and len(set(digests)) == 1
+        ok = ok and uid_ok
     dist.barrier()
     if rank == 0:
-        print(json.dumps({"plumbing_check": True, "n_gpus": world, "ranks_seen": seen, "all_gather_ok": ok,
+        print(json.dumps({"plumbing_check": True, "n_gpus": world, "ranks_seen": seen, "all_gather_ok": ok, "collective": collective,
+                          "unique_id_broadcast_ok": uid_ok, "default_workload": _default_workload(world),
                           "pages_per_rank": [shard_block(64, r, world)[1] for r in range(world)]}))
     dist.destroy_process_group()
     return 0 if ok else 1
@@ -126,8 +166,9 @@ def main():
     ap.add_argument("--conv-variant", type=int, default=int(os.environ.get("SBBSEG_CONV_VARIANT", "0")),
                     help="A/B knob of the conv kernel (see sbbseg.h sbbseg_debug_set_conv_variant)")
     ap.add_argument("--workload", default="auto", choices=["auto", "page", "pipeline3", "batch64"],
-                    help="auto = page at 1 GPU (BASELINE configs[1], the metric's config), batch64 at N > 1 (configs[3]: 64 pages of "
-                         "4000x3000 sharded over the ranks, strong scaling); pipeline3 = configs[2] (border + layout + textline)")
+                    help="auto = page at every N (BASELINE configs[1], the metric's config; weak scaling), with configs[3] (64 pages of "
+                         "4000x3000 sharded over the ranks, strong scaling) measured beside it under `batch64`; batch64 = configs[3] as the "
+                         "headline; pipeline3 = configs[2] (border + layout + textline)")
     ap.add_argument("--pages-per-step", type=int, default=16, help="page workload: pages segmented back to back per step")
     ap.add_argument("--batch-pages", type=int, default=64, help="batch64 workload: pages in the batch (64 = BASELINE configs[3])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -164,7 +205,10 @@ def main():
     if backend == "nccl" and world > n_dev:
         raise SystemExit(f"--gpus {world} but only {n_dev} GPU(s) visible (RCCL needs one device per rank)")
     device_index = local_rank % n_dev
-    workload = args.workload if args.workload != "auto" else ("page" if world == 1 else "batch64")
+    workload = args.workload if args.workload != "auto" else _default_workload(world)
+    collective = _collective_choice()
+    if collective == "capi" and backend != "nccl":
+        raise SystemExit("SBBSEG_BENCH_COLLECTIVE=capi needs one GPU per rank (RCCL): not available under the gloo check backend")
     if args.max_batch <= 0:
         # tiles per chunk: four pages' worth (4 x 70 / 4 x 108), pooled across pages by sbbseg_segment_pages_dev and run as two
         # concurrent halves -- one page's 70 tiles leave the persistent conv grids a ragged last round; 140 / 280 / 374 / 560
@@ -182,9 +226,14 @@ def main():
             dist.init_process_group(backend)
         ranks_seen = _ranks_seen(dist, world, rank, local_rank, torch.cuda.get_device_name(device_index))
 
+    comm_state = {"ctx": None}
+
     def all_gather_u8(dst, src_t):
         """the stitch exchange: every rank's u8 masks to every rank (RCCL; host-staged under the gloo check backend)"""
-        if backend == "nccl":
+        if collective == "capi":
+            # ncclAllGather on the handle's stream (= torch's current stream here), communicator owned by the library
+            comm_state["ctx"].allgather_labels_dev(src_t.data_ptr(), src_t.numel(), dst.data_ptr())
+        elif backend == "nccl":
             dist.all_gather_into_tensor(dst.view(-1), src_t.view(-1))
         else:
             h = torch.empty(dst.numel(), dtype=torch.uint8)
@@ -207,16 +256,24 @@ def main():
         return m
 
     model = make_model(args.precision)
+    if world > 1 and collective == "capi":
+        uid = _broadcast_unique_id(dist, rank, _capi.comm_unique_id)
+        model.ctx.comm_init(rank, world, uid)
+        if model.ctx.comm_info() != (rank, world):
+            raise SystemExit("sbbseg_comm_init: communicator does not report (rank, world)")
+        comm_state["ctx"] = model.ctx
     tiles_per_page = _capi.tile_grid(PAGE_H, PAGE_W, MODEL_HW, MODEL_HW)[0].shape[0]
     page0 = synthetic_page(PAGE_H, PAGE_W, seed=rank)
 
     fallbacks_of_pipeline3 = lambda: 0
+    page_state = {}
     # ---- workloads: build(model) -> (step(), tiles per step, description, scaling, gather() or None, bytes gathered)
     def build_page(m):
         P = max(1, args.pages_per_step)
         pages = [torch.from_numpy(page0 if k == 0 else synthetic_page(PAGE_H, PAGE_W, seed=rank * 1000 + k)).cuda() for k in range(P)]
         labels = torch.empty((P, PAGE_H, PAGE_W), dtype=torch.uint8, device="cuda")
         d_all = torch.empty((world, P, PAGE_H, PAGE_W), dtype=torch.uint8, device="cuda") if world > 1 else None
+        page_state[id(m)] = labels                  # the buffer the timed steps write: label_match reads it back afterwards
 
         def gather():
             all_gather_u8(d_all, labels)
@@ -233,11 +290,19 @@ def main():
             m.ctx.segment_pages_dev(page_ptrs, PAGE_H, PAGE_W, label_ptrs)
         return step, tiles_per_page * P * world, desc, "weak", (gather if world > 1 else None), P * PAGE_H * PAGE_W * world, step_local, tiles_per_page * P
 
-    def build_batch64(m):
+    def build_batch64(m, distinct=None):
+        """`distinct`: how many different synthetic pages back the batch (None = every page its own seed); the side measurement of the
+        default line cycles 8 (drawing 64 pages of 4000x3000 on one host core would cost more than the measurement itself)."""
         BH, BW, NPAGES = 4000, 3000, max(1, args.batch_pages)
         from sbb_textline_detection_amd.distributed import shard_block
         first, count, block = shard_block(NPAGES, rank, world)
-        pages = [torch.from_numpy(synthetic_page(BH, BW, seed=100 + first + k)).cuda() for k in range(count)]
+        drawn = {}
+        def page_of(k):
+            key = (first + k) if distinct is None else (first + k) % distinct
+            if key not in drawn:
+                drawn[key] = torch.from_numpy(synthetic_page(BH, BW, seed=100 + key)).cuda()
+            return drawn[key]
+        pages = [page_of(k) for k in range(count)]
         d_mine = torch.empty((block, BH, BW), dtype=torch.uint8, device="cuda")
         d_everything = torch.empty((world * block, BH, BW), dtype=torch.uint8, device="cuda") if world > 1 else None
         tpp = _capi.tile_grid(BH, BW, MODEL_HW, MODEL_HW)[0].shape[0]
@@ -327,6 +392,8 @@ def main():
     dt = statistics.median(dts)
     value = tiles_per_step * args.steps / dt
     rates = [tiles_per_step * args.steps / t for t in dts]
+    # what the timed steps themselves wrote: page 0's mask out of the pooled label buffer, read back before any other call
+    timed_labels0 = page_state[id(model)][0].cpu().numpy() if (rank == 0 and workload == "page") else None
 
     exchange, per_rank = None, None
     if gather is not None:                                          # the exchange alone: all-gather GB/s over xGMI
@@ -362,6 +429,34 @@ def main():
             rates_all = [torch.tensor([v]) for v in rl]
         pr = [round(float(t.item()), 1) for t in rates_all]
         per_rank = {"compute_only_patches_per_s": pr, "sum": round(sum(pr), 1), "what": "each rank segmenting its own shard, no all-gather, no barrier"}
+
+    # ---- BASELINE configs[3] beside the headline, at EVERY N (N = 1 = the base of its strong-scaling curve) --------------
+    batch64 = None
+    if workload == "page" and not args.no_extras:
+        try:
+            stepb, tilesb, descb, scalb, gatherb, bytesb = build_batch64(model, distinct=8)[:6]
+            nb = max(2, min(4, args.steps // 5))
+            dtb = timed(stepb, nb, 1, 1)[0]
+            batch64 = {"patches_per_s": round(tilesb * nb / dtb, 2), "ms_per_step": round(dtb / nb * 1e3, 3), "steps": nb, "warmup": 1,
+                       "scaling": scalb, "tiles_per_step": tilesb, "pages": max(1, args.batch_pages), "chunk_tiles": model.max_batch,
+                       "what": descb + f" (same handle as the headline: tiles pooled into {model.max_batch}-tile chunks on two lanes; 8 distinct synthetic pages cycled)"}
+            if gatherb is not None:
+                for _ in range(2):
+                    gatherb()
+                fence()
+                t0 = time.perf_counter()
+                for _ in range(5):
+                    gatherb()
+                fence()
+                gdtb = (time.perf_counter() - t0) / 5
+                batch64["exchange"] = {"bytes_gathered_per_rank": bytesb, "ms": round(gdtb * 1e3, 3),
+                                       "algbw_GBps": round(bytesb / gdtb / 1e9, 1),
+                                       "busbw_GBps": round(bytesb * (world - 1) / world / gdtb / 1e9, 1),
+                                       "share_of_step": round(gdtb / (dtb / nb), 4)}
+            del stepb, gatherb
+            torch.cuda.empty_cache()
+        except Exception as e:                                          # never lose the headline over the side measurement
+            batch64 = {"error": repr(e)}
 
     # ---- roofline of the dominant kernel: per-launch HIP events on the library's stream ----------
     def roofline_of(m):
@@ -529,18 +624,50 @@ def main():
             except Exception as e:                                        # torch CPU ops unavailable: keep the port
                 cpu_baseline = dict(cpu_port, note=f"torch-CPU proxy failed: {e}")
 
-        def match(m):
+        # label-exact modes: a label of the TIMED output may differ from the oracle's only where the oracle's own top-2 softmax margin
+        # is below this (tests/gpu_common.py EXACT_MARGIN: the fp32 oracle's reassociation noise, measured worst 7e-5)
+        EXACT_MARGIN = 2e-4
+
+        def match(m, timed_map):
+            """Agreement with the fp32 oracle on the sampled tiles: (a) `label_*` -- the labels the TIMED steps wrote (page 0 of the pooled
+            label buffer, read back right after the timed region) inside each sampled tile's owned region (main.py:294-364: margin crop +
+            last writer wins) against the oracle's argmax (main.py:290); (b) `max_abs_softmax_diff` -- seam 2 (`predict`) on the same tiles."""
             if ref is None:
                 return None
             got = m.predict(x)
             srt = np.sort(ref, axis=-1)
             margin = srt[..., -1] - srt[..., -2]
-            mism = ref.argmax(-1) != got.argmax(-1)
-            return {"vs": "oracle (fp32 CPU port)", "patches": int(len(pick)),
-                    "max_abs_softmax_diff": float(f"{np.abs(ref - got).max():.3g}"),
-                    "label_mismatch_frac": float(f"{mism.mean():.3g}"),
-                    "max_oracle_margin_among_mismatches": float(f"{(margin[mism].max() if mism.any() else 0.0):.3g}")}
-        label_match = match(model)
+            out = {"vs": "oracle (fp32 CPU port)", "patches": int(len(pick)),
+                   "max_abs_softmax_diff": float(f"{np.abs(ref - got).max():.3g}")}
+            if timed_map is None:                                       # not the page workload: seam 2's labels only
+                mism = ref.argmax(-1) != got.argmax(-1)
+                out.update(source="model.predict on the sampled tiles (the timed workload keeps no page-0 buffer)", label_mismatch_frac=float(f"{mism.mean():.3g}"),
+                           max_oracle_margin_among_mismatches=float(f"{(margin[mism].max() if mism.any() else 0.0):.3g}"))
+                return out
+            from oracle import tiling
+            tiles, _, _ = tiling.tile_grid(PAGE_H, PAGE_W, MODEL_HW, MODEL_HW)
+            own = tiling.owner_map(PAGE_H, PAGE_W, MODEL_HW, MODEL_HW)
+            n_px = n_mism = n_outside = 0
+            worst = 0.0
+            for i, k in enumerate(pick):
+                t = tiles[int(k)]
+                ys, xs = slice(t["y0"] + t["ylo"], t["y0"] + t["yhi"]), slice(t["x0"] + t["xlo"], t["x0"] + t["xhi"])
+                owned = own[ys, xs] == int(k)                             # the clamped last row / column overwrites part of its neighbour
+                want = ref[i, t["ylo"]:t["yhi"], t["xlo"]:t["xhi"]].argmax(-1)
+                mg = margin[i, t["ylo"]:t["yhi"], t["xlo"]:t["xhi"]]
+                mism = (timed_map[ys, xs] != want) & owned
+                n_px += int(owned.sum())
+                n_mism += int(mism.sum())
+                n_outside += int((mism & (mg > EXACT_MARGIN)).sum())
+                if mism.any():
+                    worst = max(worst, float(mg[mism].max()))
+            out.update(source="labels[0] of the timed region: page 0's mask as the timed sbbseg_segment_pages_dev steps wrote it (pooled chunks, two lanes), "
+                              "owned regions of the sampled tiles",
+                       pixels_checked=n_px, label_mismatches=n_mism, label_mismatch_frac=float(f"{n_mism / max(1, n_px):.3g}"),
+                       max_oracle_margin_among_mismatches=float(f"{worst:.3g}"),
+                       exact_margin=EXACT_MARGIN, label_mismatches_outside_exact_margin=n_outside)
+            return out
+        label_match = match(model, timed_labels0)
         modes = {args.precision: {"patches_per_s": round(value, 2), "label_match": label_match,
                                   "roofline_frac": roofline["frac"], "roofline_frac_issued": roofline["frac_issued"]}}
         other = {"f16": "f16x3", "f16x3": "f16"}.get(args.precision)
@@ -549,8 +676,9 @@ def main():
             step2, tps2 = build_page(m2)[:2]
             n2 = max(3, args.steps // 4)
             dts2 = timed(step2, n2, 1, 1)
+            timed_labels2 = page_state[id(m2)][0].cpu().numpy()
             r2, _ = roofline_of(m2)
-            modes[other] = {"patches_per_s": round(tps2 * n2 / dts2[0], 2), "label_match": match(m2),
+            modes[other] = {"patches_per_s": round(tps2 * n2 / dts2[0], 2), "label_match": match(m2, timed_labels2),
                             "roofline_kernel": r2["kernel"], "roofline_frac": r2["frac"], "roofline_frac_issued": r2["frac_issued"],
                             "roofline": {k: r2[k] for k in ("kernel", "achieved", "peak", "unit", "frac", "achieved_issued", "frac_issued", "traffic",
                                                             "avg_launch_ms", "conv3x3_stages", "all_convs") if k in r2},
@@ -560,6 +688,7 @@ def main():
             v["what"] = ("label-exact split-fp16 mode (hi+lo operands, 3 MFMAs per product; default of the Python seams)" if k == "f16x3"
                          else "fast mode: plain fp16 operands, fp32 accumulate")
 
+    exit_code = 0
     extras = None
     if rank == 0 and world == 1 and workload == "page" and not args.no_extras:
         extras = {}
@@ -601,16 +730,29 @@ def main():
             "patches_per_s_per_gpu": round(value / world, 2),
             "achieved_tflops_end_to_end": round(value / world * 2 * model.plan.macs_per_patch() / 1e12, 1),
             "roofline": roofline, "cpu_baseline": cpu_baseline, "label_match": label_match, "modes": modes, "exchange": exchange,
-            "per_rank": per_rank, "ranks_seen": ranks_seen, "host_path": host_path, "extras": extras,
+            "per_rank": per_rank, "ranks_seen": ranks_seen, "host_path": host_path, "extras": extras, "batch64": batch64,
         }
+        if world > 1:
+            out["config"]["collective"] = ("C ABI: sbbseg_comm_init + sbbseg_allgather_labels_dev (ncclAllGather on the handle's stream, librccl dlopen'ed)"
+                                           if collective == "capi" else "torch.distributed all_gather_into_tensor (backend %s)" % backend)
+        # a label-exact mode whose TIMED output differs from the oracle outside the oracle's own near-ties fails the run
+        for mode_name, mm in (modes or {}).items():
+            lm = mm.get("label_match") or {}
+            if mode_name == "f16x3" and lm.get("label_mismatches_outside_exact_margin", 0) > 0:
+                out["label_check_failed"] = True
+                exit_code = 3
         print(json.dumps(out))
         if os.environ.get("SBBSEG_BENCH_OPS"):
             with open(os.environ["SBBSEG_BENCH_OPS"], "w") as f:
                 json.dump(per_op, f, indent=1)
     if world > 1:
+        if comm_state["ctx"] is not None:
+            comm_state["ctx"].comm_destroy()
         dist.barrier()
         dist.destroy_process_group()
     model.release()
+    if exit_code:
+        raise SystemExit(exit_code)
 
 
 if __name__ == "__main__":

@@ -247,8 +247,10 @@ int sbbseg_morph(sbbseg_ctx* c, const uint8_t* src_hw, int H, int W, int op, int
  * + (cells with three pixels inside) / 2, counted over the component with its holes filled.  The device ranks the components
  * by that sum over the component as it is (a lower bound) and checks the winner against every other component's bounding-box
  * bound; a ring- or frame-shaped blob beside a solid one can leave that undecided, and only then the dilated mask is copied
- * back and the contours are traced on the host (Moore border following + shoelace: exact).  [EXT, unpinned]: equal areas are
- * broken by raster order of the components' first pixels; in the reference OpenCV's contour order decides. */
+ * back and the contours are traced on the host (Moore border following + shoelace: exact).  Equal areas: the component whose
+ * first pixel comes LAST in raster order wins -- in the reference np.argmax keeps the first maximum of cv2.findContours' list,
+ * which runs in reverse discovery order (OpenCV contours.cpp links every new contour in at the head of its parent's child
+ * list) [EXT, restated, unpinned: no cv2 build exists here to confirm it on two equal rectangles]. */
 int sbbseg_page_box_dev(sbbseg_ctx* c, const void* d_mask_hw, int H, int W, int32_t* box_xywh, int64_t* pixels);
 /* extract_page's model + glue in one call: border model on the page as upscaled to Hs x Ws (sbbseg_segment_whole_scaled),
  * then sbbseg_page_box_dev on the label plane while it is still on the device.  mask_out: Hs x Ws labels (x3 with

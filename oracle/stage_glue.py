@@ -80,8 +80,8 @@ def otsu_copy(img: np.ndarray) -> np.ndarray:
 # borderType = BORDER_CONSTANT with borderValue = morphologyDefaultBorderValue() -- +inf for erode, -inf for dilate, i.e. pixels
 # outside the image never win the min / max; `iterations` applies the filter repeatedly.  Written here LITERALLY (one 5x5 pass
 # per iteration), so the device's shortcut (one clipped (4n+1)-wide separable filter) is checked, not assumed.
-# cv2.findContours / contourArea / boundingRect are NOT restated: the largest blob is taken as the 8-connected component with
-# the most pixels (ties: first in raster order) -- see include/sbbseg.h sbbseg_page_box_dev for what that leaves [EXT, unpinned].
+# cv2.findContours / contourArea / boundingRect: restated as border following + shoelace area below (largest_component_box);
+# see include/sbbseg.h sbbseg_page_box_dev for what that leaves [EXT, unpinned].
 def _morph_once(a: np.ndarray, k: int, is_max: bool) -> np.ndarray:
     r = (k - 1) // 2
     fill = 0 if is_max else 255
@@ -151,15 +151,18 @@ def outer_contour_area2(comp: np.ndarray) -> int:
 def largest_component_box(mask: np.ndarray):
     """((x, y, w, h), pixels) of the 8-connected component of mask > 0 whose OUTER CONTOUR has the largest cv2.contourArea
     (main.py:398-404: contours[np.argmax([cv2.contourArea(c) ...])], cv2.boundingRect) -- a hole's contour never wins, it lies
-    inside its component's outer contour; ((0,0,0,0), 0) if the mask is empty.  Ties: the first component in raster order
-    [EXT, unpinned: OpenCV's own contour order decides in the reference]."""
+    inside its component's outer contour; ((0,0,0,0), 0) if the mask is empty.  Ties: the LAST component in raster order of first
+    pixels [EXT, restated from OpenCV's contours.cpp, unpinned: outer borders are discovered in raster order and every new contour
+    is linked in at the HEAD of its parent's child list (cvInsertNodeIntoTree), so cv2.findContours returns siblings in reverse
+    discovery order and np.argmax's first maximum (main.py:400-401) is the last-discovered of equal areas]."""
     from scipy import ndimage
     lab, n = ndimage.label(np.asarray(mask) > 0, structure=np.ones((3, 3), int))
     if n == 0:
         return (0, 0, 0, 0), 0
     slices = ndimage.find_objects(lab)
     areas = [outer_contour_area2(lab[sl] == k + 1) for k, sl in enumerate(slices)]
-    best = int(np.argmax(areas))                         # scipy numbers components in raster order of their first pixel: ties -> first
+    # scipy numbers components in raster order of their first pixel = OpenCV's discovery order; the reference's list is reversed
+    best = len(areas) - 1 - int(np.argmax(areas[::-1]))  # ties -> the last discovered
     sl = slices[best]
     pixels = int((lab[sl] == best + 1).sum())
     return (int(sl[1].start), int(sl[0].start), int(sl[1].stop - sl[1].start), int(sl[0].stop - sl[0].start)), pixels

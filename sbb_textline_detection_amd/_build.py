@@ -1,6 +1,6 @@
 """Compile libsbbseg.so for gfx950 in-tree (hipcc cross-compiles without a GPU).
 
-Every source is compiled to its own object under ``build/`` (git-ignored, not shipped) and only stale objects are
+Every source is compiled to its own object under ``_obj/`` next to this file (git-ignored, not shipped) and only stale objects are
 rebuilt, in parallel; the link step produces ``libsbbseg.so`` next to this file, which is what travels to the GPU box."""
 from __future__ import annotations
 
@@ -11,15 +11,19 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-OBJ_DIR = os.path.join(HERE, "..", "build", "obj")
+OBJ_DIR = os.path.join(HERE, "_obj")          # package-local (git- and gpurun-ignored): an installed copy never writes outside itself
 LIB = os.path.join(HERE, "libsbbseg.so")
-SOURCES = ["kernels.hip", "block_x3.hip", "api.hip", "comm.cpp", "loader.cpp"]
+SOURCES = ["kernels.hip", "block_x3.hip", "api.hip", "loader.cpp"]
 HEADERS = [os.path.join(CSRC, "internal.h"), os.path.join(HERE, "..", "include", "sbbseg.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
 
 
 def _sources():
-    return [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    paths = [os.path.join(CSRC, s) for s in SOURCES]
+    missing = [p for p in paths if not os.path.exists(p)]
+    if missing:                                  # a typo here used to surface as an obscure link error / missing symbols
+        raise RuntimeError("libsbbseg sources missing: " + ", ".join(missing))
+    return paths
 
 
 def needs_build() -> bool:

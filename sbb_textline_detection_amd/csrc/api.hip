@@ -577,8 +577,11 @@ void comm_release(sbbseg_ctx* c)
 // Only the OUTER contour of a component can win (a hole's contour lies inside it), so: label the 8-connected components, trace
 // each one's outer border through its boundary pixels (Moore neighbour tracing from the first pixel in raster order, whose
 // west / north neighbours are background; stop when the start pixel is re-entered in the start direction), shoelace area of
-// that closed chain (CHAIN_APPROX_SIMPLE drops collinear points only: same area).  Ties: first component in raster order
-// [EXT: OpenCV's contour order is not pinned].  Returns {x0, y0, x1, y1, pixels}; false for an empty mask.
+// that closed chain (CHAIN_APPROX_SIMPLE drops collinear points only: same area).  Ties: the LAST component in raster order of
+// first pixels (round 4) [EXT, restated from OpenCV's contours.cpp, unpinned: the border-following scanner discovers outer borders
+// in raster order and cvInsertNodeIntoTree puts each new contour at the HEAD of its parent's child list, so the list findContours
+// returns runs in REVERSE discovery order and np.argmax's "first maximum" (main.py:400-401) is the last one discovered].
+// Returns {x0, y0, x1, y1, pixels}; false for an empty mask.
 // Doubled shoelace area of the outer border of the component `inside` describes, walked from its first pixel in raster order
 // (sy, sx) -- whose west / north neighbours are background -- by Moore neighbour tracing, clockwise with y pointing down; stops
 // when the start pixel is left again in the first direction.  box = {x0, y0, x1, y1} of the border (= of the component).
@@ -644,7 +647,7 @@ bool host_largest_contour(const uint8_t* m, int H, int W, int (&out)[5])
         auto inside = [&](int y, int x) { return (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W && lab[(long)y * W + x] == id; };
         int tb[4];
         const long long area2 = trace_outer_area2(inside, (int)(s / W), (int)(s - (long)(s / W) * W), n, tb);
-        if (area2 > best_area2) { best_area2 = area2; out[0] = x0; out[1] = y0; out[2] = x1; out[3] = y1; out[4] = cnt; }
+        if (area2 >= best_area2) { best_area2 = area2; out[0] = x0; out[1] = y0; out[2] = x1; out[3] = y1; out[4] = cnt; }   // ties: the later one
     }
     return n_comp > 0;
 }
@@ -2284,7 +2287,7 @@ int sbbseg_page_box_dev(sbbseg_ctx* c, const void* d_mask_hw, int H, int W, int3
         std::vector<int> lab(pix);
         HIPCHK(hipMemcpy(lab.data(), c->d_cc_parent, pix * sizeof(int), hipMemcpyDeviceToHost));
         std::vector<int> cand;
-        cand.push_back((int)(0xffffffffu - (unsigned)(key & 0xffffffffu)));
+        cand.push_back((int)((unsigned)(key & 0xffffffffu) - 1u));
         if (out[5] <= kCcMaxRivals && !c->force_host_contours) cand.insert(cand.end(), out + 6, out + 6 + out[5]);
         else
             for (size_t i = 0; i < pix; ++i)
@@ -2295,7 +2298,7 @@ int sbbseg_page_box_dev(sbbseg_ctx* c, const void* d_mask_hw, int H, int W, int3
             auto inside = [&](int y, int x) { return (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W && lab[(size_t)y * W + x] == root; };
             int tb[4];
             const long long a2 = trace_outer_area2(inside, root / W, root % W, (long)pix, tb);
-            if (a2 > best_area2 || (a2 == best_area2 && root < best_root)) {
+            if (a2 > best_area2 || (a2 == best_area2 && root > best_root)) {           // ties: the later root (see host_largest_contour)
                 best_area2 = a2; best_root = root;
                 box[0] = tb[0]; box[1] = tb[1]; box[2] = tb[2]; box[3] = tb[3];
             }

@@ -3711,12 +3711,13 @@ __global__ __launch_bounds__(256) void cc_box_kernel(const int* parent, int* bx0
     wave_minmax_by_root(bx0, bx1, cur, lo, hi);
     wave_minmax_by_root(by0, by1, cur, y, y);
 }
-// best = max over roots of (area2 lower bound, then smallest root index); key = area2 << 32 | ~root
+// best = max over roots of (area2 lower bound, then LARGEST root index: the reference's np.argmax over OpenCV's contour list, which
+// runs in reverse discovery order, keeps the last-discovered of equal areas -- api.hip host_largest_contour); key = area2 << 32 | root + 1
 __global__ __launch_bounds__(256) void cc_best_area_kernel(const int* parent, const int* area2, long n, unsigned long long* best)
 {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     unsigned long long key = 0;
-    if (i < n && parent[i] == (int)i) key = ((unsigned long long)(unsigned)area2[i] << 32) | (0xffffffffu - (unsigned)i);
+    if (i < n && parent[i] == (int)i) key = ((unsigned long long)(unsigned)area2[i] << 32) | ((unsigned)i + 1u);
     for (int off = 32; off > 0; off >>= 1) {
         const unsigned long long o = __shfl_xor(key, off);
         key = o > key ? o : key;
@@ -3724,7 +3725,7 @@ __global__ __launch_bounds__(256) void cc_best_area_kernel(const int* parent, co
     if ((threadIdx.x & 63) == 0 && key) atomicMax(best, key);
 }
 // out[0..3] = bounding box of the best root, out[4] = its pixel count, out[5] = number of RIVALS -- other roots whose upper bound
-// 2 (w - 1)(h - 1) exceeds the best lower bound (or ties it with a smaller index) -- and out[6..] the first kCcMaxRivals of them:
+// 2 (w - 1)(h - 1) exceeds the best lower bound (or ties it with a larger index) -- and out[6..] the first kCcMaxRivals of them:
 // with rivals the ranking is not decided here
 __global__ __launch_bounds__(256) void cc_decide_kernel(const int* parent, const int* count, const int* bx0, const int* by0, const int* bx1,
                                                         const int* by1, long n, const unsigned long long* best, int* out)
@@ -3732,21 +3733,21 @@ __global__ __launch_bounds__(256) void cc_decide_kernel(const int* parent, const
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     const unsigned long long key = *best;
     if (!key || i >= n || parent[i] != (int)i) return;
-    const int root = (int)(0xffffffffu - (unsigned)(key & 0xffffffffu));
+    const int root = (int)((unsigned)(key & 0xffffffffu) - 1u);
     const long long best_lo = (long long)(key >> 32);
     if ((int)i == root) {
         out[0] = bx0[i]; out[1] = by0[i]; out[2] = bx1[i]; out[3] = by1[i]; out[4] = count[i];
         return;
     }
     const long long hi2 = 2ll * (bx1[i] - bx0[i]) * (by1[i] - by0[i]);
-    if (hi2 > best_lo || (hi2 == best_lo && (int)i < root)) {
+    if (hi2 > best_lo || (hi2 == best_lo && (int)i > root)) {
         const int k = atomicAdd(&out[5], 1);                     // out[5] = number of undecided rivals, out[6 + k] = their roots
         if (k < kCcMaxRivals) out[6 + k] = (int)i;
     }
 }
 
 // d_out: int[6 + kCcMaxRivals] = {min x, min y, max x, max y, pixels, rivals, rival roots...} of the component with the largest
-// contour-area lower bound ({2^30, 2^30, -1, -1, 0, 0} if the mask is empty); d_best: its (area2 << 32 | ~root) key.  scratch: five int arrays of H * W.
+// contour-area lower bound ({2^30, 2^30, -1, -1, 0, 0} if the mask is empty); d_best: its (area2 << 32 | root + 1) key.  scratch: five int arrays of H * W.
 hipError_t launch_largest_contour(const uint8_t* mask, int H, int W, int* parent, int* count, int* area2, int* bx0, int* by0, int* bx1,
                                   int* by1, unsigned long long* d_best, int* d_out, hipStream_t s)
 {

@@ -25,6 +25,8 @@ import warnings
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Sequence, Tuple
 
+_LAMBDA_WARNED = set()      # layer names whose Lambda lowering has been announced in this process
+
 BN_EPS_DEFAULT = 1e-3  # keras.layers.BatchNormalization default epsilon
 
 
@@ -403,8 +405,10 @@ def parse_model_config(model_config) -> Graph:
                                  f"is not the one_side_pad crop")
             if os.environ.get("SBBSEG_STRICT_LAMBDA", "0") not in ("", "0"):
                 raise ValueError(f"layer {name}: Lambda layers are refused (SBBSEG_STRICT_LAMBDA); its bytecode cannot be inspected")
-            warnings.warn(f"layer {name}: Lambda after ZeroPadding2D((1,1)) lowered as one_side_pad's crop x[:, :-1, :-1, :] (its bytecode "
-                          f"is not inspected; set SBBSEG_STRICT_LAMBDA=1 to refuse)", stacklevel=2)
+            if name not in _LAMBDA_WARNED:                  # once per process and layer name: a model is parsed several times on its way
+                _LAMBDA_WARNED.add(name)                     # to the device (SegModel, the container writer, the plan mirror)
+                warnings.warn(f"layer {name}: Lambda after ZeroPadding2D((1,1)) lowered as one_side_pad's crop x[:, :-1, :-1, :] (its bytecode "
+                              f"is not inspected; set SBBSEG_STRICT_LAMBDA=1 to refuse)", stacklevel=2)
             node = Node(name, "crop_last", ins, {}, (ish[0] - 1, ish[1] - 1, ish[2]))
         elif cls in ("Dropout", "SpatialDropout2D"):
             node = Node(name, "act", ins, {"kind": "linear"}, ish)     # identity at inference

@@ -84,7 +84,7 @@ class SegModel:
             a = self._plan_args
             flags = (0 if a["parity_split"] else 1) | (0 if a["merge_shortcut"] else 2) | (0 if a["fuse_head"] or precision == "f32" else 4) | \
                     (0 if a["fuse_tail"] or precision not in ("f16", "bf16", "f16x3") else 8)
-            source = sbbw_path if sbbw_path is not None else sbbw_bytes(model_config, weights)
+            source = sbbw_path if sbbw_path is not None else sbbw_bytes(model_config, weights, self.graph)
             self._ctx: Optional[_capi.Context] = _capi.Context.from_sbbw(source, device, prec, self.max_batch, flags)
         else:
             if weights is None:
@@ -200,8 +200,10 @@ def load_model(path: str, compile: bool = False, device: int = 0, max_batch: Opt
         # one C call: the library reads the container and lowers the graph itself (sbbseg_model_load_file)
         model = SegModel(read_sbbw_config(real), None, device=device, max_batch=max_batch, precision=precision, sbbw_path=real)
     else:
+        # SBBSEG_NATIVE_LOADER=0 (or a one-lane handle): the Python planner lowers the graph and uploads the plan step by step --
+        # the test mirror of csrc/loader.cpp, selectable for A/B; the weights are held once (no container bytes, no C-side copy)
         cfg, weights = load_sbbw(real)
-        model = SegModel(cfg, weights, device=device, max_batch=max_batch, precision=precision)
+        model = SegModel(cfg, weights, device=device, max_batch=max_batch, precision=precision, planner="python")
     if use_cache:
         _CACHE[key] = model
     model._from_cache = use_cache

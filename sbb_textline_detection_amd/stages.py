@@ -89,8 +89,8 @@ def host_morph(plane: np.ndarray, is_max: bool, ksize: int, iterations: int) -> 
 def host_page_box(mask: np.ndarray):
     """Host mirror of sbbseg_page_box_dev (foreign model objects only): dilate x 6, then the component whose outer contour has
     the largest cv2.contourArea, traced by the library's host code (``sbbseg_debug_largest_contour``: no GPU involved)."""
-    from . import _capi
     d = host_morph(np.where(np.asarray(mask) > 0, 255, 0).astype(np.uint8), True, 5, 6)
+    from . import _capi
     return _capi.host_largest_contour(d)
 
 
@@ -294,10 +294,26 @@ class InferenceStages:
         """The model-running part of run() (main.py:2056-2107) with its chaining: border model -> page box -> the layout
         and textline models on the CROPPED page (main.py:2061, 2072, 2102), text regions cleaned by erode x 3 / dilate x 4
         (main.py:2074-2075).  Returns (page mask [Hs,Ws,3], cleaned regions [h,w,3], text lines [h,w], page_coord) with
-        h x w = extract_page's box; the crop itself is never built on a SegModel."""
+        h x w = extract_page's box; the crop itself is never built on a SegModel.  (Round 3 added page_coord as a FOURTH element:
+        callers that unpacked three must be updated -- INTEGRATION.md.)  Like the reference, a failed layout stage yields
+        regions = None and skips the textline model (textlines = None); extract_page's errors propagate."""
         self.get_image_and_scales(image_u8)
-        page_mask, box, page_coord = self.page_box_only()
-        regions = self.extract_text_regions(box=box)
-        regions = self.clean_text_regions(regions)
-        textlines = self.textline_contours(box=box)
+        page_mask, box, page_coord = self.page_box_only()          # outside the try, like main.py:2061: its errors propagate
+        # main.py:2069-2091: the layout stage and its post-processing sit in a bare try/except -- any failure (the reference: a crop
+        # smaller than the model input breaks do_prediction's reshape, main.py:278-285; here: sbbseg_segment_crop refuses it) degrades
+        # to "no regions"; the textline model only runs when text regions were found (main.py:2096 `if len(contours) > 0`: contours
+        # are traced from the pixels of class 1, main.py:457-458 -- tracing them is out of scope, their existence is not)
+        try:
+            regions = self.extract_text_regions(box=box)
+            regions = self.clean_text_regions(regions)
+            plane = regions[:, :, 0] if regions.ndim == 3 else regions
+            has_text = bool((plane == 1).any())
+        except Exception:
+            regions, has_text = None, False
+        textlines = None
+        if has_text:
+            try:
+                textlines = self.textline_contours(box=box)
+            except Exception:                                       # main.py:2152-2157: the outer bare except -> empty result
+                textlines = None
         return page_mask, regions, textlines, page_coord

@@ -25,9 +25,9 @@ from .keras_graph import Graph, parse_model_config, resnet50_unet_config
 MAGIC = b"SBBW0001"
 
 
-def sbbw_bytes(model_config: dict, weights: Dict[str, np.ndarray]) -> bytes:
-    """The container as one bytes object (what ``sbbseg_model_load`` takes)."""
-    graph = parse_model_config(model_config)
+def sbbw_bytes(model_config: dict, weights: Dict[str, np.ndarray], graph: Graph = None) -> bytes:
+    """The container as one bytes object (what ``sbbseg_model_load`` takes).  ``graph``: the already parsed config, if the caller has it."""
+    graph = graph if graph is not None else parse_model_config(model_config)
     tensors, chunks, off = [], [], 0
     for name, shape in graph.weight_specs():
         if name not in weights:

@@ -91,7 +91,9 @@ def install_cv2_stubs(cv2, pages_by_name):
     def find_contours(mask, mode, method):
         from scipy import ndimage
         lab, n = ndimage.label(mask > 0, structure=np.ones((3, 3), int))
-        return [Blob(*np.nonzero(lab == k)) for k in range(1, n + 1)], None
+        # OpenCV's list order [EXT]: outer borders are discovered in raster order, each new contour is linked in at the head of its
+        # parent's child list -> reverse discovery order (the reference's np.argmax then keeps the LAST-discovered of equal areas)
+        return [Blob(*np.nonzero(lab == k)) for k in range(n, 0, -1)], None
     cv2.findContours = find_contours
     def contour_area(b):                                  # [EXT] the oracle's restatement: shoelace area of the traced outer border
         comp = np.zeros((int(b.ys.max()) + 1, int(b.xs.max()) + 1), bool)

@@ -48,3 +48,19 @@ def test_world_size_mismatch_is_refused():
     # (a WORLD_SIZE in the environment means "already launched": the check itself runs with that world and would hang
     # waiting for rank 1, so bench.py must refuse the mismatch before any rendezvous)
     assert res.returncode != 0 and "WORLD_SIZE=2 but --gpus 3" in (res.stderr + res.stdout)
+
+
+def test_collective_flag_plumbing():
+    """SBBSEG_BENCH_COLLECTIVE=capi (the all-gather inside the C ABI instead of torch.distributed): the flag reaches every rank, rank 0's
+    128-byte communicator id arrives unchanged on every rank, the default stays torch, and anything else is refused before a
+    rendezvous.  `--workload auto` is the page workload at every N (one workload along the driver's 1/2/4/8 sweep)."""
+    res = _run(["--gpus", "2", "--plumbing-check"], env_extra={"SBBSEG_BENCH_COLLECTIVE": "capi"})
+    assert res.returncode == 0, res.stderr[-2000:]
+    d = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["collective"] == "capi" and d["unique_id_broadcast_ok"] is True and d["all_gather_ok"]
+    assert d["default_workload"] == "page"
+    res = _run(["--gpus", "2", "--plumbing-check"])
+    d = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])
+    assert res.returncode == 0 and d["collective"] == "torch" and d["unique_id_broadcast_ok"] is None and d["default_workload"] == "page"
+    res = _run(["--gpus", "2", "--plumbing-check"], env_extra={"SBBSEG_BENCH_COLLECTIVE": "mpi"})
+    assert res.returncode != 0 and "SBBSEG_BENCH_COLLECTIVE=mpi" in (res.stderr + res.stdout)

@@ -64,6 +64,11 @@ def cases():
     # an island inside the frame's hole, and a C shape (open frame: no hole, contour hugs the inside)
     m = np.zeros((70, 70), np.uint8); m[5:45, 5:45] = ring(40, 40, 3); m[15:30, 15:30] = 1; m[50:68, 10:60] = 1; m[53:65, 13:60] = 0
     out.append(("island_and_c", m))
+    # two blobs of EQUAL contour area: the one discovered later in raster order wins (OpenCV's list is in reverse discovery order)
+    m = np.zeros((60, 90), np.uint8); m[4:24, 6:36] = 1; m[30:50, 50:80] = 1
+    out.append(("equal_blocks", m))
+    m = np.zeros((60, 90), np.uint8); m[30:50, 6:36] = 1; m[4:24, 50:80] = 1; m[4:24, 40:42] = 1      # + a third, smaller one in between
+    out.append(("equal_blocks_swapped", m))
     for s in range(4):
         out.append((f"random{s}", blobs(100 + s, 64, 80).astype(np.uint8)))
     out.append(("empty", np.zeros((20, 30), np.uint8)))
@@ -74,6 +79,14 @@ def cases():
 @pytest.mark.parametrize("name,mask", cases(), ids=[c[0] for c in cases()])
 def test_library_host_tracer_equals_oracle(name, mask):
     assert _capi.host_largest_contour(mask) == sg.largest_component_box(mask)
+
+
+def test_equal_areas_go_to_the_last_discovered():
+    """np.argmax over cv2.findContours' list (reverse discovery order) keeps the LAST blob in raster order of first pixels."""
+    by_name = dict(cases())
+    assert sg.largest_component_box(by_name["equal_blocks"])[0] == (50, 30, 30, 20)
+    assert sg.largest_component_box(by_name["equal_blocks_swapped"])[0] == (6, 30, 30, 20)
+    assert _capi.host_largest_contour(by_name["equal_blocks"])[0] == (50, 30, 30, 20)
 
 
 def test_frame_beats_block_unlike_pixel_count():

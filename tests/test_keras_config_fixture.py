@@ -122,10 +122,14 @@ def test_lambda_lowering_warns_and_can_be_refused(cfg, monkeypatch):
     """A Lambda's body is opaque bytecode: the parser lowers the one after ZeroPadding2D((1,1)) as upstream's one_side_pad crop, says
     so in a warning that names the layer, refuses named functions / bound arguments, and refuses everything in strict mode."""
     import warnings
+    from sbb_textline_detection_amd import keras_graph
+    keras_graph._LAMBDA_WARNED.clear()
     with warnings.catch_warnings(record=True) as rec:
         warnings.simplefilter("always")
         parse_model_config(cfg)
-    assert any("lambda_1" in str(w.message) and "one_side_pad" in str(w.message) for w in rec)
+        parse_model_config(cfg)
+    hits = [w for w in rec if "lambda_1" in str(w.message) and "one_side_pad" in str(w.message)]
+    assert len(hits) == 1                                   # announced, and only once per process and layer
     bad = copy.deepcopy(cfg)
     lam = next(l for l in bad["config"]["layers"] if l["class_name"] == "Lambda")
     lam["config"]["function_type"] = "function"
