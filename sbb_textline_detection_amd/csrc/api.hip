@@ -6,6 +6,7 @@
 // that replaces the reference's per-patch Python loop (main.py:225-380).
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -13,6 +14,7 @@
 #include <new>
 #include <stdexcept>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/sbbseg.h"
@@ -180,6 +182,17 @@ struct sbbseg_ctx {
     hipStream_t lane_stream = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int lanes = 2, lane1_batch = 0;
+    // CU-partitioned lanes (round 4, opt-in: SBBSEG_CU_SPLIT=1): two private streams, each confined to HALF of the chip's CUs (hipExtStreamCreateWithCUMask: the
+    // mask's bits are dealt round-robin over the eight XCDs, so each half = 16 CUs of every XCD).  The chip is power-capped under
+    // dense MFMA (1 350 TFLOP/s at 1.65 GHz on 256 CUs, 910 at 2.2 GHz on 128) and its HBM fabric saturates from half the CUs
+    // (4.2 of 4.4 TB/s): an MFMA-bound kernel on one half beside an HBM-bound kernel on the other half get 0.52x + 0.91x of their
+    // whole-chip rates AT THE SAME TIME (tools/probes/cu_mask_probe.hip, profiles/r04_cu_mask_probe.txt).  The lanes walk their
+    // tile units half a network apart (tile_range_impl), so that one lane's decoder (MFMA) runs beside the other's encoder (HBM).
+    hipStream_t half_stream[2] = {nullptr, nullptr};
+    hipEvent_t ev_half[2] = {nullptr, nullptr};
+    int half_cus[2] = {0, 0};
+    bool cu_split = false;           // both masked streams exist
+    int stagger_min_tiles = 64;      // tile ranges from this size on take the CU-partitioned, staggered schedule (SBBSEG_STAGGER_MIN_TILES)
     int in_H = 0, in_W = 0, in_C = 0;
     std::vector<Tensor> tensors;
     std::vector<Op> ops;
@@ -496,12 +509,17 @@ int fill_ingest(sbbseg_ctx* c, IngestParams& ip)
 constexpr int kMinLaneTiles = 8;      // a lane gets at least this many tiles, else the chunk runs whole on lane 0
 
 // activation buffers and stream of lane L become the ones run_plan / fill_ingest see
+// (halves = true: the lane's CU-masked stream, persistent grids sized for its half of the chip)
 struct LaneScope {
-    sbbseg_ctx* c; hipStream_t saved;
-    LaneScope(sbbseg_ctx* c_, int lane) : c(c_), saved(c_->stream)
+    sbbseg_ctx* c; hipStream_t saved; int saved_cus;
+    LaneScope(sbbseg_ctx* c_, int lane, bool halves = false) : c(c_), saved(c_->stream), saved_cus(c_->num_cus)
     {
-        if (lane == 1) {
+        if (lane == 1)
             for (auto& t : c->tensors) t.buf = t.lane_buf[1];
+        if (halves) {
+            c->stream = c->half_stream[lane];
+            c->num_cus = c->half_cus[lane];
+        } else if (lane == 1) {
             c->stream = c->lane_stream;
         }
     }
@@ -509,6 +527,7 @@ struct LaneScope {
     {
         for (auto& t : c->tensors) t.buf = t.lane_buf[0];
         c->stream = saved;
+        c->num_cus = saved_cus;
     }
 };
 
@@ -710,6 +729,31 @@ int sbbseg_create(int device, int precision, sbbseg_ctx** out)
         sbbseg_destroy(c);
         return fail("lane stream/event creation failed: %s", hipGetErrorString(e));
     }
+    // CU-partitioned lanes: OPT-IN (SBBSEG_CU_SPLIT=1).  Measured (profiles/r04_experiments.md): the conv kernels of this library need
+    // all 256 CUs to fill the HBM fabric -- on half the chip every op takes 1.5-1.8x as long (the streaming probe: 1.06x) -- so the
+    // staggered halves come out 2 % (f16x3) to 5 % (f16) BEHIND the shared-chip lanes; kept for A/B, off by default
+    const char* split_env = getenv("SBBSEG_CU_SPLIT");
+    if (split_env && split_env[0] == '1' && c->num_cus >= 16) {
+        const int words = (c->num_cus + 31) / 32, half = c->num_cus / 2;
+        std::vector<uint32_t> lo(words, 0u), hi(words, 0u);
+        for (int i = 0; i < c->num_cus; ++i) (i < half ? lo : hi)[i / 32] |= 1u << (i % 32);
+        hipError_t e0 = hipExtStreamCreateWithCUMask(&c->half_stream[0], (uint32_t)words, lo.data());
+        hipError_t e1 = e0 == hipSuccess ? hipExtStreamCreateWithCUMask(&c->half_stream[1], (uint32_t)words, hi.data()) : e0;
+        if (e1 == hipSuccess) e1 = hipEventCreateWithFlags(&c->ev_half[0], hipEventDisableTiming);
+        if (e1 == hipSuccess) e1 = hipEventCreateWithFlags(&c->ev_half[1], hipEventDisableTiming);
+        if (e1 == hipSuccess) {
+            c->cu_split = true;
+            c->half_cus[0] = half; c->half_cus[1] = c->num_cus - half;
+        } else {
+            (void)hipGetLastError();
+            for (int k = 0; k < 2; ++k) {
+                if (c->half_stream[k]) (void)hipStreamDestroy(c->half_stream[k]);
+                if (c->ev_half[k]) (void)hipEventDestroy(c->ev_half[k]);
+                c->half_stream[k] = nullptr; c->ev_half[k] = nullptr;
+            }
+        }
+    }
+    if (const char* v = getenv("SBBSEG_STAGGER_MIN_TILES")) c->stagger_min_tiles = atoi(v);
     *out = c;
     return 0;
     API_END
@@ -722,6 +766,8 @@ int sbbseg_destroy(sbbseg_ctx* c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->lane_stream) (void)hipStreamSynchronize(c->lane_stream);
+    for (int k = 0; k < 2; ++k)
+        if (c->half_stream[k]) (void)hipStreamSynchronize(c->half_stream[k]);
     for (auto& t : c->tensors) {
         (void)hipFree(t.lane_buf[0]);
         (void)hipFree(t.lane_buf[1]);
@@ -763,6 +809,10 @@ int sbbseg_destroy(sbbseg_ctx* c)
     for (auto e : c->free_events) (void)hipEventDestroy(e);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     if (c->lane_stream) (void)hipStreamDestroy(c->lane_stream);
+    for (int k = 0; k < 2; ++k) {
+        if (c->half_stream[k]) (void)hipStreamDestroy(c->half_stream[k]);
+        if (c->ev_half[k]) (void)hipEventDestroy(c->ev_half[k]);
+    }
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     delete c;
@@ -1774,8 +1824,8 @@ static int tile_range_impl(sbbseg_ctx* c, const void* const* d_pages, int n_page
     ip.grid_nyf = ny; ip.grid_mid_x = c->in_W - 2 * margin; ip.grid_mid_y = c->in_H - 2 * margin;
     const size_t per = (size_t)c->in_H * c->in_W;
     const size_t act = (size_t)c->elem * c->planes;          // bytes per stored element
-    auto run_chunk = [&](int lane, int first, int nb) -> int {
-        LaneScope scope(c, lane);
+    auto run_chunk = [&](int lane, int first, int nb, bool halves = false) -> int {
+        LaneScope scope(c, lane, halves);
         IngestParams lp = ip;
         if (fill_ingest(c, lp)) return 1;          // (input-form pointers of this lane)
         char* const c8_base = (char*)lp.c8;
@@ -1797,6 +1847,35 @@ static int tile_range_impl(sbbseg_ctx* c, const void* const* d_pages, int n_page
         }
         return run_plan(c, nb, (uint8_t*)d_tile_labels + first * per, nullptr);
     };
+    // CU-partitioned, staggered lanes (see sbbseg_ctx::half_stream): lane 0 takes the first half of the tile range in units of
+    // u = max_batch / 2 tiles, lane 1 the second half as [u / 2, u, u, ..., rest] -- its short first unit puts it half a network
+    // behind lane 0, so that from then on one lane's decoder (MFMA-bound, power-capped) runs beside the other lane's encoder
+    // (HBM-bound) on disjoint halves of the chip; no join before the end of the range.  Results do not depend on the schedule:
+    // every tile is computed by the same kernels from the same operands (test_two_lanes_equal_one_lane, the chunking tests).
+    if (c->cu_split && c->lane1_batch > 0 && c->lanes == 2 && !c->profiling && n_tiles >= c->stagger_min_tiles && n_tiles >= 4 * kMinLaneTiles) {
+        const int u = c->lane1_batch;                              // <= the second lane's buffers (and lane 0's hold max_batch >= u)
+        const int n0 = (n_tiles + 1) / 2, n1 = n_tiles - n0;
+        std::vector<std::pair<int, int>> units[2];                 // (first tile, count)
+        for (int o = 0; o < n0; o += u) units[0].push_back({o, n0 - o < u ? n0 - o : u});
+        int o1 = 0;
+        static const int head_pct = getenv("SBBSEG_STAGGER_HEAD_PCT") ? atoi(getenv("SBBSEG_STAGGER_HEAD_PCT")) : 50;      // probe knob
+        const int head_u = head_pct > 0 ? u * head_pct / 100 : u;
+        const int head = n1 > u ? (head_u > kMinLaneTiles ? head_u : kMinLaneTiles) : n1;
+        units[1].push_back({n0, head < n1 ? head : n1});
+        o1 = units[1][0].second;
+        for (; o1 < n1; o1 += u) units[1].push_back({n0 + o1, n1 - o1 < u ? n1 - o1 : u});
+        HIPCHK(hipEventRecord(c->ev_fork, c->stream));             // pages / thresholds / earlier ranges are ordered before both lanes
+        HIPCHK(hipStreamWaitEvent(c->half_stream[0], c->ev_fork, 0));
+        HIPCHK(hipStreamWaitEvent(c->half_stream[1], c->ev_fork, 0));
+        for (size_t i = 0; i < units[0].size() || i < units[1].size(); ++i)     // enqueue alternately: neither lane waits for the host
+            for (int lane = 0; lane < 2; ++lane)
+                if (i < units[lane].size() && run_chunk(lane, units[lane][i].first, units[lane][i].second, true)) return 1;
+        for (int lane = 0; lane < 2; ++lane) {
+            HIPCHK(hipEventRecord(c->ev_half[lane], c->half_stream[lane]));
+            HIPCHK(hipStreamWaitEvent(c->stream, c->ev_half[lane], 0));
+        }
+        return 0;
+    }
     // chunks of equal size (108 tiles at max_batch 70 -> 54 + 54, not 70 + 38): launches shrink evenly
     const int n_chunks = (n_tiles + c->max_batch - 1) / c->max_batch;
     const int chunk = n_chunks ? (n_tiles + n_chunks - 1) / n_chunks : 0;
@@ -1804,6 +1883,16 @@ static int tile_range_impl(sbbseg_ctx* c, const void* const* d_pages, int n_page
         const int nb = n_tiles - done < chunk ? n_tiles - done : chunk;
         const bool two = c->lane1_batch > 0 && c->lanes == 2 && !c->profiling && nb >= 2 * kMinLaneTiles;
         if (!two) {
+            // (probe knob SBBSEG_PROFILE_HALF=1: the profiling pass runs on lane 0's HALF of the chip, the other half idle)
+            static const bool prof_half = getenv("SBBSEG_PROFILE_HALF") && getenv("SBBSEG_PROFILE_HALF")[0] == '1';
+            if (c->profiling && prof_half && c->cu_split) {
+                HIPCHK(hipEventRecord(c->ev_fork, c->stream));
+                HIPCHK(hipStreamWaitEvent(c->half_stream[0], c->ev_fork, 0));
+                if (run_chunk(0, done, nb, true)) return 1;
+                HIPCHK(hipEventRecord(c->ev_half[0], c->half_stream[0]));
+                HIPCHK(hipStreamWaitEvent(c->stream, c->ev_half[0], 0));
+                continue;
+            }
             if (run_chunk(0, done, nb)) return 1;
             continue;
         }
@@ -1894,6 +1983,11 @@ int sbbseg_segment_pages_dev(sbbseg_ctx* c, int n_pages, const void* const* d_pa
     while (b) { const size_t t = a % b; a = b; b = t; }                 // a = gcd
     size_t G = (size_t)c->max_batch / a;                                 // pages per group with G * tpp = lcm
     if (G > 32) G = (8 * (size_t)c->max_batch + tpp - 1) / tpp;
+    if (c->cu_split && c->lanes == 2 && c->lane1_batch > 0) {
+        // the staggered lanes run a whole group without a join: groups of about eight chunks (four units per lane and more)
+        const size_t want = (8 * (size_t)c->max_batch + tpp - 1) / tpp;
+        if (G < want) G = want;
+    }
     if (G < 1) G = 1;
     if (G > (size_t)n_pages) G = (size_t)n_pages;
     REQUIRE(tpp * G < (size_t)1 << 30, "page group of %zu tiles is too large", tpp * G);
