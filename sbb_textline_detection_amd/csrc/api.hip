@@ -118,6 +118,7 @@ struct ConvOp {
     std::vector<float> h_epi;             // host copy of scale | shift | head_w | head_scale | head_shift: parity siblings are
                                           // only merged into one launch when these are identical (they share class 0's)
     uint16_t* d_stem_wfrag = nullptr;     // non-null: the op is the network stem and runs stem_conv_pairs
+    int fused_pool = -1;                  // split mode: index of the max-pool op this stem also computes (sbbseg_finalize), or -1
     uint16_t* d_d64_wfrag = nullptr;      // non-null: 3x3 s1 64->64 conv, runs conv3x3_c64_direct
     std::vector<float> h_w[2];            // host copy of a small 1x1 conv's weights ([cin][cout] per source): bottleneck fusion
                                           // (sbbseg_finalize) repacks them as MFMA A fragments
@@ -129,7 +130,10 @@ struct ConvOp {
     bool fg_pointwise = false;            // all taps (0, 0) in bounds: ConvParams::fast_gather = 2 (no masks)
 };
 
-struct PoolOp { int src, dst, k, stride, Ho, Wo; float *d_pre_scale = nullptr, *d_pre_shift = nullptr; int pre_relu = 0; };
+struct PoolOp {
+    int src, dst, k, stride, Ho, Wo; float *d_pre_scale = nullptr, *d_pre_shift = nullptr; int pre_relu = 0;
+    bool fused_into_stem = false;         // split mode: the stem op before it writes this pool's output too (stem_pool_x3); the op then launches nothing
+};
 
 struct HeadOp {
     int src, cin, classes;
@@ -245,6 +249,7 @@ struct sbbseg_ctx {
     bool ranged_walk = false;    // A/B: grouped launches walk XCD-contiguous tile ranges (conv variant bit 19)
     bool block_pq = true;        // fused bottleneck blocks run the producer / consumer form (conv variant bit 20: the one-group form)
     bool unfuse_blocks = false;  // A/B: run a fused bottleneck block as its three convs (conv variant bit 18)
+    bool unfuse_stem_pool = false;     // A/B: stem and max-pool as two launches (conv variant bit 22)
     bool plain_gather = false;   // A/B: per-load address arithmetic instead of the fast gather (conv variant bit 17)
     int contig_max_k = 0;        // short-K layers up to this K walk their tiles in per-block contiguous runs (tile map 2)
     int fused_heads = 0;
@@ -438,7 +443,13 @@ int launch_op(sbbseg_ctx* c, Op& op, int n, uint8_t* d_labels, float* d_probs)
                 sp.pairs = st.buf; sp.PHt = st.H; sp.PWt = st.W; sp.n = n; sp.Ho = co.Ho; sp.Wo = co.Wo;
                 sp.wfrag = co.d_stem_wfrag; sp.scale = co.d_scale; sp.shift = co.d_shift; sp.relu = co.d.relu; sp.wmul = co.wmul_cls[0];
                 sp.out = c->tensors[co.d.out_tensor].data();
-                HIPCHK(launch_stem(sp, c->precision, c->num_cus, c->stream));
+                if (co.fused_pool >= 0 && !c->unfuse_stem_pool) {
+                    const PoolOp& po = c->ops[co.fused_pool].pool;
+                    sp.pool_out = c->tensors[po.dst].data(); sp.pool_scale = po.d_pre_scale; sp.pool_shift = po.d_pre_shift;
+                    sp.pool_relu = po.pre_relu; sp.pool_Ho = po.Ho; sp.pool_Wo = po.Wo;
+                    HIPCHK(launch_stem_pool_x3(sp, c->num_cus, c->stream));
+                } else
+                    HIPCHK(launch_stem(sp, c->precision, c->num_cus, c->stream));
             } else if (co.d_d64_wfrag && !(c->conv_variant & 3)) {
                 const Tensor& st = c->tensors[co.d.src[0].tensor];
                 Direct64Params dp;
@@ -451,6 +462,7 @@ int launch_op(sbbseg_ctx* c, Op& op, int n, uint8_t* d_labels, float* d_probs)
             }
         } else if (op.type == kPool) {
             const PoolOp& po = op.pool;
+            if (po.fused_into_stem && !c->unfuse_stem_pool) return 0;          // written by the stem's launch (stem_pool_x3)
             const Tensor& s = c->tensors[po.src];
             HIPCHK(launch_maxpool(s.data(), c->tensors[po.dst].data(), n, s.H, s.W, s.C, po.k, po.stride, po.Ho, po.Wo,
                                   po.d_pre_scale, po.d_pre_shift, po.pre_relu, c->precision, c->stream));
@@ -1637,6 +1649,23 @@ int sbbseg_finalize(sbbseg_ctx* c, int max_batch)
     HIPCHK(hipSetDevice(c->device));
     if (fuse_bottlenecks(c)) return 1;
     if (build_fast_gather_tables(c)) return 1;
+    // split mode: the stem (dedicated kernel, raw output only) directly followed by the 3x3 / stride-2 max-pool of that tensor with an
+    // affine on every tap (bn_conv1 + ReLU) -> one launch writes both tensors (stem_pool_x3.hip); SBBSEG_STEM_POOL=0 keeps two launches
+    {
+        const char* env = getenv("SBBSEG_STEM_POOL");
+        for (size_t i = 0; c->precision == kF16X3 && !(env && env[0] == '0') && i + 1 < c->ops.size(); ++i) {
+            Op& a = c->ops[i];
+            Op& b = c->ops[i + 1];
+            if (a.type != kConv || !a.conv.d_stem_wfrag || b.type != kPool) continue;
+            const PoolOp& po = b.pool;
+            const Tensor& f1 = c->tensors[a.conv.d.out_tensor];
+            if (po.src != a.conv.d.out_tensor || po.k != 3 || po.stride != 2 || !po.d_pre_scale || f1.C != 64 || (f1.H & 15) || (f1.W & 15) ||
+                po.Ho != f1.H / 2 - 1 || po.Wo != f1.W / 2 - 1)
+                continue;
+            a.conv.fused_pool = (int)(i + 1);
+            b.pool.fused_into_stem = true;
+        }
+    }
     REQUIRE(max_batch >= 1, "max_batch must be >= 1");
     REQUIRE(c->classes > 0 && !c->ops.empty(), "plan must contain a head (head op or a conv with a fused head)");
     c->max_batch = max_batch;
@@ -2680,7 +2709,7 @@ int sbbseg_debug_counter(sbbseg_ctx* c, int which, int64_t* value)
 int sbbseg_debug_set_conv_variant(sbbseg_ctx* c, int variant)
 {
     API_BEGIN
-    REQUIRE(c && variant >= 0 && variant <= 0x3fffff, "variant: bits 0-1 = 0 auto | 1 4-wave/2-stage | 2 8-wave/3-stage; bit 2 = one block per tile (non-persistent); bit 3 = no XCD-grouped tile walk; bit 4 = half-K-step stages; bit 5 = XCD-grouped walk on single-class layers; bit 6 = drain epilogue stores; bit 7 = half-line epilogue stores; bits 8-15 = contiguous-run K limit / 64; bit 16 = 8-phase schedule on the 256x256 tile; bit 17 = plain gather everywhere; bit 18 = fused bottleneck blocks run as their three convs; bit 19 = XCD-contiguous walk for grouped launches; bit 20 = one-group form of the fused block kernel; bit 21 = extract_page ranks contours on the host always");
+    REQUIRE(c && variant >= 0 && variant <= 0x7fffff, "variant: bits 0-1 = 0 auto | 1 4-wave/2-stage | 2 8-wave/3-stage; bit 2 = one block per tile (non-persistent); bit 3 = no XCD-grouped tile walk; bit 4 = half-K-step stages; bit 5 = XCD-grouped walk on single-class layers; bit 6 = drain epilogue stores; bit 7 = half-line epilogue stores; bits 8-15 = contiguous-run K limit / 64; bit 16 = 8-phase schedule on the 256x256 tile; bit 17 = plain gather everywhere; bit 18 = fused bottleneck blocks run as their three convs; bit 19 = XCD-contiguous walk for grouped launches; bit 20 = one-group form of the fused block kernel; bit 21 = extract_page ranks contours on the host always; bit 22 = stem and max-pool as two launches");
     c->conv_variant = variant & 0xff;
     c->ph8 = (variant >> 16) & 1;
     c->plain_gather = (variant >> 17) & 1;
@@ -2688,6 +2717,7 @@ int sbbseg_debug_set_conv_variant(sbbseg_ctx* c, int variant)
     c->ranged_walk = (variant >> 19) & 1;
     c->block_pq = !((variant >> 20) & 1);
     c->force_host_contours = (variant >> 21) & 1;
+    c->unfuse_stem_pool = (variant >> 22) & 1;
     if ((variant >> 8) & 0xff) c->contig_max_k = ((variant >> 8) & 0xff) * 64;
     return 0;
     API_END

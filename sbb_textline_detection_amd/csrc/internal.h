@@ -136,6 +136,12 @@ struct StemParams {
     int relu;
     float wmul;               // multiplier of `scale` (split mode: 2^-s of the weight pre-scale; else 1)
     void* out;                // data pointer [n][Ho][Wo][64]
+    // stem_pool_x3 (stem_pool_x3.hip): the 3x3 / stride-2 / valid max-pool over ReLU(pool_scale * f1 + pool_shift) written by the same launch
+    void* pool_out = nullptr; // data pointer [n][pool_Ho][pool_Wo][64], or null (plain stem)
+    const float* pool_scale = nullptr;      // [64] the affine maxpool_kernel applies to every tap (bn_conv1)
+    const float* pool_shift = nullptr;
+    int pool_relu = 0;
+    int pool_Ho = 0, pool_Wo = 0;
 };
 
 // 3x3 stride-1 'same' conv, 64 -> 64 channels (the ResNet stage-2 bottleneck convs), as a direct conv on an
@@ -233,6 +239,7 @@ hipError_t launch_maxpool(const void* src, void* dst, int n, int H, int W, int C
 hipError_t launch_head(const HeadParams& p, int precision, hipStream_t s);
 hipError_t launch_tail(const TailParams& p, int precision, int num_cus, hipStream_t s);
 hipError_t launch_stem(const StemParams& p, int precision, int num_cus, hipStream_t s);
+hipError_t launch_stem_pool_x3(const StemParams& p, int num_cus, hipStream_t s);      // split mode: stem + max-pool in one launch (stem_pool_x3.hip)
 hipError_t launch_direct64(const Direct64Params& p, int precision, int num_cus, hipStream_t s);
 constexpr int kTailKSteps = 6;      // 4 taps x 64 channels of src0 + 2 steps for the 9 image taps
 hipError_t launch_ingest_u8(const IngestParams& p, int precision, hipStream_t s);

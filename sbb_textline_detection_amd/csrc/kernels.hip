@@ -2121,8 +2121,8 @@ __global__ __launch_bounds__(256, 1) void stem_conv_pairs_x3(const StemParams p)
                 *(float4*)&sh[4] = *(const float4*)(cst + 64 + c0 + 4);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    y[q] = acc[2 * h][ni][q] * sc[q] + sh[q];
-                    y[4 + q] = acc[2 * h + 1][ni][q] * sc[4 + q] + sh[4 + q];
+                    y[q] = __builtin_fmaf(acc[2 * h][ni][q], sc[q], sh[q]);
+                    y[4 + q] = __builtin_fmaf(acc[2 * h + 1][ni][q], sc[4 + q], sh[4 + q]);
                 }
                 if (p.relu) {
 #pragma unroll
@@ -3338,8 +3338,8 @@ __global__ __launch_bounds__(256) void maxpool_kernel(const E* src, E* dst, int 
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     float xv = from_elem<E>(v[c].v[i]);
-                    if constexpr (SPLIT) xv += from_elem<E>(vl[c].v[i]);
-                    x[i] = xv * ps[i] + pb[i];
+                    if constexpr (SPLIT) xv = __fadd_rn(xv, from_elem<E>(vl[c].v[i]));       // hi + lo: exact in fp32
+                    x[i] = __builtin_fmaf(xv, ps[i], pb[i]);                                  // (stem_pool_x3 states the same arithmetic)
                     if (pre_relu) x[i] = fmaxf(x[i], 0.f);
                 }
 #pragma unroll
@@ -3360,8 +3360,8 @@ __global__ __launch_bounds__(256) void maxpool_kernel(const E* src, E* dst, int 
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 float xv = from_elem<E>(v.v[i]);
-                if constexpr (SPLIT) xv += from_elem<E>((*(const Vec8<E>*)(row + (size_t)c * CS + split_group(C))).v[i]);
-                x[i] = xv * ps[i] + pb[i];
+                if constexpr (SPLIT) xv = __fadd_rn(xv, from_elem<E>((*(const Vec8<E>*)(row + (size_t)c * CS + split_group(C))).v[i]));
+                x[i] = __builtin_fmaf(xv, ps[i], pb[i]);
                 if (pre_relu) x[i] = fmaxf(x[i], 0.f);
             }
 #pragma unroll

@@ -182,6 +182,43 @@ def test_fused_x3_identity_blocks_match_their_three_convs(hw):
     model.release()
 
 
+@pytest.mark.parametrize("hw,nb", [((64, 96), 3), ((224, 256), 5), ((448, 448), 9)])
+def test_fused_x3_stem_pool_matches_the_two_launches(hw, nb):
+    """Split mode: the stem and its max-pool run as ONE launch (csrc/stem_pool_x3.hip: pool windows taken from the epilogue's values,
+    channel-half blocks walking 16-row strips, one recomputed row per tile).  Against the two-launch form (conv variant bit 22:
+    stem_conv_pairs_x3 + maxpool_kernel) every tensor of the plan -- the stem's raw f1 skip, the pooled tensor, everything after --
+    must be the same bits: the pool is the maximum over the same fp32 numbers (hi + lo of the stored f1, one fma, ReLU)."""
+    h, wd = hw
+    cfg, w, g, model = make_model(2, h, wd, seed=6, precision="f16x3", max_batch=nb + 2, calib_hw=min(160, max(h, wd)))
+    names = [o["name"] for o in model.ctx.ops()]
+    assert any(n.startswith("stem_") for n in names) and any(n.startswith("maxpool") for n in names), names
+    x = (patches_from_page(h, wd, nb, seed=18) / 255.0).astype(np.float32)
+
+    def read_all():
+        out = {}
+        for name, tid in model.plan.layer_tensor.items():
+            t = model.plan.tensors[tid]
+            out[name] = model.ctx.debug_read_tensor(tid, nb, (t.H, t.W, t.C))
+        return out
+    got_fused = model.predict(x)
+    t_fused = read_all()
+    model.ctx.set_conv_variant(1 << 22)
+    got_two = model.predict(x)
+    t_two = read_all()
+    model.ctx.set_conv_variant(0)
+    assert np.array_equal(model.predict(x), got_fused)                       # and back again: deterministic
+    pooled = [n for n, tid in model.plan.layer_tensor.items() if model.plan.tensors[tid].C == 64 and model.plan.tensors[tid].H == h // 4 - 1]
+    assert pooled, list(model.plan.layer_tensor)
+    for name in t_fused:
+        assert t_fused[name].shape == t_two[name].shape
+        assert np.array_equal(t_fused[name], t_two[name]), (name, float(np.abs(t_fused[name] - t_two[name]).max()))
+    assert float(np.abs(t_fused[pooled[0]]).max()) > 0
+    assert np.array_equal(got_fused, got_two)
+    ref = kf.forward(g, w, x[:2])
+    assert float(np.abs(got_fused[:2] - ref).max()) < TOL_SOFTMAX["f16x3"] and exact_label_check(ref, got_fused[:2])[1] == 0
+    model.release()
+
+
 def test_conv_tile_families_agree():
     """4-wave/2-stage and 8-wave/3-stage conv tiles, persistent or one block per tile, compute the same sums."""
     cfg, w, g, model = make_model(2, 224, 224, seed=3, precision="f16", max_batch=6)

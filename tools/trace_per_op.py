@@ -6,14 +6,14 @@ import csv
 import json
 import sys
 
-PLAN = ("conv_igemm", "maxpool", "head_kernel", "dec_tail", "stem_conv", "conv3x3_c64_direct", "bottleneck", "block_x3")
+PLAN = ("conv_igemm", "maxpool", "head_kernel", "dec_tail", "stem_conv", "stem_pool", "conv3x3_c64_direct", "bottleneck", "block_x3")
 rows = []
 with open(sys.argv[1]) as f:
     for r in csv.DictReader(f):
         if any(s in r["Kernel_Name"] for s in PLAN):
             rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
 rows.sort()
-ops = json.load(open(sys.argv[2]))
+ops = [o for o in json.load(open(sys.argv[2])) if o.get("ms_per_launch", 1.0) >= 0.02]      # (ops that launch nothing have no dispatch)
 last = rows[-len(ops):]
 print("| # | op | kernel | rocprof us | HIP-event us | algorithmic TFLOP/s (rocprof) | issued TFLOP/s (rocprof) |")
 print("|---|---|---|---|---|---|---|")
