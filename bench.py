@@ -327,8 +327,9 @@ def main():
     def build_pipeline3(m):
         """BASELINE configs[2] as textline_detector.run() chains it (main.py:2056-2107): get_image_and_scales (3500x2500 -> 4200x3000,
         fused into the gathers), border model on the whole page + page box, then the layout model (Otsu'd) and the textline model
-        on the CROPPED page, text regions cleaned by erode x 3 / dilate x 4.  Models resident; the page starts in host memory for
-        the border stage (as in the reference) and is resident in HBM for the two patch stages."""
+        on the CROPPED page, text regions cleaned by erode x 3 / dilate x 4.  Models resident; the page starts in (pinned) host memory,
+        is uploaded once per step and stays resident in HBM for all three stages (the border mask never leaves the device: in the
+        reference it is a local of extract_page, only the box and the crop leave it)."""
         from sbb_textline_detection_amd.stages import scaled_size
         cfg_b, w_b = calibrated_model(2, MODEL_HW, MODEL_HW, seed=11)
         cfg_l, w_l = calibrated_model(4, MODEL_HW, MODEL_HW, seed=12)
@@ -337,8 +338,10 @@ def main():
         m_border = make_model(m.precision, (cfg_b, w_b), max_batch=1)
         m_layout = make_model(m.precision, (cfg_l, w_l), max_batch=n_full)
         m_text = make_model(m.precision, None, max_batch=n_full) if m.max_batch < n_full else m
-        d_page = torch.from_numpy(page0).cuda()
-        _, box, pixels = m_border.ctx.extract_page_box(page0, Hs, Ws)
+        h_page = torch.from_numpy(page0).pin_memory()                              # the page starts in (pinned) host memory ...
+        d_page = torch.empty_like(h_page, device="cuda")                            # ... and is uploaded ONCE per step, for all three stages
+        d_page.copy_(h_page)
+        box, pixels = m_border.ctx.extract_page_box_dev(d_page.data_ptr(), PAGE_H, PAGE_W, Hs, Ws)
         if pixels == 0 or box[2] < MODEL_HW or box[3] < MODEL_HW:
             box = (0, 0, Ws, Hs)                                                    # main.py:417-419: fall back to the whole page
         bw, bh = box[2], box[3]
@@ -352,7 +355,8 @@ def main():
         fallbacks_of_pipeline3 = lambda: m_border.ctx.host_contour_calls() - c0      # how often the box needed the exact host ranking
 
         def step():
-            m_border.ctx.extract_page_box(page0, Hs, Ws)                            # border model + dilate x 6 + largest contour + box
+            d_page.copy_(h_page, non_blocking=True)                                 # H2D on the current stream = the handles' stream
+            m_border.ctx.extract_page_box_dev(d_page.data_ptr(), PAGE_H, PAGE_W, Hs, Ws)      # border model + dilate x 6 + largest contour + box
             m_layout.ctx.segment_crop_dev(d_page.data_ptr(), PAGE_H, PAGE_W, Hs, Ws, box, True, d_regions.data_ptr())
             m_layout.ctx.morph_dev(d_regions.data_ptr(), bh, bw, 0, 5, 3, d_clean.data_ptr())      # main.py:2074-2075
             m_layout.ctx.morph_dev(d_clean.data_ptr(), bh, bw, 1, 5, 4, d_clean.data_ptr())

@@ -257,6 +257,12 @@ int sbbseg_page_box_dev(sbbseg_ctx* c, const void* d_mask_hw, int H, int W, int3
  * sbbseg_set_label_channels(3)) or NULL. */
 int sbbseg_extract_page_box(sbbseg_ctx* c, const uint8_t* page_hwc, int Hp, int Wp, int Hs, int Ws, uint8_t* mask_out,
                             int32_t* box_xywh, int64_t* pixels);
+/* the same with the stored page already on the device (run() hands the SAME page to all three stages, main.py:2061-2102: uploaded
+ * once, it stays resident for the two patch stages): d_mask_out = device buffer of Hs x Ws labels, or NULL -- the border mask is a
+ * local of extract_page (main.py:392-404), only its box leaves the function.  Synchronises the handle's stream (the box is a host
+ * result). */
+int sbbseg_extract_page_box_dev(sbbseg_ctx* c, const void* d_page_hwc, int Hp, int Wp, int Hs, int Ws, void* d_mask_out,
+                                int32_t* box_xywh, int64_t* pixels);
 
 /* ---- stage glue: the rotate-and-project of the deskew search (return_deskew_slope, main.py:1601-1718; per text region,
  * 80 angles in [-25, 25] and 30 more in [-90, -50] -- the reference spreads the regions over cpu_count() processes,

@@ -27,7 +27,7 @@ EXPORTS = [
     "sbbseg_segment_tile_range_bin_dev", "sbbseg_segment_whole", "sbbseg_segment_whole_scaled", "sbbseg_tile_grid", "sbbseg_nearest_map", "sbbseg_segment_tiles_dev",
     "sbbseg_segment_tile_range_dev", "sbbseg_stitch_dev", "sbbseg_debug_ingest", "sbbseg_debug_read_tensor",
     "sbbseg_debug_set_conv_variant", "sbbseg_debug_inject_alloc_failure",
-    "sbbseg_morph_dev", "sbbseg_morph", "sbbseg_page_box_dev", "sbbseg_extract_page_box",
+    "sbbseg_morph_dev", "sbbseg_morph", "sbbseg_page_box_dev", "sbbseg_extract_page_box", "sbbseg_extract_page_box_dev",
     "sbbseg_deskew_side", "sbbseg_rotation_matrix", "sbbseg_deskew_profiles_dev", "sbbseg_deskew_profiles",
     "sbbseg_segment_pages",
     "sbbseg_profile_enable", "sbbseg_profile_reset", "sbbseg_profile_get",
@@ -119,6 +119,7 @@ def load_library(path: Optional[str] = None):
         "sbbseg_morph": [vp, vp, i32, i32, i32, i32, i32, vp],
         "sbbseg_page_box_dev": [vp, vp, i32, i32, vp, C.POINTER(C.c_int64)],
         "sbbseg_extract_page_box": [vp, vp, i32, i32, i32, i32, vp, vp, C.POINTER(C.c_int64)],
+        "sbbseg_extract_page_box_dev": [vp, vp, i32, i32, i32, i32, vp, vp, C.POINTER(C.c_int64)],
         "sbbseg_segment_pages": [vp, i32, vp, i32, i32, vp],
         "sbbseg_deskew_side": [i32, i32, C.POINTER(C.c_int)],
         "sbbseg_rotation_matrix": [C.c_double, C.c_double, C.c_double, vp],
@@ -454,15 +455,25 @@ class Context:
         check(self.lib.sbbseg_debug_counter(self.h, 0, C.byref(v)), "sbbseg_debug_counter")
         return int(v.value)
 
-    def extract_page_box(self, page: np.ndarray, scaled_h: int, scaled_w: int, channels: int = 1):
-        """Border model on the page as upscaled to scaled_h x scaled_w + the page box, one call: (mask, (x, y, w, h), pixels)."""
+    def extract_page_box(self, page: np.ndarray, scaled_h: int, scaled_w: int, channels: int = 1, want_mask: bool = True):
+        """Border model on the page as upscaled to scaled_h x scaled_w + the page box, one call: (mask, (x, y, w, h), pixels).
+        want_mask=False: the mask (a local of the reference's extract_page) stays on the device; returns (None, box, pixels)."""
         page = np.ascontiguousarray(page, np.uint8)
-        mask = self._label_out(scaled_h, scaled_w, channels)
+        mask = self._label_out(scaled_h, scaled_w, channels) if want_mask else None
         box = np.zeros(4, np.int32)
         px = C.c_int64(0)
-        check(self.lib.sbbseg_extract_page_box(self.h, _ptr(page), page.shape[0], page.shape[1], scaled_h, scaled_w, _ptr(mask), _ptr(box),
-                                               C.byref(px)), "sbbseg_extract_page_box")
+        check(self.lib.sbbseg_extract_page_box(self.h, _ptr(page), page.shape[0], page.shape[1], scaled_h, scaled_w,
+                                               _ptr(mask) if want_mask else None, _ptr(box), C.byref(px)), "sbbseg_extract_page_box")
         return mask, tuple(int(v) for v in box), int(px.value)
+
+    def extract_page_box_dev(self, d_page: int, Hp: int, Wp: int, scaled_h: int, scaled_w: int, d_mask: int = 0):
+        """The same on a page that is already on the device (pointer); d_mask = device buffer of scaled_h x scaled_w labels or 0.
+        Returns ((x, y, w, h), pixels)."""
+        box = np.zeros(4, np.int32)
+        px = C.c_int64(0)
+        check(self.lib.sbbseg_extract_page_box_dev(self.h, C.c_void_p(d_page), Hp, Wp, scaled_h, scaled_w, C.c_void_p(d_mask) if d_mask else None,
+                                                   _ptr(box), C.byref(px)), "sbbseg_extract_page_box_dev")
+        return tuple(int(v) for v in box), int(px.value)
 
     def segment_pages(self, pages, channels: int = 1):
         """do_prediction(patches=True) for a list of HOST pages of one size, upload / compute / download pipelined:

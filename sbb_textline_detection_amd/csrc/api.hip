@@ -219,6 +219,8 @@ struct sbbseg_ctx {
     int *d_own_x = nullptr, *d_own_y = nullptr; size_t own_cap = 0;
     int own_Hp = -1, own_Wp = -1, own_nyf = 0;
     int *d_map = nullptr; size_t map_cap = 0;
+    int *d_wmap = nullptr; size_t wmap_cap = 0;      // gather tables of the whole-image branch, cached per geometry
+    int wmap_key[6] = {0, 0, 0, 0, 0, 0};            // {Hp, Wp, Hs, Ws, out_h, out_w} (0 = none)
     int map_key[4] = {0, 0, 0, 0};     // {Hs, Ws, Hp, Wp} the nearest maps in d_map were built for (sbbseg_segment_crop_dev; 0 = none)
     // stage glue scratch (morphology planes, union-find arrays, result words)
     uint8_t *d_morph_a = nullptr, *d_morph_b = nullptr; size_t morph_a_cap = 0, morph_b_cap = 0;
@@ -804,7 +806,7 @@ int sbbseg_destroy(sbbseg_ctx* c)
     }
     (void)hipFree(c->d_lut); (void)hipFree(c->d_hist); (void)hipFree(c->d_tile_xy); (void)hipFree(c->d_batch_labels); (void)hipFree(c->d_probs); (void)hipFree(c->d_xin);
     (void)hipFree(c->d_page); (void)hipFree(c->d_page_labels); (void)hipFree(c->d_page_labels3); (void)hipFree(c->d_tile_labels);
-    (void)hipFree(c->d_own_x); (void)hipFree(c->d_own_y); (void)hipFree(c->d_map);
+    (void)hipFree(c->d_own_x); (void)hipFree(c->d_own_y); (void)hipFree(c->d_map); (void)hipFree(c->d_wmap);
     (void)hipFree(c->d_deskew);
     for (int k = 0; k < 2; ++k) {
         (void)hipHostFree(c->pp_h_in[k]); (void)hipHostFree(c->pp_h_out[k]);
@@ -2302,47 +2304,63 @@ int sbbseg_segment_whole(sbbseg_ctx* c, const uint8_t* page_hwc, int Hp, int Wp,
     API_END
 }
 
+// do_prediction(patches=False) on the page as upscaled to Hs x Ws: the page comes from host memory (page_hwc) or is already on the
+// device (d_page_in); the label plane lands in c->d_page_labels and, if labels_out is given, in host memory too.
+static int whole_scaled_impl(sbbseg_ctx* c, const uint8_t* page_hwc, const void* d_page_in, int Hp, int Wp, int Hs, int Ws, int out_h, int out_w,
+                             uint8_t* labels_out)
+{
+    const size_t pix = (size_t)Hp * Wp, opix = (size_t)out_h * out_w;
+    if (!d_page_in && ensure(c, (void**)&c->d_page, &c->page_cap, pix * 3)) return 1;
+    if (ensure(c, (void**)&c->d_page_labels, &c->page_labels_cap, opix + 4)) return 1;
+    const size_t need = sizeof(int) * (size_t)(c->in_H + c->in_W + out_h + out_w);
+    const bool cached = c->d_wmap && c->wmap_cap >= need && c->wmap_key[0] == Hp && c->wmap_key[1] == Wp && c->wmap_key[2] == Hs &&
+                        c->wmap_key[3] == Ws && c->wmap_key[4] == out_h && c->wmap_key[5] == out_w;
+    if (!cached) {                         // the four gather tables depend on the sizes only: built and uploaded once per geometry
+        std::vector<int> my, mx, oy, ox;
+        nearest_map(Hs, c->in_H, my);      // model row  -> row of the page do_prediction was handed (main.py:371)
+        nearest_map(Ws, c->in_W, mx);
+        if (Hs != Hp || Ws != Wp) {        // that page is itself the nearest-upscaled stored image (main.py:214): compose
+            std::vector<int> sy, sx;
+            nearest_map(Hp, Hs, sy);       // scaled row -> stored row
+            nearest_map(Wp, Ws, sx);
+            for (auto& v : my) v = sy[v];
+            for (auto& v : mx) v = sx[v];
+        }
+        nearest_map(c->in_H, out_h, oy);   // output row -> model row  (main.py:378)
+        nearest_map(c->in_W, out_w, ox);
+        if (ensure(c, (void**)&c->d_wmap, &c->wmap_cap, need)) return 1;
+        c->wmap_key[0] = 0;
+        int* d_my = c->d_wmap; int* d_mx = d_my + c->in_H; int* d_oy = d_mx + c->in_W; int* d_ox = d_oy + out_h;
+        HIPCHK(hipStreamSynchronize(c->stream));
+        HIPCHK(hipMemcpy(d_my, my.data(), sizeof(int) * c->in_H, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(d_mx, mx.data(), sizeof(int) * c->in_W, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(d_oy, oy.data(), sizeof(int) * out_h, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(d_ox, ox.data(), sizeof(int) * out_w, hipMemcpyHostToDevice));
+        c->wmap_key[0] = Hp; c->wmap_key[1] = Wp; c->wmap_key[2] = Hs; c->wmap_key[3] = Ws; c->wmap_key[4] = out_h; c->wmap_key[5] = out_w;
+    }
+    int* d_my = c->d_wmap; int* d_mx = d_my + c->in_H; int* d_oy = d_mx + c->in_W; int* d_ox = d_oy + out_h;
+    if (!d_page_in) HIPCHK(hipMemcpyAsync(c->d_page, page_hwc, pix * 3, hipMemcpyHostToDevice, c->stream));
+    IngestParams ip;
+    if (fill_ingest(c, ip)) return 1;
+    ip.page = d_page_in ? (const uint8_t*)d_page_in : c->d_page; ip.Hp = Hp; ip.Wp = Wp; ip.src_Hp = Hp; ip.src_Wp = Wp; ip.tile_xy = nullptr; ip.n_tiles = 1;
+    ip.whole = 1; ip.map_y = d_my; ip.map_x = d_mx;
+    HIPCHK(launch_ingest_u8(ip, c->precision, c->stream));
+    if (run_plan(c, 1, c->d_batch_labels, nullptr)) return 1;
+    HIPCHK(launch_resize_labels(c->d_batch_labels, c->in_H, c->in_W, d_oy, d_ox, out_h, out_w, c->d_page_labels, c->stream));
+    if (labels_out) {
+        if (labels_to_host(c, labels_out, opix)) return 1;
+        HIPCHK(hipStreamSynchronize(c->stream));
+    }
+    return 0;
+}
+
 int sbbseg_segment_whole_scaled(sbbseg_ctx* c, const uint8_t* page_hwc, int Hp, int Wp, int Hs, int Ws, int out_h, int out_w,
                                 uint8_t* labels_out)
 {
     API_BEGIN
     if (check_ready(c)) return 1;
     REQUIRE(page_hwc && labels_out && Hp > 0 && Wp > 0 && Hs > 0 && Ws > 0 && out_h > 0 && out_w > 0, "bad arguments");
-    const size_t pix = (size_t)Hp * Wp, opix = (size_t)out_h * out_w;
-    if (ensure(c, (void**)&c->d_page, &c->page_cap, pix * 3)) return 1;
-    if (ensure(c, (void**)&c->d_page_labels, &c->page_labels_cap, opix + 4)) return 1;
-    std::vector<int> my, mx, oy, ox;
-    nearest_map(Hs, c->in_H, my);          // model row  -> row of the page do_prediction was handed (main.py:371)
-    nearest_map(Ws, c->in_W, mx);
-    if (Hs != Hp || Ws != Wp) {            // that page is itself the nearest-upscaled stored image (main.py:214): compose
-        std::vector<int> sy, sx;
-        nearest_map(Hp, Hs, sy);           // scaled row -> stored row
-        nearest_map(Wp, Ws, sx);
-        for (auto& v : my) v = sy[v];
-        for (auto& v : mx) v = sx[v];
-    }
-    nearest_map(c->in_H, out_h, oy);       // output row -> model row  (main.py:378)
-    nearest_map(c->in_W, out_w, ox);
-    const size_t need = sizeof(int) * (size_t)(c->in_H + c->in_W + out_h + out_w);
-    if (ensure(c, (void**)&c->d_map, &c->map_cap, need)) return 1;
-    c->map_key[0] = 0;
-    int* d_my = c->d_map; int* d_mx = d_my + c->in_H; int* d_oy = d_mx + c->in_W; int* d_ox = d_oy + out_h;
-    HIPCHK(hipStreamSynchronize(c->stream));
-    HIPCHK(hipMemcpy(d_my, my.data(), sizeof(int) * c->in_H, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(d_mx, mx.data(), sizeof(int) * c->in_W, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(d_oy, oy.data(), sizeof(int) * out_h, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(d_ox, ox.data(), sizeof(int) * out_w, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpyAsync(c->d_page, page_hwc, pix * 3, hipMemcpyHostToDevice, c->stream));
-    IngestParams ip;
-    if (fill_ingest(c, ip)) return 1;
-    ip.page = c->d_page; ip.Hp = Hp; ip.Wp = Wp; ip.src_Hp = Hp; ip.src_Wp = Wp; ip.tile_xy = nullptr; ip.n_tiles = 1;
-    ip.whole = 1; ip.map_y = d_my; ip.map_x = d_mx;
-    HIPCHK(launch_ingest_u8(ip, c->precision, c->stream));
-    if (run_plan(c, 1, c->d_batch_labels, nullptr)) return 1;
-    HIPCHK(launch_resize_labels(c->d_batch_labels, c->in_H, c->in_W, d_oy, d_ox, out_h, out_w, c->d_page_labels, c->stream));
-    if (labels_to_host(c, labels_out, opix)) return 1;
-    HIPCHK(hipStreamSynchronize(c->stream));
-    return 0;
+    return whole_scaled_impl(c, page_hwc, nullptr, Hp, Wp, Hs, Ws, out_h, out_w, labels_out);
     API_END
 }
 
@@ -2445,13 +2463,22 @@ int sbbseg_extract_page_box(sbbseg_ctx* c, const uint8_t* page_hwc, int Hp, int 
     API_BEGIN
     if (check_ready(c)) return 1;
     REQUIRE(page_hwc && box_xywh && Hs > 0 && Ws > 0, "bad arguments");
-    // border model on the (virtually) upscaled page, result at the upscaled size (main.py:384-392) ...
-    const size_t opix = (size_t)Hs * Ws;
-    std::vector<uint8_t> scratch;
-    uint8_t* host_mask = mask_out;
-    if (!host_mask) { alloc_check(); scratch.resize(opix * (c->label_channels == 3 ? 3 : 1)); host_mask = scratch.data(); }
-    if (sbbseg_segment_whole_scaled(c, page_hwc, Hp, Wp, Hs, Ws, Hs, Ws, host_mask)) return 1;
+    // border model on the (virtually) upscaled page, result at the upscaled size (main.py:384-392) ...  (mask_out == NULL: the mask --
+    // a local of extract_page in the reference -- stays on the device)
+    if (whole_scaled_impl(c, page_hwc, nullptr, Hp, Wp, Hs, Ws, Hs, Ws, mask_out)) return 1;
     // ... whose label plane is still in d_page_labels: threshold, dilate x 6, largest component, bounding box (main.py:394-404)
+    return sbbseg_page_box_dev(c, c->d_page_labels, Hs, Ws, box_xywh, pixels);
+    API_END
+}
+
+int sbbseg_extract_page_box_dev(sbbseg_ctx* c, const void* d_page_hwc, int Hp, int Wp, int Hs, int Ws, void* d_mask_out, int32_t* box_xywh,
+                                int64_t* pixels)
+{
+    API_BEGIN
+    if (check_ready(c)) return 1;
+    REQUIRE(d_page_hwc && box_xywh && Hp > 0 && Wp > 0 && Hs > 0 && Ws > 0, "bad arguments");
+    if (whole_scaled_impl(c, nullptr, d_page_hwc, Hp, Wp, Hs, Ws, Hs, Ws, nullptr)) return 1;
+    if (d_mask_out) HIPCHK(hipMemcpyAsync(d_mask_out, c->d_page_labels, (size_t)Hs * Ws, hipMemcpyDeviceToDevice, c->stream));
     return sbbseg_page_box_dev(c, c->d_page_labels, Hs, Ws, box_xywh, pixels);
     API_END
 }

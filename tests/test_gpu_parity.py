@@ -1207,3 +1207,24 @@ def test_bench_label_match_reads_the_timed_buffer():
     assert lm["pixels_checked"] > 2 * 300 * 300 and lm["label_mismatches_outside_exact_margin"] == 0
     assert lm["label_mismatch_frac"] <= 1e-4 and lm["max_abs_softmax_diff"] < TOL_SOFTMAX["f16x3"]
     assert d["config"]["workload_id"] == "page" and d["scaling"] == "weak" and "label_check_failed" not in d
+
+
+def test_extract_page_box_dev_equals_host_entry(torch_cuda, stitch_model):
+    """sbbseg_extract_page_box_dev (the page already on the device, the border mask optional and device-side) == sbbseg_extract_page_box
+    (host page in, mask out): same box, same pixel count, same mask bytes; want_mask=False changes nothing but the download."""
+    torch = torch_cuda
+    from sbb_textline_detection_amd.stages import scaled_size
+    ctx = stitch_model.ctx
+    for seed, (h, w) in enumerate([(900, 700), (1400, 1000)]):
+        page = synthetic_page(h, w, seed=40 + seed)
+        hs, ws = scaled_size(h, w)
+        mask_h, box_h, px_h = ctx.extract_page_box(page, hs, ws)
+        none, box_n, px_n = ctx.extract_page_box(page, hs, ws, want_mask=False)
+        assert none is None and box_n == box_h and px_n == px_h
+        d_page = torch.from_numpy(page).cuda()
+        d_mask = torch.full((hs, ws), 9, dtype=torch.uint8, device="cuda")
+        box_d, px_d = ctx.extract_page_box_dev(d_page.data_ptr(), h, w, hs, ws, d_mask.data_ptr())
+        torch.cuda.synchronize()
+        assert box_d == box_h and px_d == px_h
+        assert np.array_equal(d_mask.cpu().numpy(), mask_h)
+        assert ctx.extract_page_box_dev(d_page.data_ptr(), h, w, hs, ws) == (box_h, px_h)

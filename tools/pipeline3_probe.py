@@ -1,7 +1,8 @@
 """Times the pieces of bench.py's pipeline3 step (BASELINE configs[2]) one by one."""
 import sys, time
 import numpy as np, torch
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from sbb_textline_detection_amd import _capi
 from sbb_textline_detection_amd.model import SegModel
 from sbb_textline_detection_amd.stages import scaled_size
