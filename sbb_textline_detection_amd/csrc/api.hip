@@ -119,6 +119,8 @@ struct ConvOp {
                                           // only merged into one launch when these are identical (they share class 0's)
     uint16_t* d_stem_wfrag = nullptr;     // non-null: the op is the network stem and runs stem_conv_pairs
     int fused_pool = -1;                  // split mode: index of the max-pool op this stem also computes (sbbseg_finalize), or -1
+    uint16_t* d_halo_wfrag = nullptr;     // split mode, the 224 x 224 decoder conv: the four classes' weights as MFMA A fragments (dec_halo_x3.hip)
+    int* d_halo_taps = nullptr;           //   ... and their taps in K-step order (sbbseg_finalize)
     uint16_t* d_d64_wfrag = nullptr;      // non-null: 3x3 s1 64->64 conv, runs conv3x3_c64_direct
     std::vector<float> h_w[2];            // host copy of a small 1x1 conv's weights ([cin][cout] per source): bottleneck fusion
                                           // (sbbseg_finalize) repacks them as MFMA A fragments
@@ -252,6 +254,7 @@ struct sbbseg_ctx {
     bool block_pq = true;        // fused bottleneck blocks run the producer / consumer form (conv variant bit 20: the one-group form)
     bool unfuse_blocks = false;  // A/B: run a fused bottleneck block as its three convs (conv variant bit 18)
     bool unfuse_stem_pool = false;     // A/B: stem and max-pool as two launches (conv variant bit 22)
+    bool no_dec_halo = false;          // A/B: the 224 x 224 decoder conv on the generic kernel (conv variant bit 23)
     bool plain_gather = false;   // A/B: per-load address arithmetic instead of the fast gather (conv variant bit 17)
     int contig_max_k = 0;        // short-K layers up to this K walk their tiles in per-block contiguous runs (tile map 2)
     int fused_heads = 0;
@@ -459,6 +462,14 @@ int launch_op(sbbseg_ctx* c, Op& op, int n, uint8_t* d_labels, float* d_probs)
                 dp.scale = co.d_scale; dp.shift = co.d_shift; dp.relu = co.d.relu; dp.out = c->tensors[co.d.out_tensor].data();
                 dp.wmul = co.wmul_cls[0];
                 HIPCHK(launch_direct64(dp, c->precision, c->num_cus, c->stream));
+            } else if (co.d_halo_wfrag && !c->no_dec_halo && !(c->conv_variant & 3)) {
+                const Tensor& s0 = c->tensors[co.d.src[0].tensor];
+                DecHaloParams hp;
+                hp.src0 = s0.buf; hp.skip = c->tensors[co.d.src[1].tensor].buf; hp.PH = s0.H; hp.PW = s0.W; hp.n = n;
+                hp.wfrag = co.d_halo_wfrag; hp.taps = co.d_halo_taps; hp.scale = co.d_scale; hp.shift = co.d_shift;
+                for (int q = 0; q < 4; ++q) hp.wmul[q] = co.wmul_cls[q];
+                hp.relu = co.d.relu; hp.out = c->tensors[co.d.out_tensor].data();
+                HIPCHK(launch_dec_halo_x3(hp, c->num_cus, c->stream));
             } else {
                 HIPCHK(launch_conv(p, c->precision, c->stream));
             }
@@ -798,6 +809,7 @@ int sbbseg_destroy(sbbseg_ctx* c)
         (void)hipFree(op.conv.d_ktab); (void)hipFree(op.conv.d_kstep); (void)hipFree(op.conv.d_w); (void)hipFree(op.conv.d_scale); (void)hipFree(op.conv.d_shift);
         (void)hipFree(op.conv.d_rscale); (void)hipFree(op.conv.d_rshift);
         (void)hipFree(op.conv.d_head_w); (void)hipFree(op.conv.d_head_scale); (void)hipFree(op.conv.d_head_shift); (void)hipFree(op.conv.d_stem_wfrag); (void)hipFree(op.conv.d_d64_wfrag);
+        (void)hipFree(op.conv.d_halo_wfrag); (void)hipFree(op.conv.d_halo_taps);
         for (int q = 1; q < 4; ++q) { (void)hipFree(op.conv.d_w_cls[q]); (void)hipFree(op.conv.d_kstep_cls[q]); (void)hipFree(op.conv.d_ktab_cls[q]); }
         (void)hipFree(op.head.d_w); (void)hipFree(op.head.d_scale); (void)hipFree(op.head.d_shift);
         (void)hipFree(op.pool.d_pre_scale); (void)hipFree(op.pool.d_pre_shift);
@@ -1651,6 +1663,59 @@ int sbbseg_finalize(sbbseg_ctx* c, int max_batch)
     HIPCHK(hipSetDevice(c->device));
     if (fuse_bottlenecks(c)) return 1;
     if (build_fast_gather_tables(c)) return 1;
+    // split mode: the decoder conv at 224 x 224 -- four merged parity classes of  conv3x3([up2(128 ch @ 112 x 112), 64 ch @ 224 x 224]) -> 64 ch
+    // -- runs dec_halo_x3 (source halos resident in LDS, dec_halo_x3.hip) on the classes' OWN packed weights and K-step order:
+    // the rows of every class matrix are read back and re-laid as MFMA A fragments.  SBBSEG_DEC_HALO=0 keeps the generic kernel.
+    {
+        const char* env = getenv("SBBSEG_DEC_HALO");
+        for (size_t i = 0; c->precision == kF16X3 && !(env && env[0] == '0') && i < c->ops.size(); ++i) {
+            Op& op = c->ops[i];
+            if (op.type != kConv) continue;
+            ConvOp& co = op.conv;
+            const sbbseg_conv_desc& d = co.d;
+            if (co.n_cls != 4 || d.n_src != 2 || d.cout != 64 || co.ksteps[0] != 16 || co.ksteps[1] != 18 || !co.fg_ok || d.residual_tensor >= 0 ||
+                d.raw_out_tensor >= 0 || d.head_classes > 0 || d.out_tensor < 0 || d.out_stride_y != 2 || d.out_stride_x != 2)
+                continue;
+            const Tensor &t0 = c->tensors[d.src[0].tensor], &t1 = c->tensors[d.src[1].tensor], &to = c->tensors[d.out_tensor];
+            if (t0.C != 128 || d.src[0].channels != 128 || t1.C != 64 || d.src[1].channels != 64 || d.src[0].stride_y != 1 || d.src[0].stride_x != 1 ||
+                d.src[0].up_shift != 0 || d.src[1].stride_y != 2 || d.src[1].stride_x != 2 || t0.is_input_form || t1.is_input_form ||
+                t1.H != 2 * t0.H || t1.W != 2 * t0.W || to.H != t1.H || to.W != t1.W || d.out_h != t0.H || d.out_w != t0.W || (t0.H & 7) || (t0.W & 7))
+                continue;
+            // class q must be the output parity (q >> 1, q & 1) -- the kernel's wave <-> class map -- and its taps must stay inside the halos
+            bool ok = true;
+            std::vector<int> taps(4 * 16, 0);
+            for (int q = 0; q < 4 && ok; ++q) {
+                ok = co.ooy_cls[q] == (q >> 1) && co.oox_cls[q] == (q & 1) && (int)co.h_ksteps_cls[q].size() == 34;
+                for (int t = 0; t < 34 && ok; ++t) {
+                    const KStepRec& r = co.h_ksteps_cls[q][t];
+                    const int g = t < 16 ? t >> 2 : (t - 16) / 9, ti = t < 16 ? t & 3 : (t - 16) % 9;
+                    ok = !r.irregular && r.coff == g * 128;                                   // channel group g of the stored pixel
+                    if (t < 16) ok = ok && r.dy >= -1 && r.dy <= 1 && r.dx >= -1 && r.dx <= 1;             // halo row i + dy + 1 in [0, 9]
+                    else ok = ok && r.dy >= -1 && r.dy <= 2 && r.dx >= -1 && r.dx <= 2;                    // halo row 2 i + dy + 1 in [0, 17]
+                    const int word = (r.dy & 255) | ((r.dx & 255) << 8);
+                    const int slot = q * 16 + (t < 16 ? ti : 4 + ti);
+                    if (g == 0) taps[slot] = word;
+                    else ok = ok && taps[slot] == word;                                       // every group walks the same taps
+                }
+            }
+            if (!ok) continue;
+            alloc_check();
+            const size_t row_halves = (size_t)co.Ktot, frag_halves = (size_t)4 * 34 * 4 * 2 * 64 * 8;
+            std::vector<uint16_t> mat((size_t)64 * row_halves), frag(frag_halves);
+            for (int q = 0; q < 4; ++q) {
+                HIPCHK(hipMemcpy(mat.data(), co.d_w_cls[q], mat.size() * sizeof(uint16_t), hipMemcpyDeviceToHost));     // packed rows 0..63
+                for (int t = 0; t < 34; ++t)
+                    for (int mi = 0; mi < 4; ++mi)
+                        for (int lo = 0; lo < 2; ++lo)
+                            for (int l = 0; l < 64; ++l) {
+                                const uint16_t* src = &mat[(size_t)(mi * 16 + (l & 15)) * row_halves + (size_t)t * 64 + lo * 32 + (l >> 4) * 8];
+                                uint16_t* dst = &frag[((((size_t)(q * 34 + t) * 4 + mi) * 2 + lo) * 64 + l) * 8];
+                                for (int e = 0; e < 8; ++e) dst[e] = src[e];
+                            }
+            }
+            if (upload(c, &co.d_halo_wfrag, frag.data(), frag.size()) || upload(c, &co.d_halo_taps, taps.data(), taps.size())) return 1;
+        }
+    }
     // split mode: the stem (dedicated kernel, raw output only) directly followed by the 3x3 / stride-2 max-pool of that tensor with an
     // affine on every tap (bn_conv1 + ReLU) -> one launch writes both tensors (stem_pool_x3.hip); SBBSEG_STEM_POOL=0 keeps two launches
     {
@@ -2736,7 +2801,7 @@ int sbbseg_debug_counter(sbbseg_ctx* c, int which, int64_t* value)
 int sbbseg_debug_set_conv_variant(sbbseg_ctx* c, int variant)
 {
     API_BEGIN
-    REQUIRE(c && variant >= 0 && variant <= 0x7fffff, "variant: bits 0-1 = 0 auto | 1 4-wave/2-stage | 2 8-wave/3-stage; bit 2 = one block per tile (non-persistent); bit 3 = no XCD-grouped tile walk; bit 4 = half-K-step stages; bit 5 = XCD-grouped walk on single-class layers; bit 6 = drain epilogue stores; bit 7 = half-line epilogue stores; bits 8-15 = contiguous-run K limit / 64; bit 16 = 8-phase schedule on the 256x256 tile; bit 17 = plain gather everywhere; bit 18 = fused bottleneck blocks run as their three convs; bit 19 = XCD-contiguous walk for grouped launches; bit 20 = one-group form of the fused block kernel; bit 21 = extract_page ranks contours on the host always; bit 22 = stem and max-pool as two launches");
+    REQUIRE(c && variant >= 0 && variant <= 0xffffff, "variant: bits 0-1 = 0 auto | 1 4-wave/2-stage | 2 8-wave/3-stage; bit 2 = one block per tile (non-persistent); bit 3 = no XCD-grouped tile walk; bit 4 = half-K-step stages; bit 5 = XCD-grouped walk on single-class layers; bit 6 = drain epilogue stores; bit 7 = half-line epilogue stores; bits 8-15 = contiguous-run K limit / 64; bit 16 = 8-phase schedule on the 256x256 tile; bit 17 = plain gather everywhere; bit 18 = fused bottleneck blocks run as their three convs; bit 19 = XCD-contiguous walk for grouped launches; bit 20 = one-group form of the fused block kernel; bit 21 = extract_page ranks contours on the host always; bit 22 = stem and max-pool as two launches; bit 23 = the 224 x 224 decoder conv on the generic kernel");
     c->conv_variant = variant & 0xff;
     c->ph8 = (variant >> 16) & 1;
     c->plain_gather = (variant >> 17) & 1;
@@ -2745,6 +2810,7 @@ int sbbseg_debug_set_conv_variant(sbbseg_ctx* c, int variant)
     c->block_pq = !((variant >> 20) & 1);
     c->force_host_contours = (variant >> 21) & 1;
     c->unfuse_stem_pool = (variant >> 22) & 1;
+    c->no_dec_halo = (variant >> 23) & 1;
     if ((variant >> 8) & 0xff) c->contig_max_k = ((variant >> 8) & 0xff) * 64;
     return 0;
     API_END

@@ -97,6 +97,8 @@ struct ConvParams {
     float* probs;             // [n][TH][TW][classes] or null
     uint32_t howo_magic, howo_shift, wo_magic, wo_shift, nct_magic, nct_shift;   // FastDiv pairs for Ho * Wo, Wo and the number of
                                                            // channel tiles, filled by the launcher (kernels.hip)
+    int tile2d, tpr;                  // 1: pixel indices are cut into 16 x 16 blocks (tpr = Wo / 16 blocks per row), see decode_yx in conv_igemm_mfma
+    uint32_t tpr_magic, tpr_shift;    //    (filled by the launcher)
     const FgStepRec* fgstep_cls[4];   // fast gather: per-class tables read in place of kstep / kstep_cls (class 0 = entry 0)
     int fast_gather;          // every K-step regular, each source's taps within a 4 x 4 window, no upsampling source, buffers < 2 GiB:
                               // run the FG form of conv_igemm_mfma (kernels.hip)
@@ -192,6 +194,21 @@ struct BlockParams {
     float wmul1 = 1.f, wmul2 = 1.f, wmul3 = 1.f;
 };
 
+// The decoder conv at 224 x 224 in the split mode with LDS-resident source halos (dec_halo_x3.hip): the grouped launch of the four
+// output-parity classes of  conv3x3([up2(src0: 128 ch), skip: 64 ch]) -> 64 ch  as ONE direct kernel on 16 x 16 output tiles.
+struct DecHaloParams {
+    const char* src0;         // buffer start (zero header), [n][PH][PW][128] split layout (512 B per pixel)
+    const char* skip;         // buffer start (zero header), [n][2 PH][2 PW][64] split layout (256 B per pixel)
+    int PH, PW, n;
+    const void* wfrag;        // [4 classes][34 K-steps][4 row blocks][hi | lo][64 lanes] x 16 B: MFMA A fragments of the classes' packed weights
+    const int* taps;          // [4 classes][16]: the class's 4 src0 taps, then its 9 skip taps, in K-step order: (dy & 255) | (dx & 255) << 8
+    const float* scale;       // [64]
+    const float* shift;
+    float wmul[4];            // per class: 2^-s of its power-of-two weight pre-scale
+    int relu;
+    void* out;                // data pointer [n][2 PH][2 PW][64] split layout
+};
+
 struct HeadParams {
     const void* src;          // [M][cin] activations (data pointer)
     int cin;                  // <= 64, multiple of 8
@@ -239,6 +256,7 @@ hipError_t launch_maxpool(const void* src, void* dst, int n, int H, int W, int C
 hipError_t launch_head(const HeadParams& p, int precision, hipStream_t s);
 hipError_t launch_tail(const TailParams& p, int precision, int num_cus, hipStream_t s);
 hipError_t launch_stem(const StemParams& p, int precision, int num_cus, hipStream_t s);
+hipError_t launch_dec_halo_x3(const DecHaloParams& p, int num_cus, hipStream_t s);     // split mode: dec4 with LDS-resident halos (dec_halo_x3.hip)
 hipError_t launch_stem_pool_x3(const StemParams& p, int num_cus, hipStream_t s);      // split mode: stem + max-pool in one launch (stem_pool_x3.hip)
 hipError_t launch_direct64(const Direct64Params& p, int precision, int num_cus, hipStream_t s);
 constexpr int kTailKSteps = 6;      // 4 taps x 64 channels of src0 + 2 steps for the 9 image taps

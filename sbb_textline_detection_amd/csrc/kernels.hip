@@ -278,6 +278,22 @@ void conv_igemm_mfma(const ConvParams p)
     const int lswz = GS == 8 ? lrow : ((0x78 >> (2 * ((lrow >> 2) & 3))) & 3);
     const int gsrc = (lane % GS) ^ lswz;                // source granule (within the stage) this lane fetches
     const int HoWo = p.Ho * p.Wo;
+    // output-grid pixel index inside one patch -> (oy, ox).  Linear: row-major, a pixel tile = a strip of BP consecutive pixels.
+    // tile2d (round 4; Ho, Wo multiples of 16): the index space is cut into 16 x 16 BLOCKS (256 consecutive indices = one block, blocks
+    // row-major), so a pixel tile is one or two square blocks: the taps of a 3x3 / 2x2 conv re-read an 18 x 18 halo INSIDE the tile's
+    // own K loop (L2 hits a few microseconds apart) instead of rows that the tiles above / below fetch at other times on other CUs.
+    // Which pixels share a tile changes, what is computed for a pixel does not: results are bit-identical.
+    auto decode_yx = [&](int rem, int& oy, int& ox) __attribute__((always_inline)) {
+        if (p.tile2d) {
+            const int t = rem >> 8, r = rem & 255;
+            const int ty = fast_div(t, p.tpr_magic, p.tpr_shift);
+            oy = (ty << 4) + (r >> 4);
+            ox = ((t - ty * p.tpr) << 4) + (r & 15);
+        } else {
+            oy = fast_div(rem, p.wo_magic, p.wo_shift);
+            ox = rem - oy * p.Wo;
+        }
+    };
 
     // both sources' descriptors live in SGPRs for the whole kernel
     const SrcDesc sd0 = p.src[0];
@@ -330,8 +346,8 @@ void conv_igemm_mfma(const ConvParams p)
             if (g8 < T::kPLoads && mm < p.M) {
                 const int n = fast_div(mm, p.howo_magic, p.howo_shift);
                 const int rem = mm - n * HoWo;
-                const int oy = fast_div(rem, p.wo_magic, p.wo_shift);
-                const int ox = rem - oy * p.Wo;
+                int oy, ox;
+                decode_yx(rem, oy, ox);
                 my_a = (int)((uint32_t)n * img0 + (uint32_t)(((oy << sd0.sy_shift) * sd0.PW + (ox << sd0.sx_shift)) * sd0.pix_bytes) +
                              (uint32_t)kZeroHeaderBytes);
                 // (fast_gather == 2: every tap is (0, 0) -- pointwise convs -- and in bounds for every real row)
@@ -360,8 +376,8 @@ void conv_igemm_mfma(const ConvParams p)
                 if (m < p.M) {
                     const int n = fast_div(m, p.howo_magic, p.howo_shift);
                     const int rem = m - n * HoWo;
-                    const int oy = fast_div(rem, p.wo_magic, p.wo_shift);
-                    const int ox = rem - oy * p.Wo;
+                    int oy, ox;
+                    decode_yx(rem, oy, ox);
                     r_oy[j] = (int)((uint32_t)n * img0 + (uint32_t)(((oy << sd0.sy_shift) * sd0.PW + (ox << sd0.sx_shift)) * sd0.pix_bytes) +
                                     lane_part(sd0) + (uint32_t)kZeroHeaderBytes);
                     uint32_t inv = p.fast_gather == 2 ? 0u : oob_mask(sd0, oy, ox);
@@ -381,8 +397,8 @@ void conv_igemm_mfma(const ConvParams p)
             } else if (m < p.M) {
                 const int n = fast_div(m, p.howo_magic, p.howo_shift);
                 const int rem = m - n * HoWo;
-                const int oy = fast_div(rem, p.wo_magic, p.wo_shift);
-                const int ox = rem - oy * p.Wo;
+                int oy, ox;
+                decode_yx(rem, oy, ox);
                 r_oy[j] = oy;
                 r_ox[j] = ox;
                 r_n[j] = n;
@@ -493,8 +509,8 @@ void conv_igemm_mfma(const ConvParams p)
         if (!placed) return m;
         const int n = fast_div(m, p.howo_magic, p.howo_shift);
         const int rem = m - n * HoWo;
-        const int oy = fast_div(rem, p.wo_magic, p.wo_shift);
-        const int ox = rem - oy * p.Wo;
+        int oy, ox;
+        decode_yx(rem, oy, ox);
         const int ooy = p.n_cls > 1 ? p.ooy_cls[cls] : p.ooy, oox = p.n_cls > 1 ? p.oox_cls[cls] : p.oox;
         return (n * p.TH + oy * p.osy + ooy) * p.TW + ox * p.osx + oox;
     };
@@ -814,8 +830,9 @@ void conv_igemm_mfma(const ConvParams p)
                 if (m < p.M) {
                     const int n = fast_div(m, p.howo_magic, p.howo_shift);
                     const int rem = m - n * HoWo;
-                    const int oy = fast_div(rem, p.wo_magic, p.wo_shift);
-                    q_oy[j] = oy; q_ox[j] = rem - oy * p.Wo; q_n[j] = n;
+                    int oy, ox;
+                    decode_yx(rem, oy, ox);
+                    q_oy[j] = oy; q_ox[j] = ox; q_n[j] = n;
                 } else {
                     q_oy[j] = -(1 << 20); q_ox[j] = 0; q_n[j] = 0;
                 }
@@ -1192,6 +1209,11 @@ static hipError_t launch_conv_impl(const ConvParams& p, hipStream_t s)
     make_fast_div((uint32_t)(p.Ho * p.Wo), &q.howo_magic, &q.howo_shift);
     make_fast_div((uint32_t)p.Wo, &q.wo_magic, &q.wo_shift);
     make_fast_div((uint32_t)n_ct, &q.nct_magic, &q.nct_shift);
+    // 2D pixel tiles for convs with real taps on the fast gather (A/B: SBBSEG_TILE2D=0 keeps the linear strips)
+    static const bool tile2d_on = !(getenv("SBBSEG_TILE2D") && getenv("SBBSEG_TILE2D")[0] == '0');
+    q.tile2d = (tile2d_on && p.fast_gather == 1 && p.Ho % 16 == 0 && p.Wo % 16 == 0) ? 1 : 0;
+    q.tpr = p.Wo / 16;
+    make_fast_div((uint32_t)(q.tpr > 0 ? q.tpr : 1), &q.tpr_magic, &q.tpr_shift);
     hipLaunchKernelGGL((conv_igemm_mfma<BP, BC, WP, WC, NS, F16, GS, PH8, X3, FG>), dim3(grid), dim3(T::kThreads), T::kLdsBytes, s, q);
     return hipGetLastError();
 }

@@ -219,6 +219,41 @@ def test_fused_x3_stem_pool_matches_the_two_launches(hw, nb):
     model.release()
 
 
+@pytest.mark.parametrize("hw,nb", [((64, 96), 3), ((224, 256), 5), ((448, 448), 9)])
+def test_dec_halo_x3_matches_the_generic_kernel(hw, nb):
+    """Split mode: the decoder conv at full / 2 resolution (four parity classes of conv3x3([up2(128 ch), skip 64 ch]) -> 64 ch) runs
+    dec_halo_x3 (csrc/dec_halo_x3.hip: 16 x 16 output tiles, source halos resident in LDS, weights streamed as A fragments, every
+    vector load counted by hand).  Against conv_igemm_mfma's grouped launch (conv variant bit 23) every tensor of the plan must be the
+    same bits: same K-steps in the same order, same three MFMAs per product, same epilogue.  Run three times: the hand-placed waits
+    (vmcnt counts that include the halo DMA bursts and the epilogue's stores) must not race."""
+    h, wd = hw
+    cfg, w, g, model = make_model(2, h, wd, seed=8, precision="f16x3", max_batch=nb + 2, calib_hw=min(160, max(h, wd)))
+    x = (patches_from_page(h, wd, nb, seed=28) / 255.0).astype(np.float32)
+
+    def read_all():
+        out = {}
+        for name, tid in model.plan.layer_tensor.items():
+            t = model.plan.tensors[tid]
+            out[name] = model.ctx.debug_read_tensor(tid, nb, (t.H, t.W, t.C))
+        return out
+    got_halo = model.predict(x)
+    t_halo = read_all()
+    model.ctx.set_conv_variant(1 << 23)
+    got_gen = model.predict(x)
+    t_gen = read_all()
+    model.ctx.set_conv_variant(0)
+    dec4 = [n for n, tid in model.plan.layer_tensor.items() if model.plan.tensors[tid].C == 64 and model.plan.tensors[tid].H == h // 2]
+    assert dec4, list(model.plan.layer_tensor)
+    for name in t_halo:
+        assert np.array_equal(t_halo[name], t_gen[name]), (name, float(np.abs(t_halo[name] - t_gen[name]).max()))
+    assert np.array_equal(got_halo, got_gen)
+    for _ in range(3):
+        assert np.array_equal(model.predict(x), got_halo)
+    ref = kf.forward(g, w, x[:2])
+    assert float(np.abs(got_halo[:2] - ref).max()) < TOL_SOFTMAX["f16x3"] and exact_label_check(ref, got_halo[:2])[1] == 0
+    model.release()
+
+
 def test_conv_tile_families_agree():
     """4-wave/2-stage and 8-wave/3-stage conv tiles, persistent or one block per tile, compute the same sums."""
     cfg, w, g, model = make_model(2, 224, 224, seed=3, precision="f16", max_batch=6)
