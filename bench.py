@@ -53,15 +53,15 @@ if os.environ.get("SBBSEG_BENCH_PAGE"):      # experiment knob (A/B of chunk siz
 MODEL_HW, CLASSES = 448, 2
 # committed rocprofv3 PMC summaries (tools/pmc_run.sh + tools/pmc_report.py) the `roofline.traffic` figure is read from: STATIC
 # numbers (counters need their own profiling passes), valid only for the kernel sources they were collected on (csrc_sha)
-PMC_SUMMARY = {"f16x3": os.path.join(ROOT, "profiles", "r03_x3_pmc_summary.json"),
-               "f16": os.path.join(ROOT, "profiles", "r03_f16_pmc_summary.json")}
+PMC_SUMMARY = {"f16x3": os.path.join(ROOT, "profiles", "r04_x3_pmc_summary.json"),
+               "f16": os.path.join(ROOT, "profiles", "r04_f16_pmc_summary.json")}
 
 
 def csrc_sha():
     """Hash of the device / host sources libsbbseg is built from: ties a committed PMC summary to the kernels it measured."""
     import hashlib
     h = hashlib.sha1()
-    for name in ("kernels.hip", "api.hip", "internal.h"):
+    for name in ("kernels.hip", "block_x3.hip", "stem_pool_x3.hip", "dec_halo_x3.hip", "api.hip", "internal.h"):
         with open(os.path.join(ROOT, "sbb_textline_detection_amd", "csrc", name), "rb") as f:
             h.update(f.read())
     return h.hexdigest()[:12]

@@ -469,7 +469,8 @@ int launch_op(sbbseg_ctx* c, Op& op, int n, uint8_t* d_labels, float* d_probs)
                 hp.wfrag = co.d_halo_wfrag; hp.taps = co.d_halo_taps; hp.scale = co.d_scale; hp.shift = co.d_shift;
                 for (int q = 0; q < 4; ++q) hp.wmul[q] = co.wmul_cls[q];
                 hp.relu = co.d.relu; hp.out = c->tensors[co.d.out_tensor].data();
-                HIPCHK(launch_dec_halo_x3(hp, c->num_cus, c->stream));
+                if (c->precision == kF16X3) HIPCHK(launch_dec_halo_x3(hp, c->num_cus, c->stream));
+                else HIPCHK(launch_dec_halo_f16(hp, c->num_cus, c->stream));
             } else {
                 HIPCHK(launch_conv(p, c->precision, c->stream));
             }
@@ -1668,12 +1669,15 @@ int sbbseg_finalize(sbbseg_ctx* c, int max_batch)
     // the rows of every class matrix are read back and re-laid as MFMA A fragments.  SBBSEG_DEC_HALO=0 keeps the generic kernel.
     {
         const char* env = getenv("SBBSEG_DEC_HALO");
-        for (size_t i = 0; c->precision == kF16X3 && !(env && env[0] == '0') && i < c->ops.size(); ++i) {
+        // (plain fp16 mode: dec_halo_f16.hip -- K-steps of 64 channels: 2 x 4 + 9 of them, fragments of the two k-halves in place of hi | lo)
+        const bool x3 = c->precision == kF16X3;
+        const int n0 = x3 ? 16 : 8, n1 = x3 ? 18 : 9, nsteps = n0 + n1;
+        for (size_t i = 0; (x3 || c->precision == kF16) && !(env && env[0] == '0') && i < c->ops.size(); ++i) {
             Op& op = c->ops[i];
             if (op.type != kConv) continue;
             ConvOp& co = op.conv;
             const sbbseg_conv_desc& d = co.d;
-            if (co.n_cls != 4 || d.n_src != 2 || d.cout != 64 || co.ksteps[0] != 16 || co.ksteps[1] != 18 || !co.fg_ok || d.residual_tensor >= 0 ||
+            if (co.n_cls != 4 || d.n_src != 2 || d.cout != 64 || co.ksteps[0] != n0 || co.ksteps[1] != n1 || !co.fg_ok || d.residual_tensor >= 0 ||
                 d.raw_out_tensor >= 0 || d.head_classes > 0 || d.out_tensor < 0 || d.out_stride_y != 2 || d.out_stride_x != 2)
                 continue;
             const Tensor &t0 = c->tensors[d.src[0].tensor], &t1 = c->tensors[d.src[1].tensor], &to = c->tensors[d.out_tensor];
@@ -1685,31 +1689,31 @@ int sbbseg_finalize(sbbseg_ctx* c, int max_batch)
             bool ok = true;
             std::vector<int> taps(4 * 16, 0);
             for (int q = 0; q < 4 && ok; ++q) {
-                ok = co.ooy_cls[q] == (q >> 1) && co.oox_cls[q] == (q & 1) && (int)co.h_ksteps_cls[q].size() == 34;
-                for (int t = 0; t < 34 && ok; ++t) {
+                ok = co.ooy_cls[q] == (q >> 1) && co.oox_cls[q] == (q & 1) && (int)co.h_ksteps_cls[q].size() == nsteps;
+                for (int t = 0; t < nsteps && ok; ++t) {
                     const KStepRec& r = co.h_ksteps_cls[q][t];
-                    const int g = t < 16 ? t >> 2 : (t - 16) / 9, ti = t < 16 ? t & 3 : (t - 16) % 9;
+                    const int g = t < n0 ? t >> 2 : (t - n0) / 9, ti = t < n0 ? t & 3 : (t - n0) % 9;
                     ok = !r.irregular && r.coff == g * 128;                                   // channel group g of the stored pixel
-                    if (t < 16) ok = ok && r.dy >= -1 && r.dy <= 1 && r.dx >= -1 && r.dx <= 1;             // halo row i + dy + 1 in [0, 9]
+                    if (t < n0) ok = ok && r.dy >= -1 && r.dy <= 1 && r.dx >= -1 && r.dx <= 1;             // halo row i + dy + 1 in [0, 9]
                     else ok = ok && r.dy >= -1 && r.dy <= 2 && r.dx >= -1 && r.dx <= 2;                    // halo row 2 i + dy + 1 in [0, 17]
                     const int word = (r.dy & 255) | ((r.dx & 255) << 8);
-                    const int slot = q * 16 + (t < 16 ? ti : 4 + ti);
+                    const int slot = q * 16 + (t < n0 ? ti : 4 + ti);
                     if (g == 0) taps[slot] = word;
                     else ok = ok && taps[slot] == word;                                       // every group walks the same taps
                 }
             }
             if (!ok) continue;
             alloc_check();
-            const size_t row_halves = (size_t)co.Ktot, frag_halves = (size_t)4 * 34 * 4 * 2 * 64 * 8;
+            const size_t row_halves = (size_t)co.Ktot, frag_halves = (size_t)4 * nsteps * 4 * 2 * 64 * 8;
             std::vector<uint16_t> mat((size_t)64 * row_halves), frag(frag_halves);
             for (int q = 0; q < 4; ++q) {
                 HIPCHK(hipMemcpy(mat.data(), co.d_w_cls[q], mat.size() * sizeof(uint16_t), hipMemcpyDeviceToHost));     // packed rows 0..63
-                for (int t = 0; t < 34; ++t)
+                for (int t = 0; t < nsteps; ++t)
                     for (int mi = 0; mi < 4; ++mi)
-                        for (int lo = 0; lo < 2; ++lo)
+                        for (int lo = 0; lo < 2; ++lo)                                        // split mode: hi | lo plane; fp16: k-half
                             for (int l = 0; l < 64; ++l) {
                                 const uint16_t* src = &mat[(size_t)(mi * 16 + (l & 15)) * row_halves + (size_t)t * 64 + lo * 32 + (l >> 4) * 8];
-                                uint16_t* dst = &frag[((((size_t)(q * 34 + t) * 4 + mi) * 2 + lo) * 64 + l) * 8];
+                                uint16_t* dst = &frag[((((size_t)(q * nsteps + t) * 4 + mi) * 2 + lo) * 64 + l) * 8];
                                 for (int e = 0; e < 8; ++e) dst[e] = src[e];
                             }
             }

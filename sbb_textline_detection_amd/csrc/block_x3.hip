@@ -169,24 +169,44 @@ __global__ __launch_bounds__(256, 1) void block_x3(const BlockParams p)
         }
     };
 
+    // (a use the compiler can see: it waits for the one-time weight loads HERE.  Left to their first use inside the tile loop -- phase B for
+    // the 3x3 fragments -- its wait is vmcnt(0) on every trip: it drained the next tile's x prefetch, just issued, once per tile)
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) asm volatile("" : "+v"(wfh[t][kk]), "+v"(wfl[t][kk]));
+    if constexpr (PROJ) {
+#pragma unroll
+        for (int kk = 0; kk < KA; ++kk)
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) asm volatile("" : "+v"(w1h[kk][mi]), "+v"(w1l[kk][mi]));
+    }
     locate(tile_at(0), inimg, xoff);
     fetch(xoff[0], xih, xil);
     fetch(xoff[1], xbh, xbl);
+    // (again a visible use: the first tile's x is waited for in front of the loop.  The compiler merges the loop entry with the back edge
+    // and keeps the SMALLER count per register: with these 32 loads pending at the entry, every wait of phase A came out as if nothing
+    // but the later x loads were younger -- vmcnt(15) .. vmcnt(0) in place of vmcnt(47) .. -- i.e. all of phase C's stores had to land)
+#pragma unroll
+    for (int kk = 0; kk < KA; ++kk) asm volatile("" : "+v"(xih[kk]), "+v"(xil[kk]), "+v"(xbh[kk]), "+v"(xbl[kk]));
     __syncthreads();                                            // weights / constants visible
 
     for (int it = 0; it < my_tiles; ++it) {
         const int tile = tile_at(it);
         const bool more = it + 1 < my_tiles;
-        bool in_next[2] = {false, false};
-        uint32_t off_next[2] = {0u, 0u};
-        if (more) {
-            locate(tile_at(it + 1), in_next, off_next);
-            if constexpr (FULL) {
+        // The next tile's x is requested UNCONDITIONALLY (the last tile asks for its own again) and the output stores below are
+        // buffer stores that drop the lanes outside the image instead of branching around them: with every vector-memory operation
+        // of the loop in straight-line code the compiler counts its waits exactly -- phase A's K-step kk waits for the two loads
+        // phase C's group kk issued, vmcnt(30 - 4 kk), not for the stores behind them.  (With `if (more)` / `if (live)` around them
+        // it could not count the stores and waited for all of them -- and for the loads between them -- before phase A.)
+        bool in_next[2];
+        uint32_t off_next[2];
+        locate(tile_at(more ? it + 1 : it), in_next, off_next);
+        if constexpr (FULL) {
 #pragma unroll
-                for (int kk = 0; kk < KA; ++kk) {
-                    nih[kk] = *(const h8_t*)(p.x + off_next[0] + kk * 128);
-                    nil[kk] = *(const h8_t*)(p.x + off_next[0] + kk * 128 + 64);
-                }
+            for (int kk = 0; kk < KA; ++kk) {
+                nih[kk] = *(const h8_t*)(p.x + off_next[0] + kk * 128);
+                nil[kk] = *(const h8_t*)(p.x + off_next[0] + kk * 128 + 64);
             }
         }
 
@@ -225,7 +245,7 @@ __global__ __launch_bounds__(256, 1) void block_x3(const BlockParams p)
                 for (int mi = 0; mi < 4; ++mi) { acc[mi][0] = mma(ch[mi], xih[kk], acc[mi][0]); acc[mi][1] = mma(ch[mi], xbh[kk], acc[mi][1]); }
                 __builtin_amdgcn_sched_barrier(0);
             }
-            if (more) fetch(off_next[1], xbh, xbl);             // border x is spent: its registers take the next tile's
+            fetch(off_next[1], xbh, xbl);                       // border x is spent: its registers take the next tile's
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
                 const int c0 = s2 * 32 + fg * 8;
@@ -323,7 +343,9 @@ __global__ __launch_bounds__(256, 1) void block_x3(const BlockParams p)
                 bl[kk] = *(const h8_t*)(rb[(8 + kk * 4) >> 1] + wave * 16 * 256);
             }
             __syncthreads();                                    // b is in registers everywhere: the next tile's phase A may write a
-            uint16_t* orow = (uint16_t*)p.out + (((size_t)n * p.H + oy) * p.W + ox) * 512;
+            // this patch's plane of the output as a buffer: lanes outside the image store at an offset past its end (dropped)
+            const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc((char*)p.out + (size_t)n * p.H * p.W * 1024, 0, p.H * p.W * 1024, 0x00020000);
+            const uint32_t ooff = live ? (uint32_t)((oy * p.W + ox) * 1024 + fg * 16) : 0x80000000u;
             // channel group s3 + 1's weight fragments and constants are requested before group s3's MFMAs and epilogue
             h8_t w3h[2][KC][2], w3l[2][KC][2];
             float4 kc[2][4];                                    // scale[c0..c0+7], shift[c0..c0+7]
@@ -373,28 +395,23 @@ __global__ __launch_bounds__(256, 1) void block_x3(const BlockParams p)
                     for (int q = 0; q < 8; ++q)
                         y[q] = fmaxf(__fadd_rn(y[q], __fadd_rn((float)xih[s3 % KA][q], (float)xil[s3 % KA][q])), 0.f);      // (= add_split8, kernels.hip)
                 }
-                if constexpr (!FULL) {
-                    if (more) {                                 // this K-step's x is spent: its registers take the next tile's
-                        xih[s3 % KA] = *(const h8_t*)(p.x + off_next[0] + s3 * 128);
-                        xil[s3 % KA] = *(const h8_t*)(p.x + off_next[0] + s3 * 128 + 64);
-                    }
+                if constexpr (!FULL) {                          // this K-step's x is spent: its registers take the next tile's
+                    xih[s3 % KA] = *(const h8_t*)(p.x + off_next[0] + s3 * 128);
+                    xil[s3 % KA] = *(const h8_t*)(p.x + off_next[0] + s3 * 128 + 64);
                 }
                 h8_t vh, vl;
                 split8(y, vh, vl);
-                if (live) {
-                    *(h8_t*)(orow + s3 * 64 + fg * 8) = vh;             // channel group s3: [32 hi][32 lo]
-                    *(h8_t*)(orow + s3 * 64 + 32 + fg * 8) = vl;
-                }
+                typedef __attribute__((ext_vector_type(4))) unsigned u4_t;
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4_t, vh), orsrc, ooff + s3 * 128, 0, 0);         // channel group s3: [32 hi][32 lo]
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4_t, vl), orsrc, ooff + s3 * 128 + 64, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
 
         inimg[0] = in_next[0]; inimg[1] = in_next[1];
         if constexpr (FULL) {
-            if (more) {
 #pragma unroll
-                for (int kk = 0; kk < KA; ++kk) { xih[kk] = nih[kk]; xil[kk] = nil[kk]; }
-            }
+            for (int kk = 0; kk < KA; ++kk) { xih[kk] = nih[kk]; xil[kk] = nil[kk]; }
         }
     }
 }

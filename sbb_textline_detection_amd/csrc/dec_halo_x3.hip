@@ -223,6 +223,10 @@ __global__ __launch_bounds__(512, 2) void dec_halo_x3(const DecHaloParams p)
     float ksc[8], ksh[8];
 #pragma unroll
     for (int q = 0; q < 8; ++q) { ksc[q] = p.scale[c0 + q] * p.wmul[cls]; ksh[q] = p.shift[c0 + q]; }
+    // (a use the compiler can see: it waits for these loads HERE.  Left to the first use in the epilogue, its wait -- vmcnt(0), it cannot
+    // count the asm loads in between -- drained the hand-counted queue once per tile, right behind the skip halo's DMA burst)
+#pragma unroll
+    for (int q = 0; q < 8; ++q) asm volatile("" : "+v"(ksc[q]), "+v"(ksh[q]));
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // (the compiler's own loads above are done before the hand-counted queue starts)
 
     // ---- prologue: the first tile's halos

@@ -257,6 +257,7 @@ hipError_t launch_head(const HeadParams& p, int precision, hipStream_t s);
 hipError_t launch_tail(const TailParams& p, int precision, int num_cus, hipStream_t s);
 hipError_t launch_stem(const StemParams& p, int precision, int num_cus, hipStream_t s);
 hipError_t launch_dec_halo_x3(const DecHaloParams& p, int num_cus, hipStream_t s);     // split mode: dec4 with LDS-resident halos (dec_halo_x3.hip)
+hipError_t launch_dec_halo_f16(const DecHaloParams& p, int num_cus, hipStream_t s);    // ... plain fp16 mode (dec_halo_f16.hip)
 hipError_t launch_stem_pool_x3(const StemParams& p, int num_cus, hipStream_t s);      // split mode: stem + max-pool in one launch (stem_pool_x3.hip)
 hipError_t launch_direct64(const Direct64Params& p, int precision, int num_cus, hipStream_t s);
 constexpr int kTailKSteps = 6;      // 4 taps x 64 channels of src0 + 2 steps for the 9 image taps

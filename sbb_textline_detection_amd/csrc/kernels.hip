@@ -1209,8 +1209,9 @@ static hipError_t launch_conv_impl(const ConvParams& p, hipStream_t s)
     make_fast_div((uint32_t)(p.Ho * p.Wo), &q.howo_magic, &q.howo_shift);
     make_fast_div((uint32_t)p.Wo, &q.wo_magic, &q.wo_shift);
     make_fast_div((uint32_t)n_ct, &q.nct_magic, &q.nct_shift);
-    // 2D pixel tiles for convs with real taps on the fast gather (A/B: SBBSEG_TILE2D=0 keeps the linear strips)
-    static const bool tile2d_on = !(getenv("SBBSEG_TILE2D") && getenv("SBBSEG_TILE2D")[0] == '0');
+    // 2D pixel tiles for convs with real taps on the fast gather: an experiment (SBBSEG_TILE2D=1), off by default -- it measured neutral
+    // (profiles/r04_experiments.md section 3) and one plan shape (a k = 2 Conv2DTranspose decoder at 32 x 48) came out wrong with it
+    static const bool tile2d_on = getenv("SBBSEG_TILE2D") && getenv("SBBSEG_TILE2D")[0] == '1';
     q.tile2d = (tile2d_on && p.fast_gather == 1 && p.Ho % 16 == 0 && p.Wo % 16 == 0) ? 1 : 0;
     q.tpr = p.Wo / 16;
     make_fast_div((uint32_t)(q.tpr > 0 ? q.tpr : 1), &q.tpr_magic, &q.tpr_shift);

@@ -219,15 +219,17 @@ def test_fused_x3_stem_pool_matches_the_two_launches(hw, nb):
     model.release()
 
 
+@pytest.mark.parametrize("precision", ["f16x3", "f16"])
 @pytest.mark.parametrize("hw,nb", [((64, 96), 3), ((224, 256), 5), ((448, 448), 9)])
-def test_dec_halo_x3_matches_the_generic_kernel(hw, nb):
-    """Split mode: the decoder conv at full / 2 resolution (four parity classes of conv3x3([up2(128 ch), skip 64 ch]) -> 64 ch) runs
+def test_dec_halo_x3_matches_the_generic_kernel(hw, nb, precision):
+    """Split mode (and, dec_halo_f16.hip, the plain fp16 mode: 17 K-steps of two k-halves, both halos double-buffered, pair-row skip
+    layout): the decoder conv at full / 2 resolution (four parity classes of conv3x3([up2(128 ch), skip 64 ch]) -> 64 ch) runs
     dec_halo_x3 (csrc/dec_halo_x3.hip: 16 x 16 output tiles, source halos resident in LDS, weights streamed as A fragments, every
     vector load counted by hand).  Against conv_igemm_mfma's grouped launch (conv variant bit 23) every tensor of the plan must be the
     same bits: same K-steps in the same order, same three MFMAs per product, same epilogue.  Run three times: the hand-placed waits
     (vmcnt counts that include the halo DMA bursts and the epilogue's stores) must not race."""
     h, wd = hw
-    cfg, w, g, model = make_model(2, h, wd, seed=8, precision="f16x3", max_batch=nb + 2, calib_hw=min(160, max(h, wd)))
+    cfg, w, g, model = make_model(2, h, wd, seed=8, precision=precision, max_batch=nb + 2, calib_hw=min(160, max(h, wd)))
     x = (patches_from_page(h, wd, nb, seed=28) / 255.0).astype(np.float32)
 
     def read_all():
@@ -250,7 +252,10 @@ def test_dec_halo_x3_matches_the_generic_kernel(hw, nb):
     for _ in range(3):
         assert np.array_equal(model.predict(x), got_halo)
     ref = kf.forward(g, w, x[:2])
-    assert float(np.abs(got_halo[:2] - ref).max()) < TOL_SOFTMAX["f16x3"] and exact_label_check(ref, got_halo[:2])[1] == 0
+    if precision == "f16x3":
+        assert float(np.abs(got_halo[:2] - ref).max()) < TOL_SOFTMAX["f16x3"] and exact_label_check(ref, got_halo[:2])[1] == 0
+    else:
+        assert float(np.abs(got_halo[:2] - ref).max()) < 0.2
     model.release()
 
 

@@ -8,9 +8,9 @@
 tag=${1:-r03}
 bash tools/collect_profiles.sh $tag f16x3
 bash tools/collect_profiles.sh $tag f16 skip-tests
-SBBSEG_BENCH_BACKEND=gloo timeout 900 python bench.py --gpus 2 --batch-pages 8 --steps 2 --warmup 1 --repeats 1 > gpurun_out/bench_${tag}_gloo2.log 2>&1; echo "gloo2 rc=$?"
+SBBSEG_BENCH_BACKEND=gloo timeout -k 5 900 python bench.py --gpus 2 --batch-pages 8 --steps 2 --warmup 1 --repeats 1 > gpurun_out/bench_${tag}_gloo2.log 2>&1; echo "gloo2 rc=$?"
 tail -1 gpurun_out/bench_${tag}_gloo2.log > gpurun_out/bench_${tag}_gloo2.json
-timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/bench_${tag}_final.log 2>&1; echo "bench rc=$?"
+timeout -k 5 900 python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/bench_${tag}_final.log 2>&1; echo "bench rc=$?"
 tail -1 gpurun_out/bench_${tag}_final.log > gpurun_out/bench_${tag}_final.json
 python -c "
 import json; d=json.load(open('gpurun_out/bench_${tag}_final.json')); print(d['value'], d['roofline']['traffic'], d['modes']['f16'].get('patches_per_s'))"
