@@ -122,6 +122,10 @@ struct ConvOp {
     uint16_t* d_halo_wfrag = nullptr;     // split mode, the 224 x 224 decoder conv: the four classes' weights as MFMA A fragments (dec_halo_x3.hip)
     int* d_halo_taps = nullptr;           //   ... and their taps in K-step order (sbbseg_finalize)
     uint16_t* d_d64_wfrag = nullptr;      // non-null: 3x3 s1 64->64 conv, runs conv3x3_c64_direct
+    int fused_reduce = -1;                // split mode: index of the NEXT block's first 1x1 conv, computed by this (expand) conv's launch too
+                                          // (expand_reduce_x3.hip; sbbseg_finalize), or -1
+    uint16_t *d_er_w3 = nullptr, *d_er_w1 = nullptr;      //   ... the two convs' packed rows as MFMA A fragments
+    bool fused_into_expand = false;       // split mode: this op's output is written by the launch of the op before it; it launches nothing
     std::vector<float> h_w[2];            // host copy of a small 1x1 conv's weights ([cin][cout] per source): bottleneck fusion
                                           // (sbbseg_finalize) repacks them as MFMA A fragments
     bool fg_ok = true;                    // every K-step (of every class) regular: the fast gather of conv_igemm_mfma applies
@@ -255,6 +259,7 @@ struct sbbseg_ctx {
     bool unfuse_blocks = false;  // A/B: run a fused bottleneck block as its three convs (conv variant bit 18)
     bool unfuse_stem_pool = false;     // A/B: stem and max-pool as two launches (conv variant bit 22)
     bool no_dec_halo = false;          // A/B: the 224 x 224 decoder conv on the generic kernel (conv variant bit 23)
+    bool no_expand_reduce = false;     // A/B: expand + next reduce 1x1 convs as two launches (conv variant bit 24)
     bool plain_gather = false;   // A/B: per-load address arithmetic instead of the fast gather (conv variant bit 17)
     int contig_max_k = 0;        // short-K layers up to this K walk their tiles in per-block contiguous runs (tile map 2)
     int fused_heads = 0;
@@ -386,6 +391,7 @@ int launch_op(sbbseg_ctx* c, Op& op, int n, uint8_t* d_labels, float* d_probs)
             else HIPCHK(launch_bottleneck(bp, c->precision, c->num_cus, c->stream));
         } else if (op.type == kConv) {
             const ConvOp& co = op.conv;
+            if (co.fused_into_expand && !c->no_expand_reduce && !(c->conv_variant & 3)) return 0;      // written by the expand conv's launch (expand_reduce_x3)
             ConvParams p;
             memset(&p, 0, sizeof(p));
             p.n_src = co.d.n_src;
@@ -462,6 +468,16 @@ int launch_op(sbbseg_ctx* c, Op& op, int n, uint8_t* d_labels, float* d_probs)
                 dp.scale = co.d_scale; dp.shift = co.d_shift; dp.relu = co.d.relu; dp.out = c->tensors[co.d.out_tensor].data();
                 dp.wmul = co.wmul_cls[0];
                 HIPCHK(launch_direct64(dp, c->precision, c->num_cus, c->stream));
+            } else if (co.fused_reduce >= 0 && !c->no_expand_reduce && !(c->conv_variant & 3)) {
+                const ConvOp& ro = c->ops[co.fused_reduce].conv;
+                ExpRedParams ep;
+                ep.b = c->tensors[co.d.src[0].tensor].buf; ep.x = c->tensors[co.d.residual_tensor].buf;
+                ep.y = c->tensors[co.d.out_tensor].buf; ep.a2 = c->tensors[ro.d.out_tensor].buf;
+                ep.M = n * co.Ho * co.Wo; ep.C = co.d.src[0].channels;
+                ep.w3frag = co.d_er_w3; ep.w1frag = co.d_er_w1;
+                ep.s3 = co.d_scale; ep.h3 = co.d_shift; ep.s1 = ro.d_scale; ep.h1 = ro.d_shift;
+                ep.wmul3 = co.wmul_cls[0]; ep.wmul1 = ro.wmul_cls[0];
+                HIPCHK(launch_expand_reduce_x3(ep, c->num_cus, c->stream));
             } else if (co.d_halo_wfrag && !c->no_dec_halo && !(c->conv_variant & 3)) {
                 const Tensor& s0 = c->tensors[co.d.src[0].tensor];
                 DecHaloParams hp;
@@ -811,6 +827,7 @@ int sbbseg_destroy(sbbseg_ctx* c)
         (void)hipFree(op.conv.d_rscale); (void)hipFree(op.conv.d_rshift);
         (void)hipFree(op.conv.d_head_w); (void)hipFree(op.conv.d_head_scale); (void)hipFree(op.conv.d_head_shift); (void)hipFree(op.conv.d_stem_wfrag); (void)hipFree(op.conv.d_d64_wfrag);
         (void)hipFree(op.conv.d_halo_wfrag); (void)hipFree(op.conv.d_halo_taps);
+        (void)hipFree(op.conv.d_er_w3); (void)hipFree(op.conv.d_er_w1);
         for (int q = 1; q < 4; ++q) { (void)hipFree(op.conv.d_w_cls[q]); (void)hipFree(op.conv.d_kstep_cls[q]); (void)hipFree(op.conv.d_ktab_cls[q]); }
         (void)hipFree(op.head.d_w); (void)hipFree(op.head.d_scale); (void)hipFree(op.head.d_shift);
         (void)hipFree(op.pool.d_pre_scale); (void)hipFree(op.pool.d_pre_shift);
@@ -1718,6 +1735,68 @@ int sbbseg_finalize(sbbseg_ctx* c, int max_batch)
                             }
             }
             if (upload(c, &co.d_halo_wfrag, frag.data(), frag.size()) || upload(c, &co.d_halo_taps, taps.data(), taps.size())) return 1;
+        }
+    }
+    // split mode, encoder stages 3 / 4: an identity block's last 1x1 conv (C -> 4C, + residual, ReLU) directly followed by the next block's
+    // first 1x1 conv (4C -> C, stride 1, ReLU) -> one launch writes both outputs (expand_reduce_x3.hip: y is contracted from LDS instead
+    // of being read back).  Both matrices are read back and re-laid as MFMA A fragments.  SBBSEG_EXPAND_REDUCE=0 keeps two launches.
+    {
+        const char* env = getenv("SBBSEG_EXPAND_REDUCE");
+        auto pointwise = [&](const ConvOp& co, int cin, int cout) -> bool {
+            const sbbseg_conv_desc& d = co.d;
+            if (co.n_cls != 1 || d.n_src != 1 || d.cout != cout || d.src[0].channels != cin || d.src[0].kh != 1 || d.src[0].kw != 1 ||
+                d.src[0].stride_y != 1 || d.src[0].stride_x != 1 || d.src[0].pad_top || d.src[0].pad_left || d.src[0].up_shift || d.src[0].off_y ||
+                d.src[0].off_x || !d.relu || d.raw_out_tensor >= 0 || d.head_classes > 0 || d.out_tensor < 0 || d.out_stride_y != 1 || d.out_stride_x != 1 ||
+                d.out_off_y || d.out_off_x || co.d_stem_wfrag || co.d_d64_wfrag || co.d_halo_wfrag || co.total_ksteps != cin / 32 ||
+                co.Ktot != cin * 2 || co.cout_pad < cout || (int)co.h_ksteps_cls[0].size() != cin / 32)
+                return false;
+            const Tensor& t = c->tensors[d.src[0].tensor];
+            if (t.C != cin || t.is_input_form || t.H != d.out_h || t.W != d.out_w) return false;
+            for (int k = 0; k < cin / 32; ++k) {
+                const KStepRec& r = co.h_ksteps_cls[0][k];
+                if (r.irregular || r.dy || r.dx || r.coff != k * 128) return false;     // K-step k = channel group k of the stored pixel
+            }
+            return true;
+        };
+        for (size_t i = 0; c->precision == kF16X3 && !(env && env[0] == '0') && i + 1 < c->ops.size(); ++i) {
+            if (c->ops[i].type != kConv || c->ops[i + 1].type != kConv) continue;
+            ConvOp& e = c->ops[i].conv;
+            ConvOp& r = c->ops[i + 1].conv;
+            const int C = e.d.src[0].channels;
+            if ((C != 128 && C != 256) || !pointwise(e, C, 4 * C) || !pointwise(r, 4 * C, C)) continue;
+            if (e.d.residual_tensor < 0 || r.d.residual_tensor >= 0 || r.d.src[0].tensor != e.d.out_tensor || e.fused_into_expand) continue;
+            const Tensor &tx = c->tensors[e.d.residual_tensor], &ty = c->tensors[e.d.out_tensor], &ta = c->tensors[r.d.out_tensor];
+            if (tx.C != 4 * C || tx.H != ty.H || tx.W != ty.W || ty.C != 4 * C || ty.H != e.d.out_h || ty.W != e.d.out_w || ta.C != C ||
+                ta.H != ty.H || ta.W != ty.W || tx.is_input_form)
+                continue;
+            alloc_check();
+            const int KS1 = C / 32, NCH = C / 64, MI2 = C / 128;
+            std::vector<uint16_t> m3((size_t)e.cout_pad * e.Ktot), m1((size_t)r.cout_pad * r.Ktot);
+            HIPCHK(hipMemcpy(m3.data(), e.d_w, m3.size() * sizeof(uint16_t), hipMemcpyDeviceToHost));
+            HIPCHK(hipMemcpy(m1.data(), r.d_w, m1.size() * sizeof(uint16_t), hipMemcpyDeviceToHost));
+            std::vector<uint16_t> f3((size_t)NCH * KS1 * 8 * 2 * 2 * 64 * 8), f1((size_t)NCH * 8 * 8 * MI2 * 2 * 64 * 8);
+            for (int j = 0; j < NCH; ++j)
+                for (int w = 0; w < 8; ++w)
+                    for (int lo = 0; lo < 2; ++lo)
+                        for (int l = 0; l < 64; ++l) {
+                            for (int k = 0; k < KS1; ++k)
+                                for (int m = 0; m < 2; ++m) {
+                                    const int row = (j * 16 + w * 2 + m) * 16 + (l & 15);
+                                    const uint16_t* src = &m3[(size_t)row * e.Ktot + (size_t)k * 64 + lo * 32 + (l >> 4) * 8];
+                                    uint16_t* dst = &f3[((((((size_t)j * KS1 + k) * 8 + w) * 2 + m) * 2 + lo) * 64 + l) * 8];
+                                    for (int q = 0; q < 8; ++q) dst[q] = src[q];
+                                }
+                            for (int k = 0; k < 8; ++k)
+                                for (int m = 0; m < MI2; ++m) {
+                                    const int row = (w * MI2 + m) * 16 + (l & 15);
+                                    const uint16_t* src = &m1[(size_t)row * r.Ktot + (size_t)(j * 8 + k) * 64 + lo * 32 + (l >> 4) * 8];
+                                    uint16_t* dst = &f1[((((((size_t)j * 8 + k) * 8 + w) * MI2 + m) * 2 + lo) * 64 + l) * 8];
+                                    for (int q = 0; q < 8; ++q) dst[q] = src[q];
+                                }
+                        }
+            if (upload(c, &e.d_er_w3, f3.data(), f3.size()) || upload(c, &e.d_er_w1, f1.data(), f1.size())) return 1;
+            e.fused_reduce = (int)(i + 1);
+            r.fused_into_expand = true;
         }
     }
     // split mode: the stem (dedicated kernel, raw output only) directly followed by the 3x3 / stride-2 max-pool of that tensor with an
@@ -2805,7 +2884,7 @@ int sbbseg_debug_counter(sbbseg_ctx* c, int which, int64_t* value)
 int sbbseg_debug_set_conv_variant(sbbseg_ctx* c, int variant)
 {
     API_BEGIN
-    REQUIRE(c && variant >= 0 && variant <= 0xffffff, "variant: bits 0-1 = 0 auto | 1 4-wave/2-stage | 2 8-wave/3-stage; bit 2 = one block per tile (non-persistent); bit 3 = no XCD-grouped tile walk; bit 4 = half-K-step stages; bit 5 = XCD-grouped walk on single-class layers; bit 6 = drain epilogue stores; bit 7 = half-line epilogue stores; bits 8-15 = contiguous-run K limit / 64; bit 16 = 8-phase schedule on the 256x256 tile; bit 17 = plain gather everywhere; bit 18 = fused bottleneck blocks run as their three convs; bit 19 = XCD-contiguous walk for grouped launches; bit 20 = one-group form of the fused block kernel; bit 21 = extract_page ranks contours on the host always; bit 22 = stem and max-pool as two launches; bit 23 = the 224 x 224 decoder conv on the generic kernel");
+    REQUIRE(c && variant >= 0 && variant <= 0x1ffffff, "variant: bits 0-1 = 0 auto | 1 4-wave/2-stage | 2 8-wave/3-stage; bit 2 = one block per tile (non-persistent); bit 3 = no XCD-grouped tile walk; bit 4 = half-K-step stages; bit 5 = XCD-grouped walk on single-class layers; bit 6 = drain epilogue stores; bit 7 = half-line epilogue stores; bits 8-15 = contiguous-run K limit / 64; bit 16 = 8-phase schedule on the 256x256 tile; bit 17 = plain gather everywhere; bit 18 = fused bottleneck blocks run as their three convs; bit 19 = XCD-contiguous walk for grouped launches; bit 20 = one-group form of the fused block kernel; bit 21 = extract_page ranks contours on the host always; bit 22 = stem and max-pool as two launches; bit 23 = the 224 x 224 decoder conv on the generic kernel; bit 24 = expand + next reduce 1x1 convs as two launches");
     c->conv_variant = variant & 0xff;
     c->ph8 = (variant >> 16) & 1;
     c->plain_gather = (variant >> 17) & 1;
@@ -2815,6 +2894,7 @@ int sbbseg_debug_set_conv_variant(sbbseg_ctx* c, int variant)
     c->force_host_contours = (variant >> 21) & 1;
     c->unfuse_stem_pool = (variant >> 22) & 1;
     c->no_dec_halo = (variant >> 23) & 1;
+    c->no_expand_reduce = (variant >> 24) & 1;
     if ((variant >> 8) & 0xff) c->contig_max_k = ((variant >> 8) & 0xff) * 64;
     return 0;
     API_END

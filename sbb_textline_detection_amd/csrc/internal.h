@@ -209,6 +209,22 @@ struct DecHaloParams {
     void* out;                // data pointer [n][2 PH][2 PW][64] split layout
 };
 
+// Split mode, stages 3 / 4 of the encoder: the last 1x1 conv of an identity bottleneck block (C -> 4C, BN, + residual, ReLU) and the first
+// 1x1 conv of the next block (4C -> C, BN, ReLU) in one launch (expand_reduce_x3.hip): y is written once and contracted from LDS.
+struct ExpRedParams {
+    const char* b;            // buffer start (zero header), [M][C] split layout: the expand's input
+    const char* x;            // buffer start (zero header), [M][4C]: the residual
+    char* y;                  // buffer start (zero header), [M][4C]: the expand's output
+    char* a2;                 // buffer start (zero header), [M][C]: the reduce's output
+    int M;                    // pixels (patches x H x W)
+    int C;                    // 128 | 256
+    const void* w3frag;       // [4C / 256 chunks][C / 32 K-steps][8 waves][2 row blocks][hi | lo][64 lanes] x 16 B: A fragments of the expand's packed rows
+    const void* w1frag;       // [4C / 256 chunks][8 K-steps][8 waves][C / 128 row blocks][hi | lo][64 lanes] x 16 B: ... of the reduce's
+    const float *s3, *h3;     // [4C] scale / shift of the expand
+    const float *s1, *h1;     // [C]  ... of the reduce
+    float wmul3, wmul1;       // 2^-s of the power-of-two weight pre-scales
+};
+
 struct HeadParams {
     const void* src;          // [M][cin] activations (data pointer)
     int cin;                  // <= 64, multiple of 8
@@ -257,7 +273,8 @@ hipError_t launch_head(const HeadParams& p, int precision, hipStream_t s);
 hipError_t launch_tail(const TailParams& p, int precision, int num_cus, hipStream_t s);
 hipError_t launch_stem(const StemParams& p, int precision, int num_cus, hipStream_t s);
 hipError_t launch_dec_halo_x3(const DecHaloParams& p, int num_cus, hipStream_t s);     // split mode: dec4 with LDS-resident halos (dec_halo_x3.hip)
-hipError_t launch_dec_halo_f16(const DecHaloParams& p, int num_cus, hipStream_t s);    // ... plain fp16 mode (dec_halo_f16.hip)
+hipError_t launch_dec_halo_f16(const DecHaloParams& p, int num_cus, hipStream_t s);
+hipError_t launch_expand_reduce_x3(const ExpRedParams& p, int num_cus, hipStream_t s);   // split mode: expand + next reduce 1x1 (expand_reduce_x3.hip)    // ... plain fp16 mode (dec_halo_f16.hip)
 hipError_t launch_stem_pool_x3(const StemParams& p, int num_cus, hipStream_t s);      // split mode: stem + max-pool in one launch (stem_pool_x3.hip)
 hipError_t launch_direct64(const Direct64Params& p, int precision, int num_cus, hipStream_t s);
 constexpr int kTailKSteps = 6;      // 4 taps x 64 channels of src0 + 2 steps for the 9 image taps

@@ -67,6 +67,19 @@ __device__ inline float f16_hi(uint32_t v) { return (float)__builtin_bit_cast(f1
 template <bool F16> __device__ inline uint32_t pack2(float a, float b) { return F16 ? pack_f16x2(a, b) : pack_bf16x2(a, b); }
 template <bool F16> __device__ inline float unpack_lo(uint32_t v) { return F16 ? f16_lo(v) : bf16_lo(v); }
 template <bool F16> __device__ inline float unpack_hi(uint32_t v) { return F16 ? f16_hi(v) : bf16_hi(v); }
+// One LDS-DMA wave-instruction the compiler does not see (lane l's 16 bytes at gsrc(l) land at lds_dst + 16 l; M0 is written in the
+// statement that reads it).  After the BUILTIN the compiler waits vmcnt(0) in front of the next LDS access it cannot tell apart from the
+// DMA's destination -- in stem_conv_pairs that was the epilogue-constant read in the middle of a tile, i.e. the NEXT tile's halo, just
+// requested, had to land there (0.260 -> 0.252 ms per 140 patches; the same change measured nothing on dec_tail_fused, two blocks per CU,
+// which keeps the builtin).  A kernel that uses this waits for its DMA by hand (counted s_waitcnt at the top of a tile).
+__device__ __attribute__((always_inline)) inline void glds16_hidden(const void* gsrc, const char* lds_dst)
+{
+    const uint32_t dst = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(const LDS_AS char*)lds_dst);
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
+}
+
 template <bool F16> __device__ inline f32x4_t mfma16(bf16x8_t a, bf16x8_t b, f32x4_t c)
 {
     if constexpr (F16)
@@ -1966,7 +1979,7 @@ __global__ __launch_bounds__(256, 2) void stem_conv_pairs(const StemParams p)
             const int Y = 32 * ty + r, X = 16 * tx + cc;          // (granule 19 of a row is never read: whatever lies there)
             uint32_t off = (uint32_t)((n * p.PHt + Y) * p.PWt + X) * 16u + (uint32_t)kZeroHeaderBytes;
             off = r < kStemRows ? off : 0u;
-            __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(p.pairs + off), (LDS_AS void*)(lds + ii * 1024), 16, 0, 0);
+            glds16_hidden(p.pairs + off, lds + ii * 1024);
         }
     };
 

@@ -259,6 +259,39 @@ def test_dec_halo_x3_matches_the_generic_kernel(hw, nb, precision):
     model.release()
 
 
+@pytest.mark.parametrize("hw,nb", [((64, 96), 3), ((224, 256), 5), ((448, 448), 9), ((448, 448), 2)])
+def test_expand_reduce_x3_matches_the_two_launches(hw, nb):
+    """Split mode, encoder stages 3 / 4: an identity block's last 1x1 conv (+ residual, ReLU) and the next block's first 1x1 conv run as ONE
+    launch (csrc/expand_reduce_x3.hip: the 4C-channel tensor is written once and contracted from LDS, weights streamed, every vector-memory
+    operation counted by hand).  Against the two conv_igemm_mfma launches (conv variant bit 24) every tensor of the plan must be the same
+    bits.  64 x 96 patches give 3 x 96 / 3 x 24 pixels per launch: ragged last tiles (loads read zeros, stores are dropped past the end).
+    Run three times: the hand-placed waits must not race."""
+    h, wd = hw
+    cfg, w, g, model = make_model(2, h, wd, seed=9, precision="f16x3", max_batch=nb + 2, calib_hw=min(160, max(h, wd)))
+    x = (patches_from_page(h, wd, nb, seed=29) / 255.0).astype(np.float32)
+
+    def read_all():
+        out = {}
+        for name, tid in model.plan.layer_tensor.items():
+            t = model.plan.tensors[tid]
+            out[name] = model.ctx.debug_read_tensor(tid, nb, (t.H, t.W, t.C))
+        return out
+    got_fused = model.predict(x)
+    t_fused = read_all()
+    model.ctx.set_conv_variant(1 << 24)
+    got_two = model.predict(x)
+    t_two = read_all()
+    model.ctx.set_conv_variant(0)
+    for name in t_fused:
+        assert np.array_equal(t_fused[name], t_two[name]), (name, float(np.abs(t_fused[name] - t_two[name]).max()))
+    assert np.array_equal(got_fused, got_two)
+    for _ in range(3):
+        assert np.array_equal(model.predict(x), got_fused)
+    ref = kf.forward(g, w, x[:2])
+    assert float(np.abs(got_fused[:2] - ref).max()) < TOL_SOFTMAX["f16x3"] and exact_label_check(ref, got_fused[:2])[1] == 0
+    model.release()
+
+
 def test_conv_tile_families_agree():
     """4-wave/2-stage and 8-wave/3-stage conv tiles, persistent or one block per tile, compute the same sums."""
     cfg, w, g, model = make_model(2, 224, 224, seed=3, precision="f16", max_batch=6)

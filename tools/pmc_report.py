@@ -19,7 +19,7 @@ def csrc_sha():
     import hashlib
     h = hashlib.sha1()
     base = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "sbb_textline_detection_amd", "csrc")
-    for name in ("kernels.hip", "block_x3.hip", "stem_pool_x3.hip", "dec_halo_x3.hip", "api.hip", "internal.h"):
+    for name in ("kernels.hip", "block_x3.hip", "stem_pool_x3.hip", "dec_halo_x3.hip", "dec_halo_f16.hip", "expand_reduce_x3.hip", "api.hip", "internal.h"):
         with open(os.path.join(base, name), "rb") as f:
             h.update(f.read())
     return h.hexdigest()[:12]
@@ -42,7 +42,7 @@ fe, meta_f = load("fetch")
 wr, meta_w = load("write")
 # plan kernels only (conv / maxpool / head), in dispatch order; one chunk = 61 ops
 def plan_ids(meta):
-    return [d for d in sorted(meta) if any(s in meta[d][0] for s in ("conv_igemm", "maxpool", "head_kernel", "dec_tail", "stem_conv", "stem_pool", "dec_halo", "conv3x3_c64_direct", "bottleneck_fused", "block_x3"))]
+    return [d for d in sorted(meta) if any(s in meta[d][0] for s in ("conv_igemm", "maxpool", "head_kernel", "dec_tail", "stem_conv", "stem_pool", "dec_halo", "expand_reduce", "conv3x3_c64_direct", "bottleneck_fused", "block_x3"))]
 ids, idf, idw = plan_ids(meta), plan_ids(meta_f), plan_ids(meta_w)
 names = None
 if ops_json:

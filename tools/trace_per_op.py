@@ -6,7 +6,7 @@ import csv
 import json
 import sys
 
-PLAN = ("conv_igemm", "maxpool", "head_kernel", "dec_tail", "stem_conv", "stem_pool", "dec_halo", "conv3x3_c64_direct", "bottleneck", "block_x3")
+PLAN = ("conv_igemm", "maxpool", "head_kernel", "dec_tail", "stem_conv", "stem_pool", "dec_halo", "expand_reduce", "conv3x3_c64_direct", "bottleneck", "block_x3")
 rows = []
 with open(sys.argv[1]) as f:
     for r in csv.DictReader(f):
