@@ -477,6 +477,7 @@ int launch_op(sbbseg_ctx* c, Op& op, int n, uint8_t* d_labels, float* d_probs)
                 ep.w3frag = co.d_er_w3; ep.w1frag = co.d_er_w1;
                 ep.s3 = co.d_scale; ep.h3 = co.d_shift; ep.s1 = ro.d_scale; ep.h1 = ro.d_shift;
                 ep.wmul3 = co.wmul_cls[0]; ep.wmul1 = ro.wmul_cls[0];
+                { static const int er_dbg = getenv("SBBSEG_ER_DBG") ? atoi(getenv("SBBSEG_ER_DBG")) : 0; ep.dbg = er_dbg; }
                 HIPCHK(launch_expand_reduce_x3(ep, c->num_cus, c->stream));
             } else if (co.d_halo_wfrag && !c->no_dec_halo && !(c->conv_variant & 3)) {
                 const Tensor& s0 = c->tensors[co.d.src[0].tensor];

@@ -171,14 +171,15 @@ __global__ __launch_bounds__(512, 2) void expand_reduce_x3(const ExpRedParams p)
     u4_t xh[4], xl[4];                                          // the residual of the chunk ahead: [pixel block]
     auto issue_w = [&](int u, u4_t (&d)[4]) __attribute__((always_inline)) {             // u in [0, STEPS)
         const int j = u / (KS1 + 8), r = u % (KS1 + 8);
-        if (r < KS1) wload4(d[0], d[1], d[2], d[3], wlane + (uint32_t)((j * KS1 + r) * 8 * 4096), w3rsrc);
-        else if constexpr (MI2 == 2) wload4(d[0], d[1], d[2], d[3], wlane + (uint32_t)((j * 8 + r - KS1) * 8 * 4096), w1rsrc);
-        else wload2(d[0], d[1], wlane + (uint32_t)((j * 8 + r - KS1) * 8 * 2048), w1rsrc);
+        const uint32_t wm = (p.dbg & 1) ? 0u : 1u;                 // (timing probe: every request reads the first step's fragments)
+        if (r < KS1) wload4(d[0], d[1], d[2], d[3], wlane + wm * (uint32_t)((j * KS1 + r) * 8 * 4096), w3rsrc);
+        else if constexpr (MI2 == 2) wload4(d[0], d[1], d[2], d[3], wlane + wm * (uint32_t)((j * 8 + r - KS1) * 8 * 4096), w1rsrc);
+        else wload2(d[0], d[1], wlane + wm * (uint32_t)((j * 8 + r - KS1) * 8 * 2048), w1rsrc);
     };
     auto issue_x = [&](int tile, int j) __attribute__((always_inline)) {                  // 8 loads
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni)
-            xload2(xh[ni], xl[ni], xlane + (uint32_t)(tile * 64 + ni * 16) * (uint32_t)PY + (uint32_t)(j * 1024), xrsrc);
+            xload2(xh[ni], xl[ni], ((p.dbg & 4) ? 0xf0000000u : 0u) + xlane + (uint32_t)(tile * 64 + ni * 16) * (uint32_t)PY + (uint32_t)(j * 1024), xrsrc);
     };
     auto load_frags = [&](const char* base, int row_bytes, int slots, int k, h8_t (&dh)[4], h8_t (&dl)[4]) __attribute__((always_inline)) {
         const int sh = (rot + 8 * k) & (slots - 1), sl = (rot + 8 * k + 4) & (slots - 1);
@@ -301,7 +302,7 @@ __global__ __launch_bounds__(512, 2) void expand_reduce_x3(const ExpRedParams p)
                     for (int q = 0; q < 8; ++q) y[q] = fmaxf(__fadd_rn(y[q], __fadd_rn((float)rh[q], (float)rl[q])), 0.f);      // (= add_split8 + ReLU, kernels.hip)
                     h8_t vh, vl;
                     split_n<8>(y, vh, vl);
-                    const uint32_t off = xlane + (uint32_t)(tile * 64 + ni * 16) * (uint32_t)PY + (uint32_t)(j * 1024);
+                    const uint32_t off = ((p.dbg & 2) ? 0xf0000000u : 0u) + xlane + (uint32_t)(tile * 64 + ni * 16) * (uint32_t)PY + (uint32_t)(j * 1024);
                     asm volatile("buffer_store_dwordx4 %1, %0, %3, 0 offen\n\tbuffer_store_dwordx4 %2, %0, %3, 0 offen offset:64"
                                  :: "v"(off), "v"(vh), "v"(vl), "s"(yrsrc) : "memory");
                     char* row = lds_y + (ni * 16 + frv) * 1024;

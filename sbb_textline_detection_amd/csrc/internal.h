@@ -223,6 +223,7 @@ struct ExpRedParams {
     const float *s3, *h3;     // [4C] scale / shift of the expand
     const float *s1, *h1;     // [C]  ... of the reduce
     float wmul3, wmul1;       // 2^-s of the power-of-two weight pre-scales
+    int dbg;                  // timing probes (SBBSEG_ER_DBG; results are WRONG with any bit set): 1 = one weight block, 2 = y stores dropped, 4 = x reads dropped
 };
 
 struct HeadParams {
