@@ -329,7 +329,8 @@ int sbbseg_debug_read_tensor(sbbseg_ctx* c, int tensor_id, int n, float* out, si
  * bit 17 = plain gather (per-load address arithmetic) instead of the fast gather on every layer;
  * bit 18 = fused bottleneck blocks run as the three convs they replace; bit 19 = grouped (parity-class) launches walk
  * XCD-contiguous tile ranges; bit 20 = fused bottleneck blocks run bottleneck_fused (one group of four waves per tile)
- * instead of bottleneck_fused_pq (producer / consumer wave groups); bit 21 = sbbseg_page_box_dev always ranks on the host;
+ * instead of bottleneck_fused_pq (producer / consumer wave groups) -- split mode: block_x3 prefetches the next tile's inner x in
+ * place (inside phase C) instead of into its own registers a tile ahead; bit 21 = sbbseg_page_box_dev always ranks on the host;
  * bit 22 = split mode: stem and max-pool as two launches (stem_conv_pairs_x3 + maxpool_kernel) instead of stem_pool_x3;
  * bit 23 = the 224 x 224 decoder conv on conv_igemm_mfma instead of dec_halo_x3 / dec_halo_f16 (LDS-resident halos);
  * bit 24 = split mode: an identity block's last 1x1 conv and the next block's first 1x1 conv (encoder stages 3 / 4) as two

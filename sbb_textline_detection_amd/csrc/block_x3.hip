@@ -348,8 +348,16 @@ __global__ __launch_bounds__(256, 1) void block_x3(const BlockParams p)
             const uint32_t ooff = live ? (uint32_t)((oy * p.W + ox) * 1024 + fg * 16) : 0x80000000u;
             // channel group s3 + 1's weight fragments and constants are requested before group s3's MFMAs and epilogue
             h8_t w3h[2][KC][2], w3l[2][KC][2];
-            float4 kc[2][4];                                    // scale[c0..c0+7], shift[c0..c0+7]
-            auto load_c = [&](int s3, h8_t (&dh)[KC][2], h8_t (&dl)[KC][2], float4 (&dk)[4]) __attribute__((always_inline)) {
+            // (the constants are requested a group ahead too, except in the FULL form: it has no 16 registers left for the second set --
+            // there they are requested in front of the group's own MFMAs)
+            constexpr int KCS = FULL && !PROJ ? 1 : 2;
+            float4 kc[KCS][4];                                  // scale[c0..c0+7], shift[c0..c0+7]
+            auto load_k = [&](int s3, float4 (&dk)[4]) __attribute__((always_inline)) {
+                const int c0 = s3 * 32 + fg * 8;
+                dk[0] = *(const float4*)(cst + 256 + c0); dk[1] = *(const float4*)(cst + 256 + c0 + 4);
+                dk[2] = *(const float4*)(cst + 512 + c0); dk[3] = *(const float4*)(cst + 512 + c0 + 4);
+            };
+            auto load_c = [&](int s3, h8_t (&dh)[KC][2], h8_t (&dl)[KC][2]) __attribute__((always_inline)) {
 #pragma unroll
                 for (int kk = 0; kk < KC; ++kk)
 #pragma unroll
@@ -357,14 +365,16 @@ __global__ __launch_bounds__(256, 1) void block_x3(const BlockParams p)
                         dh[kk][m] = *(const h8_t*)(lds_w3 + ((kk * 16 + 2 * s3 + m) * 2 + 0) * 1024 + lane * 16);
                         dl[kk][m] = *(const h8_t*)(lds_w3 + ((kk * 16 + 2 * s3 + m) * 2 + 1) * 1024 + lane * 16);
                     }
-                const int c0 = s3 * 32 + fg * 8;
-                dk[0] = *(const float4*)(cst + 256 + c0); dk[1] = *(const float4*)(cst + 256 + c0 + 4);
-                dk[2] = *(const float4*)(cst + 512 + c0); dk[3] = *(const float4*)(cst + 512 + c0 + 4);
             };
-            load_c(0, w3h[0], w3l[0], kc[0]);
+            load_c(0, w3h[0], w3l[0]);
+            if constexpr (KCS == 2) load_k(0, kc[0]);
 #pragma unroll
             for (int s3 = 0; s3 < 8; ++s3) {
-                if (s3 + 1 < 8) load_c(s3 + 1, w3h[(s3 + 1) & 1], w3l[(s3 + 1) & 1], kc[(s3 + 1) & 1]);
+                if (s3 + 1 < 8) {
+                    load_c(s3 + 1, w3h[(s3 + 1) & 1], w3l[(s3 + 1) & 1]);
+                    if constexpr (KCS == 2) load_k(s3 + 1, kc[(s3 + 1) & 1]);
+                }
+                if constexpr (KCS == 1) load_k(s3, kc[0]);
                 f4_t acc[2] = {(f4_t){0.f, 0.f, 0.f, 0.f}, (f4_t){0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
                 for (int kk = 0; kk < KC; ++kk) {
@@ -379,8 +389,8 @@ __global__ __launch_bounds__(256, 1) void block_x3(const BlockParams p)
                     acc[0] = mma(wh[0], qh, acc[0]); acc[1] = mma(wh[1], qh, acc[1]);
                 }
                 float sc[8], sh[8], y[8];
-                *(float4*)&sc[0] = kc[s3 & 1][0]; *(float4*)&sc[4] = kc[s3 & 1][1];
-                *(float4*)&sh[0] = kc[s3 & 1][2]; *(float4*)&sh[4] = kc[s3 & 1][3];
+                *(float4*)&sc[0] = kc[s3 & (KCS - 1)][0]; *(float4*)&sc[4] = kc[s3 & (KCS - 1)][1];
+                *(float4*)&sh[0] = kc[s3 & (KCS - 1)][2]; *(float4*)&sh[4] = kc[s3 & (KCS - 1)][3];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     y[q] = __builtin_fmaf(acc[0][q], sc[q], sh[q]);
@@ -435,10 +445,11 @@ hipError_t launch_block_x3(const BlockParams& p, int num_cus, hipStream_t s)
         attr_done[dev & 63] = true;
     }
     if (p.proj) hipLaunchKernelGGL((block_x3<true, true>), dim3(grid), dim3(256), kBlockX3LdsBytes, s, p);
-    // identity blocks: the in-place x prefetch is the default (the software-pipelined phases need the 64 registers a full
-    // next-tile buffer would take: that form spills); conv variant bit 20 (pq cleared) selects the full buffer for A/B
-    else if (p.pq) hipLaunchKernelGGL((block_x3<false, false>), dim3(grid), dim3(256), kBlockX3LdsBytes, s, p);
-    else hipLaunchKernelGGL((block_x3<true, false>), dim3(grid), dim3(256), kBlockX3LdsBytes, s, p);
+    // identity blocks: the full next-tile buffer is the default since round 4 (its inner x is requested a whole tile ahead; with the
+    // constants of phase C single-buffered it fits 256 + 248 registers without scratch: 1.23 -> 1.18 ms per 140 patches); conv variant
+    // bit 20 (pq cleared) selects the in-place prefetch for A/B
+    else if (p.pq) hipLaunchKernelGGL((block_x3<true, false>), dim3(grid), dim3(256), kBlockX3LdsBytes, s, p);
+    else hipLaunchKernelGGL((block_x3<false, false>), dim3(grid), dim3(256), kBlockX3LdsBytes, s, p);
     return hipGetLastError();
 }
 
