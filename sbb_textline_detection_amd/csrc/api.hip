@@ -473,7 +473,7 @@ int launch_op(sbbseg_ctx* c, Op& op, int n, uint8_t* d_labels, float* d_probs)
                 ExpRedParams ep;
                 ep.b = c->tensors[co.d.src[0].tensor].buf; ep.x = c->tensors[co.d.residual_tensor].buf;
                 ep.y = c->tensors[co.d.out_tensor].buf; ep.a2 = c->tensors[ro.d.out_tensor].buf;
-                ep.M = n * co.Ho * co.Wo; ep.C = co.d.src[0].channels;
+                ep.M = n * co.Ho * co.Wo; ep.C = co.d.src[0].channels; ep.x3 = c->precision == kF16X3;
                 ep.w3frag = co.d_er_w3; ep.w1frag = co.d_er_w1;
                 ep.s3 = co.d_scale; ep.h3 = co.d_shift; ep.s1 = ro.d_scale; ep.h1 = ro.d_shift;
                 ep.wmul3 = co.wmul_cls[0]; ep.wmul1 = ro.wmul_cls[0];
@@ -1738,28 +1738,30 @@ int sbbseg_finalize(sbbseg_ctx* c, int max_batch)
             if (upload(c, &co.d_halo_wfrag, frag.data(), frag.size()) || upload(c, &co.d_halo_taps, taps.data(), taps.size())) return 1;
         }
     }
-    // split mode, encoder stages 3 / 4: an identity block's last 1x1 conv (C -> 4C, + residual, ReLU) directly followed by the next block's
+    // split and plain fp16 modes, encoder stages 3 / 4: an identity block's last 1x1 conv (C -> 4C, + residual, ReLU) directly followed by the next block's
     // first 1x1 conv (4C -> C, stride 1, ReLU) -> one launch writes both outputs (expand_reduce_x3.hip: y is contracted from LDS instead
     // of being read back).  Both matrices are read back and re-laid as MFMA A fragments.  SBBSEG_EXPAND_REDUCE=0 keeps two launches.
     {
         const char* env = getenv("SBBSEG_EXPAND_REDUCE");
+        const bool x3 = c->precision == kF16X3;
+        const int kch = x3 ? 32 : 64;                                  // channels per K-step (plain fp16: two k-halves in place of hi | lo)
         auto pointwise = [&](const ConvOp& co, int cin, int cout) -> bool {
             const sbbseg_conv_desc& d = co.d;
             if (co.n_cls != 1 || d.n_src != 1 || d.cout != cout || d.src[0].channels != cin || d.src[0].kh != 1 || d.src[0].kw != 1 ||
                 d.src[0].stride_y != 1 || d.src[0].stride_x != 1 || d.src[0].pad_top || d.src[0].pad_left || d.src[0].up_shift || d.src[0].off_y ||
                 d.src[0].off_x || !d.relu || d.raw_out_tensor >= 0 || d.head_classes > 0 || d.out_tensor < 0 || d.out_stride_y != 1 || d.out_stride_x != 1 ||
-                d.out_off_y || d.out_off_x || co.d_stem_wfrag || co.d_d64_wfrag || co.d_halo_wfrag || co.total_ksteps != cin / 32 ||
-                co.Ktot != cin * 2 || co.cout_pad < cout || (int)co.h_ksteps_cls[0].size() != cin / 32)
+                d.out_off_y || d.out_off_x || co.d_stem_wfrag || co.d_d64_wfrag || co.d_halo_wfrag || co.total_ksteps != cin / kch ||
+                co.Ktot != cin * (x3 ? 2 : 1) || co.cout_pad < cout || (int)co.h_ksteps_cls[0].size() != cin / kch)
                 return false;
             const Tensor& t = c->tensors[d.src[0].tensor];
             if (t.C != cin || t.is_input_form || t.H != d.out_h || t.W != d.out_w) return false;
-            for (int k = 0; k < cin / 32; ++k) {
+            for (int k = 0; k < cin / kch; ++k) {
                 const KStepRec& r = co.h_ksteps_cls[0][k];
                 if (r.irregular || r.dy || r.dx || r.coff != k * 128) return false;     // K-step k = channel group k of the stored pixel
             }
             return true;
         };
-        for (size_t i = 0; c->precision == kF16X3 && !(env && env[0] == '0') && i + 1 < c->ops.size(); ++i) {
+        for (size_t i = 0; (x3 || c->precision == kF16) && !(env && env[0] == '0') && i + 1 < c->ops.size(); ++i) {
             if (c->ops[i].type != kConv || c->ops[i + 1].type != kConv) continue;
             ConvOp& e = c->ops[i].conv;
             ConvOp& r = c->ops[i + 1].conv;
@@ -1771,11 +1773,11 @@ int sbbseg_finalize(sbbseg_ctx* c, int max_batch)
                 ta.H != ty.H || ta.W != ty.W || tx.is_input_form)
                 continue;
             alloc_check();
-            const int KS1 = C / 32, NCH = C / 64, MI2 = C / 128;
+            const int KS1 = C / kch, G2S = 256 / kch, NCH = C / 64, MI2 = C / 128;
             std::vector<uint16_t> m3((size_t)e.cout_pad * e.Ktot), m1((size_t)r.cout_pad * r.Ktot);
             HIPCHK(hipMemcpy(m3.data(), e.d_w, m3.size() * sizeof(uint16_t), hipMemcpyDeviceToHost));
             HIPCHK(hipMemcpy(m1.data(), r.d_w, m1.size() * sizeof(uint16_t), hipMemcpyDeviceToHost));
-            std::vector<uint16_t> f3((size_t)NCH * KS1 * 8 * 2 * 2 * 64 * 8), f1((size_t)NCH * 8 * 8 * MI2 * 2 * 64 * 8);
+            std::vector<uint16_t> f3((size_t)NCH * KS1 * 8 * 2 * 2 * 64 * 8), f1((size_t)NCH * G2S * 8 * MI2 * 2 * 64 * 8);
             for (int j = 0; j < NCH; ++j)
                 for (int w = 0; w < 8; ++w)
                     for (int lo = 0; lo < 2; ++lo)
@@ -1787,11 +1789,11 @@ int sbbseg_finalize(sbbseg_ctx* c, int max_batch)
                                     uint16_t* dst = &f3[((((((size_t)j * KS1 + k) * 8 + w) * 2 + m) * 2 + lo) * 64 + l) * 8];
                                     for (int q = 0; q < 8; ++q) dst[q] = src[q];
                                 }
-                            for (int k = 0; k < 8; ++k)
+                            for (int k = 0; k < G2S; ++k)
                                 for (int m = 0; m < MI2; ++m) {
                                     const int row = (w * MI2 + m) * 16 + (l & 15);
-                                    const uint16_t* src = &m1[(size_t)row * r.Ktot + (size_t)(j * 8 + k) * 64 + lo * 32 + (l >> 4) * 8];
-                                    uint16_t* dst = &f1[((((((size_t)j * 8 + k) * 8 + w) * MI2 + m) * 2 + lo) * 64 + l) * 8];
+                                    const uint16_t* src = &m1[(size_t)row * r.Ktot + (size_t)(j * G2S + k) * 64 + lo * 32 + (l >> 4) * 8];
+                                    uint16_t* dst = &f1[((((((size_t)j * G2S + k) * 8 + w) * MI2 + m) * 2 + lo) * 64 + l) * 8];
                                     for (int q = 0; q < 8; ++q) dst[q] = src[q];
                                 }
                         }

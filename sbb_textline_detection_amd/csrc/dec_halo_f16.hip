@@ -302,7 +302,7 @@ __global__ __launch_bounds__(512, 2) void dec_halo_f16(const DecHaloParams p)
                     u4_t r;
                     r[0] = pack_h2(y[0], y[1]); r[1] = pack_h2(y[2], y[3]); r[2] = pack_h2(y[4], y[5]); r[3] = pack_h2(y[6], y[7]);
                     uint16_t* dst = (uint16_t*)p.out + ((size_t)(n * H + oy) * W + ox) * 64 + c0;
-                    asm volatile("global_store_dwordx4 %0, %1, off" :: "v"(dst), "v"(r) : "memory");
+                    asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" :: "v"(dst), "v"(r) : "memory");      // (s_nop: the store-data WAR wait state hipcc cannot insert behind inline asm)
                 }
             }
         });

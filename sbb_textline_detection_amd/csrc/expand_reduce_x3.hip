@@ -20,6 +20,9 @@
 //   epilogue 2  BN, ReLU, split, stores of a'
 // Both contractions walk the K-steps in the order of the convs they replace, three MFMAs per product (lo*hi, hi*lo, hi*hi), one
 // accumulator per output, and state the same epilogue arithmetic: y and a' are bit-identical to the two launches (tests/test_gpu_parity.py).
+// (Every asm store ends in `s_nop 1`: the hazard recognizer does not see a store inside inline asm, so it does not insert the wait state the
+// ISA wants between a store of more than 64 bits and a VALU write of its data registers -- lanes 12-15 of the first data register came out
+// as the NEXT pixel block's values in the plain mode, where the compiler reuses the registers at once.)
 // Every vector-memory operation of the loop is issued from inline asm and waited for by a hand-counted vmcnt (retirement is in issue
 // order): see dec_halo_x3.hip for why.  Pixel rows in LDS are C * 4 bytes (b) / 1 KB (y chunk); 16-byte slot s of pixel p sits at slot
 // (s + 2 (p & 15)) mod row: conflict-free for the 16-lane groups of ds_read_b128 and the 8-lane groups of ds_write_b128.
@@ -56,6 +59,16 @@ template <int N, class V> __device__ inline void split_n(const float (&y)[N], V&
         hi[q] = h;
         lo[q] = (_Float16)(v - (float)h);
     }
+}
+
+typedef __attribute__((ext_vector_type(2))) _Float16 h2_t;
+// kernels.hip's pack_f16x2: saturate, round to nearest even
+__device__ inline uint32_t pack_h2(float a, float b)
+{
+    a = fminf(fmaxf(a, -65504.f), 65504.f);
+    b = fminf(fmaxf(b, -65504.f), 65504.f);
+    h2_t v = {(_Float16)a, (_Float16)b};
+    return __builtin_bit_cast(uint32_t, v);
 }
 
 __device__ __attribute__((always_inline)) inline void wload4(u4_t& a, u4_t& b, u4_t& c, u4_t& d, uint32_t voff, u4_t rsrc)
@@ -102,19 +115,26 @@ __device__ inline u4_t make_rsrc(const void* base, uint32_t bytes)
 
 }  // namespace
 
-// C = channels of b and a' (128: stage 3, 256: stage 4); y and x have 4 C
-template <int C>
-__global__ __launch_bounds__(512, 2) void expand_reduce_x3(const ExpRedParams p)
+// C = channels of b and a' (128: stage 3, 256: stage 4); y and x have 4 C.  X3: split mode (hi | lo planes, K-steps of 32 channels, three
+// MFMAs per product); else plain fp16 (K-steps of 64 channels = two k-halves: the fragment pair (hi, lo) of the text above reads (kk = 0,
+// kk = 1), one MFMA each, half the bytes everywhere) -- the same K-steps / accumulation order / epilogue arithmetic as conv_igemm_mfma's
+// plain mode: bit-identical there too.
+template <int C, bool X3>
+__global__ __launch_bounds__(512, 2) void expand_reduce(const ExpRedParams p)
 {
-    constexpr int KS1 = C / 32;                                 // K-steps of GEMM 1
+    constexpr int EB = X3 ? 4 : 2;                              // stored bytes per channel
+    constexpr int KCH = X3 ? 32 : 64;                           // channels per K-step
+    constexpr int KS1 = C / KCH;                                // K-steps of GEMM 1
+    constexpr int G2S = 256 / KCH;                              // K-steps of GEMM 2 per chunk
     constexpr int NCH = C / 64;                                 // 256-channel chunks of y
     constexpr int MI2 = C / 128;                                // row blocks of a' per wave
     constexpr int LG2 = 2 * MI2;                                // weight loads per K-step of GEMM 2
-    constexpr int PB = C * 4, PY = C * 16, PA = C * 4;          // bytes per stored pixel: b, y / x, a'
-    constexpr int SLB = PB / 16;                                // 16-byte slots per b row in LDS
-    constexpr int kBBytes = 64 * PB, kYBytes = 64 * 1024;
-    constexpr int STEPS = NCH * (KS1 + 8);                      // K-steps per tile, both GEMMs (even)
-    constexpr int kEpi1 = 16, kEpi2 = 8;                        // vector-memory operations of the epilogues: 8 y stores + 8 x loads; 8 a' stores
+    constexpr int PB = C * EB, PY = 4 * C * EB, PA = C * EB;    // bytes per stored pixel: b, y / x, a'
+    constexpr int YROW = 256 * EB;                              // bytes per pixel of the y chunk's LDS image
+    constexpr int SLB = PB / 16, SLY = YROW / 16;               // 16-byte slots per LDS row
+    constexpr int kBBytes = 64 * PB, kYBytes = 64 * YROW;
+    constexpr int STEPS = NCH * (KS1 + G2S);                    // K-steps per tile, both GEMMs (even)
+    constexpr int kEpi1 = X3 ? 16 : 8, kEpi2 = X3 ? 8 : 4;      // vector-memory operations of the epilogues: y stores + x loads; a' stores
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const lds_b = smem;
     char* const lds_y = smem + kBBytes;
@@ -155,31 +175,34 @@ __global__ __launch_bounds__(512, 2) void expand_reduce_x3(const ExpRedParams p)
     const u4_t arsrc = make_rsrc(p.a2 + kZeroHeaderBytes, (uint32_t)p.M * (uint32_t)PA);
     // weights: w3frag = [chunk][K-step][wave][m][hi | lo][64 lanes x 16 B] (4 KB per wave and step), w1frag = [chunk][K-step][wave][mi2][hi | lo][..]
     const u4_t w3rsrc = make_rsrc((const char*)p.w3frag + wave * 4096, (uint32_t)(NCH * KS1 * 8 * 4096));
-    const u4_t w1rsrc = make_rsrc((const char*)p.w1frag + wave * (LG2 * 1024), (uint32_t)(NCH * 8 * 8 * LG2 * 1024));
+    const u4_t w1rsrc = make_rsrc((const char*)p.w1frag + wave * (LG2 * 1024), (uint32_t)(NCH * G2S * 8 * LG2 * 1024));
     uint32_t wlane = (uint32_t)lane * 16u;
     int frv = frow, fgv = fg;                                   // (copies the tile loop re-derives its addresses from: see the asm at its top)
 
     // lane-constant pieces of the addresses
     int rot = fg + 2 * frow;                                    // slot of granule fg of this lane's pixel row, before the K-step's 8 k
-    uint32_t xlane = (uint32_t)(frow * PY + wave * 128 + fg * 16);      // x / y: pixel frow of a 16-pixel block, channel group `wave` of a chunk
-    uint32_t alane = MI2 == 2 ? (uint32_t)(frow * PA + wave * 128 + fg * 16)
-                              : (uint32_t)(frow * PA + (wave >> 1) * 128 + fg * 16 + (wave & 1) * 8);
+    uint32_t xlane = (uint32_t)(frow * PY + wave * (32 * EB) + fg * 16);      // x / y: pixel frow of a 16-pixel block, the wave's 32 channels of a chunk
+    uint32_t alane = MI2 == 2 ? (uint32_t)(frow * PA + wave * (32 * EB) + fg * 16)
+                              : (uint32_t)(frow * PA + (wave >> 1) * (32 * EB) + fg * 16 + (wave & 1) * 8);
 
     // step u of a tile: chunk j, GEMM 1 K-step k (u % (KS1 + 8) < KS1) or GEMM 2 K-step k
     u4_t w[2][4];                                               // weight ring: step u in set u & 1
     h8_t bh[2][4], bl[2][4];                                    // pixel fragments of step u in set u & 1
     u4_t xh[4], xl[4];                                          // the residual of the chunk ahead: [pixel block]
     auto issue_w = [&](int u, u4_t (&d)[4]) __attribute__((always_inline)) {             // u in [0, STEPS)
-        const int j = u / (KS1 + 8), r = u % (KS1 + 8);
+        const int j = u / (KS1 + G2S), r = u % (KS1 + G2S);
         const uint32_t wm = (p.dbg & 1) ? 0u : 1u;                 // (timing probe: every request reads the first step's fragments)
         if (r < KS1) wload4(d[0], d[1], d[2], d[3], wlane + wm * (uint32_t)((j * KS1 + r) * 8 * 4096), w3rsrc);
-        else if constexpr (MI2 == 2) wload4(d[0], d[1], d[2], d[3], wlane + wm * (uint32_t)((j * 8 + r - KS1) * 8 * 4096), w1rsrc);
-        else wload2(d[0], d[1], wlane + wm * (uint32_t)((j * 8 + r - KS1) * 8 * 2048), w1rsrc);
+        else if constexpr (MI2 == 2) wload4(d[0], d[1], d[2], d[3], wlane + wm * (uint32_t)((j * G2S + r - KS1) * 8 * 4096), w1rsrc);
+        else wload2(d[0], d[1], wlane + wm * (uint32_t)((j * G2S + r - KS1) * 8 * 2048), w1rsrc);
     };
-    auto issue_x = [&](int tile, int j) __attribute__((always_inline)) {                  // 8 loads
+    auto issue_x = [&](int tile, int j) __attribute__((always_inline)) {                  // 8 loads (plain mode: 4)
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni)
-            xload2(xh[ni], xl[ni], ((p.dbg & 4) ? 0xf0000000u : 0u) + xlane + (uint32_t)(tile * 64 + ni * 16) * (uint32_t)PY + (uint32_t)(j * 1024), xrsrc);
+        for (int ni = 0; ni < 4; ++ni) {
+            const uint32_t off = ((p.dbg & 4) ? 0xf0000000u : 0u) + xlane + (uint32_t)(tile * 64 + ni * 16) * (uint32_t)PY + (uint32_t)(j * YROW);
+            if constexpr (X3) xload2(xh[ni], xl[ni], off, xrsrc);
+            else asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=&v"(xh[ni]) : "v"(off), "s"(xrsrc) : "memory");
+        }
     };
     auto load_frags = [&](const char* base, int row_bytes, int slots, int k, h8_t (&dh)[4], h8_t (&dl)[4]) __attribute__((always_inline)) {
         const int sh = (rot + 8 * k) & (slots - 1), sl = (rot + 8 * k + 4) & (slots - 1);
@@ -196,7 +219,10 @@ __global__ __launch_bounds__(512, 2) void expand_reduce_x3(const ExpRedParams p)
     issue_x(tile_at(0), 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
-    for (int ni = 0; ni < 4; ++ni) asm volatile("" : "+v"(xh[ni]), "+v"(xl[ni]));
+    for (int ni = 0; ni < 4; ++ni) {
+        asm volatile("" : "+v"(xh[ni]));
+        if constexpr (X3) asm volatile("" : "+v"(xl[ni]));
+    }
     __syncthreads();                                            // b, constants visible
     issue_w(0, w[0]);
     issue_w(1, w[1]);
@@ -212,14 +238,14 @@ __global__ __launch_bounds__(512, 2) void expand_reduce_x3(const ExpRedParams p)
         f4_t acc1[2][4];
         static_for<0, STEPS>([&](auto uc) __attribute__((always_inline)) {
             constexpr int u = decltype(uc)::value;
-            constexpr int j = u / (KS1 + 8), r = u % (KS1 + 8);
+            constexpr int j = u / (KS1 + G2S), r = u % (KS1 + G2S);
             constexpr bool g1 = r < KS1;
             constexpr int k = g1 ? r : r - KS1;
             constexpr int set = u & 1;
             // loads per weight request of the step after this one (its request is the only one younger than this step's, but for the
             // epilogues in between)
             constexpr int un = (u + 1) % STEPS;
-            constexpr int Lnext = (un % (KS1 + 8)) < KS1 ? 4 : LG2;
+            constexpr int Lnext = (un % (KS1 + G2S)) < KS1 ? 4 : LG2;
             // vector-memory operations issued between this step's weight request (end of step u - 2) and here, beside that one request:
             //   GEMM 2 steps 0, 1: epilogue 1 (+ the b DMA behind the last chunk's)     GEMM 1 steps 0, 1 of chunk 0: the previous tile's epilogue 2
             constexpr int extra = (!g1 && k < 2) ? kEpi1 + (j == NCH - 1 ? KS1 : 0) : 0;
@@ -230,10 +256,10 @@ __global__ __launch_bounds__(512, 2) void expand_reduce_x3(const ExpRedParams p)
                     for (int ni = 0; ni < 4; ++ni) acc1[m][ni] = (f4_t){0.f, 0.f, 0.f, 0.f};
                 load_frags(lds_b, PB, SLB, 0, bh[set], bl[set]);                 // (not requested ahead across the barrier in front of this phase)
             }
-            if constexpr (!g1 && k == 0) load_frags(lds_y, 1024, 64, 0, bh[set], bl[set]);
+            if constexpr (!g1 && k == 0) load_frags(lds_y, YROW, SLY, 0, bh[set], bl[set]);
             // the next step's pixel fragments, inside a phase
             if constexpr (g1 && k + 1 < KS1) load_frags(lds_b, PB, SLB, k + 1, bh[set ^ 1], bl[set ^ 1]);
-            if constexpr (!g1 && k + 1 < 8) load_frags(lds_y, 1024, 64, k + 1, bh[set ^ 1], bl[set ^ 1]);
+            if constexpr (!g1 && k + 1 < G2S) load_frags(lds_y, YROW, SLY, k + 1, bh[set ^ 1], bl[set ^ 1]);
             u4_t (&cw)[4] = w[set];
             if constexpr (g1 && j == 0 && k < 2) {
                 if (it == 0) wait4<Lnext>(cw[0], cw[1], cw[2], cw[3]);
@@ -244,36 +270,52 @@ __global__ __launch_bounds__(512, 2) void expand_reduce_x3(const ExpRedParams p)
             const h8_t (&ph)[4] = bh[set];
             const h8_t (&pl)[4] = bl[set];
             if constexpr (g1) {
-                const h8_t ah[2] = {__builtin_bit_cast(h8_t, cw[0]), __builtin_bit_cast(h8_t, cw[2])};
-                const h8_t al[2] = {__builtin_bit_cast(h8_t, cw[1]), __builtin_bit_cast(h8_t, cw[3])};
+                const h8_t ah[2] = {__builtin_bit_cast(h8_t, cw[0]), __builtin_bit_cast(h8_t, cw[2])};       // (plain mode: k-half 0)
+                const h8_t al[2] = {__builtin_bit_cast(h8_t, cw[1]), __builtin_bit_cast(h8_t, cw[3])};       // (             k-half 1)
+                if constexpr (X3) {
 #pragma unroll
-                for (int m = 0; m < 2; ++m)
+                    for (int m = 0; m < 2; ++m)
 #pragma unroll
-                    for (int ni = 0; ni < 4; ++ni) acc1[m][ni] = mma(al[m], ph[ni], acc1[m][ni]);
+                        for (int ni = 0; ni < 4; ++ni) acc1[m][ni] = mma(al[m], ph[ni], acc1[m][ni]);
 #pragma unroll
-                for (int m = 0; m < 2; ++m)
+                    for (int m = 0; m < 2; ++m)
 #pragma unroll
-                    for (int ni = 0; ni < 4; ++ni) acc1[m][ni] = mma(ah[m], pl[ni], acc1[m][ni]);
+                        for (int ni = 0; ni < 4; ++ni) acc1[m][ni] = mma(ah[m], pl[ni], acc1[m][ni]);
+                }
 #pragma unroll
                 for (int m = 0; m < 2; ++m)
 #pragma unroll
                     for (int ni = 0; ni < 4; ++ni) acc1[m][ni] = mma(ah[m], ph[ni], acc1[m][ni]);
+                if constexpr (!X3) {
+#pragma unroll
+                    for (int m = 0; m < 2; ++m)
+#pragma unroll
+                        for (int ni = 0; ni < 4; ++ni) acc1[m][ni] = mma(al[m], pl[ni], acc1[m][ni]);
+                }
             } else {
                 h8_t ah[MI2], al[MI2];
 #pragma unroll
                 for (int m = 0; m < MI2; ++m) { ah[m] = __builtin_bit_cast(h8_t, cw[2 * m]); al[m] = __builtin_bit_cast(h8_t, cw[2 * m + 1]); }
+                if constexpr (X3) {
 #pragma unroll
-                for (int m = 0; m < MI2; ++m)
+                    for (int m = 0; m < MI2; ++m)
 #pragma unroll
-                    for (int ni = 0; ni < 4; ++ni) acc2[m][ni] = mma(al[m], ph[ni], acc2[m][ni]);
+                        for (int ni = 0; ni < 4; ++ni) acc2[m][ni] = mma(al[m], ph[ni], acc2[m][ni]);
 #pragma unroll
-                for (int m = 0; m < MI2; ++m)
+                    for (int m = 0; m < MI2; ++m)
 #pragma unroll
-                    for (int ni = 0; ni < 4; ++ni) acc2[m][ni] = mma(ah[m], pl[ni], acc2[m][ni]);
+                        for (int ni = 0; ni < 4; ++ni) acc2[m][ni] = mma(ah[m], pl[ni], acc2[m][ni]);
+                }
 #pragma unroll
                 for (int m = 0; m < MI2; ++m)
 #pragma unroll
                     for (int ni = 0; ni < 4; ++ni) acc2[m][ni] = mma(ah[m], ph[ni], acc2[m][ni]);
+                if constexpr (!X3) {
+#pragma unroll
+                    for (int m = 0; m < MI2; ++m)
+#pragma unroll
+                        for (int ni = 0; ni < 4; ++ni) acc2[m][ni] = mma(al[m], pl[ni], acc2[m][ni]);
+                }
             }
             // this set's weights are spent: step u + 2 (of the next tile behind the last two; always issued: the counts stay constant)
             issue_w((u + 2) % STEPS, cw);
@@ -282,13 +324,17 @@ __global__ __launch_bounds__(512, 2) void expand_reduce_x3(const ExpRedParams p)
             if constexpr (g1 && k == KS1 - 1) {
                 // ---- epilogue 1: y = ReLU(s3 * acc + h3 + x) -> hi | lo: to HBM and into the LDS image of the chunk.  x of this chunk was requested
                 // an epilogue ago: older than every weight request already waited for (the wait below only ties the registers to that fact)
-                asm volatile("s_waitcnt vmcnt(%8)" : "+v"(xh[0]), "+v"(xh[1]), "+v"(xh[2]), "+v"(xh[3]), "+v"(xl[0]), "+v"(xl[1]), "+v"(xl[2]), "+v"(xl[3])
-                             : "n"(2 * LG2) : "memory");
+                if constexpr (X3)
+                    asm volatile("s_waitcnt vmcnt(%8)" : "+v"(xh[0]), "+v"(xh[1]), "+v"(xh[2]), "+v"(xh[3]), "+v"(xl[0]), "+v"(xl[1]), "+v"(xl[2]), "+v"(xl[3])
+                                 : "n"(2 * LG2) : "memory");
+                else
+                    asm volatile("s_waitcnt vmcnt(%4)" : "+v"(xh[0]), "+v"(xh[1]), "+v"(xh[2]), "+v"(xh[3]) : "n"(2 * LG2) : "memory");
                 const int c0 = j * 256 + wave * 32 + fgv * 8;
                 float sc[8], sh[8];
                 *(float4*)&sc[0] = *(const float4*)(cst + c0); *(float4*)&sc[4] = *(const float4*)(cst + c0 + 4);
                 *(float4*)&sh[0] = *(const float4*)(cst + 4 * C + c0); *(float4*)&sh[4] = *(const float4*)(cst + 4 * C + c0 + 4);
-                const int s_hi = (wave * 8 + rot) & 63, s_lo = (wave * 8 + 4 + rot) & 63;
+                // the wave's 32 channels = granules wave * 4 + fg of the chunk (split mode: group `wave`, hi granules fg, lo granules 4 + fg)
+                const int s_hi = (wave * (X3 ? 8 : 4) + rot) & (SLY - 1), s_lo = (wave * 8 + 4 + rot) & (SLY - 1);
 #pragma unroll
                 for (int ni = 0; ni < 4; ++ni) {
                     float y[8];
@@ -297,17 +343,27 @@ __global__ __launch_bounds__(512, 2) void expand_reduce_x3(const ExpRedParams p)
                         y[q] = __builtin_fmaf(acc1[0][ni][q], sc[q], sh[q]);
                         y[4 + q] = __builtin_fmaf(acc1[1][ni][q], sc[4 + q], sh[4 + q]);
                     }
-                    const h8_t rh = __builtin_bit_cast(h8_t, xh[ni]), rl = __builtin_bit_cast(h8_t, xl[ni]);
+                    const uint32_t off = ((p.dbg & 2) ? 0xf0000000u : 0u) + xlane + (uint32_t)(tile * 64 + ni * 16) * (uint32_t)PY + (uint32_t)(j * YROW);
+                    char* row = lds_y + (ni * 16 + frv) * YROW;
+                    if constexpr (X3) {
+                        const h8_t rh = __builtin_bit_cast(h8_t, xh[ni]), rl = __builtin_bit_cast(h8_t, xl[ni]);
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) y[q] = fmaxf(__fadd_rn(y[q], __fadd_rn((float)rh[q], (float)rl[q])), 0.f);      // (= add_split8 + ReLU, kernels.hip)
-                    h8_t vh, vl;
-                    split_n<8>(y, vh, vl);
-                    const uint32_t off = ((p.dbg & 2) ? 0xf0000000u : 0u) + xlane + (uint32_t)(tile * 64 + ni * 16) * (uint32_t)PY + (uint32_t)(j * 1024);
-                    asm volatile("buffer_store_dwordx4 %1, %0, %3, 0 offen\n\tbuffer_store_dwordx4 %2, %0, %3, 0 offen offset:64"
-                                 :: "v"(off), "v"(vh), "v"(vl), "s"(yrsrc) : "memory");
-                    char* row = lds_y + (ni * 16 + frv) * 1024;
-                    *(h8_t*)(row + (s_hi << 4)) = vh;
-                    *(h8_t*)(row + (s_lo << 4)) = vl;
+                        for (int q = 0; q < 8; ++q) y[q] = fmaxf(__fadd_rn(y[q], __fadd_rn((float)rh[q], (float)rl[q])), 0.f);      // (= add_split8 + ReLU, kernels.hip)
+                        h8_t vh, vl;
+                        split_n<8>(y, vh, vl);
+                        asm volatile("buffer_store_dwordx4 %1, %0, %3, 0 offen\n\tbuffer_store_dwordx4 %2, %0, %3, 0 offen offset:64\n\ts_nop 1"
+                                     :: "v"(off), "v"(vh), "v"(vl), "s"(yrsrc) : "memory");
+                        *(h8_t*)(row + (s_hi << 4)) = vh;
+                        *(h8_t*)(row + (s_lo << 4)) = vl;
+                    } else {
+                        const h8_t rr = __builtin_bit_cast(h8_t, xh[ni]);
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) y[q] = fmaxf(__fadd_rn(y[q], (float)rr[q]), 0.f);
+                        u4_t v;
+                        v[0] = pack_h2(y[0], y[1]); v[1] = pack_h2(y[2], y[3]); v[2] = pack_h2(y[4], y[5]); v[3] = pack_h2(y[6], y[7]);
+                        asm volatile("buffer_store_dwordx4 %1, %0, %2, 0 offen\n\ts_nop 1" :: "v"(off), "v"(v), "s"(yrsrc) : "memory");
+                        *(u4_t*)(row + (s_hi << 4)) = v;
+                    }
                 }
                 // the residual of the chunk after this one (the next tile's first behind the last)
                 if constexpr (j + 1 < NCH) issue_x(tile, j + 1);
@@ -317,7 +373,7 @@ __global__ __launch_bounds__(512, 2) void expand_reduce_x3(const ExpRedParams p)
                 asm volatile("" ::: "memory");
                 if constexpr (j == NCH - 1) issue_b(tile_next);
             }
-            if constexpr (!g1 && k == 7) {
+            if constexpr (!g1 && k == G2S - 1) {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();                   // every wave has taken its last fragment of this y chunk (last chunk: and has waited
                 asm volatile("" ::: "memory");                  // for its share of the next tile's b: steps >= 2 of this GEMM)
@@ -337,25 +393,30 @@ __global__ __launch_bounds__(512, 2) void expand_reduce_x3(const ExpRedParams p)
 #pragma unroll
             for (int ni = 0; ni < 4; ++ni) {
                 const uint32_t off = alane + (uint32_t)(tile * 64 + ni * 16) * (uint32_t)PA;
-                if constexpr (MI2 == 2) {
-                    float y[8];
+                float y[4 * MI2];
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        y[q] = fmaxf(__builtin_fmaf(acc2[0][ni][q], sc[q], sh[q]), 0.f);
-                        y[4 + q] = fmaxf(__builtin_fmaf(acc2[MI2 - 1][ni][q], sc[4 * (MI2 - 1) + q], sh[4 * (MI2 - 1) + q]), 0.f);
-                    }
+                for (int q = 0; q < 4; ++q) {
+                    y[q] = fmaxf(__builtin_fmaf(acc2[0][ni][q], sc[q], sh[q]), 0.f);
+                    if constexpr (MI2 == 2) y[4 + q] = fmaxf(__builtin_fmaf(acc2[MI2 - 1][ni][q], sc[4 * (MI2 - 1) + q], sh[4 * (MI2 - 1) + q]), 0.f);
+                }
+                if constexpr (X3 && MI2 == 2) {
                     h8_t vh, vl;
                     split_n<8>(y, vh, vl);
-                    asm volatile("buffer_store_dwordx4 %1, %0, %3, 0 offen\n\tbuffer_store_dwordx4 %2, %0, %3, 0 offen offset:64"
+                    asm volatile("buffer_store_dwordx4 %1, %0, %3, 0 offen\n\tbuffer_store_dwordx4 %2, %0, %3, 0 offen offset:64\n\ts_nop 1"
                                  :: "v"(off), "v"(vh), "v"(vl), "s"(arsrc) : "memory");
-                } else {
-                    float y[4];
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) y[q] = fmaxf(__builtin_fmaf(acc2[0][ni][q], sc[q], sh[q]), 0.f);
+                } else if constexpr (X3) {
                     h4_t vh, vl;
                     split_n<4>(y, vh, vl);
-                    asm volatile("buffer_store_dwordx2 %1, %0, %3, 0 offen\n\tbuffer_store_dwordx2 %2, %0, %3, 0 offen offset:64"
+                    asm volatile("buffer_store_dwordx2 %1, %0, %3, 0 offen\n\tbuffer_store_dwordx2 %2, %0, %3, 0 offen offset:64\n\ts_nop 1"
                                  :: "v"(off), "v"(vh), "v"(vl), "s"(arsrc) : "memory");
+                } else if constexpr (MI2 == 2) {
+                    u4_t v;
+                    v[0] = pack_h2(y[0], y[1]); v[1] = pack_h2(y[2], y[3]); v[2] = pack_h2(y[4 % (4 * MI2)], y[5 % (4 * MI2)]); v[3] = pack_h2(y[6 % (4 * MI2)], y[7 % (4 * MI2)]);
+                    asm volatile("buffer_store_dwordx4 %1, %0, %2, 0 offen\n\ts_nop 1" :: "v"(off), "v"(v), "s"(arsrc) : "memory");
+                } else {
+                    u2_t v;
+                    v[0] = pack_h2(y[0], y[1]); v[1] = pack_h2(y[2], y[3]);
+                    asm volatile("buffer_store_dwordx2 %1, %0, %2, 0 offen\n\ts_nop 1" :: "v"(off), "v"(v), "s"(arsrc) : "memory");
                 }
             }
         }
@@ -363,28 +424,29 @@ __global__ __launch_bounds__(512, 2) void expand_reduce_x3(const ExpRedParams p)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-template <int C> static hipError_t launch_one(const ExpRedParams& p, int num_cus, hipStream_t s)
+template <int C, bool X3> static hipError_t launch_one(const ExpRedParams& p, int num_cus, hipStream_t s)
 {
-    constexpr int lds = 64 * C * 4 + 64 * 1024 + 10 * C * 4;
+    constexpr int EB = X3 ? 4 : 2;
+    constexpr int lds = 64 * C * EB + 64 * 256 * EB + 10 * C * 4;
     static bool attr_done[64] = {};
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
     if (!attr_done[dev & 63]) {
-        e = hipFuncSetAttribute((const void*)expand_reduce_x3<C>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        e = hipFuncSetAttribute((const void*)expand_reduce<C, X3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return e;
         attr_done[dev & 63] = true;
     }
     const int n_tiles = (p.M + 63) / 64;
     const int grid = n_tiles < num_cus ? n_tiles : num_cus;
-    hipLaunchKernelGGL(expand_reduce_x3<C>, dim3(grid), dim3(512), lds, s, p);
+    hipLaunchKernelGGL((expand_reduce<C, X3>), dim3(grid), dim3(512), lds, s, p);
     return hipGetLastError();
 }
 
 hipError_t launch_expand_reduce_x3(const ExpRedParams& p, int num_cus, hipStream_t s)
 {
-    if (p.C == 128) return launch_one<128>(p, num_cus, s);
-    if (p.C == 256) return launch_one<256>(p, num_cus, s);
+    if (p.C == 128) return p.x3 ? launch_one<128, true>(p, num_cus, s) : launch_one<128, false>(p, num_cus, s);
+    if (p.C == 256) return p.x3 ? launch_one<256, true>(p, num_cus, s) : launch_one<256, false>(p, num_cus, s);
     return hipErrorInvalidValue;
 }
 

@@ -218,6 +218,7 @@ struct ExpRedParams {
     char* a2;                 // buffer start (zero header), [M][C]: the reduce's output
     int M;                    // pixels (patches x H x W)
     int C;                    // 128 | 256
+    int x3;                   // 1: split mode (hi | lo planes); 0: plain fp16 (the fragment pairs are the two k-halves of a 64-channel K-step)
     const void* w3frag;       // [4C / 256 chunks][C / 32 K-steps][8 waves][2 row blocks][hi | lo][64 lanes] x 16 B: A fragments of the expand's packed rows
     const void* w1frag;       // [4C / 256 chunks][8 K-steps][8 waves][C / 128 row blocks][hi | lo][64 lanes] x 16 B: ... of the reduce's
     const float *s3, *h3;     // [4C] scale / shift of the expand

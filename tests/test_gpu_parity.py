@@ -215,7 +215,10 @@ def test_fused_x3_stem_pool_matches_the_two_launches(hw, nb):
     assert float(np.abs(t_fused[pooled[0]]).max()) > 0
     assert np.array_equal(got_fused, got_two)
     ref = kf.forward(g, w, x[:2])
-    assert float(np.abs(got_fused[:2] - ref).max()) < TOL_SOFTMAX["f16x3"] and exact_label_check(ref, got_fused[:2])[1] == 0
+    if precision == "f16x3":
+        assert float(np.abs(got_fused[:2] - ref).max()) < TOL_SOFTMAX["f16x3"] and exact_label_check(ref, got_fused[:2])[1] == 0
+    else:
+        assert float(np.abs(got_fused[:2] - ref).max()) < 0.2
     model.release()
 
 
@@ -259,15 +262,17 @@ def test_dec_halo_x3_matches_the_generic_kernel(hw, nb, precision):
     model.release()
 
 
+@pytest.mark.parametrize("precision", ["f16x3", "f16"])
 @pytest.mark.parametrize("hw,nb", [((64, 96), 3), ((224, 256), 5), ((448, 448), 9), ((448, 448), 2)])
-def test_expand_reduce_x3_matches_the_two_launches(hw, nb):
-    """Split mode, encoder stages 3 / 4: an identity block's last 1x1 conv (+ residual, ReLU) and the next block's first 1x1 conv run as ONE
+def test_expand_reduce_x3_matches_the_two_launches(hw, nb, precision):
+    """Split mode (and the plain fp16 mode: the same kernel on K-steps of two k-halves), encoder stages 3 / 4: an identity block's last
+    1x1 conv (+ residual, ReLU) and the next block's first 1x1 conv run as ONE
     launch (csrc/expand_reduce_x3.hip: the 4C-channel tensor is written once and contracted from LDS, weights streamed, every vector-memory
     operation counted by hand).  Against the two conv_igemm_mfma launches (conv variant bit 24) every tensor of the plan must be the same
     bits.  64 x 96 patches give 3 x 96 / 3 x 24 pixels per launch: ragged last tiles (loads read zeros, stores are dropped past the end).
     Run three times: the hand-placed waits must not race."""
     h, wd = hw
-    cfg, w, g, model = make_model(2, h, wd, seed=9, precision="f16x3", max_batch=nb + 2, calib_hw=min(160, max(h, wd)))
+    cfg, w, g, model = make_model(2, h, wd, seed=9, precision=precision, max_batch=nb + 2, calib_hw=min(160, max(h, wd)))
     x = (patches_from_page(h, wd, nb, seed=29) / 255.0).astype(np.float32)
 
     def read_all():
@@ -288,7 +293,10 @@ def test_expand_reduce_x3_matches_the_two_launches(hw, nb):
     for _ in range(3):
         assert np.array_equal(model.predict(x), got_fused)
     ref = kf.forward(g, w, x[:2])
-    assert float(np.abs(got_fused[:2] - ref).max()) < TOL_SOFTMAX["f16x3"] and exact_label_check(ref, got_fused[:2])[1] == 0
+    if precision == "f16x3":
+        assert float(np.abs(got_fused[:2] - ref).max()) < TOL_SOFTMAX["f16x3"] and exact_label_check(ref, got_fused[:2])[1] == 0
+    else:
+        assert float(np.abs(got_fused[:2] - ref).max()) < 0.2
     model.release()
 
 
