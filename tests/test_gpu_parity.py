@@ -215,10 +215,7 @@ def test_fused_x3_stem_pool_matches_the_two_launches(hw, nb):
     assert float(np.abs(t_fused[pooled[0]]).max()) > 0
     assert np.array_equal(got_fused, got_two)
     ref = kf.forward(g, w, x[:2])
-    if precision == "f16x3":
-        assert float(np.abs(got_fused[:2] - ref).max()) < TOL_SOFTMAX["f16x3"] and exact_label_check(ref, got_fused[:2])[1] == 0
-    else:
-        assert float(np.abs(got_fused[:2] - ref).max()) < 0.2
+    assert float(np.abs(got_fused[:2] - ref).max()) < TOL_SOFTMAX["f16x3"] and exact_label_check(ref, got_fused[:2])[1] == 0
     model.release()
 
 
@@ -623,7 +620,7 @@ def test_c_abi_error_paths_do_not_abort(stitch_model):
     with pytest.raises(RuntimeError):
         m.ctx.debug_read_tensor(0, 10 ** 6, (1, 1, 1))
     with pytest.raises(RuntimeError, match="variant"):
-        m.ctx.set_conv_variant(1 << 24)
+        m.ctx.set_conv_variant(1 << 25)
     page = synthetic_page(448, 448, seed=1)              # 448x448 page -> 4 identical clamped tiles
     lab = m.segment_page(page)
     assert lab.shape == (448, 448)
