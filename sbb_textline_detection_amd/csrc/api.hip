@@ -458,6 +458,7 @@ int launch_op(sbbseg_ctx* c, Op& op, int n, uint8_t* d_labels, float* d_probs)
                     const PoolOp& po = c->ops[co.fused_pool].pool;
                     sp.pool_out = c->tensors[po.dst].data(); sp.pool_scale = po.d_pre_scale; sp.pool_shift = po.d_pre_shift;
                     sp.pool_relu = po.pre_relu; sp.pool_Ho = po.Ho; sp.pool_Wo = po.Wo;
+                    sp.x3 = c->precision == kF16X3;
                     HIPCHK(launch_stem_pool_x3(sp, c->num_cus, c->stream));
                 } else
                     HIPCHK(launch_stem(sp, c->precision, c->num_cus, c->stream));
@@ -1802,11 +1803,15 @@ int sbbseg_finalize(sbbseg_ctx* c, int max_batch)
             r.fused_into_expand = true;
         }
     }
-    // split mode: the stem (dedicated kernel, raw output only) directly followed by the 3x3 / stride-2 max-pool of that tensor with an
+    // split and plain fp16 modes: the stem (dedicated kernel, raw output only) directly followed by the 3x3 / stride-2 max-pool of that tensor with an
     // affine on every tap (bn_conv1 + ReLU) -> one launch writes both tensors (stem_pool_x3.hip); SBBSEG_STEM_POOL=0 keeps two launches
     {
         const char* env = getenv("SBBSEG_STEM_POOL");
-        for (size_t i = 0; c->precision == kF16X3 && !(env && env[0] == '0') && i + 1 < c->ops.size(); ++i) {
+        // (plain fp16 mode: the one-plane form stem_pool<false> is bit-identical too but no faster than the two launches -- 0.53 against
+        // 0.26 + 0.29 ms per 140 patches: with one MFMA per product the pool stage is most of the kernel -- so it is opt-in: SBBSEG_STEM_POOL_F16=1)
+        const char* env16 = getenv("SBBSEG_STEM_POOL_F16");
+        const bool on = c->precision == kF16X3 || (c->precision == kF16 && env16 && env16[0] == '1');
+        for (size_t i = 0; on && !(env && env[0] == '0') && i + 1 < c->ops.size(); ++i) {
             Op& a = c->ops[i];
             Op& b = c->ops[i + 1];
             if (a.type != kConv || !a.conv.d_stem_wfrag || b.type != kPool) continue;

@@ -144,6 +144,7 @@ struct StemParams {
     const float* pool_shift = nullptr;
     int pool_relu = 0;
     int pool_Ho = 0, pool_Wo = 0;
+    int x3 = 1;               // stem_pool: 1 = split mode (hi | lo planes), 0 = plain fp16
 };
 
 // 3x3 stride-1 'same' conv, 64 -> 64 channels (the ResNet stage-2 bottleneck convs), as a direct conv on an

@@ -37,6 +37,7 @@ constexpr int kSaveBytes = 2 * 8 * 2 * kColStride * 4;          // [tile parity]
 constexpr int kCstBytes = 4 * 64 * 4;               // stem scale * wmul, stem shift, pool scale, pool shift
 constexpr int kWloBytes = 7 * 2 * 1024;              // the lo weight fragments of this block's two row blocks [7 ky][2 m][64 lanes x 16 B]
 constexpr int kStemPoolLdsBytes = 2 * kPlaneBytes + kStageVBytes + kStageRBytes + kSaveBytes + kCstBytes + kWloBytes;      // 78 848: two blocks per CU
+constexpr int kStemPoolF16LdsBytes = kPlaneBytes + kStageVBytes + kStageRBytes + kSaveBytes + kCstBytes;                  // plain fp16 mode: one plane, no lo weights
 
 __device__ inline f4_t mma(h8_t a, h8_t b, f4_t c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
 
@@ -60,15 +61,20 @@ __device__ inline void split1(float v, _Float16& hi, _Float16& lo)
 
 }  // namespace
 
-__global__ __launch_bounds__(256, 2) void stem_pool_x3(const StemParams p)
+// X3: split mode (text above).  !X3: the plain fp16 mode, same structure with one plane: a PAIRS granule is 16 bytes, one MFMA per
+// product, f1 and the pooled tensor are fp16 ([64] halves per pixel), and what the pool reads back is the ROUNDED f1 value (maxpool_kernel
+// reads the stored fp16): bit-identical to stem_conv_pairs + maxpool_kernel there too.
+template <bool X3>
+__global__ __launch_bounds__(256, 2) void stem_pool(const StemParams p)
 {
+    constexpr int NPL = X3 ? 2 : 1;                                 // halo planes
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* halo = smem;                                              // hi plane | lo plane
-    float* stageV = (float*)(smem + 2 * kPlaneBytes);
-    float* stageR = (float*)(smem + 2 * kPlaneBytes + kStageVBytes);
-    float* save = (float*)(smem + 2 * kPlaneBytes + kStageVBytes + kStageRBytes);
-    float* cst = (float*)(smem + 2 * kPlaneBytes + kStageVBytes + kStageRBytes + kSaveBytes);
-    char* wlo_lds = smem + 2 * kPlaneBytes + kStageVBytes + kStageRBytes + kSaveBytes + kCstBytes;
+    float* stageV = (float*)(smem + NPL * kPlaneBytes);
+    float* stageR = (float*)(smem + NPL * kPlaneBytes + kStageVBytes);
+    float* save = (float*)(smem + NPL * kPlaneBytes + kStageVBytes + kStageRBytes);
+    float* cst = (float*)(smem + NPL * kPlaneBytes + kStageVBytes + kStageRBytes + kSaveBytes);
+    char* wlo_lds = smem + NPL * kPlaneBytes + kStageVBytes + kStageRBytes + kSaveBytes + kCstBytes;      // (split mode only)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -93,10 +99,11 @@ __global__ __launch_bounds__(256, 2) void stem_pool_x3(const StemParams p)
         for (int ky = 0; ky < 7; ++ky)
 #pragma unroll
             for (int m = 0; m < 2; ++m) whi[ky][m] = __builtin_bit_cast(h8_t, src[(size_t)(ky * 4 + 2 * half + m) * 64]);
-        for (int i = tid; i < 7 * 2 * 64; i += 256) {
-            const int f = i >> 6, l = i & 63;                       // f = ky * 2 + m
-            ((uint4*)wlo_lds)[i] = ((const uint4*)p.wfrag)[(size_t)(28 + (f >> 1) * 4 + 2 * half + (f & 1)) * 64 + l];
-        }
+        if constexpr (X3)
+            for (int i = tid; i < 7 * 2 * 64; i += 256) {
+                const int f = i >> 6, l = i & 63;                   // f = ky * 2 + m
+                ((uint4*)wlo_lds)[i] = ((const uint4*)p.wfrag)[(size_t)(28 + (f >> 1) * 4 + 2 * half + (f & 1)) * 64 + l];
+            }
     }
     const int c0 = half * 32 + fg * 8;              // this lane's 8 channels in the epilogue (MFMA rows fg * 4 + q of row blocks 2 half, 2 half + 1)
 
@@ -104,7 +111,7 @@ __global__ __launch_bounds__(256, 2) void stem_pool_x3(const StemParams p)
     auto issue_halo = [&](int n, int ty, int tx) __attribute__((always_inline)) {
         const int rows = ty == tiles_y - 1 ? kHaloRows - 2 : kHaloRows;      // no row below the last strip
 #pragma unroll
-        for (int pl = 0; pl < 2; ++pl)
+        for (int pl = 0; pl < NPL; ++pl)
 #pragma unroll
             for (int j = 0; j < (kHaloInstr + 3) / 4; ++j) {
                 const int ii = wave + 4 * j;
@@ -112,7 +119,7 @@ __global__ __launch_bounds__(256, 2) void stem_pool_x3(const StemParams p)
                     const int s = ii * 64 + lane;
                     const int r = s / kSlots, cc = s - r * kSlots;
                     const int Y = 32 * ty + r, X = 16 * tx + cc;
-                    uint32_t off = (uint32_t)((n * p.PHt + Y) * p.PWt + X) * 32u + (uint32_t)(pl * 16 + kZeroHeaderBytes);
+                    uint32_t off = (uint32_t)((n * p.PHt + Y) * p.PWt + X) * (uint32_t)(16 * NPL) + (uint32_t)(pl * 16 + kZeroHeaderBytes);
                     off = r < rows ? off : 0u;
                     glds16_hidden(p.pairs + off, halo_lds + (uint32_t)(pl * kPlaneBytes + ii * 1024));
                 }
@@ -129,7 +136,8 @@ __global__ __launch_bounds__(256, 2) void stem_pool_x3(const StemParams p)
             // order: behind a tile's halo loads every wave issues its 8 f1 stores (+ 0..2 pooled ones), so "all but the youngest 8" covers
             // the halo and leaves the stores in flight.  Raw barriers: __syncthreads() would drain those stores (vmcnt(0)) at every tile.
             if (first) { issue_halo(n, ty, tx); first = 0; asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-            else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else if constexpr (X3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");      // (plain mode: 4 f1 stores + 0..1 pooled one per wave behind the halo loads)
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
@@ -147,11 +155,13 @@ __global__ __launch_bounds__(256, 2) void stem_pool_x3(const StemParams p)
                     const int ky = step >> 2, ni = step & 3;
                     const int at = ((2 * (wave * 4 + ni) + ky) * kSlots + frow + fg) * 16;
                     dh = *(const h8_t*)(halo + at);
-                    dl = *(const h8_t*)(halo + kPlaneBytes + at);
+                    if constexpr (X3) dl = *(const h8_t*)(halo + kPlaneBytes + at);
                 };
                 auto wfrag = [&](int ky, h8_t (&d)[2]) __attribute__((always_inline)) {
+                    if constexpr (X3) {
 #pragma unroll
-                    for (int m = 0; m < 2; ++m) d[m] = *(const h8_t*)(wlo_lds + ((ky * 2 + m) * 64 + lane) * 16);
+                        for (int m = 0; m < 2; ++m) d[m] = *(const h8_t*)(wlo_lds + ((ky * 2 + m) * 64 + lane) * 16);
+                    }
                 };
                 wfrag(0, wlo[0]);
                 frag(0, bh[0], bl[0]);
@@ -162,18 +172,23 @@ __global__ __launch_bounds__(256, 2) void stem_pool_x3(const StemParams p)
                     if (ni == 0 && ky + 1 < 7) wfrag(ky + 1, wlo[(ky + 1) & 1]);
 #pragma unroll
                     for (int m = 0; m < 2; ++m) {
-                        acc[m][ni] = mma(wlo[ky & 1][m], bh[step & 1], acc[m][ni]);
-                        acc[m][ni] = mma(whi[ky][m], bl[step & 1], acc[m][ni]);
+                        if constexpr (X3) {
+                            acc[m][ni] = mma(wlo[ky & 1][m], bh[step & 1], acc[m][ni]);
+                            acc[m][ni] = mma(whi[ky][m], bl[step & 1], acc[m][ni]);
+                        }
                         acc[m][ni] = mma(whi[ky][m], bh[step & 1], acc[m][ni]);
                     }
                     if (ni == 3 && wave == 3 && !last_ty) {       // the extra row 16 (wave-uniform branch): same accumulation order as the tile below uses for its row 0
                         const int at = ((32 + ky) * kSlots + frow + fg) * 16;
                         const h8_t xh = *(const h8_t*)(halo + at);
-                        const h8_t xl = *(const h8_t*)(halo + kPlaneBytes + at);
+                        h8_t xl = xh;
+                        if constexpr (X3) xl = *(const h8_t*)(halo + kPlaneBytes + at);
 #pragma unroll
                         for (int m = 0; m < 2; ++m) {
-                            accx[m] = mma(wlo[ky & 1][m], xh, accx[m]);
-                            accx[m] = mma(whi[ky][m], xl, accx[m]);
+                            if constexpr (X3) {
+                                accx[m] = mma(wlo[ky & 1][m], xh, accx[m]);
+                                accx[m] = mma(whi[ky][m], xl, accx[m]);
+                            }
                             accx[m] = mma(whi[ky][m], xh, accx[m]);
                         }
                     }
@@ -204,14 +219,23 @@ __global__ __launch_bounds__(256, 2) void stem_pool_x3(const StemParams p)
                     for (int q = 0; q < 8; ++q) {
                         float y = __builtin_fmaf(acc[q >> 2][ni][q & 3], sc[q], sh[q]);
                         if (p.relu) y = fmaxf(y, 0.f);
-                        _Float16 a, b;
-                        split1(y, a, b);
-                        vh[q] = a; vl[q] = b;
-                        acc[q >> 2][ni][q & 3] = __fadd_rn((float)a, (float)b);      // exact in fp32
+                        if constexpr (X3) {
+                            _Float16 a, b;
+                            split1(y, a, b);
+                            vh[q] = a; vl[q] = b;
+                            acc[q >> 2][ni][q & 3] = __fadd_rn((float)a, (float)b);      // exact in fp32
+                        } else {
+                            vh[q] = (_Float16)__builtin_amdgcn_fmed3f(y, -65504.f, 65504.f);      // (= pack_f16x2: saturate, round to nearest even)
+                            acc[q >> 2][ni][q & 3] = (float)vh[q];                       // what maxpool_kernel reads back
+                        }
                     }
-                    uint16_t* dst = (uint16_t*)p.out + pix * 128 + half * 64 + fg * 8;      // channel group `half`: [32 hi][32 lo]
-                    *(h8_t*)dst = vh;
-                    *(h8_t*)(dst + 32) = vl;
+                    if constexpr (X3) {
+                        uint16_t* dst = (uint16_t*)p.out + pix * 128 + half * 64 + fg * 8;      // channel group `half`: [32 hi][32 lo]
+                        *(h8_t*)dst = vh;
+                        *(h8_t*)(dst + 32) = vl;
+                    } else {
+                        *(h8_t*)((uint16_t*)p.out + pix * 64 + half * 32 + fg * 8) = vh;
+                    }
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -259,9 +283,15 @@ __global__ __launch_bounds__(256, 2) void stem_pool_x3(const StemParams p)
                 for (int q = 0; q < 8; ++q) {
                     float y = __builtin_fmaf(accx[q >> 2][q & 3], sc[q], sh[q]);
                     if (p.relu) y = fmaxf(y, 0.f);
-                    _Float16 a, b;
-                    split1(y, a, b);
-                    float v = __builtin_fmaf(__fadd_rn((float)a, (float)b), ps[q], pb[q]);
+                    float back;
+                    if constexpr (X3) {
+                        _Float16 a, b;
+                        split1(y, a, b);
+                        back = __fadd_rn((float)a, (float)b);
+                    } else {
+                        back = (float)(_Float16)__builtin_amdgcn_fmed3f(y, -65504.f, 65504.f);
+                    }
+                    float v = __builtin_fmaf(back, ps[q], pb[q]);
                     if (p.pool_relu) v = fmaxf(v, 0.f);
                     zx[q] = v;
                 }
@@ -311,11 +341,17 @@ __global__ __launch_bounds__(256, 2) void stem_pool_x3(const StemParams p)
                 }
                 if (row_ok && PX >= 0 && PX < p.pool_Wo) {
                     h8_t vh, vl;
+                    if constexpr (X3) {
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) { _Float16 a, b; split1(m[q], a, b); vh[q] = a; vl[q] = b; }
-                    uint16_t* dst = (uint16_t*)p.pool_out + (((size_t)n * p.pool_Ho + PY) * p.pool_Wo + PX) * 128 + half * 64 + oc * 8;
-                    *(h8_t*)dst = vh;
-                    *(h8_t*)(dst + 32) = vl;
+                        for (int q = 0; q < 8; ++q) { _Float16 a, b; split1(m[q], a, b); vh[q] = a; vl[q] = b; }
+                        uint16_t* dst = (uint16_t*)p.pool_out + (((size_t)n * p.pool_Ho + PY) * p.pool_Wo + PX) * 128 + half * 64 + oc * 8;
+                        *(h8_t*)dst = vh;
+                        *(h8_t*)(dst + 32) = vl;
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) vh[q] = (_Float16)__builtin_amdgcn_fmed3f(m[q], -65504.f, 65504.f);      // (= to_elem<_Float16>)
+                        *(h8_t*)((uint16_t*)p.pool_out + (((size_t)n * p.pool_Ho + PY) * p.pool_Wo + PX) * 64 + half * 32 + oc * 8) = vh;
+                    }
                 }
             }
             par ^= 1;
@@ -330,7 +366,9 @@ hipError_t launch_stem_pool_x3(const StemParams& p, int num_cus, hipStream_t s)
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
     if (!attr_done[dev & 63]) {
-        e = hipFuncSetAttribute((const void*)stem_pool_x3, hipFuncAttributeMaxDynamicSharedMemorySize, kStemPoolLdsBytes);
+        e = hipFuncSetAttribute((const void*)stem_pool<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kStemPoolLdsBytes);
+        if (e != hipSuccess) return e;
+        e = hipFuncSetAttribute((const void*)stem_pool<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kStemPoolF16LdsBytes);
         if (e != hipSuccess) return e;
         attr_done[dev & 63] = true;
     }
@@ -339,7 +377,8 @@ hipError_t launch_stem_pool_x3(const StemParams& p, int num_cus, hipStream_t s)
     int groups = (n_strips + 7) / 8;
     const int max_groups = (2 * num_cus) / 16 > 0 ? (2 * num_cus) / 16 : 1;
     if (groups > max_groups) groups = max_groups;
-    hipLaunchKernelGGL(stem_pool_x3, dim3(groups * 16), dim3(256), kStemPoolLdsBytes, s, p);
+    if (p.x3) hipLaunchKernelGGL(stem_pool<true>, dim3(groups * 16), dim3(256), kStemPoolLdsBytes, s, p);
+    else hipLaunchKernelGGL(stem_pool<false>, dim3(groups * 16), dim3(256), kStemPoolF16LdsBytes, s, p);
     return hipGetLastError();
 }
 

@@ -182,14 +182,19 @@ def test_fused_x3_identity_blocks_match_their_three_convs(hw):
     model.release()
 
 
+@pytest.mark.parametrize("precision", ["f16x3", "f16"])
 @pytest.mark.parametrize("hw,nb", [((64, 96), 3), ((224, 256), 5), ((448, 448), 9)])
-def test_fused_x3_stem_pool_matches_the_two_launches(hw, nb):
-    """Split mode: the stem and its max-pool run as ONE launch (csrc/stem_pool_x3.hip: pool windows taken from the epilogue's values,
+def test_fused_x3_stem_pool_matches_the_two_launches(hw, nb, precision):
+    """Split mode (and the plain fp16 mode: `stem_pool<false>`, one plane, the pool reads back the ROUNDED f1): the stem and its max-pool run as ONE launch (csrc/stem_pool_x3.hip: pool windows taken from the epilogue's values,
     channel-half blocks walking 16-row strips, one recomputed row per tile).  Against the two-launch form (conv variant bit 22:
     stem_conv_pairs_x3 + maxpool_kernel) every tensor of the plan -- the stem's raw f1 skip, the pooled tensor, everything after --
     must be the same bits: the pool is the maximum over the same fp32 numbers (hi + lo of the stored f1, one fma, ReLU)."""
     h, wd = hw
-    cfg, w, g, model = make_model(2, h, wd, seed=6, precision="f16x3", max_batch=nb + 2, calib_hw=min(160, max(h, wd)))
+    os.environ["SBBSEG_STEM_POOL_F16"] = "1"                 # (the plain mode's fused form is opt-in: no faster than the two launches)
+    try:
+        cfg, w, g, model = make_model(2, h, wd, seed=6, precision=precision, max_batch=nb + 2, calib_hw=min(160, max(h, wd)))
+    finally:
+        del os.environ["SBBSEG_STEM_POOL_F16"]
     names = [o["name"] for o in model.ctx.ops()]
     assert any(n.startswith("stem_") for n in names) and any(n.startswith("maxpool") for n in names), names
     x = (patches_from_page(h, wd, nb, seed=18) / 255.0).astype(np.float32)
@@ -215,7 +220,10 @@ def test_fused_x3_stem_pool_matches_the_two_launches(hw, nb):
     assert float(np.abs(t_fused[pooled[0]]).max()) > 0
     assert np.array_equal(got_fused, got_two)
     ref = kf.forward(g, w, x[:2])
-    assert float(np.abs(got_fused[:2] - ref).max()) < TOL_SOFTMAX["f16x3"] and exact_label_check(ref, got_fused[:2])[1] == 0
+    if precision == "f16x3":
+        assert float(np.abs(got_fused[:2] - ref).max()) < TOL_SOFTMAX["f16x3"] and exact_label_check(ref, got_fused[:2])[1] == 0
+    else:
+        assert float(np.abs(got_fused[:2] - ref).max()) < 0.2
     model.release()
 
 
