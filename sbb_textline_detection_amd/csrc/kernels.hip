@@ -2029,8 +2029,8 @@ __global__ __launch_bounds__(256, 2) void stem_conv_pairs(const StemParams p)
                 *(float4*)&sh[4] = *(const float4*)(cst + 64 + c0 + 4);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    y[q] = __builtin_fmaf(acc[2 * h][ni][q], sc[q], sh[q]);              // (stem_pool<false> states the same arithmetic)
-                    y[4 + q] = __builtin_fmaf(acc[2 * h + 1][ni][q], sc[4 + q], sh[4 + q]);
+                    y[q] = acc[2 * h][ni][q] * sc[q] + sh[q];                             // (contracted to one fma; stem_pool<false> states the same arithmetic)
+                    y[4 + q] = acc[2 * h + 1][ni][q] * sc[4 + q] + sh[4 + q];
                 }
                 if (p.relu) {
 #pragma unroll
