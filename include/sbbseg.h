@@ -80,6 +80,14 @@ int sbbseg_set_lanes(sbbseg_ctx* c, int lanes);
  * uint8 plane [H][W]; 3 = the reference's own return layout, uint8 [H][W][3] with three identical channels
  * (main.py:366, 380) -- replicated on the device, the host buffer must hold 3 x H x W bytes. */
 int sbbseg_set_label_channels(sbbseg_ctx* c, int channels);
+/* Duplicate clamped tiles (default on; SBBSEG_DEDUPE=0 or on = 0 switches it off): when (extent % mid) lies in (0, tile - mid]
+ * -- mid = tile - 2 * margin = 360 for the 448-pixel models, so 88 of every 360 page extents -- the inward clamp of main.py:276-281
+ * gives the LAST TWO tiles of that axis the same origin: the reference runs the same forward twice and pastes the same labels
+ * twice (a 448 x 448 page: four identical forwards).  The fused page entry points (sbbseg_segment_page[_dev / _scaled / _otsu],
+ * _segment_pages[_dev], _segment_crop[_dev]) compute each distinct tile once; the label map is the same byte for byte.  The
+ * tile-indexed entry points (sbbseg_tile_grid, _segment_tiles_dev, _segment_tile_range[_bin]_dev, _stitch_dev -- the multi-rank
+ * protocol) always keep the reference's call list. */
+int sbbseg_set_dedupe(sbbseg_ctx* c, int on);
 
 /* ---- plan building: the host-side planner (planner.py) lowers the Keras model_config that the
  * reference would have handed to keras.models.load_model (main.py:221) into these calls, in
@@ -339,7 +347,7 @@ int sbbseg_debug_set_conv_variant(sbbseg_ctx* c, int variant);
 /* the exact host-side contour ranking of sbbseg_page_box_dev on a host mask that is ALREADY dilated (no GPU needed; tests) */
 int sbbseg_debug_largest_contour(const uint8_t* mask_hw, int H, int W, int32_t* box_xywh, int64_t* pixels);
 /* counters: which 0 = how often sbbseg_page_box_dev had to fall back to the host ranking on this handle */
-int sbbseg_debug_counter(sbbseg_ctx* c, int which, int64_t* value);
+int sbbseg_debug_counter(sbbseg_ctx* c, int which, int64_t* value);      /* which: 0 = exact host contour rankings, 1 = patches run through the plan */
 /* Test hook for the no-abort guarantee: the nth_check-th next internal host-allocation checkpoint throws
  * std::bad_alloc, which every entry point turns into a non-zero status + sbbseg_last_error() instead of
  * terminating the process (main.py:2061-2157 relies on ordinary exceptions).  0 disarms.  Process-global. */

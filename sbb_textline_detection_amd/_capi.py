@@ -20,7 +20,7 @@ INPUT_C8, INPUT_PAIRS = 0, 1
 EXPORTS = [
     "sbbseg_last_error", "sbbseg_abi_version", "sbbseg_device_count", "sbbseg_create", "sbbseg_destroy",
     "sbbseg_model_load", "sbbseg_model_load_file", "sbbseg_debug_plan_summary",
-    "sbbseg_set_stream", "sbbseg_set_lanes", "sbbseg_set_label_channels", "sbbseg_synchronize", "sbbseg_set_input", "sbbseg_input_form", "sbbseg_add_tensor",
+    "sbbseg_set_stream", "sbbseg_set_lanes", "sbbseg_set_label_channels", "sbbseg_set_dedupe", "sbbseg_synchronize", "sbbseg_set_input", "sbbseg_input_form", "sbbseg_add_tensor",
     "sbbseg_add_conv", "sbbseg_add_maxpool", "sbbseg_add_tail", "sbbseg_add_head", "sbbseg_finalize", "sbbseg_model_info",
     "sbbseg_num_ops", "sbbseg_op_info", "sbbseg_op_issued_flops", "sbbseg_device_bytes", "sbbseg_predict", "sbbseg_segment_page",
     "sbbseg_segment_page_dev", "sbbseg_segment_pages_dev", "sbbseg_segment_page_scaled", "sbbseg_segment_page_otsu", "sbbseg_segment_crop", "sbbseg_segment_crop_dev", "sbbseg_debug_largest_contour", "sbbseg_debug_counter", "sbbseg_comm_unique_id", "sbbseg_comm_init", "sbbseg_comm_info", "sbbseg_comm_destroy", "sbbseg_allgather_labels_dev", "sbbseg_otsu_dev",
@@ -75,6 +75,7 @@ def load_library(path: Optional[str] = None):
         "sbbseg_synchronize": [vp],
         "sbbseg_set_lanes": [vp, i32],
         "sbbseg_set_label_channels": [vp, i32],
+        "sbbseg_set_dedupe": [vp, i32],
         "sbbseg_set_input": [vp, i32, i32, i32],
         "sbbseg_input_form": [vp, i32, i32, C.POINTER(C.c_int)],
         "sbbseg_add_tensor": [vp, i32, i32, i32, C.POINTER(C.c_int)],
@@ -284,6 +285,16 @@ class Context:
     def set_lanes(self, lanes: int):
         """1 = one stream; 2 (default) = chunks of >= 16 tiles run as two concurrent halves (see sbbseg.h)."""
         check(self.lib.sbbseg_set_lanes(self.h, int(lanes)), "sbbseg_set_lanes")
+
+    def set_dedupe(self, on: bool):
+        """Fused page paths compute a repeated clamped tile once (default on; same label map).  See sbbseg.h."""
+        check(self.lib.sbbseg_set_dedupe(self.h, int(bool(on))), "sbbseg_set_dedupe")
+
+    def forwards(self) -> int:
+        """Patches run through the plan on this handle so far."""
+        v = C.c_int64(0)
+        check(self.lib.sbbseg_debug_counter(self.h, 1, C.byref(v)), "sbbseg_debug_counter")
+        return int(v.value)
 
     def _label_out(self, h: int, w: int, channels: int) -> np.ndarray:
         """Output array for a host label map: one plane, or the reference's 3 identical channels (replicated on the

@@ -224,6 +224,13 @@ struct sbbseg_ctx {
     uint8_t* d_tile_labels = nullptr; size_t tile_labels_cap = 0;
     int *d_own_x = nullptr, *d_own_y = nullptr; size_t own_cap = 0;
     int own_Hp = -1, own_Wp = -1, own_nyf = 0;
+    bool own_dedupe = false;          // the cached owner tables index the deduplicated grid (see fused_grid)
+    // Duplicate clamped tiles: when extent % mid lies in (0, tile - mid] the inward clamp (main.py:276-281) gives the LAST
+    // TWO tiles of an axis the same origin -- the reference runs the same forward twice and pastes the same labels twice.  The fused
+    // page paths skip the repeat (same label map, 1 / n of the forwards of that axis saved); the tile-indexed entry points
+    // (sbbseg_tile_grid, _segment_tile_range_dev, _stitch_dev: the multi-rank protocol) keep the reference's call list.
+    bool dedupe = true;               // sbbseg_set_dedupe / SBBSEG_DEDUPE=0
+    int64_t forwards = 0;             // patches run through the plan so far (sbbseg_debug_counter 1)
     int *d_map = nullptr; size_t map_cap = 0;
     int *d_wmap = nullptr; size_t wmap_cap = 0;      // gather tables of the whole-image branch, cached per geometry
     int wmap_key[6] = {0, 0, 0, 0, 0, 0};            // {Hp, Wp, Hs, Ws, out_h, out_w} (0 = none)
@@ -521,6 +528,7 @@ int launch_op(sbbseg_ctx* c, Op& op, int n, uint8_t* d_labels, float* d_probs)
 
 int run_plan(sbbseg_ctx* c, int n, uint8_t* d_labels, float* d_probs)
 {
+    c->forwards += n;
     for (size_t i = 0; i < c->ops.size(); ++i) {
         Op& op = c->ops[i];
         hipEvent_t ea = nullptr, eb = nullptr;
@@ -766,7 +774,19 @@ int sbbseg_create(int device, int precision, sbbseg_ctx** out)
         return fail("hipStreamCreate failed: %s", hipGetErrorString(e));
     }
     c->stream = c->own_stream;
-    e = hipStreamCreateWithFlags(&c->lane_stream, hipStreamNonBlocking);
+    // The second lane's stream is created in ANOTHER PRIORITY CLASS than the handle's own stream.  HIP multiplexes streams onto a few
+    // hardware queues per priority class (GPU_MAX_HW_QUEUES, default 4, dealt round robin): when a handle's two streams land on the
+    // same queue its lanes serialise behind each other's barrier packets -- measured 26.4 ms instead of 22.9 ms per 108-tile page on the
+    // SECOND handle of a process (the fourth with 8 queues, none of five with 16: tools/handle_order_probe.py, profiles/r04_experiments.md
+    // section 10); configs[2]'s layout stage was that handle.  Queues of different priority classes are never shared.
+    // SBBSEG_LANE_PRIORITY: -1 (default) = the device's highest priority, 0 = same class as the own stream (the old behaviour), 1 = lowest
+    {
+        int least = 0, greatest = 0, want = -1;
+        if (const char* v = getenv("SBBSEG_LANE_PRIORITY")) want = atoi(v);
+        if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) { (void)hipGetLastError(); least = greatest = 0; }
+        const int prio = want < 0 ? greatest : want > 0 ? least : 0;
+        e = prio != 0 ? hipStreamCreateWithPriority(&c->lane_stream, hipStreamNonBlocking, prio) : hipStreamCreateWithFlags(&c->lane_stream, hipStreamNonBlocking);
+    }
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming);
     if (e != hipSuccess) {
@@ -798,6 +818,7 @@ int sbbseg_create(int device, int precision, sbbseg_ctx** out)
         }
     }
     if (const char* v = getenv("SBBSEG_STAGGER_MIN_TILES")) c->stagger_min_tiles = atoi(v);
+    if (const char* v = getenv("SBBSEG_DEDUPE")) c->dedupe = v[0] != '0';
     *out = c;
     return 0;
     API_END
@@ -892,6 +913,15 @@ int sbbseg_set_label_channels(sbbseg_ctx* c, int channels)
     API_BEGIN
     REQUIRE(c && (channels == 1 || channels == 3), "label channels must be 1 or 3");
     c->label_channels = channels;
+    return 0;
+    API_END
+}
+
+int sbbseg_set_dedupe(sbbseg_ctx* c, int on)
+{
+    API_BEGIN
+    REQUIRE(c && (on == 0 || on == 1), "dedupe must be 0 or 1");
+    c->dedupe = on != 0;
     return 0;
     API_END
 }
@@ -1990,16 +2020,31 @@ int sbbseg_segment_tiles_dev(sbbseg_ctx* c, const void* d_page_hwc, int Hp, int 
     API_END
 }
 
+// Tile grid of the FUSED page paths: the reference's grid (sbbseg_tile_grid) minus the repeated last tile of an axis whose last two
+// origins coincide (at most the last two can: three equal origins would need 2 * mid < tile - mid).  Origins are still
+// min(t * mid, extent - tile) for t < n', so the ingest kernel's closed form holds on the smaller grid; the dropped tile's pixels
+// [origin + margin, origin + tile) are exactly what tile n' - 1 pastes as the new last tile (axis_owner with dedupe).
+static int fused_grid(const sbbseg_ctx* c, int Hp, int Wp, bool dedupe, int* nx, int* ny)
+{
+    if (sbbseg_tile_grid(Hp, Wp, c->in_H, c->in_W, nullptr, 0, nx, ny)) return 1;
+    if (!dedupe) return 0;
+    const int margin = margin_of(c->in_W);
+    std::vector<int> o;
+    if (axis_tiles(Wp, c->in_W, margin, o) >= 2 && o[o.size() - 1] == o[o.size() - 2]) --*nx;
+    if (axis_tiles(Hp, c->in_H, margin, o) >= 2 && o[o.size() - 1] == o[o.size() - 2]) --*ny;
+    return 0;
+}
+
 // Tiles [first_tile, first_tile + n_tiles) of the tile list of `n_pages` equally sized pages (page-major: tile g = page g / tpp,
 // grid index g % tpp) -> d_tile_labels[g - first_tile].  Chunks of <= max_batch tiles may span pages: big launches fill the chip's
 // persistent grids better than one page's 70 tiles (profiles/r02_experiments.md).
 static int tile_range_impl(sbbseg_ctx* c, const void* const* d_pages, int n_pages, int src_Hp, int src_Wp, const int* d_map_y, const int* d_map_x,
-                           int Hp, int Wp, int first_tile, int n_tiles, void* d_tile_labels, const int* d_bin_thr = nullptr)
+                           int Hp, int Wp, int first_tile, int n_tiles, void* d_tile_labels, const int* d_bin_thr = nullptr, bool dedupe = false)
 {
     REQUIRE(d_pages && n_pages >= 1 && d_tile_labels && first_tile >= 0 && n_tiles >= 0, "bad arguments");
     for (int k = 0; k < n_pages; ++k) REQUIRE(d_pages[k], "null page pointer (page %d)", k);
     int nx = 0, ny = 0;
-    if (sbbseg_tile_grid(Hp, Wp, c->in_H, c->in_W, nullptr, 0, &nx, &ny)) return 1;
+    if (fused_grid(c, Hp, Wp, dedupe, &nx, &ny)) return 1;
     const int tpp = nx * ny;
     REQUIRE((long)first_tile + n_tiles <= (long)tpp * n_pages, "tile range [%d,%d) exceeds the %d tiles of the %d page(s)", first_tile,
             first_tile + n_tiles, tpp * n_pages, n_pages);
@@ -2103,14 +2148,18 @@ int sbbseg_segment_tile_range_dev(sbbseg_ctx* c, const void* d_page_hwc, int Hp,
     API_END
 }
 
-static int prepare_owner(sbbseg_ctx* c, int Hp, int Wp)
+static int prepare_owner(sbbseg_ctx* c, int Hp, int Wp, bool dedupe)
 {
-    if (c->own_Hp == Hp && c->own_Wp == Wp) return 0;
+    if (c->own_Hp == Hp && c->own_Wp == Wp && c->own_dedupe == dedupe) return 0;
     alloc_check();
     std::vector<int> ox, oy, own_x, own_y;
     const int margin = margin_of(c->in_W);
-    const int nx = axis_tiles(Wp, c->in_W, margin, ox), ny = axis_tiles(Hp, c->in_H, margin, oy);
+    int nx = axis_tiles(Wp, c->in_W, margin, ox), ny = axis_tiles(Hp, c->in_H, margin, oy);
     REQUIRE(nx > 0 && ny > 0, "page %dx%d is smaller than the model input", Hp, Wp);
+    if (dedupe) {                              // (fused_grid: the repeated last tile of an axis is not computed)
+        if (nx >= 2 && ox[nx - 1] == ox[nx - 2]) ox.resize(--nx);
+        if (ny >= 2 && oy[ny - 1] == oy[ny - 2]) oy.resize(--ny);
+    }
     axis_owner(Wp, c->in_W, margin, ox, own_x);
     axis_owner(Hp, c->in_H, margin, oy, own_y);
     const size_t need = sizeof(int) * (size_t)(Hp > Wp ? Hp : Wp);
@@ -2124,7 +2173,16 @@ static int prepare_owner(sbbseg_ctx* c, int Hp, int Wp)
     HIPCHK(hipStreamSynchronize(c->stream));   // tables may still be in use by an earlier stitch
     HIPCHK(hipMemcpy(c->d_own_x, own_x.data(), sizeof(int) * Wp, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(c->d_own_y, own_y.data(), sizeof(int) * Hp, hipMemcpyHostToDevice));
-    c->own_Hp = Hp; c->own_Wp = Wp; c->own_nyf = ny;
+    c->own_Hp = Hp; c->own_Wp = Wp; c->own_nyf = ny; c->own_dedupe = dedupe;
+    return 0;
+}
+
+static int stitch_impl(sbbseg_ctx* c, const void* d_tile_labels, int Hp, int Wp, void* d_labels_hw, bool dedupe)
+{
+    REQUIRE(d_tile_labels && d_labels_hw, "bad arguments");
+    if (prepare_owner(c, Hp, Wp, dedupe)) return 1;
+    HIPCHK(launch_stitch((const uint8_t*)d_tile_labels, c->in_H, c->in_W, c->d_own_x, c->d_own_y, c->own_nyf, Hp, Wp,
+                         (uint8_t*)d_labels_hw, c->stream));
     return 0;
 }
 
@@ -2132,11 +2190,7 @@ int sbbseg_stitch_dev(sbbseg_ctx* c, const void* d_tile_labels, int Hp, int Wp, 
 {
     API_BEGIN
     if (check_ready(c)) return 1;
-    REQUIRE(d_tile_labels && d_labels_hw, "bad arguments");
-    if (prepare_owner(c, Hp, Wp)) return 1;
-    HIPCHK(launch_stitch((const uint8_t*)d_tile_labels, c->in_H, c->in_W, c->d_own_x, c->d_own_y, c->own_nyf, Hp, Wp,
-                         (uint8_t*)d_labels_hw, c->stream));
-    return 0;
+    return stitch_impl(c, d_tile_labels, Hp, Wp, d_labels_hw, false);      // tile labels in the reference's call order
     API_END
 }
 
@@ -2145,10 +2199,10 @@ int sbbseg_segment_page_dev(sbbseg_ctx* c, const void* d_page_hwc, int Hp, int W
     API_BEGIN
     if (check_ready(c)) return 1;
     int nx = 0, ny = 0;
-    if (sbbseg_tile_grid(Hp, Wp, c->in_H, c->in_W, nullptr, 0, &nx, &ny)) return 1;
+    if (fused_grid(c, Hp, Wp, c->dedupe, &nx, &ny)) return 1;
     if (ensure(c, (void**)&c->d_tile_labels, &c->tile_labels_cap, (size_t)nx * ny * c->in_H * c->in_W)) return 1;
-    if (sbbseg_segment_tile_range_dev(c, d_page_hwc, Hp, Wp, 0, nx * ny, c->d_tile_labels)) return 1;
-    return sbbseg_stitch_dev(c, c->d_tile_labels, Hp, Wp, d_labels_hw);
+    if (tile_range_impl(c, &d_page_hwc, 1, Hp, Wp, nullptr, nullptr, Hp, Wp, 0, nx * ny, c->d_tile_labels, nullptr, c->dedupe)) return 1;
+    return stitch_impl(c, c->d_tile_labels, Hp, Wp, d_labels_hw, c->dedupe);
     API_END
 }
 
@@ -2159,7 +2213,7 @@ int sbbseg_segment_pages_dev(sbbseg_ctx* c, int n_pages, const void* const* d_pa
     REQUIRE(n_pages >= 1 && d_pages_hwc && d_labels_hw, "bad arguments");
     for (int k = 0; k < n_pages; ++k) REQUIRE(d_pages_hwc[k] && d_labels_hw[k], "null page / label pointer (page %d)", k);
     int nx = 0, ny = 0;
-    if (sbbseg_tile_grid(Hp, Wp, c->in_H, c->in_W, nullptr, 0, &nx, &ny)) return 1;
+    if (fused_grid(c, Hp, Wp, c->dedupe, &nx, &ny)) return 1;
     const size_t per = (size_t)c->in_H * c->in_W, tpp = (size_t)nx * ny;
     // Pages are pooled in GROUPS whose tile count is a whole number of chunks where that is possible with few pages
     // (lcm(tiles per page, max_batch)), else about eight chunks: the tile-label scratch stays bounded by the group, not
@@ -2181,9 +2235,9 @@ int sbbseg_segment_pages_dev(sbbseg_ctx* c, int n_pages, const void* const* d_pa
     if (ensure(c, (void**)&c->d_tile_labels, &c->tile_labels_cap, tpp * G * per)) return 1;
     for (size_t g0 = 0; g0 < (size_t)n_pages; g0 += G) {
         const size_t np = g0 + G <= (size_t)n_pages ? G : (size_t)n_pages - g0;
-        if (tile_range_impl(c, d_pages_hwc + g0, (int)np, Hp, Wp, nullptr, nullptr, Hp, Wp, 0, (int)(tpp * np), c->d_tile_labels)) return 1;
+        if (tile_range_impl(c, d_pages_hwc + g0, (int)np, Hp, Wp, nullptr, nullptr, Hp, Wp, 0, (int)(tpp * np), c->d_tile_labels, nullptr, c->dedupe)) return 1;
         for (size_t k = 0; k < np; ++k)
-            if (sbbseg_stitch_dev(c, c->d_tile_labels + k * tpp * per, Hp, Wp, d_labels_hw[g0 + k])) return 1;
+            if (stitch_impl(c, c->d_tile_labels + k * tpp * per, Hp, Wp, d_labels_hw[g0 + k], c->dedupe)) return 1;
     }
     return 0;
     API_END
@@ -2200,7 +2254,7 @@ int sbbseg_segment_pages(sbbseg_ctx* c, int n_pages, const uint8_t* const* pages
     for (int k = 0; k < n_pages; ++k) REQUIRE(pages_hwc[k] && labels_hw[k], "null page / label pointer (page %d)", k);
     REQUIRE(Hp >= c->in_H && Wp >= c->in_W, "page %dx%d is smaller than the model input %dx%d (unsupported by the reference too, main.py:278-281)", Hp, Wp, c->in_H, c->in_W);
     int nx = 0, ny = 0;
-    if (sbbseg_tile_grid(Hp, Wp, c->in_H, c->in_W, nullptr, 0, &nx, &ny)) return 1;
+    if (fused_grid(c, Hp, Wp, c->dedupe, &nx, &ny)) return 1;
     const size_t pix = (size_t)Hp * Wp, in_b = pix * 3, ch = c->label_channels == 3 ? 3 : 1, out_b = pix * ch;
     const size_t out3_b = (pix + 3) / 4 * 12;                          // launch_replicate3 writes whole 12-byte groups
     int G = c->max_batch / (nx * ny);
@@ -2323,11 +2377,11 @@ int sbbseg_segment_page_scaled(sbbseg_ctx* c, const uint8_t* page_hwc, int Hs, i
     HIPCHK(hipMemcpy(d_mx, mx.data(), sizeof(int) * Wp, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpyAsync(c->d_page, page_hwc, spix * 3, hipMemcpyHostToDevice, c->stream));
     int nx = 0, ny = 0;
-    if (sbbseg_tile_grid(Hp, Wp, c->in_H, c->in_W, nullptr, 0, &nx, &ny)) return 1;
+    if (fused_grid(c, Hp, Wp, c->dedupe, &nx, &ny)) return 1;
     if (ensure(c, (void**)&c->d_tile_labels, &c->tile_labels_cap, (size_t)nx * ny * c->in_H * c->in_W)) return 1;
     const void* pg_ = c->d_page;
-    if (tile_range_impl(c, &pg_, 1, Hs, Ws, d_my, d_mx, Hp, Wp, 0, nx * ny, c->d_tile_labels)) return 1;
-    if (sbbseg_stitch_dev(c, c->d_tile_labels, Hp, Wp, c->d_page_labels)) return 1;
+    if (tile_range_impl(c, &pg_, 1, Hs, Ws, d_my, d_mx, Hp, Wp, 0, nx * ny, c->d_tile_labels, nullptr, c->dedupe)) return 1;
+    if (stitch_impl(c, c->d_tile_labels, Hp, Wp, c->d_page_labels, c->dedupe)) return 1;
     if (labels_to_host(c, labels_hw, pix)) return 1;
     HIPCHK(hipStreamSynchronize(c->stream));
     return 0;
@@ -2381,11 +2435,11 @@ int sbbseg_segment_page_otsu(sbbseg_ctx* c, const uint8_t* page_hwc, int Hs, int
     int* d_thr = (int*)(c->d_hist + 256);
     HIPCHK(launch_otsu(c->d_page, Ws, Hp, Wp, d_my, d_mx, c->d_hist, d_thr, c->num_cus, c->stream));
     int nx = 0, ny = 0;
-    if (sbbseg_tile_grid(Hp, Wp, c->in_H, c->in_W, nullptr, 0, &nx, &ny)) return 1;
+    if (fused_grid(c, Hp, Wp, c->dedupe, &nx, &ny)) return 1;
     if (ensure(c, (void**)&c->d_tile_labels, &c->tile_labels_cap, (size_t)nx * ny * c->in_H * c->in_W)) return 1;
     const void* pg_ = c->d_page;
-    if (tile_range_impl(c, &pg_, 1, Hs, Ws, d_my, d_mx, Hp, Wp, 0, nx * ny, c->d_tile_labels, d_thr)) return 1;
-    if (sbbseg_stitch_dev(c, c->d_tile_labels, Hp, Wp, c->d_page_labels)) return 1;
+    if (tile_range_impl(c, &pg_, 1, Hs, Ws, d_my, d_mx, Hp, Wp, 0, nx * ny, c->d_tile_labels, d_thr, c->dedupe)) return 1;
+    if (stitch_impl(c, c->d_tile_labels, Hp, Wp, c->d_page_labels, c->dedupe)) return 1;
     if (labels_to_host(c, labels_hw, pix)) return 1;
     int thr = 0;
     HIPCHK(hipMemcpyAsync(&thr, d_thr, sizeof(int), hipMemcpyDeviceToHost, c->stream));
@@ -2426,10 +2480,10 @@ int sbbseg_segment_crop_dev(sbbseg_ctx* c, const void* d_page_hwc, int Hs, int W
         HIPCHK(launch_otsu((const uint8_t*)d_page_hwc, Ws, ch, cw, d_my, d_mx, c->d_hist, d_thr, c->num_cus, c->stream));
     }
     int nx = 0, ny = 0;
-    if (sbbseg_tile_grid(ch, cw, c->in_H, c->in_W, nullptr, 0, &nx, &ny)) return 1;
+    if (fused_grid(c, ch, cw, c->dedupe, &nx, &ny)) return 1;
     if (ensure(c, (void**)&c->d_tile_labels, &c->tile_labels_cap, (size_t)nx * ny * c->in_H * c->in_W)) return 1;
-    if (tile_range_impl(c, &d_page_hwc, 1, Hs, Ws, d_my, d_mx, ch, cw, 0, nx * ny, c->d_tile_labels, d_thr)) return 1;
-    return sbbseg_stitch_dev(c, c->d_tile_labels, ch, cw, d_labels_hw);
+    if (tile_range_impl(c, &d_page_hwc, 1, Hs, Ws, d_my, d_mx, ch, cw, 0, nx * ny, c->d_tile_labels, d_thr, c->dedupe)) return 1;
+    return stitch_impl(c, c->d_tile_labels, ch, cw, d_labels_hw, c->dedupe);
     API_END
 }
 
@@ -2883,8 +2937,8 @@ int sbbseg_debug_largest_contour(const uint8_t* mask_hw, int H, int W, int32_t* 
 int sbbseg_debug_counter(sbbseg_ctx* c, int which, int64_t* value)
 {
     API_BEGIN
-    REQUIRE(c && value && which == 0, "unknown counter %d", which);
-    *value = c->host_contour_calls;
+    REQUIRE(c && value && (which == 0 || which == 1), "unknown counter %d (0 = exact host contour rankings, 1 = patches run through the plan)", which);
+    *value = which == 0 ? (int64_t)c->host_contour_calls : c->forwards;
     return 0;
     API_END
 }

@@ -1314,3 +1314,43 @@ def test_extract_page_box_dev_equals_host_entry(torch_cuda, stitch_model):
         assert box_d == box_h and px_d == px_h
         assert np.array_equal(d_mask.cpu().numpy(), mask_h)
         assert ctx.extract_page_box_dev(d_page.data_ptr(), h, w, hs, ws) == (box_h, px_h)
+
+
+def test_fused_paths_compute_repeated_clamped_tiles_once():
+    """when the inward clamp (main.py:276-281) gives the last two tiles of an axis the same origin the reference
+    runs the same forward twice.  The fused page paths skip the repeat: same label map as the reference loop (oracle tiling code
+    over the HIP model's predict), fewer patches through the plan; sbbseg_set_dedupe(0) restores the reference's call count."""
+    cfg, w, g, model = make_model(2, 224, 224, seed=5, precision="f16", max_batch=20)
+    mid = 224 - 2 * 22                                             # 180
+    # (page h, page w, distinct tiles, reference calls): repeat in y, in x, in both, in neither, and the one-tile page
+    cases = [(2 * mid + 30, 3 * mid + 100, 2 * 4, 3 * 4), (3 * mid + 100, 2 * mid + 44, 4 * 2, 4 * 3), (224, 2 * mid + 7, 1 * 2, 2 * 3),
+             (2 * mid + 45, 2 * mid + 45, 3 * 3, 3 * 3), (224, 224, 1, 4)]
+    for hp, wp, distinct, calls in cases:
+        page = synthetic_page(hp, wp, seed=hp + 3 * wp)
+        xy, nx, ny = _capi.tile_grid(hp, wp, 224, 224)
+        assert nx * ny == calls and len({tuple(o) for o in xy.tolist()}) == distinct, (hp, wp)
+        loop = tiling.do_prediction(True, page, model)            # the reference loop: one predict per call, repeats included
+        model.ctx.set_dedupe(True)
+        f0 = model.ctx.forwards()
+        fused = predict.do_prediction(True, page, model)
+        assert model.ctx.forwards() - f0 == distinct, (hp, wp)
+        model.ctx.set_dedupe(False)
+        f0 = model.ctx.forwards()
+        plain = predict.do_prediction(True, page, model)
+        assert model.ctx.forwards() - f0 == calls, (hp, wp)
+        assert np.array_equal(fused, loop) and np.array_equal(plain, loop), (hp, wp)
+    # pooled pages and the crop entry point index the same smaller grid
+    model.ctx.set_dedupe(True)
+    hp, wp = 2 * mid + 30, 3 * mid + 100
+    pages = [synthetic_page(hp, wp, seed=s) for s in (1, 2, 3)]
+    f0 = model.ctx.forwards()
+    pooled = model.ctx.segment_pages(pages)
+    assert model.ctx.forwards() - f0 == 3 * 8
+    for pg, got in zip(pages, pooled):
+        assert np.array_equal(got, model.segment_page(pg))
+    big = synthetic_page(hp + 60, wp + 40, seed=9)
+    box = (17, 23, wp, hp)
+    got = model.ctx.segment_crop(big, hp + 60, wp + 40, box, False)
+    want = model.segment_page(np.ascontiguousarray(big[23:23 + hp, 17:17 + wp]))
+    assert np.array_equal(got[0], want)
+    model.release()
