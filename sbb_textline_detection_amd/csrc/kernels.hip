@@ -1299,13 +1299,9 @@ static hipError_t launch_conv_x3(const ConvParams& p, hipStream_t s)
         if (p.cout % 256 == 0 && p.Ktot >= k256 && t256 >= 200) return launch_conv_t<256, 256, 2, 4, 2, true, 8, false, true>(p, s);
         if (p.Ktot >= k512 && t512 >= 200) return launch_conv_t<512, 128, 4, 2, 2, true, 8, false, true>(p, s);
     }
-    // launches of less than one round of tiles (one patch, the border model's whole-image forward: 2-32 tiles of 100-300 K-steps each):
-    // a K-step then costs the latency of its own loads (~1.4 us against 0.3 us of MFMAs) -- a deeper ring keeps more of them in flight
-    static const int small_ns = getenv("SBBSEG_X3_SMALL_NS") ? atoi(getenv("SBBSEG_X3_SMALL_NS")) : 0;      // probe knob: 3 or 4
-    if (bc == 128 && small_ns >= 3 && p.total_ksteps >= 8) {
-        const long t128 = (long)p.n_cls * ((p.M + 127) / 128) * ((p.cout + 127) / 128);
-        if (t128 <= 256) return small_ns == 3 ? launch_conv_t<128, 128, 2, 2, 3, true, 8, false, true>(p, s) : launch_conv_t<128, 128, 2, 2, 4, true, 8, false, true>(p, s);
-    }
+    // (launches of less than one round of tiles -- one patch, the border model's whole-image forward -- cost the latency of their K-steps'
+    // loads, ~1.4 us a step; 3- and 4-stage rings of the 128 x 128 tile were probed there and LOST, 3.57 vs 2.67 ms per one-patch forward:
+    // the deeper rings run the plain gather, whose address arithmetic outweighs the extra loads in flight; profiles/r04_experiments.md section 12)
     if (bc == 128) return launch_conv_t<128, 128, 2, 2, 2, true, 8, false, true>(p, s);
     if (bc == 64) return launch_conv_t<256, 64, 4, 1, 2, true, 8, false, true>(p, s);
     return launch_conv_t<256, 32, 4, 1, 2, true, 8, false, true>(p, s);
