@@ -192,6 +192,7 @@ struct sbbseg_ctx {
     hipStream_t lane_stream = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int lanes = 2, lane1_batch = 0;
+    int lane_prio = 0, prio_least = 0, prio_greatest = 0;      // priority class of lane_stream (never the own stream's class: see sbbseg_create)
     // CU-partitioned lanes (round 4, opt-in: SBBSEG_CU_SPLIT=1): two private streams, each confined to HALF of the chip's CUs (hipExtStreamCreateWithCUMask: the
     // mask's bits are dealt round-robin over the eight XCDs, so each half = 16 CUs of every XCD).  The chip is power-capped under
     // dense MFMA (1 350 TFLOP/s at 1.65 GHz on 256 CUs, 910 at 2.2 GHz on 128) and its HBM fabric saturates from half the CUs
@@ -786,6 +787,7 @@ int sbbseg_create(int device, int precision, sbbseg_ctx** out)
         if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) { (void)hipGetLastError(); least = greatest = 0; }
         const int prio = want < 0 ? greatest : want > 0 ? least : 0;
         e = prio != 0 ? hipStreamCreateWithPriority(&c->lane_stream, hipStreamNonBlocking, prio) : hipStreamCreateWithFlags(&c->lane_stream, hipStreamNonBlocking);
+        c->lane_prio = prio; c->prio_least = least; c->prio_greatest = greatest;
     }
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming);
@@ -894,6 +896,20 @@ int sbbseg_set_stream(sbbseg_ctx* c, void* hip_stream)
     if (resolve_pending(c)) return 1;
     // NULL is a real stream (the legacy default stream torch uses unless told otherwise)
     c->stream = hip_stream == SBBSEG_OWN_STREAM ? c->own_stream : (hipStream_t)hip_stream;
+    // a caller's stream of the lane stream's own priority class could share its hardware queue (see sbbseg_create): move the lane
+    // stream to the other end of the range
+    int up = 0;
+    if (hip_stream != SBBSEG_OWN_STREAM && hip_stream && c->lane_prio != 0 && c->prio_least != c->prio_greatest &&
+        hipStreamGetPriority((hipStream_t)hip_stream, &up) == hipSuccess && up == c->lane_prio) {
+        const int other = c->lane_prio == c->prio_greatest ? c->prio_least : c->prio_greatest;
+        hipStream_t ns = nullptr;
+        if (other != 0 && hipStreamCreateWithPriority(&ns, hipStreamNonBlocking, other) == hipSuccess) {
+            HIPCHK(hipStreamSynchronize(c->lane_stream));
+            HIPCHK(hipStreamDestroy(c->lane_stream));
+            c->lane_stream = ns;
+            c->lane_prio = other;
+        } else (void)hipGetLastError();
+    }
     return 0;
     API_END
 }
