@@ -1017,39 +1017,91 @@ void conv_igemm_mfma(const ConvParams p)
         const bool late_issue = kSplitIssue && wave >= NW / 2 && !(p.variant_flags & 8);
         if (!late_issue && issued < total) issue(nxt);
         const char* sb = smem + cur * T::kStageBytes;
+        if constexpr (X3 && T::kNI >= 8) {
+            // issue() has just requested the NEXT stage's K-step record through the scalar cache (s_load: lgkmcnt, may return out of order).
+            // With it pending the compiler must wait lgkmcnt(0) -- for ALL sixteen fragment requests below -- in front of the first MFMA; a use
+            // it can see makes it wait for the record HERE (a few dozen cycles, scalar cache hit), after which the fragment waits are counted.
+            asm volatile("" ::"s"(rec_yx), "s"(rec_coff), "s"(rec_irr));
+        }
         if constexpr (X3) {
             // split mode: slots 0-3 hold the hi halves of the stage's 32 channels, slots 4-7 the lo halves (rd_k0 / rd_k1
             // address exactly these).  value = hi + lo on both operands: w*x ~= wl*xh + wh*xl + wh*xh, small terms first.
             // Three sweeps over the wave tile keep MFMAs on the same accumulator 16 instructions apart.
             // Wide wave tiles (8 pixel blocks) take the pixel fragments in two halves: the fragments of a stage do not all fit
             // beside 128 accumulator registers.
-            constexpr int NIH = T::kNI >= 8 ? T::kNI / 2 : T::kNI;
-            bf16x8_t ah[T::kMI], al[T::kMI];
+            if constexpr (T::kNI >= 8) {
+                // Wide wave tiles (8 pixel blocks: the 8-wave 256 x 256 and 512 x 128 tiles): phases of NQ pixel blocks, the pixel fragments of
+                // phase i + 1 requested BEFORE the MFMAs of phase i (register double buffer: two sets of NQ hi + NQ lo fragments = the
+                // registers one set of four blocks took).  Left to itself hipcc loads every fragment right in front of its first MFMA --
+                // a dozen `s_waitcnt lgkmcnt(0)` per K-step, each exposing an LDS round trip to the matrix pipe.
+                // Request order at the head of the K-step = the order of use: the first sweep (wl x xh) needs 4 + NQ fragments, not all 16 --
+                // LDS returns in order, all eight waves ask at once behind the barrier (16 KB each: ~1 000 cycles of the LDS pipe for the
+                // whole burst), and the matrix pipe idles until a wave's first operands are there.
+                // (Per accumulator the order of its three MFMAs is unchanged: same bits.)
+                constexpr int NQ = 2;
+                constexpr int NPH = T::kNI / NQ;
+                bf16x8_t ah[T::kMI], al[T::kMI];
+                bf16x8_t bh[2][NQ], bl[2][NQ];
 #pragma unroll
-            for (int mi = 0; mi < T::kMI; ++mi) {
-                ah[mi] = *(const bf16x8_t*)(sb + w_rd + mi * 16 * RB + rd_k0);
-                al[mi] = *(const bf16x8_t*)(sb + w_rd + mi * 16 * RB + rd_k1);
-            }
+                for (int mi = 0; mi < T::kMI; ++mi) al[mi] = *(const bf16x8_t*)(sb + w_rd + mi * 16 * RB + rd_k1);
 #pragma unroll
-            for (int h = 0; h < T::kNI / NIH; ++h) {
-                bf16x8_t bh[NIH], bl[NIH];
+                for (int q = 0; q < NQ; ++q) bh[0][q] = *(const bf16x8_t*)(sb + p_rd + q * 16 * RB + rd_k0);
 #pragma unroll
-                for (int q = 0; q < NIH; ++q) {
-                    bh[q] = *(const bf16x8_t*)(sb + p_rd + (h * NIH + q) * 16 * RB + rd_k0);
-                    bl[q] = *(const bf16x8_t*)(sb + p_rd + (h * NIH + q) * 16 * RB + rd_k1);
+                for (int mi = 0; mi < T::kMI; ++mi) ah[mi] = *(const bf16x8_t*)(sb + w_rd + mi * 16 * RB + rd_k0);
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) bl[0][q] = *(const bf16x8_t*)(sb + p_rd + q * 16 * RB + rd_k1);
+                auto load_b = [&](int ph, bf16x8_t (&dh)[NQ], bf16x8_t (&dl)[NQ]) __attribute__((always_inline)) {
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q) {
+                        dh[q] = *(const bf16x8_t*)(sb + p_rd + (ph * NQ + q) * 16 * RB + rd_k0);
+                        dl[q] = *(const bf16x8_t*)(sb + p_rd + (ph * NQ + q) * 16 * RB + rd_k1);
+                    }
+                };
+#pragma unroll
+                for (int ph = 0; ph < NPH; ++ph) {
+                    if (ph + 1 < NPH) {
+                        load_b(ph + 1, bh[(ph + 1) & 1], bl[(ph + 1) & 1]);
+                        __builtin_amdgcn_sched_barrier(0);          // (the requests stay in FRONT of this phase's MFMAs)
+                    }
+#pragma unroll
+                    for (int mi = 0; mi < T::kMI; ++mi)
+#pragma unroll
+                        for (int q = 0; q < NQ; ++q) acc[mi][ph * NQ + q] = mfma16<true>(al[mi], bh[ph & 1][q], acc[mi][ph * NQ + q]);
+#pragma unroll
+                    for (int mi = 0; mi < T::kMI; ++mi)
+#pragma unroll
+                        for (int q = 0; q < NQ; ++q) acc[mi][ph * NQ + q] = mfma16<true>(ah[mi], bl[ph & 1][q], acc[mi][ph * NQ + q]);
+#pragma unroll
+                    for (int mi = 0; mi < T::kMI; ++mi)
+#pragma unroll
+                        for (int q = 0; q < NQ; ++q) acc[mi][ph * NQ + q] = mfma16<true>(ah[mi], bh[ph & 1][q], acc[mi][ph * NQ + q]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else {
+                bf16x8_t ah[T::kMI], al[T::kMI];
+#pragma unroll
+                for (int mi = 0; mi < T::kMI; ++mi) {
+                    ah[mi] = *(const bf16x8_t*)(sb + w_rd + mi * 16 * RB + rd_k0);
+                    al[mi] = *(const bf16x8_t*)(sb + w_rd + mi * 16 * RB + rd_k1);
+                }
+                bf16x8_t bh[T::kNI], bl[T::kNI];
+#pragma unroll
+                for (int q = 0; q < T::kNI; ++q) {
+                    bh[q] = *(const bf16x8_t*)(sb + p_rd + q * 16 * RB + rd_k0);
+                    bl[q] = *(const bf16x8_t*)(sb + p_rd + q * 16 * RB + rd_k1);
                 }
 #pragma unroll
                 for (int mi = 0; mi < T::kMI; ++mi)
 #pragma unroll
-                    for (int q = 0; q < NIH; ++q) acc[mi][h * NIH + q] = mfma16<true>(al[mi], bh[q], acc[mi][h * NIH + q]);
+                    for (int q = 0; q < T::kNI; ++q) acc[mi][q] = mfma16<true>(al[mi], bh[q], acc[mi][q]);
 #pragma unroll
                 for (int mi = 0; mi < T::kMI; ++mi)
 #pragma unroll
-                    for (int q = 0; q < NIH; ++q) acc[mi][h * NIH + q] = mfma16<true>(ah[mi], bl[q], acc[mi][h * NIH + q]);
+                    for (int q = 0; q < T::kNI; ++q) acc[mi][q] = mfma16<true>(ah[mi], bl[q], acc[mi][q]);
 #pragma unroll
                 for (int mi = 0; mi < T::kMI; ++mi)
 #pragma unroll
-                    for (int q = 0; q < NIH; ++q) acc[mi][h * NIH + q] = mfma16<true>(ah[mi], bh[q], acc[mi][h * NIH + q]);
+                    for (int q = 0; q < T::kNI; ++q) acc[mi][q] = mfma16<true>(ah[mi], bh[q], acc[mi][q]);
             }
         } else {
             // The K-step's MFMAs run in phases of (k-half kk, group of <= 4 pixel blocks); the LDS

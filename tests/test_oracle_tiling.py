@@ -84,3 +84,60 @@ def test_resize_nearest_hand_computed_cases():
         a = np.arange(src).reshape(src, 1)
         assert tiling.resize_nearest(a, dst, 1)[:, 0].tolist() == want, (src, dst)
         assert tiling.resize_nearest(a.T, 1, dst)[0].tolist() == want, (src, dst)
+
+
+class _ContentModel:
+    """A model whose output depends on the PATCH CONTENT only (as a real network's does) -- unlike FakeModel, whose label also
+    depends on the call index."""
+
+    class _L:
+        def __init__(self, shp):
+            self.output_shape = shp
+
+    def __init__(self, H, W, C=8):
+        self.layers = [self._L((None, H, W, C))]
+        self.H, self.W, self.C, self.calls = H, W, C, 0
+
+    def predict(self, x):
+        self.calls += 1
+        p = np.rint(np.asarray(x[0], np.float64) * 255.0).astype(np.int64)
+        yy, xx = np.mgrid[0:self.H, 0:self.W]
+        lab = (yy * 3 + xx * 7 + p[:, :, 0] + 2 * p[:, :, 1] + 5 * p[:, :, 2] + (p[::-1, ::-1, 0])) % self.C
+        out = np.zeros((1, self.H, self.W, self.C), np.float32)
+        np.put_along_axis(out[0], lab[:, :, None], 1.0, axis=2)
+        return out
+
+
+@pytest.mark.parametrize("hp,wp,distinct,calls", [(390, 640, 8, 12), (640, 404, 8, 12), (224, 367, 2, 6), (405, 405, 9, 9), (224, 224, 1, 4),
+                                                   (225, 224 + 180, 4, 6), (3 * 180 + 1, 5 * 180 + 44, 15, 24)])
+def test_repeated_clamped_tiles_can_be_computed_once(hp, wp, distinct, calls):
+    """The library's fused page paths drop the reference's repeated forward when the clamp (main.py:276-281) gives the last two
+    tiles of an axis one origin (sbbseg_set_dedupe).  Claim checked here on the CPU, against the restated reference loop: pasting
+    the grid WITHOUT the repeated tile -- the remaining last tile pasting through to the edge -- gives the same map, for any model
+    that is a function of the patch content."""
+    H = W = 224
+    margin = int(0.1 * W)
+    rng = np.random.RandomState(hp * 31 + wp)
+    page = rng.randint(0, 256, (hp, wp, 3)).astype(np.uint8)
+    m = _ContentModel(H, W)
+    ref = tiling.do_prediction(True, page, m)[:, :, 0]
+    assert m.calls == calls
+
+    def dedup(axis):
+        t = tiling.axis_tiles(axis, H, margin)
+        if len(t) >= 2 and t[-1][0] == t[-2][0]:
+            t = t[:-1]
+            d, lo, _, k = t[-1]
+            t[-1] = (d, lo, H, k)                              # the new last tile keeps its far side
+        return t
+    xs, ys = dedup(wp), dedup(hp)
+    assert len(xs) * len(ys) == distinct
+    out = np.zeros((hp, wp), np.uint8)
+    m2 = _ContentModel(H, W)
+    img = page / 255.0
+    for (x0, xlo, xhi, _) in xs:
+        for (y0, ylo, yhi, _) in ys:
+            lab = np.argmax(m2.predict(img[y0:y0 + H, x0:x0 + W][None]), axis=3)[0]
+            out[y0 + ylo:y0 + yhi, x0 + xlo:x0 + xhi] = lab[ylo:yhi, xlo:xhi]
+    assert m2.calls == distinct
+    assert np.array_equal(out, ref)
