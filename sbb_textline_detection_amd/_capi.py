@@ -20,7 +20,7 @@ INPUT_C8, INPUT_PAIRS = 0, 1
 EXPORTS = [
     "sbbseg_last_error", "sbbseg_abi_version", "sbbseg_device_count", "sbbseg_create", "sbbseg_destroy",
     "sbbseg_model_load", "sbbseg_model_load_file", "sbbseg_debug_plan_summary",
-    "sbbseg_set_stream", "sbbseg_set_lanes", "sbbseg_set_label_channels", "sbbseg_set_dedupe", "sbbseg_synchronize", "sbbseg_set_input", "sbbseg_input_form", "sbbseg_add_tensor",
+    "sbbseg_set_stream", "sbbseg_set_lanes", "sbbseg_set_label_channels", "sbbseg_set_dedupe", "sbbseg_set_ksplit", "sbbseg_synchronize", "sbbseg_set_input", "sbbseg_input_form", "sbbseg_add_tensor",
     "sbbseg_add_conv", "sbbseg_add_maxpool", "sbbseg_add_tail", "sbbseg_add_head", "sbbseg_finalize", "sbbseg_model_info",
     "sbbseg_num_ops", "sbbseg_op_info", "sbbseg_op_issued_flops", "sbbseg_device_bytes", "sbbseg_predict", "sbbseg_segment_page",
     "sbbseg_segment_page_dev", "sbbseg_segment_pages_dev", "sbbseg_segment_page_scaled", "sbbseg_segment_page_otsu", "sbbseg_segment_crop", "sbbseg_segment_crop_dev", "sbbseg_debug_largest_contour", "sbbseg_debug_counter", "sbbseg_comm_unique_id", "sbbseg_comm_init", "sbbseg_comm_info", "sbbseg_comm_destroy", "sbbseg_allgather_labels_dev", "sbbseg_otsu_dev",
@@ -76,6 +76,7 @@ def load_library(path: Optional[str] = None):
         "sbbseg_set_lanes": [vp, i32],
         "sbbseg_set_label_channels": [vp, i32],
         "sbbseg_set_dedupe": [vp, i32],
+        "sbbseg_set_ksplit": [vp, i32],
         "sbbseg_set_input": [vp, i32, i32, i32],
         "sbbseg_input_form": [vp, i32, i32, C.POINTER(C.c_int)],
         "sbbseg_add_tensor": [vp, i32, i32, i32, C.POINTER(C.c_int)],
@@ -289,6 +290,10 @@ class Context:
     def set_dedupe(self, on: bool):
         """Fused page paths compute a repeated clamped tile once (default on; same label map).  See sbbseg.h."""
         check(self.lib.sbbseg_set_dedupe(self.h, int(bool(on))), "sbbseg_set_dedupe")
+
+    def set_ksplit(self, on: bool):
+        """Whole-image branch: split the K range of one-patch launches over the idle CUs (default on; see sbbseg.h)."""
+        check(self.lib.sbbseg_set_ksplit(self.h, int(bool(on))), "sbbseg_set_ksplit")
 
     def forwards(self) -> int:
         """Patches run through the plan on this handle so far."""

@@ -218,6 +218,8 @@ struct sbbseg_ctx {
     uint8_t* d_batch_labels = nullptr; // [max_batch][H][W] (predict / whole-image path)
     float* d_probs = nullptr;          // [max_batch][H][W][classes], lazily allocated
     float* d_xin = nullptr;            // predict(): staged float input, lazily allocated
+    float* d_ks_ws = nullptr; size_t ks_ws_cap = 0;      // split-K partial sums (whole-image branch, split mode)
+    bool ksplit = true, ksplit_now = false;              // SBBSEG_KSPLIT=0 switches it off; _now: inside the whole-image branch's run_plan
     uint8_t* d_page = nullptr; size_t page_cap = 0;
     uint8_t* d_page_labels = nullptr; size_t page_labels_cap = 0;
     uint8_t* d_page_labels3 = nullptr; size_t page_labels3_cap = 0;   // 3-channel copy for label_channels == 3
@@ -401,6 +403,7 @@ int launch_op(sbbseg_ctx* c, Op& op, int n, uint8_t* d_labels, float* d_probs)
             const ConvOp& co = op.conv;
             if (co.fused_into_expand && !c->no_expand_reduce && !(c->conv_variant & 3)) return 0;      // written by the expand conv's launch (expand_reduce_x3)
             ConvParams p;
+            p.ks_shift = 0; p.ks_ws = nullptr; p.ks_split_elems = 0;
             memset(&p, 0, sizeof(p));
             p.n_src = co.d.n_src;
             // (short-K layers keep the plain gather: the per-tile mask set-up costs them 1-10 %; from ~9 K-steps on the fast
@@ -498,7 +501,28 @@ int launch_op(sbbseg_ctx* c, Op& op, int n, uint8_t* d_labels, float* d_probs)
                 if (c->precision == kF16X3) HIPCHK(launch_dec_halo_x3(hp, c->num_cus, c->stream));
                 else HIPCHK(launch_dec_halo_f16(hp, c->num_cus, c->stream));
             } else {
-                HIPCHK(launch_conv(p, c->precision, c->stream));
+                // One patch through a long-K conv = 2-32 tiles of 100-400 K-steps at ~1 us a step on as many CUs: the whole-image branch
+                // (extract_page's border model, 1 forward per page) splits the K range over the idle CUs -- up to 16 blocks per tile, each
+                // at least 4 K-steps, fp32 partial sums added in split order by splitk_finish_x3.  Only there: a split launch differs from
+                // the unsplit one in the last bits, and seam 2 / the patch paths promise batch-size-independent results.
+                int ks = 0;
+                if (c->ksplit_now && n == 1 && c->precision == kF16X3 && p.fast_gather && conv_tile_bc(p.cout) == 128 && !p.raw_out && !p.head_classes &&
+                    p.out && p.cout % 8 == 0 &&
+                    ((p.n_cls == 1 && p.osy == 1 && p.osx == 1 && p.ooy == 0 && p.oox == 0 && p.TH == p.Ho && p.TW == p.Wo) ||
+                     (p.n_cls == 4 && p.osy == 2 && p.osx == 2 && p.TH == 2 * p.Ho && p.TW == 2 * p.Wo))) {
+                    const long tiles = (long)p.n_cls * ((p.M + 127) / 128) * ((p.cout + 127) / 128);
+                    while (ks < 4 && (tiles << (ks + 1)) <= 512 && p.total_ksteps % (2 << ks) == 0 && (p.total_ksteps >> (ks + 1)) >= 4) ++ks;
+                }
+                if (ks > 0) {
+                    const size_t split_elems = (size_t)n * p.TH * p.TW * p.cout;
+                    if (ensure(c, (void**)&c->d_ks_ws, &c->ks_ws_cap, (split_elems << ks) * sizeof(float))) return 1;
+                    p.ks_shift = ks; p.ks_ws = c->d_ks_ws; p.ks_split_elems = (long)split_elems; p.tile_map = 0; p.cls_minor = 0;
+                    HIPCHK(launch_conv(p, c->precision, c->stream));
+                    HIPCHK(launch_splitk_finish_x3(c->d_ks_ws, 1 << ks, (long)split_elems, (long)n * p.TH * p.TW, p.cout, p.scale, p.shift, p.residual,
+                                                   p.relu, p.out, c->stream));
+                } else {
+                    HIPCHK(launch_conv(p, c->precision, c->stream));
+                }
             }
         } else if (op.type == kPool) {
             const PoolOp& po = op.pool;
@@ -821,6 +845,7 @@ int sbbseg_create(int device, int precision, sbbseg_ctx** out)
     }
     if (const char* v = getenv("SBBSEG_STAGGER_MIN_TILES")) c->stagger_min_tiles = atoi(v);
     if (const char* v = getenv("SBBSEG_DEDUPE")) c->dedupe = v[0] != '0';
+    if (const char* v = getenv("SBBSEG_KSPLIT")) c->ksplit = v[0] != '0';
     *out = c;
     return 0;
     API_END
@@ -859,7 +884,7 @@ int sbbseg_destroy(sbbseg_ctx* c)
         (void)hipFree(op.tail.d_wfrag); (void)hipFree(op.tail.d_scale); (void)hipFree(op.tail.d_shift); (void)hipFree(op.tail.d_head_w);
         (void)hipFree(op.tail.d_head_scale); (void)hipFree(op.tail.d_head_shift);
     }
-    (void)hipFree(c->d_lut); (void)hipFree(c->d_hist); (void)hipFree(c->d_tile_xy); (void)hipFree(c->d_batch_labels); (void)hipFree(c->d_probs); (void)hipFree(c->d_xin);
+    (void)hipFree(c->d_lut); (void)hipFree(c->d_hist); (void)hipFree(c->d_tile_xy); (void)hipFree(c->d_batch_labels); (void)hipFree(c->d_probs); (void)hipFree(c->d_xin); (void)hipFree(c->d_ks_ws);
     (void)hipFree(c->d_page); (void)hipFree(c->d_page_labels); (void)hipFree(c->d_page_labels3); (void)hipFree(c->d_tile_labels);
     (void)hipFree(c->d_own_x); (void)hipFree(c->d_own_y); (void)hipFree(c->d_map); (void)hipFree(c->d_wmap);
     (void)hipFree(c->d_deskew);
@@ -938,6 +963,15 @@ int sbbseg_set_dedupe(sbbseg_ctx* c, int on)
     API_BEGIN
     REQUIRE(c && (on == 0 || on == 1), "dedupe must be 0 or 1");
     c->dedupe = on != 0;
+    return 0;
+    API_END
+}
+
+int sbbseg_set_ksplit(sbbseg_ctx* c, int on)
+{
+    API_BEGIN
+    REQUIRE(c && (on == 0 || on == 1), "ksplit must be 0 or 1");
+    c->ksplit = on != 0;
     return 0;
     API_END
 }
@@ -2571,7 +2605,10 @@ static int whole_scaled_impl(sbbseg_ctx* c, const uint8_t* page_hwc, const void*
     ip.page = d_page_in ? (const uint8_t*)d_page_in : c->d_page; ip.Hp = Hp; ip.Wp = Wp; ip.src_Hp = Hp; ip.src_Wp = Wp; ip.tile_xy = nullptr; ip.n_tiles = 1;
     ip.whole = 1; ip.map_y = d_my; ip.map_x = d_mx;
     HIPCHK(launch_ingest_u8(ip, c->precision, c->stream));
-    if (run_plan(c, 1, c->d_batch_labels, nullptr)) return 1;
+    c->ksplit_now = c->ksplit;
+    const int plan_rc = run_plan(c, 1, c->d_batch_labels, nullptr);
+    c->ksplit_now = false;
+    if (plan_rc) return 1;
     HIPCHK(launch_resize_labels(c->d_batch_labels, c->in_H, c->in_W, d_oy, d_ox, out_h, out_w, c->d_page_labels, c->stream));
     if (labels_out) {
         if (labels_to_host(c, labels_out, opix)) return 1;

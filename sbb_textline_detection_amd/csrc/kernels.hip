@@ -204,11 +204,15 @@ template <int N> __device__ inline void wait_vmcnt()
 // load's scalar offset, an out-of-bounds tap sets bit 31 of the lane offset (past num_records -> the load writes zeros
 // to LDS, tools/probes/buffer_lds_oob_probe.hip).  Two VALU ops per load instead of ~18: on the long-K tiles the
 // address arithmetic of the plain gather costs 20-25 % of the loop (tools/probes/mfma_loop_probe.hip).
-template <int BP, int BC, int WP, int WC, int NS, bool F16, int GS = 8, bool PH8 = false, bool X3 = false, bool FG = false>
+// KS = split-K (ConvParams::ks_shift): tile index = tile * 2^ks_shift + split; split s walks K-steps [s * nt, (s + 1) * nt) of the tile and stores
+// fp32 partial sums instead of running the epilogue.  A launch of 2-32 tiles of 100-400 K-steps (one patch) leaves most CUs idle for ~1 us per
+// K-step; results of a split launch differ from the unsplit one in the last bits (association), so only the whole-image branch uses it.
+template <int BP, int BC, int WP, int WC, int NS, bool F16, int GS = 8, bool PH8 = false, bool X3 = false, bool FG = false, bool KS = false>
 __global__ __launch_bounds__(64 * WP * WC, (conv_blocks_per_cu(BP, BC, WP, WC, NS, GS) * (WP * WC) / 4))
 void conv_igemm_mfma(const ConvParams p)
 {
     static_assert(!X3 || (F16 && GS == 8 && !PH8), "split mode: fp16 halves, whole-K-step stages, plain loop");
+    static_assert(!KS || (X3 && FG && BP == 128 && BC == 128 && NS == 2), "split-K: the split mode's 128 x 128 tile on the fast gather");
     static_assert(!FG || !PH8, "the 8-phase schedule keeps the plain gather");
     constexpr int PL = X3 ? 2 : 1;                       // 16-bit planes per stored activation element
     using T = ConvTile<BP, BC, WP, WC, NS, GS>;
@@ -228,9 +232,11 @@ void conv_igemm_mfma(const ConvParams p)
     // grouped walk, on the same XCD -- they read the same source pixels, which then come from one L2.
     // Pixel tiles are padded to a multiple of 8 per class there (padding tiles are fully masked).
     const int n_pt1e = p.cls_minor ? (n_pt1 + 7) & ~7 : n_pt1;
-    const int n_tiles = p.n_cls * n_ct * n_pt1e;
+    const int n_tiles = (p.n_cls * n_ct * n_pt1e) << (KS ? p.ks_shift : 0);
     const int G = gridDim.x;
-    const int nt = p.total_ksteps;
+    const int nt_full = p.total_ksteps;
+    const int nt = KS ? nt_full >> p.ks_shift : nt_full;       // K-steps this block walks per tile
+    auto split_of = [&](int tile) __attribute__((always_inline)) -> int { return KS ? tile & ((1 << p.ks_shift) - 1) : 0; };
     // Tile walk of this (persistent) block.  map 0: tiles b, b+G, ... (channel tile fastest): every
     // XCD keeps ONE channel-tile's weight slab hot -- right when the weights dwarf the L2.
     // map 1 (small weight matrices): XCD x = b % 8 owns pixel tiles x, x+8, ...; its blocks walk them
@@ -238,6 +244,7 @@ void conv_igemm_mfma(const ConvParams p)
     // back and the pixel operand is fetched into that L2 once instead of once per XCD.
     const int n_pt = p.n_cls * n_pt1e;                  // "extended" pixel tiles (class x pixel tile)
     auto decode = [&](int tile, int& ctile, int& cls, int& ptile) __attribute__((always_inline)) {
+        if constexpr (KS) tile >>= p.ks_shift;
         const int e = fast_div(tile, p.nct_magic, p.nct_shift);
         ctile = tile - e * n_ct;
         if (p.cls_minor) {                              // (n_cls is 1, 2 or 4)
@@ -311,7 +318,7 @@ void conv_igemm_mfma(const ConvParams p)
     // both sources' descriptors live in SGPRs for the whole kernel
     const SrcDesc sd0 = p.src[0];
     const SrcDesc sd1 = p.n_src > 1 ? p.src[1] : p.src[0];
-    const int ks0 = p.n_src > 1 ? sd0.ksteps : nt;
+    const int ks0 = p.n_src > 1 ? sd0.ksteps : nt_full;
     const uint32_t img0 = (uint32_t)(sd0.PH * sd0.PW * sd0.pix_bytes), img1 = (uint32_t)(sd1.PH * sd1.PW * sd1.pix_bytes);
     // load-side class state (weights, tap tables), switched in setup_rows
     const char* wbase = (const char*)p.w;
@@ -427,6 +434,7 @@ void conv_igemm_mfma(const ConvParams p)
     };
 
     int l_t = 0, l_h = 0, l_q = 0, issued = 0;          // load side: K-step, stage inside it, tile
+    int l_end = nt;                                     // (split-K: the K-step behind this split's range)
     int rec_yx = kstep_tab[0], rec_coff = kstep_tab[1], rec_irr = kstep_tab[2];   // record of the NEXT stage issued
     auto issue = [&](int buf) __attribute__((always_inline)) {
         const int t = l_t;
@@ -490,9 +498,13 @@ void conv_igemm_mfma(const ConvParams p)
         ++issued;
         if (++l_h == SPK) {
             l_h = 0;
-            if (++l_t == nt) {
+            if (++l_t == (KS ? l_end : nt)) {
                 l_t = 0;
-                if (++l_q < my_tiles) setup_rows(tile_at(l_q));
+                if (++l_q < my_tiles) {
+                    setup_rows(tile_at(l_q));
+                    if constexpr (KS) l_t = split_of(tile_at(l_q)) * nt;
+                }
+                if constexpr (KS) l_end = l_t + nt;
             }
             rec_yx = kstep_tab[l_t * 4 + 0]; rec_coff = kstep_tab[l_t * 4 + 1]; rec_irr = kstep_tab[l_t * 4 + 2];
         }
@@ -592,6 +604,33 @@ void conv_igemm_mfma(const ConvParams p)
     auto epilogue = [&](int tile) __attribute__((always_inline)) -> bool {
         int ctile, cls, ptile;
         decode(tile, ctile, cls, ptile);
+        if constexpr (KS) {
+            // this split's partial sums, scaled by the class's power-of-two weight multiplier (exact), at the FINAL pixel index of the
+            // output tensor: splitk_finish_x3 is then a plain elementwise pass over [pixels][cout]
+            float* ws = p.ks_ws + (size_t)split_of(tile) * (size_t)p.ks_split_elems;
+            const float wm = p.wmul_cls[cls];
+#pragma unroll
+            for (int ni = 0; ni < T::kNI; ++ni) {
+                const int m = ptile * BP + wp * T::kWPX + ni * 16 + frow;
+                if (m < p.M) {
+                    const size_t o = (size_t)out_pixel(m, cls) * p.cout;
+#pragma unroll
+                    for (int s2 = 0; s2 < T::kMI / 2; ++s2) {
+                        const int c0 = ctile * BC + wc * T::kWCH + s2 * 32 + fg * 8;
+                        if (c0 < p.cout) {
+                            const f32x4_t a = acc[2 * s2][ni], b = acc[2 * s2 + 1][ni];
+                            *(float4*)(ws + o + c0) = make_float4(a[0] * wm, a[1] * wm, a[2] * wm, a[3] * wm);
+                            *(float4*)(ws + o + c0 + 4) = make_float4(b[0] * wm, b[1] * wm, b[2] * wm, b[3] * wm);
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int mi = 0; mi < T::kMI; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < T::kNI; ++ni) acc[mi][ni] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+            return false;
+        }
         const bool full = (ptile * BP + (wp + 1) * T::kWPX <= p.M) && (ctile * BC + (wc + 1) * T::kWCH <= p.cout) &&
                           p.out != nullptr && !(BC == 32 && p.head_classes > 0);
         int opix[T::kNI];
@@ -993,7 +1032,8 @@ void conv_igemm_mfma(const ConvParams p)
     // ---- prologue: D stages in flight, stage 0 landed
     if (total == 0) return;
     setup_rows(tile_at(0));
-    rec_yx = kstep_tab[0]; rec_coff = kstep_tab[1]; rec_irr = kstep_tab[2];     // (the first tile's class may not be class 0)
+    if constexpr (KS) { l_t = split_of(tile_at(0)) * nt; l_end = l_t + nt; }
+    rec_yx = kstep_tab[l_t * 4 + 0]; rec_coff = kstep_tab[l_t * 4 + 1]; rec_irr = kstep_tab[l_t * 4 + 2];     // (the first tile's class may not be class 0)
 #pragma unroll
     for (int d = 0; d < D; ++d)
         if (d < total) issue(d);
@@ -1248,7 +1288,7 @@ static void make_fast_div(uint32_t d, uint32_t* magic, uint32_t* shift)
     *shift = s2;
 }
 
-template <int BP, int BC, int WP, int WC, int NS, bool F16, int GS, bool PH8, bool X3, bool FG>
+template <int BP, int BC, int WP, int WC, int NS, bool F16, int GS, bool PH8, bool X3, bool FG, bool KS = false>
 static hipError_t launch_conv_impl(const ConvParams& p, hipStream_t s)
 {
     using T = ConvTile<BP, BC, WP, WC, NS, GS>;
@@ -1257,14 +1297,14 @@ static hipError_t launch_conv_impl(const ConvParams& p, hipStream_t s)
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
     if (!attr_done[dev & 63]) {
-        e = hipFuncSetAttribute((const void*)conv_igemm_mfma<BP, BC, WP, WC, NS, F16, GS, PH8, X3, FG>,
+        e = hipFuncSetAttribute((const void*)conv_igemm_mfma<BP, BC, WP, WC, NS, F16, GS, PH8, X3, FG, KS>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, T::kLdsBytes);
         if (e != hipSuccess) return e;
         attr_done[dev & 63] = true;
     }
     const int n_ct = (p.cout + BC - 1) / BC;
     const int n_pt = (p.M + BP - 1) / BP;
-    const int n_tiles = p.n_cls * n_ct * (p.cls_minor ? (n_pt + 7) & ~7 : n_pt);
+    const int n_tiles = (p.n_cls * n_ct * (p.cls_minor ? (n_pt + 7) & ~7 : n_pt)) << (KS ? p.ks_shift : 0);
     // persistent grid: as many blocks as are resident at once (2 per CU for the 4-wave tiles, 1 for
     // the 8-wave ones); p.persist_blocks == 0 -> one block per tile (A/B)
     const int resident = p.persist_blocks > 0 ? p.persist_blocks * T::kBlocksPerCU : n_tiles;
@@ -1280,7 +1320,7 @@ static hipError_t launch_conv_impl(const ConvParams& p, hipStream_t s)
     q.tile2d = (tile2d_on && p.fast_gather == 1 && p.Ho % 16 == 0 && p.Wo % 16 == 0) ? 1 : 0;
     q.tpr = p.Wo / 16;
     make_fast_div((uint32_t)(q.tpr > 0 ? q.tpr : 1), &q.tpr_magic, &q.tpr_shift);
-    hipLaunchKernelGGL((conv_igemm_mfma<BP, BC, WP, WC, NS, F16, GS, PH8, X3, FG>), dim3(grid), dim3(T::kThreads), T::kLdsBytes, s, q);
+    hipLaunchKernelGGL((conv_igemm_mfma<BP, BC, WP, WC, NS, F16, GS, PH8, X3, FG, KS>), dim3(grid), dim3(T::kThreads), T::kLdsBytes, s, q);
     return hipGetLastError();
 }
 
@@ -1343,6 +1383,10 @@ static hipError_t launch_conv_16(const ConvParams& p, hipStream_t s)
 static hipError_t launch_conv_x3(const ConvParams& p, hipStream_t s)
 {
     const int bc = conv_tile_bc(p.cout);
+    if (p.ks_shift > 0) {                                       // split-K (the caller has checked: 128-channel tiles, fast gather, whole K ranges)
+        if (bc != 128 || !p.fast_gather || p.tile_map != 0 || p.cls_minor || (p.total_ksteps & ((1 << p.ks_shift) - 1))) return hipErrorInvalidValue;
+        return launch_conv_impl<128, 128, 2, 2, 2, true, 8, false, true, true, true>(p, s);
+    }
     if (p.variant == 0 && bc == 128 && !p.residual) {          // the long-K decoder launches: same 8-wave tiles as the plain modes
         const long t256 = (long)p.n_cls * ((p.M + 255) / 256) * (p.cout / 256);
         const long t512 = (long)p.n_cls * ((p.M + 511) / 512) * ((p.cout + 127) / 128);
@@ -1357,6 +1401,45 @@ static hipError_t launch_conv_x3(const ConvParams& p, hipStream_t s)
     if (bc == 128) return launch_conv_t<128, 128, 2, 2, 2, true, 8, false, true>(p, s);
     if (bc == 64) return launch_conv_t<256, 64, 4, 1, 2, true, 8, false, true>(p, s);
     return launch_conv_t<256, 32, 4, 1, 2, true, 8, false, true>(p, s);
+}
+
+// Second half of a split-K launch (split mode): partial sums of the 2^ks_shift splits added in split order, then the conv's epilogue -- scale /
+// shift, residual, ReLU, hi + lo split -- on 8 channels of one pixel per thread.
+__global__ __launch_bounds__(256) void splitk_finish_x3(const float* __restrict__ ws, int splits, long split_elems, long n_groups, int cout,
+                                                         const float* __restrict__ scale, const float* __restrict__ shift,
+                                                         const uint16_t* __restrict__ residual, int relu, uint16_t* __restrict__ out)
+{
+    const long g = (long)blockIdx.x * 256 + threadIdx.x;
+    if (g >= n_groups) return;
+    const int cg = cout >> 3;
+    const long pix = g / cg;
+    const int c0 = (int)(g - pix * cg) * 8;
+    float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const float* src = ws + pix * cout + c0;
+    for (int s = 0; s < splits; ++s) {
+        const float4 a = *(const float4*)(src + (size_t)s * split_elems), b = *(const float4*)(src + (size_t)s * split_elems + 4);
+        v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w; v[4] += b.x; v[5] += b.y; v[6] += b.z; v[7] += b.w;
+    }
+    float y[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) y[q] = __builtin_fmaf(v[q], scale[c0 + q], shift[c0 + q]);
+    const size_t o = (size_t)pix * (cout * 2) + split_hi_elem(cout, c0);
+    const int lo_d = split_group(cout);
+    if (residual) add_split8(residual + o, lo_d, y);
+    if (relu) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) y[q] = fmaxf(y[q], 0.f);
+    }
+    store_split8(out + o, lo_d, y);
+}
+
+hipError_t launch_splitk_finish_x3(const float* ws, int splits, long split_elems, long pixels, int cout, const float* scale, const float* shift,
+                                   const void* residual, int relu, void* out, hipStream_t s)
+{
+    const long n_groups = pixels * (cout / 8);
+    hipLaunchKernelGGL(splitk_finish_x3, dim3((unsigned)((n_groups + 255) / 256)), dim3(256), 0, s, ws, splits, split_elems, n_groups, cout, scale, shift,
+                       (const uint16_t*)residual, relu, (uint16_t*)out);
+    return hipGetLastError();
 }
 
 hipError_t launch_conv(const ConvParams& p0, int precision, hipStream_t s)

@@ -866,11 +866,15 @@ def test_whole_image_branch_fused_equals_reference_structure(stitch_model):
     fixtures -- driven with the SAME HIP model through seam 2 (model.predict): same net, same kernels, so any
     difference is a structural one (which size is resized to which, main.py:378's self.image.shape)."""
     m = stitch_model
-    for (h, w, fh, fw) in ((700, 520, 840, 624), (611, 503, 2800, 2305), (448, 448, 448, 448), (1234, 777, 333, 257)):
-        page = synthetic_page(h, w, seed=h + w)
-        fused = predict.do_prediction(False, page, m, full_image_shape=(fh, fw, 3))
-        loop = tiling.do_prediction(False, page, m, full_image_shape=(fh, fw, 3))
-        assert fused.shape == (fh, fw, 3) and fused.dtype == np.uint8 and np.array_equal(fused, loop), (h, w, fh, fw)
+    m.ctx.set_ksplit(False)      # "same kernels": the branch's split-K launches (round 4) differ from seam 2's in the last bits; they have
+    try:                         # their own test (test_whole_image_branch_split_k_matches_oracle_and_the_unsplit_launches)
+        for (h, w, fh, fw) in ((700, 520, 840, 624), (611, 503, 2800, 2305), (448, 448, 448, 448), (1234, 777, 333, 257)):
+            page = synthetic_page(h, w, seed=h + w)
+            fused = predict.do_prediction(False, page, m, full_image_shape=(fh, fw, 3))
+            loop = tiling.do_prediction(False, page, m, full_image_shape=(fh, fw, 3))
+            assert fused.shape == (fh, fw, 3) and fused.dtype == np.uint8 and np.array_equal(fused, loop), (h, w, fh, fw)
+    finally:
+        m.ctx.set_ksplit(True)
 
 
 def test_model_load_survives_injected_bad_alloc():
@@ -1354,3 +1358,38 @@ def test_fused_paths_compute_repeated_clamped_tiles_once():
     want = model.segment_page(np.ascontiguousarray(big[23:23 + hp, 17:17 + wp]))
     assert np.array_equal(got[0], want)
     model.release()
+
+
+def test_whole_image_branch_split_k_matches_oracle_and_the_unsplit_launches():
+    """The whole-image branch (main.py:368-380: one forward per page) runs its long-K convs split over the idle CUs (split-K, fp32
+    partial sums added in split order).  Checked at the model size the stages use (448, split mode): labels against the fp32 oracle
+    under the label-exact margin rule, against a handle with sbbseg_set_ksplit(0) (equal except at near-ties), bit-identical
+    across repeats, and seam 2 (`predict` of the same single patch) is NOT split: it still equals the unsplit launches bit for bit."""
+    from sbb_textline_detection_amd.model import SegModel
+    from tools.synth_model import calibrated_model
+    cfg, w = calibrated_model(2, 448, 448, seed=3)
+    page = synthetic_page(1100, 900, seed=21)
+    om = kf.OracleModel(cfg, w)
+    x = tiling.resize_nearest(page / 255.0, 448, 448)[None].astype(np.float32)
+    pr = om.predict(x)[0]
+    ref = np.argmax(pr, axis=-1).astype(np.uint8)
+    srt = np.sort(pr, axis=-1)
+    margin = srt[..., -1] - srt[..., -2]
+    split = SegModel(cfg, w, device=0, max_batch=2, precision="f16x3")
+    f0 = split.ctx.forwards()
+    got = split.segment_whole(page, 448, 448)
+    again = split.segment_whole(page, 448, 448)
+    assert split.ctx.forwards() - f0 == 2
+    assert np.array_equal(got, again)
+    mism = got != ref
+    assert not (mism & (margin > EXACT_MARGIN)).any(), int((mism & (margin > EXACT_MARGIN)).sum())
+    p_split = split.predict(x)
+    plain = SegModel(cfg, w, device=0, max_batch=2, precision="f16x3")
+    plain.ctx.set_ksplit(False)
+    base = plain.segment_whole(page, 448, 448)
+    differ = got != base
+    assert differ.mean() < 1e-4 and not (differ & (margin > EXACT_MARGIN)).any()
+    assert np.array_equal(p_split, plain.predict(x))           # seam 2 is batch-size independent: never split
+    assert np.abs(p_split[0] - pr).max() < TOL_SOFTMAX["f16x3"]
+    split.release()
+    plain.release()
