@@ -361,6 +361,15 @@ def main():
             m_layout.ctx.morph_dev(d_regions.data_ptr(), bh, bw, 0, 5, 3, d_clean.data_ptr())      # main.py:2074-2075
             m_layout.ctx.morph_dev(d_clean.data_ptr(), bh, bw, 1, 5, 4, d_clean.data_ptr())
             m_text.ctx.segment_crop_dev(d_page.data_ptr(), PAGE_H, PAGE_W, Hs, Ws, box, False, d_lines.data_ptr())
+        # the same calls one by one, for the breakdown printed beside the total (each timed alone, with a synchronize on both sides)
+        step.stages = {
+            "upload_ms": lambda: d_page.copy_(h_page, non_blocking=True),
+            "border_forward_and_page_box_ms": lambda: m_border.ctx.extract_page_box_dev(d_page.data_ptr(), PAGE_H, PAGE_W, Hs, Ws),
+            "layout_stage_ms": lambda: m_layout.ctx.segment_crop_dev(d_page.data_ptr(), PAGE_H, PAGE_W, Hs, Ws, box, True, d_regions.data_ptr()),
+            "erode3_dilate4_ms": lambda: (m_layout.ctx.morph_dev(d_regions.data_ptr(), bh, bw, 0, 5, 3, d_clean.data_ptr()),
+                                          m_layout.ctx.morph_dev(d_clean.data_ptr(), bh, bw, 1, 5, 4, d_clean.data_ptr())),
+            "textline_stage_ms": lambda: m_text.ctx.segment_crop_dev(d_page.data_ptr(), PAGE_H, PAGE_W, Hs, Ws, box, False, d_lines.data_ptr()),
+        }
         desc = (f"BASELINE configs[2]: three-model pipeline on one {PAGE_H}x{PAGE_W} page per GPU, chained as main.py:2056-2107: upscale to "
                 f"{Hs}x{Ws} (fused), border (whole image, 1 forward) + page box {box}, layout (Otsu'd crop, 4 classes, {tiles_crop} tiles) + "
                 f"erode x 3 / dilate x 4, textline (crop, {tiles_crop} tiles); models resident")
@@ -715,6 +724,15 @@ def main():
             extras["pipeline3_patches_per_s"] = round(tps3 * n3 / d3, 1)
             extras["pipeline3_what"] = desc3
             extras["pipeline3_host_contour_fallbacks_per_page"] = round(fallbacks_of_pipeline3() / float(n3 + 2), 2)
+            parts = {}
+            for name, fn in step3.stages.items():                      # each piece alone: where the page's milliseconds go
+                fn(); torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(n3):
+                    fn()
+                torch.cuda.synchronize()
+                parts[name] = round((time.perf_counter() - t0) / n3 * 1e3, 3)
+            extras["pipeline3_breakdown"] = parts
         except Exception as e:                                         # never lose the headline over a side measurement
             extras["pipeline3_error"] = repr(e)
 

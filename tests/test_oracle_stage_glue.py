@@ -118,3 +118,32 @@ def test_page_box_by_hand():
     # 8-connectivity: two blobs touching at a corner are ONE component
     d = np.zeros((40, 40), np.uint8); d[0:10, 0:10] = 1; d[10:20, 10:20] = 1
     assert stage_glue.largest_component_box(d) == ((0, 0, 20, 20), 200)
+
+
+def test_morph_and_components_against_scipy():
+    """An implementation that shares no code with the oracle's: scipy.ndimage's grey erosion / dilation with a 5 x 5 flat footprint and a
+    constant border that can never win (cv2's morphologyDefaultBorderValue), iterated; and ndimage.label (8-connectivity) +
+    find_objects for the bounding box of the largest blob where one blob is clearly the largest (no area ties, the one case where
+    cv2.contourArea's ranking and a pixel count can differ is avoided by construction: solid rectangles)."""
+    from scipy import ndimage
+    rng = np.random.RandomState(11)
+    for shape in ((37, 53), (64, 64), (5, 9), (120, 31)):
+        grey = rng.randint(0, 4, shape).astype(np.uint8)                      # layout classes 0..3
+        binary = ((rng.rand(*shape) > 0.8) * 255).astype(np.uint8)
+        for a in (grey, binary):
+            for it in (1, 3, 4, 6):
+                e, d = a.copy(), a.copy()
+                for _ in range(it):
+                    e = ndimage.grey_erosion(e, size=(5, 5), mode="constant", cval=255)
+                    d = ndimage.grey_dilation(d, size=(5, 5), mode="constant", cval=0)
+                assert np.array_equal(stage_glue.morph(a, "erode", 5, it), e), (shape, it)
+                assert np.array_equal(stage_glue.morph(a, "dilate", 5, it), d), (shape, it)
+    m = np.zeros((90, 70), np.uint8)
+    m[10:50, 5:40] = 1                                                      # 40 x 35, the largest
+    m[60:80, 30:65] = 1                                                     # 20 x 35
+    m[2:6, 60:68] = 1
+    lab, n = ndimage.label(m, structure=np.ones((3, 3), int))
+    sizes = ndimage.sum(m, lab, range(1, n + 1))
+    sl = ndimage.find_objects(lab)[int(np.argmax(sizes))]
+    box, _ = stage_glue.largest_component_box(m)
+    assert tuple(box) == (sl[1].start, sl[0].start, sl[1].stop - sl[1].start, sl[0].stop - sl[0].start) == (5, 10, 35, 40)
