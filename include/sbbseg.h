@@ -88,10 +88,10 @@ int sbbseg_set_label_channels(sbbseg_ctx* c, int channels);
  * tile-indexed entry points (sbbseg_tile_grid, _segment_tiles_dev, _segment_tile_range[_bin]_dev, _stitch_dev -- the multi-rank
  * protocol) always keep the reference's call list. */
 int sbbseg_set_dedupe(sbbseg_ctx* c, int on);
-/* Split-K in the whole-image branch (sbbseg_segment_whole[_scaled], sbbseg_extract_page_box[_dev]; split mode; default on, SBBSEG_KSPLIT=0 or
+/* Split-K in the whole-image branch (sbbseg_segment_whole[_scaled], sbbseg_extract_page_box[_dev]; every mode but fp32; default on, SBBSEG_KSPLIT=0 or
  * on = 0 switches it off): one patch through a long-K conv occupies 2-32 CUs for 100-400 K-steps, so the K range of such a launch is
  * split over up to 16 blocks per tile and the fp32 partial sums are added in split order by a second launch -- 3.4 -> 1.9 ms per
- * whole-image forward of the 448 model.  Deterministic, but the last bits differ from the unsplit launches (summation order): the
+ * whole-image forward of the 448 model in the split mode, 2.1 -> 1.5 ms in plain fp16.  Deterministic, but the last bits differ from the unsplit launches (summation order): the
  * patch paths and sbbseg_predict never split, their results do not depend on the batch size. */
 int sbbseg_set_ksplit(sbbseg_ctx* c, int on);
 

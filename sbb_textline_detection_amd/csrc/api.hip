@@ -218,7 +218,7 @@ struct sbbseg_ctx {
     uint8_t* d_batch_labels = nullptr; // [max_batch][H][W] (predict / whole-image path)
     float* d_probs = nullptr;          // [max_batch][H][W][classes], lazily allocated
     float* d_xin = nullptr;            // predict(): staged float input, lazily allocated
-    float* d_ks_ws = nullptr; size_t ks_ws_cap = 0;      // split-K partial sums (whole-image branch, split mode)
+    float* d_ks_ws = nullptr; size_t ks_ws_cap = 0;      // split-K partial sums (whole-image branch)
     bool ksplit = true, ksplit_now = false;              // SBBSEG_KSPLIT=0 switches it off; _now: inside the whole-image branch's run_plan
     uint8_t* d_page = nullptr; size_t page_cap = 0;
     uint8_t* d_page_labels = nullptr; size_t page_labels_cap = 0;
@@ -503,10 +503,10 @@ int launch_op(sbbseg_ctx* c, Op& op, int n, uint8_t* d_labels, float* d_probs)
             } else {
                 // One patch through a long-K conv = 2-32 tiles of 100-400 K-steps at ~1 us a step on as many CUs: the whole-image branch
                 // (extract_page's border model, 1 forward per page) splits the K range over the idle CUs -- up to 16 blocks per tile, each
-                // at least 4 K-steps, fp32 partial sums added in split order by splitk_finish_x3.  Only there: a split launch differs from
+                // at least 4 K-steps, fp32 partial sums added in split order by splitk_finish.  Only there: a split launch differs from
                 // the unsplit one in the last bits, and seam 2 / the patch paths promise batch-size-independent results.
                 int ks = 0;
-                if (c->ksplit_now && n == 1 && c->precision == kF16X3 && p.fast_gather && conv_tile_bc(p.cout) == 128 && !p.raw_out && !p.head_classes &&
+                if (c->ksplit_now && n == 1 && c->precision != kF32 && p.fast_gather && conv_tile_bc(p.cout) == 128 && !p.raw_out && !p.head_classes &&
                     p.out && p.cout % 8 == 0 &&
                     ((p.n_cls == 1 && p.osy == 1 && p.osx == 1 && p.ooy == 0 && p.oox == 0 && p.TH == p.Ho && p.TW == p.Wo) ||
                      (p.n_cls == 4 && p.osy == 2 && p.osx == 2 && p.TH == 2 * p.Ho && p.TW == 2 * p.Wo))) {
@@ -518,8 +518,8 @@ int launch_op(sbbseg_ctx* c, Op& op, int n, uint8_t* d_labels, float* d_probs)
                     if (ensure(c, (void**)&c->d_ks_ws, &c->ks_ws_cap, (split_elems << ks) * sizeof(float))) return 1;
                     p.ks_shift = ks; p.ks_ws = c->d_ks_ws; p.ks_split_elems = (long)split_elems; p.tile_map = 0; p.cls_minor = 0;
                     HIPCHK(launch_conv(p, c->precision, c->stream));
-                    HIPCHK(launch_splitk_finish_x3(c->d_ks_ws, 1 << ks, (long)split_elems, (long)n * p.TH * p.TW, p.cout, p.scale, p.shift, p.residual,
-                                                   p.relu, p.out, c->stream));
+                    HIPCHK(launch_splitk_finish(c->d_ks_ws, 1 << ks, (long)split_elems, (long)n * p.TH * p.TW, p.cout, p.scale, p.shift, p.residual,
+                                                p.relu, p.out, c->precision, c->stream));
                 } else {
                     HIPCHK(launch_conv(p, c->precision, c->stream));
                 }

@@ -102,8 +102,8 @@ struct ConvParams {
     const FgStepRec* fgstep_cls[4];   // fast gather: per-class tables read in place of kstep / kstep_cls (class 0 = entry 0)
     int fast_gather;          // every K-step regular, each source's taps within a 4 x 4 window, no upsampling source, buffers < 2 GiB:
                               // run the FG form of conv_igemm_mfma (kernels.hip)
-    // split-K (one-patch launches of the whole-image branch, split mode): 2^ks_shift blocks share a tile's K-steps, each writes its fp32
-    // partial sums (x the class's power-of-two weight scale) to ks_ws[split][output pixel][cout]; splitk_finish_x3 adds them in split order
+    // split-K (one-patch launches of the whole-image branch, 16-bit and split modes): 2^ks_shift blocks share a tile's K-steps, each writes its fp32
+    // partial sums (x the class's power-of-two weight scale) to ks_ws[split][output pixel][cout]; splitk_finish adds them in split order
     // and runs the epilogue.  0 = off
     int ks_shift;
     float* ks_ws;
@@ -275,8 +275,8 @@ inline bool is_split(int precision) { return precision == kF16X3; }
 
 // launchers implemented in kernels.hip ---------------------------------------------------------
 hipError_t launch_conv(const ConvParams& p, int precision, hipStream_t s);
-hipError_t launch_splitk_finish_x3(const float* ws, int splits, long split_elems, long pixels, int cout, const float* scale, const float* shift,
-                                   const void* residual, int relu, void* out, hipStream_t s);
+hipError_t launch_splitk_finish(const float* ws, int splits, long split_elems, long pixels, int cout, const float* scale, const float* shift,
+                                const void* residual, int relu, void* out, int precision, hipStream_t s);
 hipError_t launch_maxpool(const void* src, void* dst, int n, int H, int W, int C, int k, int stride,
                           int Ho, int Wo, const float* pre_scale, const float* pre_shift, int pre_relu,
                           int precision, hipStream_t s);

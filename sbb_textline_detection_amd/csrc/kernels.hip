@@ -212,7 +212,7 @@ __global__ __launch_bounds__(64 * WP * WC, (conv_blocks_per_cu(BP, BC, WP, WC, N
 void conv_igemm_mfma(const ConvParams p)
 {
     static_assert(!X3 || (F16 && GS == 8 && !PH8), "split mode: fp16 halves, whole-K-step stages, plain loop");
-    static_assert(!KS || (X3 && FG && BP == 128 && BC == 128 && NS == 2), "split-K: the split mode's 128 x 128 tile on the fast gather");
+    static_assert(!KS || (FG && BP == 128 && BC == 128 && NS == 2 && GS == 8 && !PH8), "split-K: the 128 x 128 tile on the fast gather");
     static_assert(!FG || !PH8, "the 8-phase schedule keeps the plain gather");
     constexpr int PL = X3 ? 2 : 1;                       // 16-bit planes per stored activation element
     using T = ConvTile<BP, BC, WP, WC, NS, GS>;
@@ -1353,6 +1353,10 @@ static hipError_t launch_conv_16(const ConvParams& p, hipStream_t s)
     const long big_blocks = (long)((p.M + 255) / 256) * ((p.cout + bc - 1) / bc);
     const bool big = variant == 2;
     (void)big_blocks;
+    if (p.ks_shift > 0) {                                       // split-K (see launch_conv_x3)
+        if (bc != 128 || !p.fast_gather || p.tile_map != 0 || p.cls_minor || (p.total_ksteps & ((1 << p.ks_shift) - 1))) return hipErrorInvalidValue;
+        return launch_conv_impl<128, 128, 2, 2, 2, F16, 8, false, false, true, true>(p, s);
+    }
     if (p.half_stages) {   // A/B: half-K-step stages, 4-deep ring (3 stages in flight across the barriers)
         const long t256 = (long)p.n_cls * ((p.M + 255) / 256) * (p.cout / 256);
         if (bc == 128 && !p.residual && p.cout % 256 == 0 && p.Ktot >= 512 && t256 >= 200) return launch_conv_t<256, 256, 2, 4, 4, F16, 4>(p, s);
@@ -1403,11 +1407,12 @@ static hipError_t launch_conv_x3(const ConvParams& p, hipStream_t s)
     return launch_conv_t<256, 32, 4, 1, 2, true, 8, false, true>(p, s);
 }
 
-// Second half of a split-K launch (split mode): partial sums of the 2^ks_shift splits added in split order, then the conv's epilogue -- scale /
-// shift, residual, ReLU, hi + lo split -- on 8 channels of one pixel per thread.
-__global__ __launch_bounds__(256) void splitk_finish_x3(const float* __restrict__ ws, int splits, long split_elems, long n_groups, int cout,
-                                                         const float* __restrict__ scale, const float* __restrict__ shift,
-                                                         const uint16_t* __restrict__ residual, int relu, uint16_t* __restrict__ out)
+// Second half of a split-K launch: partial sums of the 2^ks_shift splits added in split order, then the conv's epilogue -- scale / shift,
+// residual, ReLU, store -- on 8 channels of one pixel per thread.  MODE 0 = split mode ([32 hi][32 lo] channel groups), 1 = fp16, 2 = bf16.
+template <int MODE>
+__global__ __launch_bounds__(256) void splitk_finish(const float* __restrict__ ws, int splits, long split_elems, long n_groups, int cout,
+                                                      const float* __restrict__ scale, const float* __restrict__ shift,
+                                                      const uint16_t* __restrict__ residual, int relu, uint16_t* __restrict__ out)
 {
     const long g = (long)blockIdx.x * 256 + threadIdx.x;
     if (g >= n_groups) return;
@@ -1423,22 +1428,47 @@ __global__ __launch_bounds__(256) void splitk_finish_x3(const float* __restrict_
     float y[8];
 #pragma unroll
     for (int q = 0; q < 8; ++q) y[q] = __builtin_fmaf(v[q], scale[c0 + q], shift[c0 + q]);
-    const size_t o = (size_t)pix * (cout * 2) + split_hi_elem(cout, c0);
-    const int lo_d = split_group(cout);
-    if (residual) add_split8(residual + o, lo_d, y);
-    if (relu) {
+    if constexpr (MODE == 0) {
+        const size_t o = (size_t)pix * (cout * 2) + split_hi_elem(cout, c0);
+        const int lo_d = split_group(cout);
+        if (residual) add_split8(residual + o, lo_d, y);
+        if (relu) {
 #pragma unroll
-        for (int q = 0; q < 8; ++q) y[q] = fmaxf(y[q], 0.f);
+            for (int q = 0; q < 8; ++q) y[q] = fmaxf(y[q], 0.f);
+        }
+        store_split8(out + o, lo_d, y);
+    } else {
+        constexpr bool F16 = MODE == 1;
+        const size_t o = (size_t)pix * cout + c0;
+        if (residual) {                                         // (the same additions, in the same order, as conv_igemm_mfma's epilogue)
+            const uint4 rr = *(const uint4*)(residual + o);
+            y[0] += unpack_lo<F16>(rr.x); y[1] += unpack_hi<F16>(rr.x);
+            y[2] += unpack_lo<F16>(rr.y); y[3] += unpack_hi<F16>(rr.y);
+            y[4] += unpack_lo<F16>(rr.z); y[5] += unpack_hi<F16>(rr.z);
+            y[6] += unpack_lo<F16>(rr.w); y[7] += unpack_hi<F16>(rr.w);
+        }
+        if (relu) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) y[q] = fmaxf(y[q], 0.f);
+        }
+        uint4 r;
+        r.x = pack2<F16>(y[0], y[1]); r.y = pack2<F16>(y[2], y[3]);
+        r.z = pack2<F16>(y[4], y[5]); r.w = pack2<F16>(y[6], y[7]);
+        *(uint4*)(out + o) = r;
     }
-    store_split8(out + o, lo_d, y);
 }
 
-hipError_t launch_splitk_finish_x3(const float* ws, int splits, long split_elems, long pixels, int cout, const float* scale, const float* shift,
-                                   const void* residual, int relu, void* out, hipStream_t s)
+hipError_t launch_splitk_finish(const float* ws, int splits, long split_elems, long pixels, int cout, const float* scale, const float* shift,
+                                const void* residual, int relu, void* out, int precision, hipStream_t s)
 {
     const long n_groups = pixels * (cout / 8);
-    hipLaunchKernelGGL(splitk_finish_x3, dim3((unsigned)((n_groups + 255) / 256)), dim3(256), 0, s, ws, splits, split_elems, n_groups, cout, scale, shift,
-                       (const uint16_t*)residual, relu, (uint16_t*)out);
+    const dim3 grid((unsigned)((n_groups + 255) / 256));
+    if (precision == kF16X3)
+        hipLaunchKernelGGL(splitk_finish<0>, grid, dim3(256), 0, s, ws, splits, split_elems, n_groups, cout, scale, shift, (const uint16_t*)residual, relu, (uint16_t*)out);
+    else if (precision == kF16)
+        hipLaunchKernelGGL(splitk_finish<1>, grid, dim3(256), 0, s, ws, splits, split_elems, n_groups, cout, scale, shift, (const uint16_t*)residual, relu, (uint16_t*)out);
+    else
+        hipLaunchKernelGGL(splitk_finish<2>, grid, dim3(256), 0, s, ws, splits, split_elems, n_groups, cout, scale, shift, (const uint16_t*)residual, relu, (uint16_t*)out);
     return hipGetLastError();
 }
 

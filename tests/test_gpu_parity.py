@@ -1360,7 +1360,8 @@ def test_fused_paths_compute_repeated_clamped_tiles_once():
     model.release()
 
 
-def test_whole_image_branch_split_k_matches_oracle_and_the_unsplit_launches():
+@pytest.mark.parametrize("precision", ["f16x3", "f16"])
+def test_whole_image_branch_split_k_matches_oracle_and_the_unsplit_launches(precision):
     """The whole-image branch (main.py:368-380: one forward per page) runs its long-K convs split over the idle CUs (split-K, fp32
     partial sums added in split order).  Checked at the model size the stages use (448, split mode): labels against the fp32 oracle
     under the label-exact margin rule, against a handle with sbbseg_set_ksplit(0) (equal except at near-ties), bit-identical
@@ -1375,21 +1376,23 @@ def test_whole_image_branch_split_k_matches_oracle_and_the_unsplit_launches():
     ref = np.argmax(pr, axis=-1).astype(np.uint8)
     srt = np.sort(pr, axis=-1)
     margin = srt[..., -1] - srt[..., -2]
-    split = SegModel(cfg, w, device=0, max_batch=2, precision="f16x3")
+    split = SegModel(cfg, w, device=0, max_batch=2, precision=precision)
     f0 = split.ctx.forwards()
     got = split.segment_whole(page, 448, 448)
     again = split.segment_whole(page, 448, 448)
     assert split.ctx.forwards() - f0 == 2
     assert np.array_equal(got, again)
+    # split mode: the label-exact margin rule; plain fp16: labels may differ where the oracle's margin is inside twice the mode's softmax tolerance
+    lim = EXACT_MARGIN if precision == "f16x3" else 2 * TOL_SOFTMAX["f16"]
     mism = got != ref
-    assert not (mism & (margin > EXACT_MARGIN)).any(), int((mism & (margin > EXACT_MARGIN)).sum())
+    assert not (mism & (margin > lim)).any(), int((mism & (margin > lim)).sum())
     p_split = split.predict(x)
-    plain = SegModel(cfg, w, device=0, max_batch=2, precision="f16x3")
+    plain = SegModel(cfg, w, device=0, max_batch=2, precision=precision)
     plain.ctx.set_ksplit(False)
     base = plain.segment_whole(page, 448, 448)
     differ = got != base
-    assert differ.mean() < 1e-4 and not (differ & (margin > EXACT_MARGIN)).any()
+    assert differ.mean() < (1e-4 if precision == "f16x3" else 2e-3) and not (differ & (margin > lim)).any()
     assert np.array_equal(p_split, plain.predict(x))           # seam 2 is batch-size independent: never split
-    assert np.abs(p_split[0] - pr).max() < TOL_SOFTMAX["f16x3"]
+    assert np.abs(p_split[0] - pr).max() < TOL_SOFTMAX[precision]
     split.release()
     plain.release()
