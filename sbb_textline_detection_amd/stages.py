@@ -290,6 +290,70 @@ class InferenceStages:
         finally:
             session.close()
 
+    def _run_resident(self):
+        """run()'s three stages with the stored page uploaded ONCE and kept in device memory for all of them (run() hands the same
+        page to every stage, main.py:2061-2102), the border mask and the region map staying on the device between their model and
+        their glue: the `_dev` entry points of the C ABI on buffers that torch allocates (plumbing only).  Same return value as the
+        stage-by-stage path below, which remains the path for foreign model objects, for boxes without torch / a GPU and for
+        SBBSEG_STAGES_RESIDENT=0.  Returns None when it does not apply."""
+        import os
+        if os.environ.get("SBBSEG_STAGES_RESIDENT", "1") == "0":
+            return None
+        try:
+            import torch
+            if not torch.cuda.is_available():
+                return None
+        except Exception:
+            return None
+        opened = [start_new_session_and_model(d, **self.kw) for d in (self.model_page_dir, self.model_region_dir, self.model_textline_dir)]
+        try:
+            (m_page, _), (m_region, _), (m_text, _) = opened
+            if not all(isinstance(m, SegModel) for m in (m_page, m_region, m_text)):
+                return None
+            dev = torch.device("cuda", m_page.device if hasattr(m_page, "device") and isinstance(m_page.device, int) else torch.cuda.current_device())
+            H, W = self.image_stored.shape[:2]
+            Hs, Ws = self.img_hight_int, self.img_width_int
+            d_page = torch.from_numpy(np.ascontiguousarray(self.image_stored, np.uint8)).to(dev)      # the one upload of the page
+            d_mask = torch.empty((Hs, Ws), dtype=torch.uint8, device=dev)
+            # extract_page (main.py:384-437), outside the try like main.py:2061: its errors propagate
+            box, pixels = m_page.ctx.extract_page_box_dev(d_page.data_ptr(), H, W, Hs, Ws, d_mask.data_ptr())
+            m_page.ctx.synchronize()
+            if pixels == 0:
+                raise ValueError("attempt to get argmax of an empty sequence")          # what main.py:401 raises
+            x, y, w, h = box
+            self.page_box = (x, y, w, h)
+            page_coord = [y, y + h, x, x + w]
+            self.cont_page = [np.array([[page_coord[2], page_coord[0]], [page_coord[3], page_coord[0]],
+                                        [page_coord[3], page_coord[1]], [page_coord[2], page_coord[1]]])]
+            self.page_mask = d_mask.unsqueeze(-1).expand(-1, -1, 3).contiguous().cpu().numpy()
+            regions, has_text = None, False
+            try:                                                     # main.py:2069-2091: a failed layout stage = no regions
+                d_regions = torch.empty((h, w), dtype=torch.uint8, device=dev)
+                d_clean = torch.empty((h, w), dtype=torch.uint8, device=dev)
+                d_thr = torch.zeros(1, dtype=torch.int32, device=dev)
+                m_region.ctx.segment_crop_dev(d_page.data_ptr(), H, W, Hs, Ws, box, True, d_regions.data_ptr(), d_thr.data_ptr())
+                m_region.ctx.morph_dev(d_regions.data_ptr(), h, w, 0, 5, 3, d_clean.data_ptr())      # main.py:2074-2075
+                m_region.ctx.morph_dev(d_clean.data_ptr(), h, w, 1, 5, 4, d_clean.data_ptr())
+                m_region.ctx.synchronize()
+                self.otsu_threshold = int(d_thr.item())
+                has_text = bool((d_clean == 1).any().item())
+                regions = d_clean.unsqueeze(-1).expand(-1, -1, 3).contiguous().cpu().numpy()
+            except Exception:
+                regions, has_text = None, False
+            textlines = None
+            if has_text:
+                try:
+                    d_lines = torch.empty((h, w), dtype=torch.uint8, device=dev)
+                    m_text.ctx.segment_crop_dev(d_page.data_ptr(), H, W, Hs, Ws, box, False, d_lines.data_ptr())
+                    m_text.ctx.synchronize()
+                    textlines = d_lines.cpu().numpy()
+                except Exception:                                   # main.py:2152-2157
+                    textlines = None
+            return self.page_mask, regions, textlines, page_coord
+        finally:
+            for _, session in opened:
+                session.close()
+
     def run(self, image_u8: np.ndarray):
         """The model-running part of run() (main.py:2056-2107) with its chaining: border model -> page box -> the layout
         and textline models on the CROPPED page (main.py:2061, 2072, 2102), text regions cleaned by erode x 3 / dilate x 4
@@ -298,6 +362,9 @@ class InferenceStages:
         callers that unpacked three must be updated -- INTEGRATION.md.)  Like the reference, a failed layout stage yields
         regions = None and skips the textline model (textlines = None); extract_page's errors propagate."""
         self.get_image_and_scales(image_u8)
+        resident = self._run_resident()
+        if resident is not None:
+            return resident
         page_mask, box, page_coord = self.page_box_only()          # outside the try, like main.py:2061: its errors propagate
         # main.py:2069-2091: the layout stage and its post-processing sit in a bare try/except -- any failure (the reference: a crop
         # smaller than the model input breaks do_prediction's reshape, main.py:278-285; here: sbbseg_segment_crop refuses it) degrades

@@ -1396,3 +1396,32 @@ def test_whole_image_branch_split_k_matches_oracle_and_the_unsplit_launches(prec
     assert np.abs(p_split[0] - pr).max() < TOL_SOFTMAX[precision]
     split.release()
     plain.release()
+
+
+def test_run_with_the_page_resident_equals_the_stage_by_stage_run(tmp_path, monkeypatch):
+    """InferenceStages.run() uploads the stored page once and keeps it (and the border mask, and the region map) in device memory for
+    all three stages (`_run_resident`, the `_dev` entry points); SBBSEG_STAGES_RESIDENT=0 runs the stages one by one through the
+    host entry points as before.  Same masks, same box, same Otsu threshold; and the 'no text' / 'crop too small' fallbacks agree."""
+    from sbb_textline_detection_amd import clear_session, stages
+    from sbb_textline_detection_amd.weights import save_sbbw
+    from tools.synth_model import calibrated_model
+    specs = {"model_page_mixed_best": 2, "model_strukturerkennung": 4, "model_textline_new": 2}      # main.py:58-60
+    for name, classes in specs.items():
+        cfg, w = calibrated_model(classes, 224, 224, seed=classes)
+        save_sbbw(str(tmp_path / (name + ".sbbw")), cfg, w)
+    st = stages.InferenceStages(*[str(tmp_path / (n + ".h5")) for n in specs], model_kwargs={"max_batch": 16})
+    for hw, seed in (((520, 400), 9), ((700, 610), 4)):
+        page = synthetic_page(*hw, seed=seed)
+        monkeypatch.setenv("SBBSEG_STAGES_RESIDENT", "1")
+        a = st.run(page)
+        box_a, thr_a = st.page_box, st.otsu_threshold
+        monkeypatch.setenv("SBBSEG_STAGES_RESIDENT", "0")
+        b = st.run(page)
+        assert box_a == st.page_box and thr_a == st.otsu_threshold and a[3] == b[3]
+        for x, y in zip(a[:3], b[:3]):
+            assert (x is None) == (y is None)
+            if x is not None:
+                assert x.shape == y.shape and x.dtype == y.dtype and np.array_equal(x, y)
+    monkeypatch.setenv("SBBSEG_STAGES_RESIDENT", "1")
+    assert st._run_resident() is not None                               # (the resident path really ran above: it applies here)
+    clear_session()
