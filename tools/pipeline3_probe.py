@@ -16,6 +16,10 @@ page = synthetic_page(H, W, seed=0)
 mb = SegModel(*calibrated_model(2, 448, 448, seed=11), max_batch=1, precision=prec)
 ml = SegModel(*calibrated_model(4, 448, 448, seed=12), max_batch=108, precision=prec)
 mt = SegModel(*calibrated_model(2, 448, 448, seed=0), max_batch=280, precision=prec)
+if os.environ.get("PROBE_NULL_STREAM") == "1":              # as bench.py runs its handles: on torch's current (the legacy default) stream
+    for m_ in (mb, ml, mt):
+        m_.ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    print("handles on the legacy default stream")
 d_page = torch.from_numpy(page).cuda()
 _, box, px = mb.ctx.extract_page_box(page, Hs, Ws)
 print("box", box, px)
