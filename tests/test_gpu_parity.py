@@ -979,6 +979,12 @@ def test_device_morphology_and_page_box(torch_cuda, stitch_model):
     for op, name, it in ((0, "erode", 3), (1, "dilate", 4), (1, "dilate", 6), (0, "erode", 1)):
         assert np.array_equal(m.ctx.morph(lay, op, 5, it), stage_glue.morph(lay, name, 5, it)), (name, it)
     assert np.array_equal(m.ctx.morph(m.ctx.morph(lay, 0, 5, 3), 1, 5, 4), stage_glue.region_cleanup(lay))
+    # widths that are multiples of 4 take the four-pixels-per-thread passes (round 4): the same map cut to 876 columns, and planes
+    # narrower than the filter (the window is clipped on both sides at once)
+    for plane in (np.ascontiguousarray(lay[:, :876]), np.ascontiguousarray(lay[:37, :12]), rng.randint(0, 4, (5, 8)).astype(np.uint8),
+                  rng.randint(0, 256, (3, 4)).astype(np.uint8), rng.randint(0, 256, (90, 64)).astype(np.uint8)):
+        for op, name, it in ((0, "erode", 3), (1, "dilate", 4), (1, "dilate", 6), (0, "erode", 1), (1, "dilate", 1)):
+            assert np.array_equal(m.ctx.morph(plane, op, 5, it), stage_glue.morph(plane, name, 5, it)), (plane.shape, name, it)
     masks = []
     a = np.zeros((700, 520), np.uint8); a[40:660, 30:500] = 1; a[rng.rand(*a.shape) < 0.002] = 1; masks.append(a)     # page + specks
     b = np.zeros((300, 300), np.uint8); b[0:100, 0:100] = 1; b[125:200, 125:290] = 1; masks.append(b)                 # two blobs, 25 px apart -> merge after dilation
