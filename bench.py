@@ -288,6 +288,7 @@ def main():
                 f"margin 0.1), textline model (ResNet-50-U-Net, {CLASSES} classes, seeded synthetic weights)")
         def step_local():
             m.ctx.segment_pages_dev(page_ptrs, PAGE_H, PAGE_W, label_ptrs)
+        step.ctxs = step_local.ctxs = [m.ctx]
         return step, tiles_per_page * P * world, desc, "weak", (gather if world > 1 else None), P * PAGE_H * PAGE_W * world, step_local, tiles_per_page * P
 
     def build_batch64(m, distinct=None):
@@ -322,6 +323,7 @@ def main():
         def step_local():
             if count:
                 m.ctx.segment_pages_dev(page_ptrs, BH, BW, label_ptrs)
+        step.ctxs = step_local.ctxs = [m.ctx]
         return step, tpp * NPAGES, desc, "strong", (gather if world > 1 else None), world * block * BH * BW, step_local, tpp * count
 
     def build_pipeline3(m):
@@ -370,6 +372,7 @@ def main():
                                           m_layout.ctx.morph_dev(d_clean.data_ptr(), bh, bw, 1, 5, 4, d_clean.data_ptr())),
             "textline_stage_ms": lambda: m_text.ctx.segment_crop_dev(d_page.data_ptr(), PAGE_H, PAGE_W, Hs, Ws, box, False, d_lines.data_ptr()),
         }
+        step.ctxs = [m_border.ctx, m_layout.ctx] + ([m_text.ctx] if m_text is not m_layout else [])
         desc = (f"BASELINE configs[2]: three-model pipeline on one {PAGE_H}x{PAGE_W} page per GPU, chained as main.py:2056-2107: upscale to "
                 f"{Hs}x{Ws} (fused), border (whole image, 1 forward) + page box {box}, layout (Otsu'd crop, 4 classes, {tiles_crop} tiles) + "
                 f"erode x 3 / dilate x 4, textline (crop, {tiles_crop} tiles); models resident")
@@ -400,7 +403,24 @@ def main():
             out.append(dt)
         return out
 
-    step, tiles_per_step, workload_desc, scaling, gather, gathered_bytes, step_local, local_tiles = builders[workload](model)
+    def forwards_of(step_fn, whole_job=True):
+        """Forwards the handles REALLY run in one step (sbbseg_debug_counter 1 = patches through the plan), summed over the ranks.  The
+        fused page paths compute a repeated clamped tile once (sbbseg_set_dedupe, default on): on page sizes with extent % 360 in (0, 88]
+        this is less than the reference's call count (4000 x 3000: 99 forwards for 108 calls) -- rates are quoted on what ran."""
+        ctxs = list({id(c): c for c in step_fn.ctxs}.values())
+        before = sum(c.forwards() for c in ctxs)
+        step_fn()
+        torch.cuda.synchronize()
+        n = sum(c.forwards() for c in ctxs) - before
+        if whole_job and world > 1:
+            t = torch.tensor([n], dtype=torch.int64, device="cuda" if backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            n = int(t.item())
+        return int(n)
+
+    step, reference_calls_per_step, workload_desc, scaling, gather, gathered_bytes, step_local, local_calls = builders[workload](model)
+    tiles_per_step = forwards_of(step)                              # what `value` counts: forwards executed, whole job
+    local_tiles = forwards_of(step_local, whole_job=False) if step_local is not None else tiles_per_step // world
     dts = timed(step, args.steps, args.warmup, max(1, args.repeats))
     dt = statistics.median(dts)
     value = tiles_per_step * args.steps / dt
@@ -447,12 +467,16 @@ def main():
     batch64 = None
     if workload == "page" and not args.no_extras:
         try:
-            stepb, tilesb, descb, scalb, gatherb, bytesb = build_batch64(model, distinct=8)[:6]
+            stepb, callsb, descb, scalb, gatherb, bytesb = build_batch64(model, distinct=8)[:6]
+            tilesb = forwards_of(stepb)                                 # forwards executed (4000 x 3000: 99 per page, the reference calls 108)
             nb = max(2, min(4, args.steps // 5))
-            dtb = timed(stepb, nb, 1, 1)[0]
+            dtb = timed(stepb, nb, 0, 1)[0]
             batch64 = {"patches_per_s": round(tilesb * nb / dtb, 2), "ms_per_step": round(dtb / nb * 1e3, 3), "steps": nb, "warmup": 1,
-                       "scaling": scalb, "tiles_per_step": tilesb, "pages": max(1, args.batch_pages), "chunk_tiles": model.max_batch,
-                       "what": descb + f" (same handle as the headline: tiles pooled into {model.max_batch}-tile chunks on two lanes; 8 distinct synthetic pages cycled)"}
+                       "scaling": scalb, "tiles_per_step": tilesb, "forwards_per_step": tilesb, "reference_calls_per_step": callsb,
+                       "dedupe": tilesb != callsb, "reference_calls_per_s": round(callsb * nb / dtb, 2),
+                       "pages": max(1, args.batch_pages), "chunk_tiles": model.max_batch,
+                       "what": descb + f" (same handle as the headline: tiles pooled into {model.max_batch}-tile chunks on two lanes; 8 distinct synthetic pages cycled; "
+                                       "patches_per_s counts the forwards the handle executed -- repeated clamped tiles of the reference's call list run once)"}
             if gatherb is not None:
                 for _ in range(2):
                     gatherb()
@@ -686,7 +710,8 @@ def main():
         other = {"f16": "f16x3", "f16x3": "f16"}.get(args.precision)
         if other and not args.no_second_mode and workload == "page":
             m2 = make_model(other)
-            step2, tps2 = build_page(m2)[:2]
+            step2 = build_page(m2)[0]
+            tps2 = forwards_of(step2)
             n2 = max(3, args.steps // 4)
             dts2 = timed(step2, n2, 1, 1)
             timed_labels2 = page_state[id(m2)][0].cpu().numpy()
@@ -708,7 +733,8 @@ def main():
         # one page per step (BASELINE configs[1] literally: ONE 3500x2500 page = 70 tiles per call)
         keep = args.pages_per_step
         args.pages_per_step = 1
-        step1, tps1 = build_page(model)[:2]
+        step1 = build_page(model)[0]
+        tps1 = forwards_of(step1)
         n1 = max(10, args.steps)
         d1 = timed(step1, n1, 2, 1)[0]
         args.pages_per_step = keep
@@ -716,11 +742,13 @@ def main():
         extras["one_page_ms"] = round(d1 / n1 * 1e3, 3)
         # BASELINE configs[2]: border (whole image) + layout (Otsu'd, 4 classes) + textline on ONE page, models resident
         try:
-            step3, tps3, desc3 = build_pipeline3(model)[:3]
+            step3, calls3, desc3 = build_pipeline3(model)[:3]
+            tps3 = forwards_of(step3)
             n3 = max(5, args.steps // 2)
             d3 = timed(step3, n3, 2, 1)[0]
             extras["pipeline3_ms_per_page"] = round(d3 / n3 * 1e3, 3)
             extras["pipeline3_forwards_per_page"] = tps3
+            extras["pipeline3_reference_calls_per_page"] = calls3
             extras["pipeline3_patches_per_s"] = round(tps3 * n3 / d3, 1)
             extras["pipeline3_what"] = desc3
             extras["pipeline3_host_contour_fallbacks_per_page"] = round(fallbacks_of_pipeline3() / float(n3 + 2), 2)
@@ -743,7 +771,9 @@ def main():
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": scaling,
             "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
             "config": {"workload": workload_desc, "workload_id": workload,
-                       "tiles_per_step": tiles_per_step, "max_batch": args.max_batch,
+                       "tiles_per_step": tiles_per_step, "forwards_per_step": tiles_per_step,
+                       "reference_calls_per_step": reference_calls_per_step, "dedupe": tiles_per_step != reference_calls_per_step,
+                       "max_batch": args.max_batch,
                        "lanes": int(os.environ.get("SBBSEG_LANES", "2")),
                        "exchange": ("all_gather of u8 label maps over RCCL" if backend == "nccl" else f"all_gather staged through the host ({backend})") if world > 1 else "none (1 GPU)",
                        "flops_per_patch": 2 * model.plan.macs_per_patch()},

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SBBSEG_ABI_VERSION 3
+#define SBBSEG_ABI_VERSION 4
 
 typedef struct sbbseg_ctx sbbseg_ctx;
 
@@ -278,6 +278,25 @@ int sbbseg_extract_page_box(sbbseg_ctx* c, const uint8_t* page_hwc, int Hp, int 
 int sbbseg_extract_page_box_dev(sbbseg_ctx* c, const void* d_page_hwc, int Hp, int Wp, int Hs, int Ws, void* d_mask_out,
                                 int32_t* box_xywh, int64_t* pixels);
 
+/* get_text_region_contours_and_boxes' existence test (main.py:456-480), the `if len(contours) > 0` that decides whether run() calls
+ * the textline model at all (main.py:2083-2096): pixels == label -> 255, cv2.morphologyEx MORPH_OPEN then MORPH_CLOSE with the 5x5
+ * kernel, cv2.findContours(RETR_TREE), keep parentless contours whose polygon area >= min_area * H * W (the reference: min_area =
+ * 0.00001, max_area = 1).  *present = 1 when at least one contour is kept.  Decided from the largest outer-contour area of the
+ * opened / closed plane (the ranking of sbbseg_page_box_dev); the polygons themselves are not produced.  Synchronises the stream. */
+int sbbseg_text_regions_present_dev(sbbseg_ctx* c, const void* d_regions_hw, int H, int W, int label, double min_area, int* present);
+
+/* ---- device buffers for callers without a device runtime of their own.  The reference's environment is Keras/TF (requirements.txt),
+ * not PyTorch: what run() keeps resident across its three stages (main.py:2056-2107: the stored page, the border mask, the region
+ * map, the textline map) lives in buffers the library hands out, and every `_dev` entry point above accepts them.  A buffer belongs
+ * to the handle that allocated it (sbbseg_destroy frees what is left); any handle on the same device may use it.  upload / download
+ * return when the copy is complete.  sbbseg_download_labels: a u8 label plane [pixels] as 1 channel or as the 3 identical channels
+ * do_prediction returns (main.py:366), replicated on the device. */
+int sbbseg_device_alloc(sbbseg_ctx* c, size_t bytes, void** d_ptr);
+int sbbseg_device_free(sbbseg_ctx* c, void* d_ptr);                       /* NULL ok; a pointer of another handle is an error */
+int sbbseg_upload(sbbseg_ctx* c, void* d_dst, const void* src, size_t bytes);
+int sbbseg_download(sbbseg_ctx* c, void* dst, const void* d_src, size_t bytes);
+int sbbseg_download_labels(sbbseg_ctx* c, uint8_t* dst, const void* d_labels_hw, size_t pixels, int channels);
+
 /* ---- stage glue: the rotate-and-project of the deskew search (return_deskew_slope, main.py:1601-1718; per text region,
  * 80 angles in [-25, 25] and 30 more in [-90, -50] -- the reference spreads the regions over cpu_count() processes,
  * main.py:1760-1799).  The H x W u8 region mask is centred on a zero square of side S = (int)(1.4 * max(H, W))
@@ -352,6 +371,8 @@ int sbbseg_debug_read_tensor(sbbseg_ctx* c, int tensor_id, int n, float* out, si
 int sbbseg_debug_set_conv_variant(sbbseg_ctx* c, int variant);
 /* the exact host-side contour ranking of sbbseg_page_box_dev on a host mask that is ALREADY dilated (no GPU needed; tests) */
 int sbbseg_debug_largest_contour(const uint8_t* mask_hw, int H, int W, int32_t* box_xywh, int64_t* pixels);
+/* ... and TWICE the largest outer-contour area itself (host mirror of sbbseg_text_regions_present_dev's ranking; 0 for an empty mask) */
+int sbbseg_debug_largest_contour_area2(const uint8_t* mask_hw, int H, int W, int64_t* area2);
 /* counters: which 0 = how often sbbseg_page_box_dev had to fall back to the host ranking on this handle */
 int sbbseg_debug_counter(sbbseg_ctx* c, int which, int64_t* value);      /* which: 0 = exact host contour rankings, 1 = patches run through the plan */
 /* Test hook for the no-abort guarantee: the nth_check-th next internal host-allocation checkpoint throws

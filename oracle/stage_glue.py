@@ -114,19 +114,19 @@ _DX8 = (1, 1, 0, -1, -1, -1, 0, 1)          # E, SE, S, SW, W, NW, N, NE: clockw
 _DY8 = (0, 1, 1, 1, 0, -1, -1, -1)
 
 
-def outer_contour_area2(comp: np.ndarray) -> int:
-    """TWICE the area cv2.contourArea gives for the OUTER contour cv2.findContours traces around the 8-connected component
-    ``comp`` (bool [H,W], exactly one component) [EXT: OpenCV's border following visits the component's boundary pixels in
-    order; contourArea is the shoelace sum over that closed chain of pixel centres; CHAIN_APPROX_SIMPLE only drops collinear
-    points].  Moore neighbour tracing from the first pixel in raster order (its west neighbour is background), stopped when
-    the start pixel is left again in the first direction."""
+def outer_contour_chain(comp: np.ndarray):
+    """The OUTER border cv2.findContours traces around the 8-connected component ``comp`` (bool [H,W], exactly one component) as
+    the closed chain of boundary pixels [(x, y), ...] (CHAIN_APPROX_NONE; CHAIN_APPROX_SIMPLE drops the collinear ones) [EXT:
+    OpenCV's border following].  Moore neighbour tracing from the first pixel in raster order (its west neighbour is background),
+    stopped when the start pixel is left again in the first direction.  A single pixel gives a one-point chain."""
     H, W = comp.shape
     ys, xs = np.nonzero(comp)
     sy, sx = int(ys[0]), int(xs[0])                      # np.nonzero is row-major: the first pixel in raster order
 
     def inside(y, x):
         return 0 <= y < H and 0 <= x < W and bool(comp[y, x])
-    cy, cx, back, first, area2 = sy, sx, 4, None, 0
+    cy, cx, back, first = sy, sx, 4, None
+    chain = [(sx, sy)]
     for _ in range(4 * H * W + 8):
         d = None
         for k in range(1, 9):
@@ -135,16 +135,25 @@ def outer_contour_area2(comp: np.ndarray) -> int:
                 d = dd
                 break
         if d is None:
-            return 0                                     # a single pixel
+            return chain                                 # a single pixel
         if (cy, cx) == (sy, sx):
             if first is None:
                 first = d
             elif d == first:
                 break
-        ny, nx = cy + _DY8[d], cx + _DX8[d]
-        area2 += cx * ny - nx * cy
-        cy, cx = ny, nx
+        cy, cx = cy + _DY8[d], cx + _DX8[d]
+        chain.append((cx, cy))
         back = (d + (5 if d & 1 else 6)) & 7             # the background neighbour examined just before, seen from the new pixel
+    return chain[:-1]                                    # the last step re-entered the start pixel
+
+
+def outer_contour_area2(comp: np.ndarray) -> int:
+    """TWICE the area cv2.contourArea gives for that outer contour: the shoelace sum over the closed chain of pixel centres."""
+    c = outer_contour_chain(comp)
+    area2 = 0
+    for k in range(len(c)):
+        (x0, y0), (x1, y1) = c[k], c[(k + 1) % len(c)]
+        area2 += x0 * y1 - x1 * y0
     return abs(area2)
 
 
@@ -181,3 +190,56 @@ def crop_image_inside_box(box, img):
     """main.py:174-176."""
     x, y, w, h = box
     return img[y:y + h, x:x + w], [y, y + h, x, x + w]
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# get_text_region_contours_and_boxes (main.py:456-480): run() calls the textline model only when this returns at least
+# one contour (main.py:2083, 2096 `if len(contours) > 0`).  Restated down to the list of kept contours' areas; the
+# polygons themselves (CHAIN_APPROX_SIMPLE point lists, boundingRect) are outside the hot path's scope.
+#   mask_texts = np.all(image == (1, 1, 1), axis=-1)  -> * 255 -> uint8                      main.py:457-461
+#   cv2.morphologyEx(MORPH_OPEN, kernel) = dilate(erode(x)); MORPH_CLOSE = erode(dilate(x))    main.py:463-464  [EXT]
+#   cvtColor(BGR2GRAY) of three equal channels = the channel; threshold(imgray, 0, 255, 0) = > 0     main.py:467-469
+#   cv2.findContours(RETR_TREE, CHAIN_APPROX_SIMPLE) [EXT Suzuki-Abe border following]: one outer border per
+#     8-connected component, one hole border per 4-connected background component that does not reach the frame;
+#     hierarchy[0][j][3] == -1 <=> contour j is the outer border of a component that lies in the frame-connected background
+#   filter_contours_area_of_image(thresh, contours, hierarchy, max_area=1, min_area=0.00001)    main.py:77-92:
+#     keep contour j when len(c) >= 3, min_area * H * W <= shapely Polygon(c).area <= max_area * H * W and it has no parent.
+#     (Polygon(...).area of a ring = |shoelace sum| / 2 = cv2.contourArea; dropping collinear points does not change it.)
+# Quirk of the reference NOT restated: contours with fewer than three points `continue` past `jv += 1` (main.py:82-83),
+# after which hierarchy[0][jv] belongs to an earlier contour.  It cannot fire here: after OPEN and CLOSE every component
+# and every hole is a union of 5x5 squares, whose border has at least four corner points.
+def text_region_contour_areas(regions: np.ndarray, label: int = 1, min_area: float = 0.00001, max_area: float = 1.0):
+    """Areas (cv2.contourArea units) of the contours get_text_region_contours_and_boxes keeps, in raster order of the
+    components' first pixels.  ``regions``: uint8 [H,W,3] (all three channels are compared, main.py:457-458) or [H,W]."""
+    from scipy import ndimage
+    a = np.asarray(regions)
+    m = np.all(a == label, axis=-1) if a.ndim == 3 else (a == label)
+    img = np.where(m, 255, 0).astype(np.uint8)
+    img = morph(morph(img, "erode", 5, 1), "dilate", 5, 1)               # MORPH_OPEN
+    img = morph(morph(img, "dilate", 5, 1), "erode", 5, 1)               # MORPH_CLOSE
+    fg = img > 0
+    H, W = fg.shape
+    lab, n = ndimage.label(fg, structure=np.ones((3, 3), int))           # 8-connected foreground
+    if n == 0:
+        return []
+    # frame-connected background: 4-connected flood of the complement from a one-pixel frame around the image
+    bg = np.pad(~fg, 1, constant_values=True)
+    blab, _ = ndimage.label(bg, structure=[[0, 1, 0], [1, 1, 1], [0, 1, 0]])
+    outer_bg = (blab == blab[0, 0])
+    touch = np.zeros(n + 1, bool)                                        # component k is 4-adjacent to the frame-connected background
+    pl = np.pad(lab, 1, constant_values=0)
+    for dy, dx in ((0, 1), (0, -1), (1, 0), (-1, 0)):
+        sh = np.roll(outer_bg, (dy, dx), axis=(0, 1))
+        touch[np.unique(pl[sh & (pl > 0)])] = True
+    kept = []
+    total = float(np.prod(fg.shape[:2]))
+    for k, sl in enumerate(ndimage.find_objects(lab)):
+        area = outer_contour_area2(lab[sl] == k + 1) / 2.0
+        if min_area * total <= area <= max_area * total and touch[k + 1]:
+            kept.append(area)
+    return kept
+
+
+def text_regions_present(regions: np.ndarray, label: int = 1, min_area: float = 0.00001) -> bool:
+    """`len(contours) > 0` of main.py:2096 for the cleaned layout map."""
+    return len(text_region_contour_areas(regions, label, min_area)) > 0

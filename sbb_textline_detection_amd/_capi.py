@@ -31,6 +31,7 @@ EXPORTS = [
     "sbbseg_deskew_side", "sbbseg_rotation_matrix", "sbbseg_deskew_profiles_dev", "sbbseg_deskew_profiles",
     "sbbseg_segment_pages",
     "sbbseg_profile_enable", "sbbseg_profile_reset", "sbbseg_profile_get",
+    "sbbseg_debug_largest_contour_area2", "sbbseg_text_regions_present_dev", "sbbseg_device_alloc", "sbbseg_device_free", "sbbseg_upload", "sbbseg_download", "sbbseg_download_labels",
 ]
 
 
@@ -131,12 +132,19 @@ def load_library(path: Optional[str] = None):
         "sbbseg_profile_enable": [vp, i32],
         "sbbseg_profile_reset": [vp],
         "sbbseg_profile_get": [vp, i32, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_int64)],
+        "sbbseg_text_regions_present_dev": [vp, vp, i32, i32, i32, C.c_double, C.POINTER(C.c_int)],
+        "sbbseg_debug_largest_contour_area2": [vp, i32, i32, C.POINTER(C.c_int64)],
+        "sbbseg_device_alloc": [vp, C.c_size_t, C.POINTER(vp)],
+        "sbbseg_device_free": [vp, vp],
+        "sbbseg_upload": [vp, vp, vp, C.c_size_t],
+        "sbbseg_download": [vp, vp, vp, C.c_size_t],
+        "sbbseg_download_labels": [vp, vp, vp, C.c_size_t, i32],
     }
     for name, args in sigs.items():
         fn = getattr(lib, name)
         fn.argtypes = args
         fn.restype = C.c_int
-    if lib.sbbseg_abi_version() != 3:
+    if lib.sbbseg_abi_version() != 4:
         raise RuntimeError("libsbbseg ABI version mismatch")
     if path is None:
         _lib = lib
@@ -459,6 +467,46 @@ class Context:
     def morph_dev(self, d_src: int, H: int, W: int, op: int, ksize: int, iterations: int, d_dst: int):
         check(self.lib.sbbseg_morph_dev(self.h, C.c_void_p(d_src), H, W, int(op), int(ksize), int(iterations), C.c_void_p(d_dst)), "sbbseg_morph_dev")
 
+    # -- device buffers (callers without torch: stages.InferenceStages.run) ------------------------------------------
+    def device_alloc(self, nbytes: int) -> int:
+        p = C.c_void_p()
+        check(self.lib.sbbseg_device_alloc(self.h, int(nbytes), C.byref(p)), "sbbseg_device_alloc")
+        return int(p.value)
+
+    def device_free(self, d_ptr: int):
+        if d_ptr and getattr(self, "h", None):
+            check(self.lib.sbbseg_device_free(self.h, C.c_void_p(d_ptr)), "sbbseg_device_free")
+
+    def upload(self, d_dst: int, a: np.ndarray):
+        a = np.ascontiguousarray(a)
+        check(self.lib.sbbseg_upload(self.h, C.c_void_p(d_dst), _ptr(a), a.nbytes), "sbbseg_upload")
+
+    def download(self, d_src: int, shape, dtype=np.uint8) -> np.ndarray:
+        out = np.empty(shape, dtype)
+        check(self.lib.sbbseg_download(self.h, _ptr(out), C.c_void_p(d_src), out.nbytes), "sbbseg_download")
+        return out
+
+    def download_labels(self, d_labels: int, h: int, w: int, channels: int = 1) -> np.ndarray:
+        out = np.empty((h, w, 3) if channels == 3 else (h, w), np.uint8)
+        check(self.lib.sbbseg_download_labels(self.h, _ptr(out), C.c_void_p(d_labels), h * w, channels), "sbbseg_download_labels")
+        return out
+
+    def text_regions_present_dev(self, d_regions: int, H: int, W: int, label: int = 1, min_area: float = 0.00001) -> bool:
+        """get_text_region_contours_and_boxes' `len(contours) > 0` (main.py:456-480, 2083-2096) on a device label plane."""
+        present = C.c_int(0)
+        check(self.lib.sbbseg_text_regions_present_dev(self.h, C.c_void_p(d_regions), H, W, label, float(min_area), C.byref(present)),
+              "sbbseg_text_regions_present_dev")
+        return bool(present.value)
+
+    def text_regions_present(self, regions: np.ndarray, label: int = 1, min_area: float = 0.00001) -> bool:
+        plane = np.ascontiguousarray(regions[:, :, 0] if regions.ndim == 3 else regions, np.uint8)
+        d = self.device_alloc(plane.size)
+        try:
+            self.upload(d, plane)
+            return self.text_regions_present_dev(d, plane.shape[0], plane.shape[1], label, min_area)
+        finally:
+            self.device_free(d)
+
     def page_box_dev(self, d_mask: int, H: int, W: int):
         """((x, y, w, h), pixels) of the largest component of the dilated mask (main.py:394-404); pixels == 0: empty mask."""
         box = np.zeros(4, np.int32)
@@ -548,6 +596,14 @@ def host_largest_contour(mask: np.ndarray):
     px = C.c_int64(0)
     check(load_library().sbbseg_debug_largest_contour(_ptr(mask), mask.shape[0], mask.shape[1], _ptr(box), C.byref(px)), "sbbseg_debug_largest_contour")
     return tuple(int(v) for v in box), int(px.value)
+
+
+def host_largest_contour_area2(mask: np.ndarray) -> int:
+    """TWICE the largest outer-contour area (cv2.contourArea) of a u8 mask by the library's HOST tracer; no GPU."""
+    mask = np.ascontiguousarray(mask, np.uint8)
+    a2 = C.c_int64(0)
+    check(load_library().sbbseg_debug_largest_contour_area2(_ptr(mask), mask.shape[0], mask.shape[1], C.byref(a2)), "sbbseg_debug_largest_contour_area2")
+    return int(a2.value)
 
 
 def comm_unique_id() -> bytes:

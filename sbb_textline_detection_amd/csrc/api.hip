@@ -276,6 +276,7 @@ struct sbbseg_ctx {
     int num_cus = 256;
     std::vector<PendingEvent> pending;
     std::vector<hipEvent_t> free_events;
+    std::vector<std::pair<void*, size_t>> user_bufs;      // sbbseg_device_alloc's buffers still alive (freed by sbbseg_destroy)
 };
 
 namespace {
@@ -526,7 +527,8 @@ int launch_op(sbbseg_ctx* c, Op& op, int n, uint8_t* d_labels, float* d_probs)
             }
         } else if (op.type == kPool) {
             const PoolOp& po = op.pool;
-            if (po.fused_into_stem && !c->unfuse_stem_pool) return 0;          // written by the stem's launch (stem_pool_x3)
+            // written by the stem's launch (stem_pool_x3) -- under exactly the condition that sends the stem there (launch_op, kConv)
+            if (po.fused_into_stem && !c->unfuse_stem_pool && !(c->conv_variant & 3)) return 0;
             const Tensor& s = c->tensors[po.src];
             HIPCHK(launch_maxpool(s.data(), c->tensors[po.dst].data(), n, s.H, s.W, s.C, po.k, po.stride, po.Ho, po.Wo,
                                   po.d_pre_scale, po.d_pre_shift, po.pre_relu, c->precision, c->stream));
@@ -711,7 +713,7 @@ long long trace_outer_area2(Inside inside, int sy, int sx, long n_pixels, int (&
     return area2 < 0 ? -area2 : area2;
 }
 
-bool host_largest_contour(const uint8_t* m, int H, int W, int (&out)[5])
+bool host_largest_contour(const uint8_t* m, int H, int W, int (&out)[5], long long* area2_out = nullptr)
 {
     const long n = (long)H * W;
     std::vector<int> lab(n, -1);
@@ -745,6 +747,7 @@ bool host_largest_contour(const uint8_t* m, int H, int W, int (&out)[5])
         const long long area2 = trace_outer_area2(inside, (int)(s / W), (int)(s - (long)(s / W) * W), n, tb);
         if (area2 >= best_area2) { best_area2 = area2; out[0] = x0; out[1] = y0; out[2] = x1; out[3] = y1; out[4] = cnt; }   // ties: the later one
     }
+    if (area2_out) *area2_out = best_area2 < 0 ? 0 : best_area2;
     return n_comp > 0;
 }
 
@@ -888,6 +891,7 @@ int sbbseg_destroy(sbbseg_ctx* c)
     (void)hipFree(c->d_page); (void)hipFree(c->d_page_labels); (void)hipFree(c->d_page_labels3); (void)hipFree(c->d_tile_labels);
     (void)hipFree(c->d_own_x); (void)hipFree(c->d_own_y); (void)hipFree(c->d_map); (void)hipFree(c->d_wmap);
     (void)hipFree(c->d_deskew);
+    for (auto& ub : c->user_bufs) (void)hipFree(ub.first);
     for (int k = 0; k < 2; ++k) {
         (void)hipHostFree(c->pp_h_in[k]); (void)hipHostFree(c->pp_h_out[k]);
         (void)hipFree(c->pp_d_in[k]); (void)hipFree(c->pp_d_out[k]); (void)hipFree(c->pp_d_out3[k]);
@@ -2605,10 +2609,14 @@ static int whole_scaled_impl(sbbseg_ctx* c, const uint8_t* page_hwc, const void*
     ip.page = d_page_in ? (const uint8_t*)d_page_in : c->d_page; ip.Hp = Hp; ip.Wp = Wp; ip.src_Hp = Hp; ip.src_Wp = Wp; ip.tile_xy = nullptr; ip.n_tiles = 1;
     ip.whole = 1; ip.map_y = d_my; ip.map_x = d_mx;
     HIPCHK(launch_ingest_u8(ip, c->precision, c->stream));
-    c->ksplit_now = c->ksplit;
-    const int plan_rc = run_plan(c, 1, c->d_batch_labels, nullptr);
-    c->ksplit_now = false;
-    if (plan_rc) return 1;
+    {
+        struct KsplitScope {               // reset on every way out (a throwing run_plan included): later n == 1 launches must not split
+            sbbseg_ctx* c;
+            explicit KsplitScope(sbbseg_ctx* c_) : c(c_) { c->ksplit_now = c->ksplit; }
+            ~KsplitScope() { c->ksplit_now = false; }
+        } scope(c);
+        if (run_plan(c, 1, c->d_batch_labels, nullptr)) return 1;
+    }
     HIPCHK(launch_resize_labels(c->d_batch_labels, c->in_H, c->in_W, d_oy, d_ox, out_h, out_w, c->d_page_labels, c->stream));
     if (labels_out) {
         if (labels_to_host(c, labels_out, opix)) return 1;
@@ -2656,22 +2664,20 @@ int sbbseg_morph(sbbseg_ctx* c, const uint8_t* src_hw, int H, int W, int op, int
     API_END
 }
 
-int sbbseg_page_box_dev(sbbseg_ctx* c, const void* d_mask_hw, int H, int W, int32_t* box_xywh, int64_t* pixels)
+// The contour ranking behind sbbseg_page_box_dev and sbbseg_text_regions_present_dev: 8-connected components of the 0 / 255 plane in
+// c->d_morph_b, ranked by the area of their outer contour (cv2.contourArea of cv2.findContours' outer borders).  The device ranks by a
+// lower bound of that area and checks the winner against every other component's bounding-box bound (launch_largest_contour); when
+// that leaves the ranking open -- or when the caller needs the winner's EXACT area (`exact`) -- the host walks the outer borders of
+// the candidates on the device's label plane (parent[i] = root = the component's first pixel in raster order): 4 bytes per pixel of
+// D2H + the candidates' perimeters.  box = {x0, y0, x1, y1, pixels} of the winner; *any = false for an empty plane; *area2 = twice the
+// winner's contour area (exact when traced, else the device's lower bound; *traced says which).
+static int rank_contours(sbbseg_ctx* c, int H, int W, bool exact, int (&box)[5], bool* any, long long* area2, bool* traced)
 {
-    API_BEGIN
-    if (check_ready(c)) return 1;
-    REQUIRE(d_mask_hw && box_xywh && H > 0 && W > 0, "bad arguments");
-    REQUIRE((size_t)H * W < ((size_t)1 << 31), "mask too large for 32-bit pixel indices");
     const size_t pix = (size_t)H * W;
-    if (ensure(c, (void**)&c->d_morph_a, &c->morph_a_cap, pix) || ensure(c, (void**)&c->d_morph_b, &c->morph_b_cap, pix)) return 1;
     if (ensure(c, (void**)&c->d_cc_parent, &c->cc_parent_cap, pix * sizeof(int)) || ensure(c, (void**)&c->d_cc_count, &c->cc_count_cap, pix * sizeof(int))) return 1;
     if (ensure(c, (void**)&c->d_cc_aux, &c->cc_aux_cap, 5 * pix * sizeof(int))) return 1;
     if (!c->d_cc_small && dmalloc(c, (void**)&c->d_cc_small, 4 * sizeof(unsigned long long))) return 1;
     if (!c->d_cc_list && dmalloc(c, (void**)&c->d_cc_list, (6 + kCcMaxRivals) * sizeof(int))) return 1;
-    // main.py:394-398: gray > 0 -> 255, dilate with the 5x5 kernel of ones, 6 iterations (= one clipped 25x25 maximum)
-    HIPCHK(launch_morph((const uint8_t*)d_mask_hw, c->d_morph_a, c->d_morph_b, H, W, 12, 1, 1, c->stream));
-    // main.py:398-404: the contour with the largest cv2.contourArea.  The device ranks the components by a lower bound of
-    // their outer contour's area and checks it against every other component's upper bound (launch_largest_contour)...
     int* d_out = c->d_cc_list;
     int* aux = c->d_cc_aux;
     HIPCHK(launch_largest_contour(c->d_morph_b, H, W, c->d_cc_parent, c->d_cc_count, aux, aux + pix, aux + 2 * pix, aux + 3 * pix, aux + 4 * pix,
@@ -2681,12 +2687,11 @@ int sbbseg_page_box_dev(sbbseg_ctx* c, const void* d_mask_hw, int H, int W, int3
     HIPCHK(hipMemcpyAsync(out, d_out, sizeof(out), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipMemcpyAsync(&key, c->d_cc_small, sizeof(key), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
-    int box[5] = {out[0], out[1], out[2], out[3], out[4]};
-    const bool any = out[2] >= 0;
-    if (any && (out[5] > 0 || c->force_host_contours)) {
-        // ... and when that does not decide it (a ring- or frame-shaped blob beside a solid one), the host walks the outer
-        // borders of the candidates on the device's label plane (parent[i] = root = the component's first pixel in raster
-        // order): cost = 4 bytes per pixel of D2H + the candidates' perimeters
+    for (int q = 0; q < 5; ++q) box[q] = out[q];
+    *any = out[2] >= 0;
+    *area2 = (long long)(key >> 32);
+    *traced = false;
+    if (*any && (out[5] > 0 || exact || c->force_host_contours)) {
         alloc_check();
         std::vector<int> lab(pix);
         HIPCHK(hipMemcpy(lab.data(), c->d_cc_parent, pix * sizeof(int), hipMemcpyDeviceToHost));
@@ -2709,7 +2714,27 @@ int sbbseg_page_box_dev(sbbseg_ctx* c, const void* d_mask_hw, int H, int W, int3
         }
         HIPCHK(hipMemcpy(&box[4], c->d_cc_count + best_root, sizeof(int), hipMemcpyDeviceToHost));
         c->host_contour_calls += 1;
+        *area2 = best_area2;
+        *traced = true;
     }
+    return 0;
+}
+
+int sbbseg_page_box_dev(sbbseg_ctx* c, const void* d_mask_hw, int H, int W, int32_t* box_xywh, int64_t* pixels)
+{
+    API_BEGIN
+    if (check_ready(c)) return 1;
+    REQUIRE(d_mask_hw && box_xywh && H > 0 && W > 0, "bad arguments");
+    REQUIRE((size_t)H * W < ((size_t)1 << 31), "mask too large for 32-bit pixel indices");
+    const size_t pix = (size_t)H * W;
+    if (ensure(c, (void**)&c->d_morph_a, &c->morph_a_cap, pix) || ensure(c, (void**)&c->d_morph_b, &c->morph_b_cap, pix)) return 1;
+    // main.py:394-398: gray > 0 -> 255, dilate with the 5x5 kernel of ones, 6 iterations (= one clipped 25x25 maximum)
+    HIPCHK(launch_morph((const uint8_t*)d_mask_hw, c->d_morph_a, c->d_morph_b, H, W, 12, 1, 1, c->stream));
+    // main.py:398-404: the contour with the largest cv2.contourArea
+    int box[5];
+    bool any = false, traced = false;
+    long long area2 = 0;
+    if (rank_contours(c, H, W, false, box, &any, &area2, &traced)) return 1;
     if (pixels) *pixels = any ? (int64_t)box[4] : 0;
     if (!any) {                                        // empty mask: the reference's np.argmax of an empty list raises (main.py:399-401)
         box_xywh[0] = box_xywh[1] = box_xywh[2] = box_xywh[3] = 0;
@@ -2720,12 +2745,126 @@ int sbbseg_page_box_dev(sbbseg_ctx* c, const void* d_mask_hw, int H, int W, int3
     API_END
 }
 
+// get_text_region_contours_and_boxes' EXISTENCE test (main.py:456-480, the `if len(contours) > 0` that gates the textline model,
+// main.py:2083-2096): class mask (all channels == label -> 255), MORPH_OPEN, MORPH_CLOSE with the 5x5 kernel, findContours(RETR_TREE),
+// keep the contours without a parent whose polygon area lies in [min_area, max_area = 1] x H x W.  After OPEN and CLOSE every
+// component and every hole is a union of 5x5 squares, so no contour has fewer than three points (the `jv` bookkeeping of
+// filter_contours_area_of_image, main.py:81-91, never drifts), and the largest outer contour of the plane is always a parentless one
+// (a component nested in a hole is smaller than the component around it): contours exist <=> the largest outer-contour area
+// reaches min_area * H * W.  The contours themselves (polygons, boxes) are out of scope.
+int sbbseg_text_regions_present_dev(sbbseg_ctx* c, const void* d_regions_hw, int H, int W, int label, double min_area, int* present)
+{
+    API_BEGIN
+    if (check_ready(c)) return 1;
+    REQUIRE(d_regions_hw && present && H > 0 && W > 0 && label >= 0 && label <= 255 && min_area >= 0.0, "bad arguments");
+    REQUIRE((size_t)H * W < ((size_t)1 << 31), "plane too large for 32-bit pixel indices");
+    const size_t pix = (size_t)H * W;
+    if (ensure(c, (void**)&c->d_morph_a, &c->morph_a_cap, pix) || ensure(c, (void**)&c->d_morph_b, &c->morph_b_cap, pix)) return 1;
+    // OPEN = erode, dilate; CLOSE = dilate, erode (cv2.morphologyEx, one iteration each, default border: outside pixels never win);
+    // the two dilations in a row are one clipped 9x9 maximum
+    HIPCHK(launch_morph((const uint8_t*)d_regions_hw, c->d_morph_a, c->d_morph_b, H, W, 2, 0, 0x100 | label, c->stream));
+    HIPCHK(launch_morph(c->d_morph_b, c->d_morph_a, c->d_morph_b, H, W, 4, 1, 0, c->stream));
+    HIPCHK(launch_morph(c->d_morph_b, c->d_morph_a, c->d_morph_b, H, W, 2, 0, 0, c->stream));
+    const double need = min_area * (double)((long long)H * W);            // main.py:87: area >= min_area * np.prod(image.shape[:2])
+    int box[5];
+    bool any = false, traced = false;
+    long long area2 = 0;
+    if (rank_contours(c, H, W, false, box, &any, &area2, &traced)) return 1;
+    if (any && !traced && (double)area2 * 0.5 < need) {
+        // the device's figure is a lower bound (holes not filled): only the exact area can say "too small"
+        if (rank_contours(c, H, W, true, box, &any, &area2, &traced)) return 1;
+    }
+    *present = (any && (double)area2 * 0.5 >= need) ? 1 : 0;
+    return 0;
+    API_END
+}
+
+// ---- device buffers for callers that have no device runtime of their own (the reference's environment is Keras/TF, not PyTorch):
+// what run() keeps resident across its three stages -- the stored page, the border mask, the region map, the textline map -- lives in
+// buffers the library hands out.  They belong to the handle that allocated them (sbbseg_destroy frees what is left) but any handle of
+// the same device may read and write them.
+int sbbseg_device_alloc(sbbseg_ctx* c, size_t bytes, void** d_ptr)
+{
+    API_BEGIN
+    REQUIRE(c != nullptr && d_ptr != nullptr && bytes > 0, "bad arguments");
+    HIPCHK(hipSetDevice(c->device));
+    alloc_check();
+    void* p = nullptr;
+    c->user_bufs.reserve(c->user_bufs.size() + 1);
+    if (dmalloc(c, &p, bytes)) return 1;
+    c->user_bufs.push_back({p, bytes});
+    *d_ptr = p;
+    return 0;
+    API_END
+}
+
+int sbbseg_device_free(sbbseg_ctx* c, void* d_ptr)
+{
+    API_BEGIN
+    REQUIRE(c != nullptr, "null handle");
+    if (!d_ptr) return 0;
+    for (size_t i = 0; i < c->user_bufs.size(); ++i)
+        if (c->user_bufs[i].first == d_ptr) {
+            HIPCHK(hipSetDevice(c->device));
+            HIPCHK(hipDeviceSynchronize());            // other handles' streams may still be reading it
+            HIPCHK(hipFree(d_ptr));
+            c->device_bytes -= c->user_bufs[i].second;
+            c->user_bufs.erase(c->user_bufs.begin() + (long)i);
+            return 0;
+        }
+    return fail("sbbseg_device_free: %p was not allocated by this handle", d_ptr);
+    API_END
+}
+
+// host -> device / device -> host on the handle's stream; both return when the copy is complete, so the buffer may be handed to
+// another handle (another stream) right away.
+int sbbseg_upload(sbbseg_ctx* c, void* d_dst, const void* src, size_t bytes)
+{
+    API_BEGIN
+    REQUIRE(c != nullptr && d_dst && src, "bad arguments");
+    HIPCHK(hipSetDevice(c->device));
+    if (bytes) HIPCHK(hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+    API_END
+}
+
+int sbbseg_download(sbbseg_ctx* c, void* dst, const void* d_src, size_t bytes)
+{
+    API_BEGIN
+    REQUIRE(c != nullptr && dst && d_src, "bad arguments");
+    HIPCHK(hipSetDevice(c->device));
+    if (bytes) HIPCHK(hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+    API_END
+}
+
+// a u8 label plane [pixels] on the device -> host memory, as one plane or as the three identical channels do_prediction returns
+// (main.py:366; replicated on the device, sbbseg_set_label_channels is not consulted)
+int sbbseg_download_labels(sbbseg_ctx* c, uint8_t* dst, const void* d_labels_hw, size_t pixels, int channels)
+{
+    API_BEGIN
+    REQUIRE(c != nullptr && dst && d_labels_hw && pixels > 0 && (channels == 1 || channels == 3), "bad arguments (channels: 1 or 3)");
+    HIPCHK(hipSetDevice(c->device));
+    if (channels == 3) {
+        if (ensure(c, (void**)&c->d_page_labels3, &c->page_labels3_cap, (pixels + 3) / 4 * 12)) return 1;
+        HIPCHK(launch_replicate3((const uint8_t*)d_labels_hw, c->d_page_labels3, pixels, c->stream));
+        HIPCHK(hipMemcpyAsync(dst, c->d_page_labels3, pixels * 3, hipMemcpyDeviceToHost, c->stream));
+    } else {
+        HIPCHK(hipMemcpyAsync(dst, d_labels_hw, pixels, hipMemcpyDeviceToHost, c->stream));
+    }
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+    API_END
+}
+
 int sbbseg_extract_page_box(sbbseg_ctx* c, const uint8_t* page_hwc, int Hp, int Wp, int Hs, int Ws, uint8_t* mask_out, int32_t* box_xywh,
                             int64_t* pixels)
 {
     API_BEGIN
     if (check_ready(c)) return 1;
-    REQUIRE(page_hwc && box_xywh && Hs > 0 && Ws > 0, "bad arguments");
+    REQUIRE(page_hwc && box_xywh && Hp > 0 && Wp > 0 && Hs > 0 && Ws > 0, "bad arguments");
     // border model on the (virtually) upscaled page, result at the upscaled size (main.py:384-392) ...  (mask_out == NULL: the mask --
     // a local of extract_page in the reference -- stays on the device)
     if (whole_scaled_impl(c, page_hwc, nullptr, Hp, Wp, Hs, Ws, Hs, Ws, mask_out)) return 1;
@@ -2983,6 +3122,19 @@ int sbbseg_debug_largest_contour(const uint8_t* mask_hw, int H, int W, int32_t* 
     if (pixels) *pixels = any ? out[4] : 0;
     box_xywh[0] = any ? out[0] : 0; box_xywh[1] = any ? out[1] : 0;
     box_xywh[2] = any ? out[2] - out[0] + 1 : 0; box_xywh[3] = any ? out[3] - out[1] + 1 : 0;
+    return 0;
+    API_END
+}
+
+int sbbseg_debug_largest_contour_area2(const uint8_t* mask_hw, int H, int W, int64_t* area2)
+{
+    API_BEGIN
+    REQUIRE(mask_hw && area2 && H > 0 && W > 0 && (size_t)H * W < ((size_t)1 << 31), "bad arguments");
+    alloc_check();
+    int out[5] = {0, 0, 0, 0, 0};
+    long long a2 = 0;
+    host_largest_contour(mask_hw, H, W, out, &a2);
+    *area2 = (int64_t)a2;
     return 0;
     API_END
 }

@@ -3722,6 +3722,13 @@ hipError_t launch_resize_labels(const uint8_t* labels, int H, int W, const int* 
 // n iterations of a k x k min (erode) / max (dilate) filter with cv2's default border (the outside never wins:
 // BORDER_CONSTANT with +inf / -inf) == ONE (n(k-1)+1)-wide filter over the window clipped to the image, separable.
 // pass 0: along x, pass 1: along y.
+// binarize: 0 = the plane as it is; 1 = t > 0 ? 255 : 0 (cv2.threshold(gray, 0, 255, THRESH_BINARY), main.py:395); 0x100 | label =
+// t == label ? 255 : 0 (the class mask of get_text_region_contours_and_boxes, main.py:457-461)
+__device__ __forceinline__ int morph_binarize(int t, int binarize)
+{
+    if (binarize & 0x100) return t == (binarize & 0xff) ? 255 : 0;
+    return binarize ? (t > 0 ? 255 : 0) : t;
+}
 __global__ __launch_bounds__(256) void morph_pass_kernel(const uint8_t* src, uint8_t* dst, int H, int W, int radius, int is_max,
                                                          int vertical, int binarize)
 {
@@ -3734,7 +3741,7 @@ __global__ __launch_bounds__(256) void morph_pass_kernel(const uint8_t* src, uin
         const uint8_t* row = src + (size_t)y * W;
         for (int q = lo; q <= hi; ++q) {
             int t = row[q];
-            if (binarize) t = t > 0 ? 255 : 0;             // cv2.threshold(gray, 0, 255, THRESH_BINARY) of main.py:395
+            t = morph_binarize(t, binarize);
             v = is_max ? max(v, t) : min(v, t);
         }
     } else {
@@ -3765,15 +3772,15 @@ __global__ __launch_bounds__(256) void morph_pass4_kernel(const uint8_t* src, ui
         // window of output j = [x0 + j - radius, x0 + j + radius]: bytes x0 - radius + 3 .. x0 + radius are common to all four
         int mid = ID;
         for (int q = x0 - radius + 3; q <= x0 + radius; ++q) {
-            if ((unsigned)q < (unsigned)W) { int t = row[q]; if (binarize) t = t > 0 ? 255 : 0; mid = op(mid, t); }
+            if ((unsigned)q < (unsigned)W) { const int t = morph_binarize(row[q], binarize); mid = op(mid, t); }
         }
         int e[6];                                           // the three bytes on either side of the common part
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
             const int ql = x0 - radius + j, qr = x0 + radius + 1 + j;
             int tl = ID, tr = ID;
-            if ((unsigned)ql < (unsigned)W) { tl = row[ql]; if (binarize) tl = tl > 0 ? 255 : 0; }
-            if ((unsigned)qr < (unsigned)W) { tr = row[qr]; if (binarize) tr = tr > 0 ? 255 : 0; }
+            if ((unsigned)ql < (unsigned)W) tl = morph_binarize(row[ql], binarize);
+            if ((unsigned)qr < (unsigned)W) tr = morph_binarize(row[qr], binarize);
             e[j] = tl; e[3 + j] = tr;
         }
         o0 = op(mid, op(e[0], op(e[1], e[2])));

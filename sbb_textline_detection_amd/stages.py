@@ -94,6 +94,20 @@ def host_page_box(mask: np.ndarray):
     return _capi.host_largest_contour(d)
 
 
+def host_text_regions_present(regions: np.ndarray, label: int = 1, min_area: float = 0.00001) -> bool:
+    """Host mirror of sbbseg_text_regions_present_dev (foreign model objects only; main.py:456-480): class mask -> OPEN -> CLOSE ->
+    the largest outer-contour area (the library's host tracer, no GPU) >= min_area x H x W."""
+    a = np.asarray(regions)
+    m = np.all(a == label, axis=-1) if a.ndim == 3 else a == label
+    p = np.where(m, 255, 0).astype(np.uint8)
+    p = host_morph(host_morph(p, False, 5, 1), True, 5, 2)             # OPEN's erode + dilate, CLOSE's dilate ...
+    p = host_morph(p, False, 5, 1)                                     # ... and erode
+    if not p.any():
+        return False
+    from . import _capi
+    return _capi.host_largest_contour_area2(p) * 0.5 >= min_area * float(p.shape[0] * p.shape[1])
+
+
 def _profile_statistics(y: np.ndarray, sigma: float, multiplier: float):
     """get_standard_deviation_of_summed_textline_patch_along_width (main.py:1545-1599) from the row sums on: smoothed profile z,
     its maxima and the minima of the padded, negated profile (scipy, as the reference), the "deep" minima below
@@ -290,34 +304,46 @@ class InferenceStages:
         finally:
             session.close()
 
+    def text_regions_present(self, regions: np.ndarray) -> bool:
+        """get_text_region_contours_and_boxes(...) returns at least one contour (main.py:456-480; run() gates the textline model on
+        it, main.py:2083-2096): class-1 mask -> MORPH_OPEN -> MORPH_CLOSE -> a parentless contour of area >= 1e-5 x H x W.  On the
+        device for a SegModel (``sbbseg_text_regions_present_dev``); foreign model objects get the host mirror."""
+        model, session = start_new_session_and_model(self.model_region_dir, **self.kw)
+        try:
+            if isinstance(model, SegModel):
+                return model.ctx.text_regions_present(regions, 1, 0.00001)
+            return host_text_regions_present(regions)
+        finally:
+            session.close()
+
     def _run_resident(self):
         """run()'s three stages with the stored page uploaded ONCE and kept in device memory for all of them (run() hands the same
         page to every stage, main.py:2061-2102), the border mask and the region map staying on the device between their model and
-        their glue: the `_dev` entry points of the C ABI on buffers that torch allocates (plumbing only).  Same return value as the
-        stage-by-stage path below, which remains the path for foreign model objects, for boxes without torch / a GPU and for
-        SBBSEG_STAGES_RESIDENT=0.  Returns None when it does not apply."""
+        their glue: the `_dev` entry points of the C ABI on buffers the LIBRARY allocates (``sbbseg_device_alloc`` / ``_upload`` /
+        ``_download_labels``, round 5: no PyTorch anywhere on this path -- the reference's environment has none).  Same return value
+        as the stage-by-stage path below, which remains the path for foreign model objects and for SBBSEG_STAGES_RESIDENT=0.
+        Returns None when it does not apply."""
         import os
         if os.environ.get("SBBSEG_STAGES_RESIDENT", "1") == "0":
             return None
-        try:
-            import torch
-            if not torch.cuda.is_available():
-                return None
-        except Exception:
-            return None
         opened = [start_new_session_and_model(d, **self.kw) for d in (self.model_page_dir, self.model_region_dir, self.model_textline_dir)]
+        bufs = []
         try:
             (m_page, _), (m_region, _), (m_text, _) = opened
             if not all(isinstance(m, SegModel) for m in (m_page, m_region, m_text)):
                 return None
-            dev = torch.device("cuda", m_page.device if hasattr(m_page, "device") and isinstance(m_page.device, int) else torch.cuda.current_device())
+            ctx = m_page.ctx                                         # owner of the buffers
+
+            def alloc(n):
+                bufs.append(ctx.device_alloc(n))
+                return bufs[-1]
             H, W = self.image_stored.shape[:2]
             Hs, Ws = self.img_hight_int, self.img_width_int
-            d_page = torch.from_numpy(np.ascontiguousarray(self.image_stored, np.uint8)).to(dev)      # the one upload of the page
-            d_mask = torch.empty((Hs, Ws), dtype=torch.uint8, device=dev)
+            d_page = alloc(H * W * 3)
+            ctx.upload(d_page, self.image_stored)                    # the one upload of the page
+            d_mask = alloc(Hs * Ws)
             # extract_page (main.py:384-437), outside the try like main.py:2061: its errors propagate
-            box, pixels = m_page.ctx.extract_page_box_dev(d_page.data_ptr(), H, W, Hs, Ws, d_mask.data_ptr())
-            m_page.ctx.synchronize()
+            box, pixels = ctx.extract_page_box_dev(d_page, H, W, Hs, Ws, d_mask)
             if pixels == 0:
                 raise ValueError("attempt to get argmax of an empty sequence")          # what main.py:401 raises
             x, y, w, h = box
@@ -325,32 +351,35 @@ class InferenceStages:
             page_coord = [y, y + h, x, x + w]
             self.cont_page = [np.array([[page_coord[2], page_coord[0]], [page_coord[3], page_coord[0]],
                                         [page_coord[3], page_coord[1]], [page_coord[2], page_coord[1]]])]
-            self.page_mask = d_mask.unsqueeze(-1).expand(-1, -1, 3).contiguous().cpu().numpy()
+            self.page_mask = ctx.download_labels(d_mask, Hs, Ws, 3)
             regions, has_text = None, False
             try:                                                     # main.py:2069-2091: a failed layout stage = no regions
-                d_regions = torch.empty((h, w), dtype=torch.uint8, device=dev)
-                d_clean = torch.empty((h, w), dtype=torch.uint8, device=dev)
-                d_thr = torch.zeros(1, dtype=torch.int32, device=dev)
-                m_region.ctx.segment_crop_dev(d_page.data_ptr(), H, W, Hs, Ws, box, True, d_regions.data_ptr(), d_thr.data_ptr())
-                m_region.ctx.morph_dev(d_regions.data_ptr(), h, w, 0, 5, 3, d_clean.data_ptr())      # main.py:2074-2075
-                m_region.ctx.morph_dev(d_clean.data_ptr(), h, w, 1, 5, 4, d_clean.data_ptr())
-                m_region.ctx.synchronize()
-                self.otsu_threshold = int(d_thr.item())
-                has_text = bool((d_clean == 1).any().item())
-                regions = d_clean.unsqueeze(-1).expand(-1, -1, 3).contiguous().cpu().numpy()
+                rc = m_region.ctx
+                d_regions, d_clean, d_thr = alloc(h * w), alloc(h * w), alloc(4)
+                rc.segment_crop_dev(d_page, H, W, Hs, Ws, box, True, d_regions, d_thr)
+                rc.morph_dev(d_regions, h, w, 0, 5, 3, d_clean)      # main.py:2074-2075
+                rc.morph_dev(d_clean, h, w, 1, 5, 4, d_clean)
+                self.otsu_threshold = int(rc.download(d_thr, (1,), np.int32)[0])
+                has_text = rc.text_regions_present_dev(d_clean, h, w, 1, 0.00001)      # main.py:2083, 2096 (456-480)
+                regions = rc.download_labels(d_clean, h, w, 3)
             except Exception:
                 regions, has_text = None, False
             textlines = None
             if has_text:
                 try:
-                    d_lines = torch.empty((h, w), dtype=torch.uint8, device=dev)
-                    m_text.ctx.segment_crop_dev(d_page.data_ptr(), H, W, Hs, Ws, box, False, d_lines.data_ptr())
-                    m_text.ctx.synchronize()
-                    textlines = d_lines.cpu().numpy()
+                    d_lines = alloc(h * w)
+                    m_text.ctx.segment_crop_dev(d_page, H, W, Hs, Ws, box, False, d_lines)
+                    textlines = m_text.ctx.download_labels(d_lines, h, w, 1)
                 except Exception:                                   # main.py:2152-2157
                     textlines = None
             return self.page_mask, regions, textlines, page_coord
         finally:
+            if bufs:
+                for m, _ in opened:                                  # nothing may still read the buffers when they go
+                    if isinstance(m, SegModel):
+                        m.ctx.synchronize()
+                for b in bufs:
+                    opened[0][0].ctx.device_free(b)
             for _, session in opened:
                 session.close()
 
@@ -369,12 +398,12 @@ class InferenceStages:
         # main.py:2069-2091: the layout stage and its post-processing sit in a bare try/except -- any failure (the reference: a crop
         # smaller than the model input breaks do_prediction's reshape, main.py:278-285; here: sbbseg_segment_crop refuses it) degrades
         # to "no regions"; the textline model only runs when text regions were found (main.py:2096 `if len(contours) > 0`: contours
-        # are traced from the pixels of class 1, main.py:457-458 -- tracing them is out of scope, their existence is not)
+        # are traced from the opened / closed class-1 mask and filtered by area, main.py:456-480 -- tracing them is out of scope,
+        # their existence is not: text_regions_present)
         try:
             regions = self.extract_text_regions(box=box)
             regions = self.clean_text_regions(regions)
-            plane = regions[:, :, 0] if regions.ndim == 3 else regions
-            has_text = bool((plane == 1).any())
+            has_text = self.text_regions_present(regions)           # main.py:2083, 2096
         except Exception:
             regions, has_text = None, False
         textlines = None

@@ -103,6 +103,139 @@ def install_cv2_stubs(cv2, pages_by_name):
     cv2.boundingRect = lambda b: (int(b.xs.min()), int(b.ys.min()), int(b.xs.max() - b.xs.min() + 1), int(b.ys.max() - b.ys.min() + 1))
 
 
+# (H, W, kind) -- region maps for get_text_region_contours_and_boxes; min_area 1e-5 x H x W is 16.8 px^2 on the 1400 x 1200 cases
+TEXT_REGION_CASES = [(300, 240, 0), (300, 240, 1), (1400, 1200, 2), (1400, 1200, 3), (260, 300, 4), (200, 200, 5), (220, 260, 6), (1400, 1200, 7)]
+
+
+def text_region_map(h, w, kind):
+    """uint8 [h,w,3] layout label image (classes 0..3, three equal channels unless kind == 5)."""
+    rng = np.random.RandomState(100 + kind)
+    r = np.zeros((h, w), np.uint8)
+    if kind == 0:                       # a text block, an image block of another class, specks that die in the opening
+        r[40:160, 30:200] = 1
+        r[180:260, 60:180] = 2
+        for _ in range(12):
+            y, x = rng.randint(0, h - 4), rng.randint(0, w - 4)
+            r[y:y + rng.randint(1, 4), x:x + rng.randint(1, 4)] = 1
+    elif kind == 1:                     # only specks (at most 4 x 4): nothing survives MORPH_OPEN
+        for _ in range(30):
+            y, x = rng.randint(0, h - 5), rng.randint(0, w - 5)
+            r[y:y + rng.randint(1, 5), x:x + rng.randint(1, 5)] = 1
+        r[100:104, 50:120] = 1          # a 4-pixel-high bar: thinner than the kernel
+    elif kind == 2:                     # one 5 x 5 square: survives, contour area 16 < 16.8
+        r[700:705, 600:605] = 1
+    elif kind == 3:                     # one 5 x 6 rectangle: contour area 20 >= 16.8
+        r[700:705, 600:606] = 1
+    elif kind == 4:                     # ring with an island inside its hole (the island has a parent), and a separate block
+        r[30:150, 30:170] = 1
+        r[45:135, 45:155] = 0
+        r[80:95, 90:110] = 1
+        r[180:230, 200:280] = 1
+    elif kind == 5:                     # class 1 in channel 0 only: np.all(image == (1, 1, 1)) is false everywhere
+        r[50:150, 50:150] = 1
+    elif kind == 6:                     # two blocks three pixels apart: MORPH_CLOSE joins them
+        r[60:120, 40:100] = 1
+        r[60:120, 103:170] = 1
+        r[150:200, 40:170] = 3
+    elif kind == 7:                     # thin L (5 wide) and a 4-wide bar next to it; other classes around
+        r[300:305, 200:260] = 1
+        r[300:340, 200:205] = 1
+        r[500:504, 200:400] = 1
+        r[800:1000, 300:900] = 2
+    out = np.repeat(r[:, :, None], 3, axis=2)
+    if kind == 5:
+        out[:, :, 1] = 0
+    return out
+
+
+def _ring_area(c):
+    pts = np.asarray(c, np.float64).reshape(-1, 2)
+    x, y = pts[:, 0], pts[:, 1]
+    return abs(float(np.sum(x * np.roll(y, -1) - np.roll(x, -1) * y))) / 2.0
+
+
+def install_contour_tree_stubs(cv2, ref):
+    """cv2.morphologyEx / findContours(RETR_TREE) / boundingRect on point arrays, shapely's Polygon -- for main.py:456-480."""
+    from scipy import ndimage
+    cv2.MORPH_OPEN, cv2.MORPH_CLOSE = 2, 3
+    cv2.cv2 = cv2                                          # main.py:471 writes cv2.cv2.RETR_TREE
+
+    def morphology_ex(src, op, kernel):
+        k = kernel.shape[0]
+        planes = [src[:, :, c] for c in range(src.shape[2])] if src.ndim == 3 else [src]
+        res = []
+        for pl in planes:
+            if op == cv2.MORPH_OPEN:
+                res.append(sg.morph(sg.morph(pl, "erode", k, 1), "dilate", k, 1))
+            else:
+                assert op == cv2.MORPH_CLOSE
+                res.append(sg.morph(sg.morph(pl, "dilate", k, 1), "erode", k, 1))
+        return np.stack(res, axis=2) if src.ndim == 3 else res[0]
+    cv2.morphologyEx = morphology_ex
+
+    def approx_simple(chain):
+        n = len(chain)
+        if n < 3:
+            return chain
+        keep = []
+        for i in range(n):
+            (x0, y0), (x1, y1), (x2, y2) = chain[i - 1], chain[i], chain[(i + 1) % n]
+            if (x1 - x0, y1 - y0) != (x2 - x1, y2 - y1):
+                keep.append(chain[i])
+        return keep
+
+    def find_contours(mask, mode, method):
+        assert mode == cv2.RETR_TREE and method == cv2.CHAIN_APPROX_SIMPLE
+        fg = mask > 0
+        lab, n = ndimage.label(fg, structure=np.ones((3, 3), int))
+        # [EXT] the outer border of every 8-connected component, as the oracle traces it; hole borders are left out of the list
+        # (their parent is never -1, the only thing the reference asks of them); a component lying in a hole of another gets that
+        # component's index as its parent, every other one -1
+        bg = np.pad(~fg, 1, constant_values=True)
+        blab, _ = ndimage.label(bg, structure=[[0, 1, 0], [1, 1, 1], [0, 1, 0]])
+        outer_bg = blab == blab[0, 0]
+        pl = np.pad(lab, 1, constant_values=0)
+        touch = np.zeros(n + 1, bool)
+        for dy, dx in ((0, 1), (0, -1), (1, 0), (-1, 0)):
+            sh = np.roll(outer_bg, (dy, dx), axis=(0, 1))
+            touch[np.unique(pl[sh & (pl > 0)])] = True
+        filled = [ndimage.binary_fill_holes(lab == k + 1) for k in range(n)]
+        contours, hier = [], []
+        order = list(range(n, 0, -1))                     # reverse discovery order, as in the extract_page stub
+        for k in order:
+            sl = ndimage.find_objects(lab)[k - 1]
+            chain = sg.outer_contour_chain(lab[sl] == k)
+            pts = np.array([[[x + sl[1].start, y + sl[0].start]] for (x, y) in approx_simple(chain)], np.int32)
+            parent = -1
+            if not touch[k]:
+                ys, xs = np.nonzero(lab == k)
+                for j in order:
+                    if j != k and filled[j - 1][ys[0], xs[0]]:
+                        parent = order.index(j)
+                        break
+                assert parent >= 0
+            contours.append(pts)
+            hier.append([-1, -1, -1, parent])
+        return contours, np.array([hier], np.int32)
+    cv2.findContours = find_contours
+
+    old_rect = cv2.boundingRect
+
+    def bounding_rect(c):
+        if isinstance(c, np.ndarray):
+            p = np.asarray(c, np.int64).reshape(-1, 2)
+            return (int(p[:, 0].min()), int(p[:, 1].min()), int(p[:, 0].max() - p[:, 0].min() + 1), int(p[:, 1].max() - p[:, 1].min() + 1))
+        return old_rect(c)
+    cv2.boundingRect = bounding_rect
+
+    class Polygon:                                        # shapely.geometry.Polygon of a ring: |shoelace| / 2, closed exterior
+        def __init__(self, pts):
+            self.pts = [tuple(float(v) for v in p) for p in pts]
+            self.area = _ring_area(self.pts)
+            self.exterior = type("E", (), {"coords": self.pts + self.pts[:1]})()
+    ref.geometry.Polygon = Polygon
+
+
 class BorderModel:
     """Fake border model: class 1 inside a seeded rectangle of the MODEL-sized input (plus a one-pixel speck elsewhere)."""
 
@@ -202,6 +335,19 @@ def main():
         out[f"border_crop_crc{k}"] = np.int64(zlib.crc32(np.ascontiguousarray(croped).tobytes()) & 0xFFFFFFFF)
         print("border", k, (h, w), "box", bx, "->", coord, croped.shape)
     out["border_n"] = np.int64(len(BORDER_CASES))
+    # ---- get_text_region_contours_and_boxes (main.py:456-480): the `len(contours) > 0` that gates the textline model (main.py:2096)
+    install_contour_tree_stubs(cv2, ref)
+    for k, (h, w, kind) in enumerate(TEXT_REGION_CASES):
+        regions = text_region_map(h, w, kind)
+        kept = det.get_text_region_contours_and_boxes(regions)
+        areas = sorted(_ring_area(c) for c in kept)
+        assert len(det.boxes) == len(kept)
+        out[f"regions_case{k}"] = np.array([h, w, kind], np.int64)
+        out[f"regions_map{k}"] = regions[:, :, 0].copy()
+        out[f"regions_ch1_{k}"] = np.int64(int(np.array_equal(regions[:, :, 0], regions[:, :, 1])))
+        out[f"regions_areas{k}"] = np.asarray(areas, np.float64)
+        print("regions", k, (h, w), "kind", kind, "->", len(kept), "contours", areas[:4])
+    out["regions_n"] = np.int64(len(TEXT_REGION_CASES))
     np.savez_compressed(out_path, **out)
     print("wrote", out_path, os.path.getsize(out_path), "bytes")
 

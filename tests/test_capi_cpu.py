@@ -29,7 +29,7 @@ def test_exports_match_header(lib):
 
 
 def test_abi_version(lib):
-    assert lib.sbbseg_abi_version() == 3
+    assert lib.sbbseg_abi_version() == 4
 
 
 @pytest.mark.parametrize("case", GOLD, ids=lambda c: f"{c['page_h']}x{c['page_w']}_m{c['model_h']}x{c['model_w']}")

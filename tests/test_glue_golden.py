@@ -144,3 +144,35 @@ def test_device_page_box_equals_reference(k, ctx):
     box, pixels = ctx.page_box_dev(d.data_ptr(), mask.shape[0], mask.shape[1])
     y0, y1, x0, x1 = (int(v) for v in G[f"border_coord{k}"])
     assert tuple(box) == (x0, y0, x1 - x0, y1 - y0)
+
+
+# ------------------------------------------------- get_text_region_contours_and_boxes (main.py:456-480; gate of main.py:2096)
+def _regions(k):
+    plane = G[f"regions_map{k}"]
+    out = np.repeat(plane[:, :, None], 3, axis=2)
+    if not int(G[f"regions_ch1_{k}"]):
+        out[:, :, 1] = 0                                    # the case whose channels differ (np.all(image == (1, 1, 1)) fails)
+    return out
+
+
+@pytest.mark.parametrize("k", range(int(G["regions_n"])))
+def test_oracle_text_region_contours_equal_reference(k):
+    """The oracle's restatement keeps the contours the reference's own function kept (count and areas)."""
+    assert sorted(sg.text_region_contour_areas(_regions(k))) == list(G[f"regions_areas{k}"])
+    assert sg.text_regions_present(_regions(k)) == (len(G[f"regions_areas{k}"]) > 0)
+
+
+@pytest.mark.parametrize("k", range(int(G["regions_n"])))
+def test_product_host_text_region_gate_equals_reference(k):
+    """stages.host_text_regions_present (foreign model objects; the library's host contour tracer) == `len(contours) > 0`."""
+    assert stages.host_text_regions_present(_regions(k)) == (len(G[f"regions_areas{k}"]) > 0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k", range(int(G["regions_n"])))
+def test_device_text_region_gate_equals_reference(k, ctx):
+    """sbbseg_text_regions_present_dev (class mask, OPEN, CLOSE, contour ranking on the device) == `len(contours) > 0`."""
+    r = _regions(k)
+    if not int(G[f"regions_ch1_{k}"]):
+        pytest.skip("the product's label planes have three equal channels by construction (one plane on the device)")
+    assert ctx.text_regions_present(r) == (len(G[f"regions_areas{k}"]) > 0)

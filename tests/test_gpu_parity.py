@@ -305,15 +305,26 @@ def test_expand_reduce_x3_matches_the_two_launches(hw, nb, precision):
     model.release()
 
 
-def test_conv_tile_families_agree():
-    """4-wave/2-stage and 8-wave/3-stage conv tiles, persistent or one block per tile, compute the same sums."""
-    cfg, w, g, model = make_model(2, 224, 224, seed=3, precision="f16", max_batch=6)
+@pytest.mark.parametrize("precision", ["f16", "f16x3"])
+def test_conv_tile_families_agree(precision):
+    """4-wave/2-stage and 8-wave/3-stage conv tiles, persistent or one block per tile, compute the same sums -- in the split mode
+    too, where variants 1-3 send the stem to the generic kernel and the max-pool op must then launch itself (round-4 advisory:
+    it returned early on `fused_into_stem` alone and left a stale pool tensor)."""
+    cfg, w, g, model = make_model(2, 224, 224, seed=3, precision=precision, max_batch=6)
     x = (patches_from_page(224, 224, 5, seed=2) / 255.0).astype(np.float32)
+    variants = (1, 2, 3, 5, 6, 8, 16, 32, 0x220, 64, 128, 0x10000, 0x10003, 0) if precision == "f16" else (1, 2, 3, 5, 8, 32, 0x10003, 0)
+    # bit 2 = one block per tile instead of persistent blocks; bit 3 = no XCD grouping; 3 = big 8-wave tiles; 16 = half-K-step stages in a 4-deep ring
+    other = (patches_from_page(224, 224, 5, seed=9) / 255.0).astype(np.float32)
     outs = []
-    for variant in (1, 2, 3, 5, 6, 8, 16, 32, 0x220, 64, 128, 0x10000, 0x10003, 0):       # bit 2 = one block per tile instead of persistent blocks; bit 3 = no XCD grouping; 3 = big 8-wave tiles; 16 = half-K-step stages in a 4-deep ring
-        model.ctx.set_conv_variant(variant)
+    for variant in variants:
+        model.ctx.set_conv_variant(0)
+        model.predict(other)                         # every activation buffer now holds ANOTHER input's tensors: an op that wrongly
+        model.ctx.set_conv_variant(variant)          # launches nothing under `variant` leaves them there
         outs.append(model.predict(x))
     assert all(np.array_equal(outs[0], o) for o in outs[1:])
+    if precision == "f16x3":
+        ref = kf.forward(g, w, x[:2])
+        assert float(np.abs(outs[0][:2] - ref).max()) < TOL_SOFTMAX["f16x3"] and exact_label_check(ref, outs[0][:2])[1] == 0
     model.release()
 
 
@@ -1278,7 +1289,11 @@ def test_bench_batch64_workload_on_one_gpu():
     assert res.returncode == 0, res.stderr[-2000:]
     d = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])
     assert d["n_gpus"] == 1 and d["dtype"] == "f16x3" and d["scaling"] == "strong" and d["unit"] == "patches/s"
-    assert d["config"]["workload_id"] == "batch64" and d["config"]["tiles_per_step"] == 2 * 108 and d["config"]["max_batch"] == 216
+    # 4000 % 360 = 40: the reference's call list has 12 x 9 = 108 entries per page of which one row of 9 repeats its neighbour's
+    # origin (main.py:276-281); the fused path runs 11 x 9 = 99 forwards (sbbseg_set_dedupe) -- the line counts what ran
+    cfgd = d["config"]
+    assert cfgd["workload_id"] == "batch64" and cfgd["max_batch"] == 216
+    assert cfgd["forwards_per_step"] == 2 * 99 and cfgd["tiles_per_step"] == 2 * 99 and cfgd["reference_calls_per_step"] == 2 * 108 and cfgd["dedupe"] is True
     assert d["value"] > 500 and abs(d["value"] - d["config"]["tiles_per_step"] * d["steps"] / (d["ms_per_step"] * d["steps"] / 1e3)) < 0.01 * d["value"]
     assert d["exchange"] is None and d["ranks_seen"] is None
     r = d["roofline"]
@@ -1431,3 +1446,81 @@ def test_run_with_the_page_resident_equals_the_stage_by_stage_run(tmp_path, monk
     monkeypatch.setenv("SBBSEG_STAGES_RESIDENT", "1")
     assert st._run_resident() is not None                               # (the resident path really ran above: it applies here)
     clear_session()
+
+
+def test_run_is_torch_free_at_full_size(tmp_path):
+    """run() (main.py:2056-2107) at BASELINE configs[2]'s size -- three 448 x 448 nets, a 3500 x 2500 page upscaled to 4200 x 3000 --
+    in a child interpreter where `import torch` FAILS: the page, the border mask and the region map live in buffers the library
+    allocates (sbbseg_device_alloc / _upload / _download_labels).  Resident run == stage-by-stage run there (masks, box, threshold),
+    for the normal page, for a layout model that never answers class 1 (the textline model is skipped: main.py:2083, 2096) and for
+    a border model whose page box is smaller than the layout model's input (the layout stage fails like main.py:278-285 ->
+    regions None, main.py:2089-2091).  The parent then checks the child's maps against the oracle on sampled tiles."""
+    import subprocess
+    import sys
+    from oracle import stage_glue
+    from sbb_textline_detection_amd import clear_session
+    from sbb_textline_detection_amd.keras_graph import parse_model_config
+    from sbb_textline_detection_amd.model import SegModel
+    from sbb_textline_detection_amd.predict import resize_nearest
+    from sbb_textline_detection_amd.weights import save_sbbw
+    from tools.synth_model import calibrated_model
+    specs = {"model_page_mixed_best": (2, 21), "model_strukturerkennung": (4, 22), "model_textline_new": (2, 23)}      # main.py:58-60
+    models = {name: calibrated_model(classes, 448, 448, seed=seed) for name, (classes, seed) in specs.items()}
+    page = synthetic_page(3500, 2500, seed=33)
+
+    def last_bn(cfg):
+        return [n.name for n in parse_model_config(cfg).nodes if n.op == "bn"][-1]
+    for scen in ("a", "notext", "smallbox"):
+        os.makedirs(tmp_path / scen)
+        for name, (cfg, w) in models.items():
+            w = dict(w)
+            if scen == "notext" and name == "model_strukturerkennung":
+                b = w[last_bn(cfg) + "/beta:0"].copy()
+                b[1] -= 60.0                                           # class 1 never wins the argmax
+                w[last_bn(cfg) + "/beta:0"] = b
+            if scen == "smallbox" and name == "model_page_mixed_best":
+                # shift class 1's logit so that only the three most page-like pixels of the 448 x 448 border map keep it: their
+                # blobs on the 4200 x 3000 page (about 9 x 7 pixels each, 25 x 25 more from the six dilations) stay below 448 x 448
+                m = SegModel(cfg, w, device=0, max_batch=1)
+                x = resize_nearest(resize_nearest(page, 4200, 3000), 448, 448)[None].astype(np.float32) / np.float32(255.0)
+                p = m.predict(x)[0].astype(np.float64)
+                m.release()
+                margin = np.sort((np.log(p[..., 1]) - np.log(p[..., 0])).reshape(-1))
+                b = w[last_bn(cfg) + "/beta:0"].copy()
+                b[1] -= 0.5 * (margin[-3] + margin[-4])
+                w[last_bn(cfg) + "/beta:0"] = b
+            save_sbbw(str(tmp_path / scen / (name + ".sbbw")), cfg, w)
+    clear_session()
+    out = str(tmp_path / "child.npz")
+    child = os.path.join(os.path.dirname(__file__), "torchfree_child.py")
+    r = subprocess.run([sys.executable, child, str(tmp_path), out], capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("TORCHFREE ")][-1]
+    summary = json.loads(line[len("TORCHFREE "):])
+    print(summary)
+    assert summary["torch_loaded"] is False
+    assert summary["a"]["regions"] and summary["a"]["textlines"]
+    assert summary["notext"]["regions"] and not summary["notext"]["textlines"] and summary["notext"]["class1_pixels"] == 0
+    assert not summary["smallbox"]["regions"] and not summary["smallbox"]["textlines"]
+    assert summary["smallbox"]["box"][2] < 448 or summary["smallbox"]["box"][3] < 448
+    # the child's maps against the oracle: glue bit for bit, forwards on sampled tiles (owned pixels, outside EXACT_MARGIN)
+    z = np.load(out)
+    bx, by, bw, bh = (int(v) for v in z["box"])
+    mask3 = np.repeat(z["mask"][:, :, None], 3, axis=2)
+    assert tuple(stage_glue.page_box(mask3)[0]) == (bx, by, bw, bh) and bw >= 448 and bh >= 448
+    crop = resize_nearest(page, 4200, 3000)[by:by + bh, bx:bx + bw]
+    assert int(z["thr"]) == stage_glue.otsu_threshold(crop[:, :, 0])
+    assert stage_glue.text_regions_present(z["regions"])                    # the gate the child passed (main.py:2096)
+    tiles, nxf, nyf = tiling.tile_grid(bh, bw, 448, 448)
+    own = tiling.owner_map(bh, bw, 448, 448)
+    k = len(tiles) // 2 + 1
+    t = tiles[k]
+    cfg, w = models["model_textline_new"]
+    x = (crop[t["y0"]:t["y0"] + 448, t["x0"]:t["x0"] + 448][None] / 255.0).astype(np.float32)
+    ref = kf.forward_config(cfg, w, x)[0]
+    sl = (slice(t["y0"] + t["ylo"], t["y0"] + t["yhi"]), slice(t["x0"] + t["xlo"], t["x0"] + t["xhi"]))
+    r_ = ref[t["ylo"]:t["yhi"], t["xlo"]:t["xhi"]]
+    srt = np.sort(r_, axis=-1)
+    mism = (z["lines"][sl] != r_.argmax(-1)) & (own[sl] == k)
+    assert not (mism & ((srt[..., -1] - srt[..., -2]) > EXACT_MARGIN)).any() and mism.mean() < 1e-3
+    # (the raw layout map's parity with the oracle is test_full_size_three_model_pipeline_config3's subject)
