@@ -3940,6 +3940,22 @@ __global__ __launch_bounds__(256) void cc_count_kernel(int* parent, int* count, 
     }
     wave_add_by_root(count, cur, run);
 }
+// cc_count_kernel's `parent[i] = root` races with the path halving of OTHER threads' walks through i (cc_find stores an ancestor it read
+// before the root was written): a few pixels per million were left pointing at a non-root ancestor, and the kernels below, which take
+// parent[] for the root, credited their cells / extents to that ancestor -- the lower-bound area of a blob came out a little short in
+// some runs, so equal-area blobs were ranked at random (round 5: tools/border_repeat_probe.py, three 31 x 33 blobs).  This pass runs
+// with no halving writer active: every store is a root, a reader sees an ancestor or the root, the walk ends at the root either way.
+__global__ __launch_bounds__(256) void cc_flatten_kernel(int* parent, long n)
+{
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    int p = parent[i];
+    if (p < 0) return;
+    int q = parent[p];
+    if (q == p) return;                                     // already at its root (nearly every pixel)
+    while (q != p) { p = q; q = parent[p]; }                // read-only walk
+    parent[i] = p;
+}
 // ---- ranking by cv2.contourArea (main.py:399-401).  The outer contour cv2.findContours traces runs through the centres of the
 // component's boundary pixels (8-connected steps); its polygon area is, for the component with its holes filled, the number of
 // 2 x 2 pixel cells that are completely inside plus half the number of cells with exactly three pixels inside (a diagonal
@@ -4059,6 +4075,7 @@ hipError_t launch_largest_contour(const uint8_t* mask, int H, int W, int* parent
     hipLaunchKernelGGL(cc_rows_kernel, dim3((unsigned)H), dim3(64), 0, s, mask, parent, count, H, W);
     hipLaunchKernelGGL(cc_link_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, mask, parent, H, W);
     hipLaunchKernelGGL(cc_count_kernel, dim3((unsigned)((n + 256 * 64 - 1) / (256 * 64))), dim3(256), 0, s, parent, count, n);
+    hipLaunchKernelGGL(cc_flatten_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, parent, n);
     hipLaunchKernelGGL(cc_box_init_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const int*)parent, area2, bx0, by0, bx1, by1, n);
     if (H > 1 && W > 1) {
         const long cell_strips = (long)((W - 1 + 63) / 64) * (H - 1);

@@ -1009,6 +1009,38 @@ def test_device_morphology_and_page_box(torch_cuda, stitch_model):
         assert got == stage_glue.page_box(mask), (k, got, stage_glue.page_box(mask))
 
 
+def test_page_box_ranking_is_repeatable_on_equal_blobs(stitch_model):
+    """Equal-area blobs: the LAST in raster order wins (oracle/stage_glue.largest_component_box: np.argmax over OpenCV's reversed
+    contour list) -- every time.  Round 5 found the device ranking picking one of three equal blobs at random on a 4200 x 3000 mask:
+    the flatten pass of the component labelling raced with other threads' path halving and left a few pixels pointing at a non-root
+    ancestor, so a blob's area came out short in some runs (kernels.hip cc_flatten_kernel).  Page-sized masks, many repeats; plus
+    a mask whose largest blob beats the others by ONE cell, where a short count flips the ranking outright."""
+    from oracle import stage_glue
+    c = stitch_model.ctx
+    rng = np.random.RandomState(5)
+    H, W = 4200, 3000
+    a = np.zeros((H, W), np.uint8)
+    for (y, x) in ((795, 1743), (3167, 1301), (3692, 2560), (2000, 200)):
+        a[y + 12:y + 21, x + 12:x + 19] = 1                                  # 9 x 7 seeds -> 33 x 31 blobs after dilate x 6
+    b = a.copy()
+    b[500:1700, 300:2700] = 1                                                # one big component beside the equal ones
+    b[rng.rand(H, W) < 0.00002] = 1
+    e = np.zeros((H, W), np.uint8)
+    e[100:2000, 100:2901] = 1                                                # 1900 x 2801 ...
+    e[2100:4000, 100:2900] = 1                                               # ... against 1900 x 2800: one column of cells less
+    for k, mask in enumerate((a, b, e)):
+        want = stage_glue.page_box(mask)
+        d = c.device_alloc(mask.size)
+        try:
+            c.upload(d, mask)
+            for it in range(12):
+                got = c.page_box_dev(d, H, W)
+                assert got == want, (k, it, got, want)
+        finally:
+            c.device_free(d)
+    assert stage_glue.page_box(a)[0] == (2560, 3692, 31, 33)
+
+
 def test_extract_page_stage(tmp_path):
     """extract_page (main.py:384-437) through the stage wrapper: border model on the upscaled page, box and crop; the box equals
     the oracle's box of the mask the same call returns."""
