@@ -156,20 +156,20 @@ def _plumbing_check(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--repeats", type=int, default=3, help="timed regions of exactly --steps steps each; value = their median")
     ap.add_argument("--precision", default=os.environ.get("SBBSEG_BENCH_PRECISION", "f16x3"), choices=["f16", "bf16", "f16x3"],
                     help="arithmetic mode of `value`: f16x3 = label-exact split-fp16 (default), f16 = fast plain fp16")
     ap.add_argument("--max-batch", type=int, default=int(os.environ.get("SBBSEG_MAX_BATCH", "0")),
-                    help="tiles per chunk (0 = four pages' worth: 280 for the 3500x2500 page, 432 for the 4000x3000 pages of batch64)")
+                    help="tiles per chunk (0 = 320 for the 3500x2500 pages -- two lanes of 160 --, 216 / 432 for the 4000x3000 pages of batch64)")
     ap.add_argument("--conv-variant", type=int, default=int(os.environ.get("SBBSEG_CONV_VARIANT", "0")),
                     help="A/B knob of the conv kernel (see sbbseg.h sbbseg_debug_set_conv_variant)")
     ap.add_argument("--workload", default="auto", choices=["auto", "page", "pipeline3", "batch64"],
                     help="auto = page at every N (BASELINE configs[1], the metric's config; weak scaling), with configs[3] (64 pages of "
                          "4000x3000 sharded over the ranks, strong scaling) measured beside it under `batch64`; batch64 = configs[3] as the "
                          "headline; pipeline3 = configs[2] (border + layout + textline)")
-    ap.add_argument("--pages-per-step", type=int, default=16, help="page workload: pages segmented back to back per step")
+    ap.add_argument("--pages-per-step", type=int, default=32, help="page workload: pages segmented back to back per step (32 x 70 tiles = 7 chunks of 320)")
     ap.add_argument("--batch-pages", type=int, default=64, help="batch64 workload: pages in the batch (64 = BASELINE configs[3])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-second-mode", action="store_true")
@@ -215,7 +215,12 @@ def main():
         # tiles per chunk measured 9 997 / 10 176 / 10 214 / 10 209 patches/s (profiles/r02_experiments.md)
         # (f16x3 stores 4 bytes per activation element: a tensor x batch must stay inside the 4 GiB gather window -- the largest,
         # 224x224x64, allows 334 patches -- so the 4000x3000 pages pool two at a time there, 2 x 108 tiles)
-        args.max_batch = (216 if args.precision == "f16x3" else 432) if workload == "batch64" else (280 if workload == "page" else 70)
+        # Round 5: 320 tiles per chunk = 160 per lane.  The persistent conv grids walk their tiles in rounds of 256 blocks; a lane batch
+        # of 160 patches gives the long launches 3.84 / 7.66 / 15.3 / 1.91 / 0.96 rounds (dec1 / dec2 / dec3 / the stage-4 and stage-5
+        # 3x3 convs: 160 x 196 px = 122.5 tiles of 256 px) where 140 gave 3.375 / 6.7 / 13.4 / 1.68 / 0.84 -- the last round of every such
+        # launch ran 37-84 % full.  (166 would fill them to 99 %; the fast gather's 2^31-byte window on the 224 x 224 x 64 tensor stops
+        # at 167 patches per launch.)  A step is 32 pages = 2 240 tiles = 7 chunks.
+        args.max_batch = (216 if args.precision == "f16x3" else 432) if workload == "batch64" else (320 if workload == "page" else 70)
     torch.cuda.set_device(device_index)
     ranks_seen = None
     if world > 1:
@@ -502,12 +507,16 @@ def main():
         c = m.ctx
         c.profile_enable(True)
         c.profile_reset()
-        # (profiling runs every chunk whole on one lane: launches of min(max_batch, tiles) tiles -- two pages pooled by default)
+        # (profiling runs every launch alone on one lane, in LANE-sized launches: chunks of max_batch / 2 tiles pooled across pages -- the
+        # launches the timed region's two lanes run; 16 pages = 1 120 tiles = 7 launches of 160 per op at the default max_batch of 320)
         d_page2 = torch.from_numpy(synthetic_page(PAGE_H, PAGE_W, seed=4242)).cuda()
-        d_labels2 = torch.empty((PAGE_H, PAGE_W), dtype=torch.uint8, device="cuda")
-        for _ in range(5):
-            c.segment_pages_dev([d_page.data_ptr(), d_page2.data_ptr()], PAGE_H, PAGE_W, [d_labels.data_ptr(), d_labels2.data_ptr()])
+        n_prof_pages = 16
+        d_labels_prof = torch.empty((n_prof_pages, PAGE_H, PAGE_W), dtype=torch.uint8, device="cuda")
+        prof_pages = [(d_page if k % 2 == 0 else d_page2).data_ptr() for k in range(n_prof_pages)]
+        for _ in range(2):
+            c.segment_pages_dev(prof_pages, PAGE_H, PAGE_W, [d_labels_prof[k].data_ptr() for k in range(n_prof_pages)])
         torch.cuda.synchronize()
+        del d_labels
         prof = c.profile()
         c.profile_enable(False)
         convs = [o for o in prof if ("conv" in o["name"] or o["name"].startswith("block")) and o["launches"] > 0]       # incl. stem_conv*, direct_conv*, tail_conv*, fused bottleneck blocks
@@ -581,7 +590,7 @@ def main():
                     os.path.relpath(path, ROOT), ent["l2_hit_pct"], pmc.get("csrc_sha"))
         except Exception:
             pass
-        per_op = [{"name": o["name"], "ms_per_launch": round(o["total_ms"] / o["launches"], 4),
+        per_op = [{"name": o["name"], "ms_per_launch": round(o["total_ms"] / o["launches"], 4), "patches_per_launch": o["patches"] / o["launches"],
                    "tflops": round(o["flops"] * o["patches"] / (o["total_ms"] * 1e-3) / 1e12, 1) if o["total_ms"] else 0,
                    "tflops_issued": round(o["issued_flops"] * o["patches"] / (o["total_ms"] * 1e-3) / 1e12, 1) if o["total_ms"] else 0}
                   for o in prof if o["launches"]]

@@ -2162,8 +2162,11 @@ static int tile_range_impl(sbbseg_ctx* c, const void* const* d_pages, int n_page
         }
         return 0;
     }
-    // chunks of equal size (108 tiles at max_batch 70 -> 54 + 54, not 70 + 38): launches shrink evenly
-    const int n_chunks = (n_tiles + c->max_batch - 1) / c->max_batch;
+    // chunks of equal size (108 tiles at max_batch 70 -> 54 + 54, not 70 + 38): launches shrink evenly.
+    // (Profiling runs every launch alone on one lane: its chunks are capped at the size a LANE's launch has in normal operation -- half a
+    // chunk -- so that the per-op times describe the launches the product runs, partial last rounds of the persistent grids included.)
+    const int chunk_cap = (c->profiling && c->lanes == 2 && c->lane1_batch > 0 && c->max_batch >= 4 * kMinLaneTiles) ? (c->max_batch + 1) / 2 : c->max_batch;
+    const int n_chunks = (n_tiles + chunk_cap - 1) / chunk_cap;
     const int chunk = n_chunks ? (n_tiles + n_chunks - 1) / n_chunks : 0;
     for (int done = 0; done < n_tiles; done += chunk) {
         const int nb = n_tiles - done < chunk ? n_tiles - done : chunk;
