@@ -53,8 +53,8 @@ if os.environ.get("SBBSEG_BENCH_PAGE"):      # experiment knob (A/B of chunk siz
 MODEL_HW, CLASSES = 448, 2
 # committed rocprofv3 PMC summaries (tools/pmc_run.sh + tools/pmc_report.py) the `roofline.traffic` figure is read from: STATIC
 # numbers (counters need their own profiling passes), valid only for the kernel sources they were collected on (csrc_sha)
-PMC_SUMMARY = {"f16x3": os.path.join(ROOT, "profiles", "r04_x3_pmc_summary.json"),
-               "f16": os.path.join(ROOT, "profiles", "r04_f16_pmc_summary.json")}
+PMC_SUMMARY = {"f16x3": os.path.join(ROOT, "profiles", "r05_x3_pmc_summary.json"),
+               "f16": os.path.join(ROOT, "profiles", "r05_f16_pmc_summary.json")}
 
 
 def csrc_sha():

@@ -398,6 +398,7 @@ int launch_op(sbbseg_ctx* c, Op& op, int n, uint8_t* d_labels, float* d_probs)
             bp.s3 = op.parts[2].conv.d_scale; bp.b3 = op.parts[2].conv.d_shift;
             bp.out = c->tensors[bo.out_tensor].data();
             bp.wmul1 = bo.wmul[0]; bp.wmul2 = bo.wmul[1]; bp.wmul3 = bo.wmul[2];
+            { static const int blk_dbg = getenv("SBBSEG_BLOCK_DBG") ? atoi(getenv("SBBSEG_BLOCK_DBG")) : 0; bp.dbg = blk_dbg; }
             if (c->precision == kF16X3) HIPCHK(launch_block_x3(bp, c->num_cus, c->stream));
             else HIPCHK(launch_bottleneck(bp, c->precision, c->num_cus, c->stream));
         } else if (op.type == kConv) {

@@ -145,6 +145,9 @@ __global__ __launch_bounds__(256, 1) void block_x3(const BlockParams p)
         for (int e = 0; e < 8; ++e) rb[e] = lds_ab + frow * 256 + (((s0 + 2 * e) & 15) << 4);
     }
 
+    // row rotation on the WRITE side: 2 slots per row like the reads (timing probe p.dbg & 1: 1 slot per row -- the 8-lane groups of
+    // ds_write_b128 then hit eight different bank quads instead of four twice; the reads no longer find their data: results are wrong)
+    const int wrot = (p.dbg & 1) ? 1 : 2;
     bool inimg[2];
     uint32_t xoff[2];
     auto locate = [&](int tile, bool (&in)[2], uint32_t (&off)[2]) __attribute__((always_inline)) {
@@ -264,8 +267,8 @@ __global__ __launch_bounds__(256, 1) void block_x3(const BlockParams p)
                     split8(y, vh, vl);
                     if (!inimg[j]) { vh = (h8_t){0, 0, 0, 0, 0, 0, 0, 0}; vl = vh; }
                     char* row = lds_ab + hr[j] * 256;
-                    *(h8_t*)(row + (((s2 * 4 + fg + 2 * hr[j]) & 15) << 4)) = vh;
-                    *(h8_t*)(row + (((8 + s2 * 4 + fg + 2 * hr[j]) & 15) << 4)) = vl;
+                    *(h8_t*)(row + (((s2 * 4 + fg + wrot * hr[j]) & 15) << 4)) = vh;
+                    *(h8_t*)(row + (((8 + s2 * 4 + fg + wrot * hr[j]) & 15) << 4)) = vl;
                 }
             }
         }
@@ -323,8 +326,8 @@ __global__ __launch_bounds__(256, 1) void block_x3(const BlockParams p)
                     vl[q] = (_Float16)(c - (float)h);
                 }
                 char* px = lds_ab + row * 256;
-                *(h4_t*)(px + (((sB * 4 + fg + 2 * row) & 15) << 4) + half * 8) = vh;
-                *(h4_t*)(px + (((8 + sB * 4 + fg + 2 * row) & 15) << 4) + half * 8) = vl;
+                *(h4_t*)(px + (((sB * 4 + fg + wrot * row) & 15) << 4) + half * 8) = vh;
+                *(h4_t*)(px + (((8 + sB * 4 + fg + wrot * row) & 15) << 4) + half * 8) = vl;
             }
         }
         __syncthreads();

@@ -335,6 +335,8 @@ __global__ __launch_bounds__(512, 2) void expand_reduce(const ExpRedParams p)
                 *(float4*)&sc[0] = *(const float4*)(cst + c0); *(float4*)&sc[4] = *(const float4*)(cst + c0 + 4);
                 *(float4*)&sh[0] = *(const float4*)(cst + 4 * C + c0); *(float4*)&sh[4] = *(const float4*)(cst + 4 * C + c0 + 4);
                 // the wave's 32 channels = granules wave * 4 + fg of the chunk (split mode: group `wave`, hi granules fg, lo granules 4 + fg)
+                // (round 5 timed these writes with a conflict-free rotation -- one slot per pixel, results then wrong -- and found no difference:
+                //  profiles/r05_experiments.md section 6; the probe itself made the compiler add a vmcnt wait to the loop and is not kept)
                 const int s_hi = (wave * (X3 ? 8 : 4) + rot) & (SLY - 1), s_lo = (wave * 8 + 4 + rot) & (SLY - 1);
 #pragma unroll
                 for (int ni = 0; ni < 4; ++ni) {

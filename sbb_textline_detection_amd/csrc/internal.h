@@ -199,6 +199,7 @@ struct BlockParams {
     // split mode (block_x3_identity, block_x3.hip): w1 = [8 kk][4 mi][hi | lo][64 lanes] x 16 B, w3 = [2 kk][16 mi][hi | lo][64 lanes] x 16 B,
     // w2 = [hi | lo][9][2][4 mi][64 lanes] x 16 B, every conv's weights pre-scaled by a power of two; wmulN = 2^-s undoes it in sN
     float wmul1 = 1.f, wmul2 = 1.f, wmul3 = 1.f;
+    int dbg = 0;              // timing probes (SBBSEG_BLOCK_DBG; results are WRONG with any bit set): 1 = LDS rows rotated by 1 slot per row on the WRITE side only
 };
 
 // The decoder conv at 224 x 224 in the split mode with LDS-resident source halos (dec_halo_x3.hip): the grouped launch of the four

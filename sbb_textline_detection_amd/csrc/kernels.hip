@@ -1395,7 +1395,9 @@ static hipError_t launch_conv_x3(const ConvParams& p, hipStream_t s)
         const long t256 = (long)p.n_cls * ((p.M + 255) / 256) * (p.cout / 256);
         const long t512 = (long)p.n_cls * ((p.M + 511) / 512) * ((p.cout + 127) / 128);
         static const int k512 = getenv("SBBSEG_X3_T512_MINK") ? atoi(getenv("SBBSEG_X3_T512_MINK")) : 2048;      // A/B knobs
-        static const int k256 = getenv("SBBSEG_X3_T256_MINK") ? atoi(getenv("SBBSEG_X3_T256_MINK")) : 1024;
+        // (768 since round 5: the projection-shortcut merge at the head of stage 3 -- 128 + 256 -> 512 channels at 56 x 56, K = 384 channels -- takes
+        //  the 256 x 256 tile too: 0.79 -> 0.68 ms per 160 patches; nothing else has a K between 768 and 1024)
+        static const int k256 = getenv("SBBSEG_X3_T256_MINK") ? atoi(getenv("SBBSEG_X3_T256_MINK")) : 768;
         if (p.cout % 256 == 0 && p.Ktot >= k256 && t256 >= 200) return launch_conv_t<256, 256, 2, 4, 2, true, 8, false, true>(p, s);
         if (p.Ktot >= k512 && t512 >= 200) return launch_conv_t<512, 128, 4, 2, 2, true, 8, false, true>(p, s);
     }

@@ -7,7 +7,7 @@ for cfg in "$@"; do
   i=$((i+1))
   envs=$(echo "$cfg" | tr ';' ' '); [ "$cfg" = "-" ] && envs=""
   env $envs SBBSEG_BENCH_OPS=gpurun_out/ops_ab$i.json python bench.py --no-cpu-baseline --no-second-mode --no-extras --steps 12 --warmup 3 --repeats 2 2>/dev/null | tail -1 | \
-    python -c "import sys,json; d=json.loads(sys.stdin.read()); print('[$i] $cfg:', d['value'], d['repeats']['patches_per_s'], 'label', d['label_match']['label_mismatches'], d['label_match']['label_mismatches_outside_exact_margin'])"
+    python -c "import sys,json; d=json.loads(sys.stdin.read()); print('[$i] $cfg:', d['value'], d['repeats']['patches_per_s'], 'label', (d.get('label_match') or {}).get('label_mismatches'))"
 done
 python - "$@" <<'PY'
 import json, sys

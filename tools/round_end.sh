@@ -5,7 +5,7 @@
 # code path of bench.py on one GPU (gloo-staged exchange), and -- last, so that it can use the PMC summaries just written -- the bench
 # line again.  Outputs land in gpurun_out/; copy the ones to be judged into profiles/ (see profiles/README.md) and run the last step
 # once more from the committed tree if `roofline.traffic` is to come from the committed summaries.
-tag=${1:-r04}
+tag=${1:-r05}
 bash tools/collect_profiles.sh $tag f16x3
 bash tools/collect_profiles.sh $tag f16 skip-tests
 SBBSEG_BENCH_BACKEND=gloo timeout -k 5 900 python bench.py --gpus 2 --batch-pages 8 --steps 2 --warmup 1 --repeats 1 > gpurun_out/bench_${tag}_gloo2.log 2>&1; echo "gloo2 rc=$?"
