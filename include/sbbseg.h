@@ -297,6 +297,29 @@ int sbbseg_upload(sbbseg_ctx* c, void* d_dst, const void* src, size_t bytes);
 int sbbseg_download(sbbseg_ctx* c, void* dst, const void* d_src, size_t bytes);
 int sbbseg_download_labels(sbbseg_ctx* c, uint8_t* dst, const void* d_labels_hw, size_t pixels, int channels);
 
+/* ---- the model-running part of textline_detector.run() (main.py:2056-2107) in ONE call, for callers that want neither Python glue
+ * nor device pointers: three finalized handles on one device (border, layout, textline model), the stored page in host memory, the
+ * upscaled size Hs x Ws (get_image_and_scales, main.py:196-214).  The page is uploaded once and stays on the device for all three
+ * stages.  Error behaviour mirrors run(): extract_page sits outside the reference's try (main.py:2061) -- its failures, an empty
+ * border mask included, fail the call; the layout stage and its glue sit in a bare try / except (2069-2091) -- a failure there (a
+ * crop smaller than the model input) leaves info->regions_ok = 0 and skips the textline model; the textline model runs only when
+ * get_text_region_contours_and_boxes would return a contour (2083, 2096: info->text_present) and a failure there is "no lines"
+ * (2152-2157: info->textlines_ok = 0).  Outputs, caller-allocated for the WORST case (the box may be the whole page):
+ *   page_mask_out   Hs x Ws x channels bytes or NULL   border labels at the upscaled size
+ *   regions_out     Hs x Ws x channels bytes            cleaned layout labels of the box, h x w x channels, densely packed
+ *   textlines_out   Hs x Ws bytes                       textline labels of the box, h x w
+ * channels = 1 or 3 (the reference's three identical channels, main.py:366). */
+typedef struct sbbseg_run_info {
+    int32_t box_xywh[4];      /* extract_page's box on the upscaled page (cv2.boundingRect convention) */
+    int64_t box_pixels;       /* pixels of the winning component of the dilated border mask */
+    int32_t otsu_threshold;   /* otsu_copy's threshold on the crop's channel 0 (main.py:178-194) */
+    int32_t regions_ok;       /* 1: regions_out holds the cleaned layout map */
+    int32_t text_present;     /* 1: a text-region contour would be kept (the textline model ran) */
+    int32_t textlines_ok;     /* 1: textlines_out holds the textline map */
+} sbbseg_run_info;
+int sbbseg_run_page(sbbseg_ctx* border, sbbseg_ctx* layout, sbbseg_ctx* textline, const uint8_t* page_hwc, int Hp, int Wp, int Hs, int Ws,
+                    int channels, uint8_t* page_mask_out, uint8_t* regions_out, uint8_t* textlines_out, sbbseg_run_info* info);
+
 /* ---- stage glue: the rotate-and-project of the deskew search (return_deskew_slope, main.py:1601-1718; per text region,
  * 80 angles in [-25, 25] and 30 more in [-90, -50] -- the reference spreads the regions over cpu_count() processes,
  * main.py:1760-1799).  The H x W u8 region mask is centred on a zero square of side S = (int)(1.4 * max(H, W))

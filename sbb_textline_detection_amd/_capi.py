@@ -31,7 +31,7 @@ EXPORTS = [
     "sbbseg_deskew_side", "sbbseg_rotation_matrix", "sbbseg_deskew_profiles_dev", "sbbseg_deskew_profiles",
     "sbbseg_segment_pages",
     "sbbseg_profile_enable", "sbbseg_profile_reset", "sbbseg_profile_get",
-    "sbbseg_debug_largest_contour_area2", "sbbseg_text_regions_present_dev", "sbbseg_device_alloc", "sbbseg_device_free", "sbbseg_upload", "sbbseg_download", "sbbseg_download_labels",
+    "sbbseg_debug_largest_contour_area2", "sbbseg_text_regions_present_dev", "sbbseg_run_page", "sbbseg_device_alloc", "sbbseg_device_free", "sbbseg_upload", "sbbseg_download", "sbbseg_download_labels",
 ]
 
 
@@ -39,6 +39,12 @@ class ConvSrc(C.Structure):
     _fields_ = [("tensor", C.c_int32), ("channels", C.c_int32), ("kh", C.c_int32), ("kw", C.c_int32),
                 ("stride_y", C.c_int32), ("stride_x", C.c_int32), ("pad_top", C.c_int32), ("pad_left", C.c_int32),
                 ("up_shift", C.c_int32), ("off_y", C.c_int32), ("off_x", C.c_int32)]
+
+
+class RunInfo(C.Structure):
+    """sbbseg_run_info (include/sbbseg.h)"""
+    _fields_ = [("box_xywh", C.c_int32 * 4), ("box_pixels", C.c_int64), ("otsu_threshold", C.c_int32), ("regions_ok", C.c_int32),
+                ("text_present", C.c_int32), ("textlines_ok", C.c_int32)]
 
 
 class ConvDesc(C.Structure):
@@ -134,6 +140,7 @@ def load_library(path: Optional[str] = None):
         "sbbseg_profile_get": [vp, i32, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_int64)],
         "sbbseg_text_regions_present_dev": [vp, vp, i32, i32, i32, C.c_double, C.POINTER(C.c_int)],
         "sbbseg_debug_largest_contour_area2": [vp, i32, i32, C.POINTER(C.c_int64)],
+        "sbbseg_run_page": [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, C.POINTER(RunInfo)],
         "sbbseg_device_alloc": [vp, C.c_size_t, C.POINTER(vp)],
         "sbbseg_device_free": [vp, vp],
         "sbbseg_upload": [vp, vp, vp, C.c_size_t],
@@ -596,6 +603,30 @@ def host_largest_contour(mask: np.ndarray):
     px = C.c_int64(0)
     check(load_library().sbbseg_debug_largest_contour(_ptr(mask), mask.shape[0], mask.shape[1], _ptr(box), C.byref(px)), "sbbseg_debug_largest_contour")
     return tuple(int(v) for v in box), int(px.value)
+
+
+def run_page(border: "Context", layout: "Context", textline: "Context", page: np.ndarray, scaled_h: int, scaled_w: int,
+             channels: int = 3, want_mask: bool = True):
+    """The model-running part of run() (main.py:2056-2107) in one library call (``sbbseg_run_page``): the page is uploaded once and
+    stays on the device for the border, layout and textline stages.  Returns (page mask or None, regions or None, textlines or None,
+    RunInfo); regions / textlines are cut to the page box (h x w [x channels]).  An empty border mask raises like main.py:401."""
+    page = np.ascontiguousarray(page, np.uint8)
+    pix = scaled_h * scaled_w
+    mask = np.empty((scaled_h, scaled_w, 3) if channels == 3 else (scaled_h, scaled_w), np.uint8) if want_mask else None
+    regions = np.empty(pix * channels, np.uint8)
+    lines = np.empty(pix, np.uint8)
+    info = RunInfo()
+    rc = border.lib.sbbseg_run_page(border.h, layout.h, textline.h, _ptr(page), page.shape[0], page.shape[1], scaled_h, scaled_w, channels,
+                                    _ptr(mask), _ptr(regions), _ptr(lines), C.byref(info))
+    if rc != 0:
+        msg = (border.lib.sbbseg_last_error() or b"").decode("utf-8", "replace")
+        if "empty sequence" in msg:
+            raise ValueError("attempt to get argmax of an empty sequence")          # what main.py:401 raises
+        raise RuntimeError("sbbseg_run_page: " + msg)
+    w, h = int(info.box_xywh[2]), int(info.box_xywh[3])
+    r = regions[:h * w * channels].reshape((h, w, 3) if channels == 3 else (h, w)).copy() if info.regions_ok else None
+    t = lines[:h * w].reshape(h, w).copy() if info.textlines_ok else None
+    return mask, r, t, info
 
 
 def host_largest_contour_area2(mask: np.ndarray) -> int:

@@ -252,6 +252,9 @@ struct sbbseg_ctx {
     void* comm = nullptr;
     int comm_rank = 0, comm_world = 1;
     void* d_deskew = nullptr; size_t deskew_cap = 0;      // inverse maps | bicubic table | row counts of sbbseg_deskew_profiles
+    // sbbseg_run_page's resident buffers (owned by the handle passed as `border` / `layout` / `textline` respectively)
+    uint8_t *d_run_page = nullptr, *d_run_mask = nullptr, *d_run_a = nullptr, *d_run_b = nullptr;
+    size_t run_page_cap = 0, run_mask_cap = 0, run_a_cap = 0, run_b_cap = 0;
     int *d_cc_parent = nullptr, *d_cc_count = nullptr; size_t cc_parent_cap = 0, cc_count_cap = 0;
     bool force_host_contours = false;     // test hook (conv variant bit 21): always take the exact host ranking
     int host_contour_calls = 0;           // how often the exact host ranking ran (sbbseg_debug_counter)
@@ -892,6 +895,7 @@ int sbbseg_destroy(sbbseg_ctx* c)
     (void)hipFree(c->d_page); (void)hipFree(c->d_page_labels); (void)hipFree(c->d_page_labels3); (void)hipFree(c->d_tile_labels);
     (void)hipFree(c->d_own_x); (void)hipFree(c->d_own_y); (void)hipFree(c->d_map); (void)hipFree(c->d_wmap);
     (void)hipFree(c->d_deskew);
+    (void)hipFree(c->d_run_page); (void)hipFree(c->d_run_mask); (void)hipFree(c->d_run_a); (void)hipFree(c->d_run_b);
     for (auto& ub : c->user_bufs) (void)hipFree(ub.first);
     for (int k = 0; k < 2; ++k) {
         (void)hipHostFree(c->pp_h_in[k]); (void)hipHostFree(c->pp_h_out[k]);
@@ -2886,6 +2890,59 @@ int sbbseg_extract_page_box_dev(sbbseg_ctx* c, const void* d_page_hwc, int Hp, i
     if (whole_scaled_impl(c, nullptr, d_page_hwc, Hp, Wp, Hs, Ws, Hs, Ws, nullptr)) return 1;
     if (d_mask_out) HIPCHK(hipMemcpyAsync(d_mask_out, c->d_page_labels, (size_t)Hs * Ws, hipMemcpyDeviceToDevice, c->stream));
     return sbbseg_page_box_dev(c, c->d_page_labels, Hs, Ws, box_xywh, pixels);
+    API_END
+}
+
+// ---- the model-running part of run() (main.py:2056-2107) in ONE call: the stored page is uploaded once and stays in device memory for
+// all three stages, the border mask and the region map never leave the device between their model and their glue.
+//   extract_page (main.py:2061, 384-437)            border model on the page as upscaled to Hs x Ws, dilate x 6, largest contour, box;
+//                                                   outside the reference's try: an error here is the call's error
+//   extract_text_regions (2072, 439-454)            layout model on the Otsu'd CROP, erode x 3 / dilate x 4 (2074-2075); a failure --
+//                                                   e.g. a crop smaller than the model input, main.py:278-285 -- is "no regions" (2089-2091)
+//   get_text_region_contours_and_boxes (2083, 2096) existence only: the textline model runs when a contour would be kept
+//   textline_contours (2102, 490-503)               textline model on the crop
+int sbbseg_run_page(sbbseg_ctx* border, sbbseg_ctx* layout, sbbseg_ctx* textline, const uint8_t* page_hwc, int Hp, int Wp, int Hs, int Ws,
+                    int channels, uint8_t* page_mask_out, uint8_t* regions_out, uint8_t* textlines_out, sbbseg_run_info* info)
+{
+    API_BEGIN
+    if (check_ready(border) || check_ready(layout) || check_ready(textline)) return 1;
+    REQUIRE(page_hwc && info && regions_out && textlines_out && Hp > 0 && Wp > 0 && Hs > 0 && Ws > 0 && (channels == 1 || channels == 3), "bad arguments");
+    REQUIRE(border->device == layout->device && border->device == textline->device, "the three handles must live on one device");
+    memset(info, 0, sizeof(*info));
+    const size_t spix = (size_t)Hp * Wp, pix = (size_t)Hs * Ws;
+    if (ensure(border, (void**)&border->d_run_page, &border->run_page_cap, spix * 3)) return 1;
+    if (page_mask_out && ensure(border, (void**)&border->d_run_mask, &border->run_mask_cap, pix)) return 1;
+    HIPCHK(hipMemcpyAsync(border->d_run_page, page_hwc, spix * 3, hipMemcpyHostToDevice, border->stream));      // the one upload of the page
+    int64_t pixels = 0;
+    if (sbbseg_extract_page_box_dev(border, border->d_run_page, Hp, Wp, Hs, Ws, page_mask_out ? border->d_run_mask : nullptr, info->box_xywh, &pixels)) return 1;
+    info->box_pixels = pixels;                                  // (extract_page_box_dev has synchronised the border handle's stream)
+    REQUIRE(pixels > 0, "attempt to get argmax of an empty sequence (the border model found no page: main.py:399-401 raises here)");
+    if (page_mask_out && sbbseg_download_labels(border, page_mask_out, border->d_run_mask, pix, channels)) return 1;
+    const int x = info->box_xywh[0], y = info->box_xywh[1], w = info->box_xywh[2], h = info->box_xywh[3];
+    const size_t cpix = (size_t)w * h;
+    // layout stage + its post-processing: the reference's bare try / except (main.py:2069-2091)
+    int present = 0;
+    do {
+        if (ensure(layout, (void**)&layout->d_run_a, &layout->run_a_cap, cpix + 4) || ensure(layout, (void**)&layout->d_run_b, &layout->run_b_cap, cpix + 4)) break;
+        int* d_thr = (int*)(layout->d_hist + 256);
+        if (sbbseg_segment_crop_dev(layout, border->d_run_page, Hp, Wp, Hs, Ws, x, y, w, h, 1, layout->d_run_a, d_thr)) break;
+        if (sbbseg_morph_dev(layout, layout->d_run_a, h, w, SBBSEG_MORPH_ERODE, 5, 3, layout->d_run_b)) break;          // main.py:2074
+        if (sbbseg_morph_dev(layout, layout->d_run_b, h, w, SBBSEG_MORPH_DILATE, 5, 4, layout->d_run_b)) break;         // main.py:2075
+        if (sbbseg_text_regions_present_dev(layout, layout->d_run_b, h, w, 1, 0.00001, &present)) break;                 // main.py:2083, 2096
+        if (sbbseg_download(layout, &info->otsu_threshold, d_thr, sizeof(int))) break;
+        if (sbbseg_download_labels(layout, regions_out, layout->d_run_b, cpix, channels)) break;
+        info->regions_ok = 1;
+    } while (0);
+    info->text_present = info->regions_ok ? present : 0;
+    if (info->text_present) {                                  // main.py:2096-2107; a failure = the outer except (2152-2157): no lines
+        do {
+            if (ensure(textline, (void**)&textline->d_run_a, &textline->run_a_cap, cpix + 4)) break;
+            if (sbbseg_segment_crop_dev(textline, border->d_run_page, Hp, Wp, Hs, Ws, x, y, w, h, 0, textline->d_run_a, nullptr)) break;
+            if (sbbseg_download_labels(textline, textlines_out, textline->d_run_a, cpix, 1)) break;
+            info->textlines_ok = 1;
+        } while (0);
+    }
+    return 0;
     API_END
 }
 

@@ -319,67 +319,31 @@ class InferenceStages:
     def _run_resident(self):
         """run()'s three stages with the stored page uploaded ONCE and kept in device memory for all of them (run() hands the same
         page to every stage, main.py:2061-2102), the border mask and the region map staying on the device between their model and
-        their glue: the `_dev` entry points of the C ABI on buffers the LIBRARY allocates (``sbbseg_device_alloc`` / ``_upload`` /
-        ``_download_labels``, round 5: no PyTorch anywhere on this path -- the reference's environment has none).  Same return value
-        as the stage-by-stage path below, which remains the path for foreign model objects and for SBBSEG_STAGES_RESIDENT=0.
-        Returns None when it does not apply."""
+        their glue: ONE library call, ``sbbseg_run_page`` (round 5: neither PyTorch nor device pointers on this path -- the
+        reference's environment has no torch).  Same return value as the stage-by-stage path below, which remains the path for
+        foreign model objects and for SBBSEG_STAGES_RESIDENT=0.  Returns None when it does not apply."""
         import os
         if os.environ.get("SBBSEG_STAGES_RESIDENT", "1") == "0":
             return None
         opened = [start_new_session_and_model(d, **self.kw) for d in (self.model_page_dir, self.model_region_dir, self.model_textline_dir)]
-        bufs = []
         try:
             (m_page, _), (m_region, _), (m_text, _) = opened
             if not all(isinstance(m, SegModel) for m in (m_page, m_region, m_text)):
                 return None
-            ctx = m_page.ctx                                         # owner of the buffers
-
-            def alloc(n):
-                bufs.append(ctx.device_alloc(n))
-                return bufs[-1]
-            H, W = self.image_stored.shape[:2]
-            Hs, Ws = self.img_hight_int, self.img_width_int
-            d_page = alloc(H * W * 3)
-            ctx.upload(d_page, self.image_stored)                    # the one upload of the page
-            d_mask = alloc(Hs * Ws)
-            # extract_page (main.py:384-437), outside the try like main.py:2061: its errors propagate
-            box, pixels = ctx.extract_page_box_dev(d_page, H, W, Hs, Ws, d_mask)
-            if pixels == 0:
-                raise ValueError("attempt to get argmax of an empty sequence")          # what main.py:401 raises
-            x, y, w, h = box
+            from . import _capi
+            # extract_page's errors propagate (main.py:2061 is outside the try); the other stages degrade inside the call
+            mask, regions, textlines, info = _capi.run_page(m_page.ctx, m_region.ctx, m_text.ctx, self.image_stored,
+                                                            self.img_hight_int, self.img_width_int, channels=3)
+            x, y, w, h = (int(v) for v in info.box_xywh)
             self.page_box = (x, y, w, h)
             page_coord = [y, y + h, x, x + w]
             self.cont_page = [np.array([[page_coord[2], page_coord[0]], [page_coord[3], page_coord[0]],
                                         [page_coord[3], page_coord[1]], [page_coord[2], page_coord[1]]])]
-            self.page_mask = ctx.download_labels(d_mask, Hs, Ws, 3)
-            regions, has_text = None, False
-            try:                                                     # main.py:2069-2091: a failed layout stage = no regions
-                rc = m_region.ctx
-                d_regions, d_clean, d_thr = alloc(h * w), alloc(h * w), alloc(4)
-                rc.segment_crop_dev(d_page, H, W, Hs, Ws, box, True, d_regions, d_thr)
-                rc.morph_dev(d_regions, h, w, 0, 5, 3, d_clean)      # main.py:2074-2075
-                rc.morph_dev(d_clean, h, w, 1, 5, 4, d_clean)
-                self.otsu_threshold = int(rc.download(d_thr, (1,), np.int32)[0])
-                has_text = rc.text_regions_present_dev(d_clean, h, w, 1, 0.00001)      # main.py:2083, 2096 (456-480)
-                regions = rc.download_labels(d_clean, h, w, 3)
-            except Exception:
-                regions, has_text = None, False
-            textlines = None
-            if has_text:
-                try:
-                    d_lines = alloc(h * w)
-                    m_text.ctx.segment_crop_dev(d_page, H, W, Hs, Ws, box, False, d_lines)
-                    textlines = m_text.ctx.download_labels(d_lines, h, w, 1)
-                except Exception:                                   # main.py:2152-2157
-                    textlines = None
-            return self.page_mask, regions, textlines, page_coord
+            self.page_mask = mask
+            if info.regions_ok:
+                self.otsu_threshold = int(info.otsu_threshold)
+            return mask, regions, textlines, page_coord
         finally:
-            if bufs:
-                for m, _ in opened:                                  # nothing may still read the buffers when they go
-                    if isinstance(m, SegModel):
-                        m.ctx.synchronize()
-                for b in bufs:
-                    opened[0][0].ctx.device_free(b)
             for _, session in opened:
                 session.close()
 

@@ -1556,3 +1556,56 @@ def test_run_is_torch_free_at_full_size(tmp_path):
     mism = (z["lines"][sl] != r_.argmax(-1)) & (own[sl] == k)
     assert not (mism & ((srt[..., -1] - srt[..., -2]) > EXACT_MARGIN)).any() and mism.mean() < 1e-3
     # (the raw layout map's parity with the oracle is test_full_size_three_model_pipeline_config3's subject)
+
+
+def test_run_page_one_call_equals_the_piecewise_device_calls(tmp_path):
+    """sbbseg_run_page (one call: upload, border + box, layout on the Otsu'd crop + erode x 3 / dilate x 4, the text-region gate, textline)
+    == the same chain spelt out with the `_dev` entry points on library-owned buffers (sbbseg_device_alloc / _upload / _download_labels,
+    what INTEGRATION.md shows an integrator without torch), on two small pages with 224-pixel models."""
+    from sbb_textline_detection_amd import clear_session
+    from sbb_textline_detection_amd.model import load_model
+    from sbb_textline_detection_amd.stages import scaled_size
+    from sbb_textline_detection_amd.weights import save_sbbw
+    from tools.synth_model import calibrated_model
+    specs = {"model_page_mixed_best": 2, "model_strukturerkennung": 4, "model_textline_new": 2}      # main.py:58-60
+    ms = []
+    for name, classes in specs.items():
+        cfg, w = calibrated_model(classes, 224, 224, seed=classes + 30)
+        save_sbbw(str(tmp_path / (name + ".sbbw")), cfg, w)
+        ms.append(load_model(str(tmp_path / (name + ".h5")), max_batch=16))
+    cb, cl, ct = (m.ctx for m in ms)
+    for hw, seed in (((520, 400), 9), ((700, 610), 4)):
+        page = synthetic_page(*hw, seed=seed)
+        H, W = hw
+        Hs, Ws = scaled_size(H, W)
+        mask, regions, lines, info = _capi.run_page(cb, cl, ct, page, Hs, Ws, channels=3)
+        x, y, w, h = (int(v) for v in info.box_xywh)
+        bufs = []
+
+        def alloc(n):
+            bufs.append(cb.device_alloc(n))
+            return bufs[-1]
+        try:
+            d_page, d_mask = alloc(H * W * 3), alloc(Hs * Ws)
+            cb.upload(d_page, page)
+            box, pixels = cb.extract_page_box_dev(d_page, H, W, Hs, Ws, d_mask)
+            assert box == (x, y, w, h) and pixels == info.box_pixels
+            assert np.array_equal(cb.download_labels(d_mask, Hs, Ws, 3), mask)
+            d_reg, d_clean, d_thr, d_lines = alloc(w * h), alloc(w * h), alloc(4), alloc(w * h)
+            cl.segment_crop_dev(d_page, H, W, Hs, Ws, box, True, d_reg, d_thr)
+            cl.morph_dev(d_reg, h, w, 0, 5, 3, d_clean)
+            cl.morph_dev(d_clean, h, w, 1, 5, 4, d_clean)
+            assert int(cl.download(d_thr, (1,), np.int32)[0]) == info.otsu_threshold and info.regions_ok == 1
+            assert cl.text_regions_present_dev(d_clean, h, w) == bool(info.text_present)
+            assert np.array_equal(cl.download_labels(d_clean, h, w, 3), regions)
+            if info.text_present:
+                ct.segment_crop_dev(d_page, H, W, Hs, Ws, box, False, d_lines)
+                assert info.textlines_ok == 1 and np.array_equal(ct.download_labels(d_lines, h, w, 1), lines)
+            else:
+                assert lines is None
+        finally:
+            for b in bufs:
+                cb.device_free(b)
+    with pytest.raises(RuntimeError, match="not allocated by this handle"):
+        cl.device_free(cb.device_alloc(64))
+    clear_session()
