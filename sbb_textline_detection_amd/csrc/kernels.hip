@@ -394,8 +394,11 @@ void conv_igemm_mfma(const ConvParams p)
                 (void)m;
             } else if constexpr (FG) {
                 if (m < p.M) {
-                    const int n = fast_div(m, p.howo_magic, p.howo_shift);
-                    const int rem = m - n * HoWo;
+                    // (timing probe, variant flag bit 5 / SBBSEG_CONV_PROBE_LOCAL=1: every staged row gathers from the first 1 024 output pixels'
+                    //  neighbourhood -- real data, but L2-resident: what the loop does when no pixel load misses.  Results are wrong.)
+                    const int mg = (p.variant_flags & 32) ? (m & 1023) : m;
+                    const int n = fast_div(mg, p.howo_magic, p.howo_shift);
+                    const int rem = mg - n * HoWo;
                     int oy, ox;
                     decode_yx(rem, oy, ox);
                     r_oy[j] = (int)((uint32_t)n * img0 + (uint32_t)(((oy << sd0.sy_shift) * sd0.PW + (ox << sd0.sx_shift)) * sd0.pix_bytes) +
