@@ -1394,6 +1394,14 @@ static hipError_t launch_conv_x3(const ConvParams& p, hipStream_t s)
         if (bc != 128 || !p.fast_gather || p.tile_map != 0 || p.cls_minor || (p.total_ksteps & ((1 << p.ks_shift) - 1))) return hipErrorInvalidValue;
         return launch_conv_impl<128, 128, 2, 2, 2, true, 8, false, true, true, true>(p, s);
     }
+    // Residual layers (the expand convs that `expand_reduce` does not take: the last block of stages 3 / 4, stage 5) on the 256 x 256 tile when
+    // the launch still gives every CU a block: the pixel operand is re-read by half as many channel tiles; the residual is then read in the
+    // epilogue (add_split8) instead of being prefetched -- same arithmetic.  Round 5: 0.61 -> 0.56, 0.39 -> 0.35, 0.27 -> 0.25 ms per 160
+    // patches (profiles/r05_experiments.md section 12).  SBBSEG_X3_RES256_MINK=0 switches it off.
+    static const int kres256 = getenv("SBBSEG_X3_RES256_MINK") ? atoi(getenv("SBBSEG_X3_RES256_MINK")) : 256;
+    if (p.variant == 0 && bc == 128 && p.residual && kres256 > 0 && p.cout % 256 == 0 && p.Ktot >= kres256 &&
+        (long)p.n_cls * ((p.M + 255) / 256) * (p.cout / 256) >= 200)
+        return launch_conv_t<256, 256, 2, 4, 2, true, 8, false, true>(p, s);
     if (p.variant == 0 && bc == 128 && !p.residual) {          // the long-K decoder launches: same 8-wave tiles as the plain modes
         const long t256 = (long)p.n_cls * ((p.M + 255) / 256) * (p.cout / 256);
         const long t512 = (long)p.n_cls * ((p.M + 511) / 512) * ((p.cout + 127) / 128);
