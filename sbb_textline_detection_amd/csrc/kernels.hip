@@ -1371,13 +1371,22 @@ static hipError_t launch_conv_16(const ConvParams& p, hipStream_t s)
         if (bc == 128) return launch_conv_t<512, 128, 4, 2, 2, F16>(p, s);
         if (bc == 64) return launch_conv_t<512, 64, 8, 1, 2, F16>(p, s);
     }
+    {   // round 5 (plain modes; profiles/r05_experiments.md section 13): residual layers on the 256 x 256 tile from this K on (0 = never) --
+        // the stage-4 / stage-5 expands the fused pair kernel does not take, -3..-4 % each (the K = 128 one of stage 3 loses 1.5 %: left out)
+        static const int kres256 = getenv("SBBSEG_F16_RES256_MINK") ? atoi(getenv("SBBSEG_F16_RES256_MINK")) : 256;
+        if (variant == 0 && bc == 128 && p.residual && kres256 > 0 && p.cout % 256 == 0 && p.Ktot >= kres256 &&
+            (long)p.n_cls * ((p.M + 255) / 256) * (p.cout / 256) >= 200)
+            return launch_conv_t<256, 256, 2, 4, 2, F16>(p, s);
+    }
+    // (384 since round 5: the stage-3 projection merge, K = 384 channels, on the 256 x 256 tile: 0.40 -> 0.31 ms per 160 patches in fp16)
+    static const int k256_16 = getenv("SBBSEG_F16_T256_MINK") ? atoi(getenv("SBBSEG_F16_T256_MINK")) : 384;
     if (variant == 0 && bc == 128 && !p.residual) {
         // auto (measured per layer, profiles/r01_conv_variants.md): the 8-wave tiles with 128x64 wave
         // tiles (LDS bytes per MFMA x0.75, L2 bytes per MFMA x0.5) win on long-K layers that still
         // give every CU a block; short-K / residual (HBM-bound) layers and small grids stay on 128x128
         const long t256 = (long)p.n_cls * ((p.M + 255) / 256) * (p.cout / 256);
         const long t512 = (long)p.n_cls * ((p.M + 511) / 512) * ((p.cout + 127) / 128);
-        if (p.cout % 256 == 0 && p.Ktot >= 512 && t256 >= 200) return ph8_ok(p) ? launch_conv_t<256, 256, 2, 4, 2, F16, 8, true>(p, s) : launch_conv_t<256, 256, 2, 4, 2, F16>(p, s);
+        if (p.cout % 256 == 0 && p.Ktot >= k256_16 && t256 >= 200) return ph8_ok(p) ? launch_conv_t<256, 256, 2, 4, 2, F16, 8, true>(p, s) : launch_conv_t<256, 256, 2, 4, 2, F16>(p, s);
         if (p.Ktot >= 1024 && t512 >= 200) return launch_conv_t<512, 128, 4, 2, 2, F16>(p, s);
     }
     if (bc == 128) return big ? launch_conv_t<256, 128, 4, 2, 3, F16>(p, s) : launch_conv_t<128, 128, 2, 2, 2, F16>(p, s);
