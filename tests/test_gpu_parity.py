@@ -645,6 +645,25 @@ def test_c_abi_error_paths_do_not_abort(stitch_model):
     assert lab.shape == (448, 448)
     one = m.predict((page[None] / 255.0).astype(np.float32)).argmax(-1)[0].astype(np.uint8)
     assert np.array_equal(lab, one)
+    # round 5's entry points: bad arguments are status codes too, and the handle survives them
+    import ctypes as C
+    lib, h = m.ctx.lib, m.ctx.h
+    info = _capi.RunInfo()
+    buf = np.zeros(16, np.uint8)
+    assert lib.sbbseg_run_page(h, h, h, None, 10, 10, 10, 10, 3, None, _capi._ptr(buf), _capi._ptr(buf), C.byref(info)) != 0      # no page
+    assert lib.sbbseg_run_page(h, h, None, _capi._ptr(buf), 2, 2, 2, 2, 3, None, _capi._ptr(buf), _capi._ptr(buf), C.byref(info)) != 0   # null handle
+    assert lib.sbbseg_run_page(h, h, h, _capi._ptr(buf), 2, 2, 2, 2, 2, None, _capi._ptr(buf), _capi._ptr(buf), C.byref(info)) != 0      # channels
+    p_out = C.c_void_p()
+    assert lib.sbbseg_device_alloc(h, 0, C.byref(p_out)) != 0 and lib.sbbseg_device_alloc(None, 16, C.byref(p_out)) != 0
+    assert lib.sbbseg_device_free(h, C.c_void_p(0x1000)) != 0 and b"not allocated" in lib.sbbseg_last_error()
+    pres = C.c_int(7)
+    assert lib.sbbseg_text_regions_present_dev(h, None, 4, 4, 1, C.c_double(1e-5), C.byref(pres)) != 0
+    # a page smaller than the layout model: the border stage works on any size, the layout stage fails like main.py:278-285 and the call
+    # still succeeds with "no regions" (main.py:2089-2091)
+    tiny = synthetic_page(300, 200, seed=3)
+    mask, regions, lines, info = _capi.run_page(m.ctx, m.ctx, m.ctx, tiny, 300, 200, channels=1)
+    assert mask.shape == (300, 200) and (info.regions_ok, info.text_present, info.textlines_ok) == (0, 0, 0) and regions is None and lines is None
+    assert np.array_equal(m.segment_page(page), lab)
 
 
 def test_batch_one_and_four_classes():
