@@ -76,3 +76,16 @@ def test_nearest_map_rule(lib):
         assert got[0] == 0 and got.max() <= src - 1 and np.all(np.diff(got) >= 0)
     with pytest.raises(RuntimeError):
         _capi.nearest_map(0, 5)
+
+
+def test_documents_name_only_entry_points_that_exist(lib):
+    """INTEGRATION.md / DESIGN.md / README.md are what a maintainer of the reference binds from: every `sbbseg_*` function they name
+    (wildcards like `sbbseg_comm_*` and `[_dev]` suffix notation aside) must be an export of the library."""
+    exports = set(_capi.EXPORTS)
+    for doc in ("INTEGRATION.md", "DESIGN.md", "README.md"):
+        text = open(os.path.join(ROOT, doc)).read()
+        for name in sorted(set(re.findall(r"`(sbbseg_[a-z0-9_]+)(?:\[_dev\])?`", text))):
+            if name.endswith("_") or name in ("sbbseg_ctx", "sbbseg_run_info", "sbbseg_conv_desc", "sbbseg_h"):
+                continue
+            candidates = {name, name + "_dev"}
+            assert candidates & exports or any(e.startswith(name) for e in exports), f"{doc} names {name}, which libsbbseg does not export"
