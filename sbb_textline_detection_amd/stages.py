@@ -320,7 +320,7 @@ class InferenceStages:
         """run()'s three stages with the stored page uploaded ONCE and kept in device memory for all of them (run() hands the same
         page to every stage, main.py:2061-2102), the border mask and the region map staying on the device between their model and
         their glue: ONE library call, ``sbbseg_run_page`` (round 5: neither PyTorch nor device pointers on this path -- the
-        reference's environment has no torch).  Same return value as the stage-by-stage path below, which remains the path for
+        reference's environment is Keras / TF only).  Same return value as the stage-by-stage path below, which remains the path for
         foreign model objects and for SBBSEG_STAGES_RESIDENT=0.  Returns None when it does not apply."""
         import os
         if os.environ.get("SBBSEG_STAGES_RESIDENT", "1") == "0":
