@@ -437,6 +437,7 @@ int launch_op(sbbseg_ctx* c, Op& op, int n, uint8_t* d_labels, float* d_probs)
             p.M = n * co.Ho * co.Wo;
             p.variant_flags = ((c->conv_variant & 64) ? 1 : 0) | ((c->conv_variant & 128) ? 2 : 0) | (c->ph8 ? 4 : 0);
             { static const int probe_local = getenv("SBBSEG_CONV_PROBE_LOCAL") ? atoi(getenv("SBBSEG_CONV_PROBE_LOCAL")) : 0; if (probe_local) p.variant_flags |= 32; }
+            { static const int probe_whot = getenv("SBBSEG_CONV_PROBE_WHOT") ? atoi(getenv("SBBSEG_CONV_PROBE_WHOT")) : 0; if (probe_whot) p.variant_flags |= 64; }
             // XCD-grouped walk for single-class layers: measured neutral-to-slower (it removes the n_ct-fold
             // re-fetch of the pixel operand, but those layers are not bound by fetch bytes) -> opt-in, bit 5
             // (split mode: on by default -- twice the pixel bytes; +0.7 % page throughput in two runs, profiles/r03_experiments.md)

@@ -458,7 +458,9 @@ void conv_igemm_mfma(const ConvParams p)
                 }
             };
             if (s1) rows(sd1.base - fg_bias1, sd1.bytes + fg_bias1, r_ox); else rows(sd0.base - fg_bias0, sd0.bytes + fg_bias0, r_oy);
-            const uint32_t woff = (uint32_t)(t * (kBK * 2) + l_h * GS * 16);
+            // (timing probe, variant flag bit 6 / SBBSEG_CONV_PROBE_WHOT=1: the weight rows of every K-step come from the tile's first sixteen
+            //  K-steps -- an L2-resident 32-64 KB per channel tile.  Results are wrong.)
+            const uint32_t woff = (uint32_t)(((p.variant_flags & 64) ? (t & 15) : t) * (kBK * 2) + l_h * GS * 16);
 #pragma unroll
             for (int j = 0; j < T::kWLoads; ++j)
                 buffer_load_lds16(wbase, 0x7fffffffu, (LDS_AS void*)(lds_w + (j * NW + wave) * 1024), w_off[j], woff);

@@ -34,7 +34,7 @@ __global__ __launch_bounds__(512, 2) void probe(float* out, int iters, const cha
         }
     }
     __syncthreads();
-    constexpr bool M32 = VAR & 1, ALL = VAR & 2, NOBAR = VAR & 4, PRIO = VAR & 8, REG = VAR & 16, LD = VAR & 32;
+    constexpr bool M32 = VAR & 1, ALL = VAR & 2, NOBAR = VAR & 4, PRIO = VAR & 8, REG = VAR & 16, LD = VAR & 32, X3L = VAR & 64;
     auto stage_next = [&](int it) __attribute__((always_inline)) {
         if constexpr (LD) {
             const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, 1 << 26, 0x00020000);
@@ -84,6 +84,43 @@ __global__ __launch_bounds__(512, 2) void probe(float* out, int iters, const cha
                     for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
                         for (int q = 0; q < 8; ++q) acc[mi][q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ra[kk][mi], rb[kk][q], acc[mi][q], 0, 0, 0);
+            } else if constexpr (X3L) {
+                // the SPLIT mode's K-step (round 5): the stage is 32 channels as hi (slots 0-3: rd0) and lo (slots 4-7: rd1) granules, three
+                // MFMAs per fragment pair (lo*hi, hi*lo, hi*hi), pixel fragments in four phases of two blocks requested a phase ahead --
+                // conv_igemm_mfma<256, 256, 2, 4, 2, .., X3>'s loop; 96 MFMAs per wave for the same LDS bytes and staging loads
+                f16x8 ah[4], al[4], bh[2][2], bl[2][2];
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi) al[mi] = *(const f16x8*)(sb + w_rd + mi * 2048 + rd1);
+#pragma unroll
+                for (int q = 0; q < 2; ++q) bh[0][q] = *(const f16x8*)(sb + p_rd + q * 2048 + rd0);
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi) ah[mi] = *(const f16x8*)(sb + w_rd + mi * 2048 + rd0);
+#pragma unroll
+                for (int q = 0; q < 2; ++q) bl[0][q] = *(const f16x8*)(sb + p_rd + q * 2048 + rd1);
+#pragma unroll
+                for (int ph = 0; ph < 4; ++ph) {
+                    if (ph + 1 < 4) {
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) {
+                            bh[(ph + 1) & 1][q] = *(const f16x8*)(sb + p_rd + ((ph + 1) * 2 + q) * 2048 + rd0);
+                            bl[(ph + 1) & 1][q] = *(const f16x8*)(sb + p_rd + ((ph + 1) * 2 + q) * 2048 + rd1);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+#pragma unroll
+                    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) acc[mi][ph * 2 + q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[mi], bh[ph & 1][q], acc[mi][ph * 2 + q], 0, 0, 0);
+#pragma unroll
+                    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) acc[mi][ph * 2 + q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[mi], bl[ph & 1][q], acc[mi][ph * 2 + q], 0, 0, 0);
+#pragma unroll
+                    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) acc[mi][ph * 2 + q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[mi], bh[ph & 1][q], acc[mi][ph * 2 + q], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             } else if constexpr (ALL) {
                 f16x8 a[2][4], b[2][8];
 #pragma unroll
@@ -223,7 +260,7 @@ static void run(const char* name, float* d_out, int iters)
         hipEventElapsedTime(&ms, a, b);
         if (ms < best) best = ms;
     }
-    const double flops = 2.0 * 256 * 256 * 64 * (double)iters * 256;
+    const double flops = ((VAR & 64) ? 3.0 * 2.0 * 256 * 256 * 32 : 2.0 * 256 * 256 * 64) * (double)iters * 256;      // (split loop: ISSUED MFMA work)
     unsigned long long h[2];
     hipMemcpy(h, d_clk, 16, hipMemcpyDeviceToHost);
     // clock64 = shader-clock counter, wall_clock64 = 100 MHz constant counter
@@ -249,6 +286,10 @@ int main()
     run<0, 64>("16x16x32 product loop + 64 VALU per K-step", d_out, iters);
     run<0, 128>("16x16x32 product loop + 128 VALU per K-step", d_out, iters);
     run<0, 192>("16x16x32 product loop + 192 VALU per K-step", d_out, iters);
+    run<64>("SPLIT loop (3 MFMAs per pair), LDS reads, barrier, no staging", d_out, iters);
+    run<64 | 32>("SPLIT loop + 8 staging loads per wave (the decoder's K-step)", d_out, iters);
+    run<64 | 32 | 4>("SPLIT loop + 8 staging loads, no barrier (racy)", d_out, iters);
+    run<64, 32>("SPLIT loop + 32 VALU per K-step, no staging", d_out, iters);
     run<1>("32x32x16, reads one k-chunk ahead, barrier", d_out, iters);
     run<1 | 2>("32x32x16, all fragments first, barrier", d_out, iters);
     run<1 | 2 | 8>("32x32x16, all fragments first, barrier, setprio", d_out, iters);
