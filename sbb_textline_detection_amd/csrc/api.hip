@@ -2175,10 +2175,16 @@ static int tile_range_impl(sbbseg_ctx* c, const void* const* d_pages, int n_page
     const int chunk_cap = (c->profiling && c->lanes == 2 && c->lane1_batch > 0 && c->max_batch >= 4 * kMinLaneTiles) ? (c->max_batch + 1) / 2 : c->max_batch;
     const int n_chunks = (n_tiles + chunk_cap - 1) / chunk_cap;
     const int chunk = n_chunks ? (n_tiles + n_chunks - 1) / n_chunks : 0;
+    bool forked = false;
     for (int done = 0; done < n_tiles; done += chunk) {
         const int nb = n_tiles - done < chunk ? n_tiles - done : chunk;
         const bool two = c->lane1_batch > 0 && c->lanes == 2 && !c->profiling && nb >= 2 * kMinLaneTiles;
         if (!two) {
+            if (forked) {                                       // (a one-lane chunk behind two-lane ones: lane 1 first)
+                HIPCHK(hipEventRecord(c->ev_join, c->lane_stream));
+                HIPCHK(hipStreamWaitEvent(c->stream, c->ev_join, 0));
+                forked = false;
+            }
             // (probe knob SBBSEG_PROFILE_HALF=1: the profiling pass runs on lane 0's HALF of the chip, the other half idle)
             static const bool prof_half = getenv("SBBSEG_PROFILE_HALF") && getenv("SBBSEG_PROFILE_HALF")[0] == '1';
             if (c->profiling && prof_half && c->cu_split) {
@@ -2193,10 +2199,25 @@ static int tile_range_impl(sbbseg_ctx* c, const void* const* d_pages, int n_page
             continue;
         }
         const int na = (nb + 1) / 2, nb2 = nb - na;            // nb2 <= lane1_batch
-        HIPCHK(hipEventRecord(c->ev_fork, c->stream));         // page / threshold / earlier chunks are ordered before
-        HIPCHK(hipStreamWaitEvent(c->lane_stream, c->ev_fork, 0));
+        // The lanes fork ONCE per tile range and join once behind its last chunk (round 5): a lane's halves of consecutive chunks follow each
+        // other on the lane's own stream and buffers, nothing of one lane depends on the other.  (Up to round 4 every chunk forked and joined:
+        // the lane that finished its half first waited for the other one -- 7-10 % of the timed region had ONE kernel in flight,
+        // profiles/r05_timeline_gaps.txt.  SBBSEG_JOIN_PER_CHUNK=1 restores that for A/B.)
+        static const bool join_per_chunk = getenv("SBBSEG_JOIN_PER_CHUNK") && getenv("SBBSEG_JOIN_PER_CHUNK")[0] == '1';
+        if (!forked || join_per_chunk) {
+            HIPCHK(hipEventRecord(c->ev_fork, c->stream));     // page / threshold / earlier ranges are ordered before
+            HIPCHK(hipStreamWaitEvent(c->lane_stream, c->ev_fork, 0));
+            forked = true;
+        }
         if (run_chunk(0, done, na)) return 1;
         if (run_chunk(1, done + na, nb2)) return 1;           // (starting lane 1 later -- after lane 0's op k -- measured 3-14 % slower)
+        if (join_per_chunk) {
+            HIPCHK(hipEventRecord(c->ev_join, c->lane_stream));
+            HIPCHK(hipStreamWaitEvent(c->stream, c->ev_join, 0));
+            forked = false;
+        }
+    }
+    if (forked) {
         HIPCHK(hipEventRecord(c->ev_join, c->lane_stream));
         HIPCHK(hipStreamWaitEvent(c->stream, c->ev_join, 0));
     }
