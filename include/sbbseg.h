@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SBBSEG_ABI_VERSION 4
+#define SBBSEG_ABI_VERSION 5
 
 typedef struct sbbseg_ctx sbbseg_ctx;
 
@@ -94,6 +94,22 @@ int sbbseg_set_dedupe(sbbseg_ctx* c, int on);
  * whole-image forward of the 448 model in the split mode, 2.1 -> 1.5 ms in plain fp16.  Deterministic, but the last bits differ from the unsplit launches (summation order): the
  * patch paths and sbbseg_predict never split, their results do not depend on the batch size. */
 int sbbseg_set_ksplit(sbbseg_ctx* c, int on);
+/* Owned-region launches of the decoder (round 6; default mode 1, SBBSEG_OWNED_REGIONS=0|1|2 overrides the default at creation).
+ * do_prediction pastes only part of every tile's label map into the page: the 10 % margin is cropped on every side that is not a page
+ * edge (main.py:294-364) and where the inward-clamped last tile of an axis overlaps its neighbour the later tile wins (main.py:276-281
+ * + the paste order) -- a 3500 x 2500 page keeps 8.75 of the 14.05 Mpx its 70 tiles produce.  The decoder is local (3x3 convs over
+ * nearest-x2 upsamplings, pointwise epilogues), so each decoder level is launched only over the rows / columns the kept pixels depend
+ * on: the owned rectangle dilated by one pixel per 3x3 conv above the level and halved per upsampling.  The encoder (receptive field
+ * = the tile) runs whole.  Every computed pixel goes through the arithmetic of the full launch: the stitched label map is the same
+ * byte for byte.
+ *   mode 0: off.  mode 1: the fused page entry points (sbbseg_segment_page[_dev / _scaled / _otsu], _segment_pages[_dev],
+ *   _segment_crop[_dev], sbbseg_run_page).  mode 2: also sbbseg_segment_tile_range[_bin]_dev -- the tile labels they return are then
+ *   DEFINED ONLY ON EACH TILE'S OWNED REGION (everything sbbseg_stitch_dev reads); a repeated clamped tile owns nothing.
+ * sbbseg_predict, sbbseg_segment_tiles_dev and the whole-image branch always compute whole patches. */
+int sbbseg_set_owned_regions(sbbseg_ctx* c, int mode);
+/* decoder levels (the fused tail + the parity-split decoder convs below it) the handle's plan runs as owned-region launches; 0 = none
+ * (fp32 handles, unfused heads, decoders of another shape: everything is computed whole) */
+int sbbseg_owned_region_levels(sbbseg_ctx* c, int* levels);
 
 /* ---- plan building: the host-side planner (planner.py) lowers the Keras model_config that the
  * reference would have handed to keras.models.load_model (main.py:221) into these calls, in
@@ -396,6 +412,14 @@ int sbbseg_debug_set_conv_variant(sbbseg_ctx* c, int variant);
 int sbbseg_debug_largest_contour(const uint8_t* mask_hw, int H, int W, int32_t* box_xywh, int64_t* pixels);
 /* ... and TWICE the largest outer-contour area itself (host mirror of sbbseg_text_regions_present_dev's ranking; 0 for an empty mask) */
 int sbbseg_debug_largest_contour_area2(const uint8_t* mask_hw, int H, int W, int64_t* area2);
+/* closed forms of the owned-region launches (no GPU needed; tests): [lo, hi) in tile coordinates of what the stitch keeps of tile t of an
+ * axis of n_tiles tiles (origin(t) = min(t * (tile - 2 margin), extent - tile)), and the rows every decoder level below must produce for
+ * it: lo_hi[2 k], lo_hi[2 k + 1] for level k = 0 .. levels - 1, level_size[k] = rows of level k (level 0 = the network output) */
+int sbbseg_debug_owned_range(int extent, int tile, int margin, int n_tiles, int t, int* lo, int* hi);
+int sbbseg_debug_region_rows(int extent, int tile, int margin, int n_tiles, int t, int levels, const int32_t* level_size, int32_t* lo_hi);
+/* fill every activation buffer (both lanes) and the tile-label scratch with `byte_value` (tests: a launch that reads what an owned-region
+ * launch did not write then shows; 0xFF = NaN in every 16-bit format) */
+int sbbseg_debug_poison_activations(sbbseg_ctx* c, int byte_value);
 /* counters: which 0 = how often sbbseg_page_box_dev had to fall back to the host ranking on this handle */
 int sbbseg_debug_counter(sbbseg_ctx* c, int which, int64_t* value);      /* which: 0 = exact host contour rankings, 1 = patches run through the plan */
 /* Test hook for the no-abort guarantee: the nth_check-th next internal host-allocation checkpoint throws
@@ -408,6 +432,11 @@ int sbbseg_profile_enable(sbbseg_ctx* c, int enable);
 int sbbseg_profile_reset(sbbseg_ctx* c);
 /* accumulated since reset: total ms and number of launches for op `op` */
 int sbbseg_profile_get(sbbseg_ctx* c, int op, double* total_ms, int64_t* launches, int64_t* patches);
+/* Work op `op` EXECUTED since sbbseg_profile_reset, in whole-patch equivalents: a launch over n patches counts n, an owned-region
+ * launch n x (output pixels walked / output pixels of the whole grid).  exec_patches: every launch; timed_exec_patches: the launches
+ * the profiling events timed (the denominator's counterpart of sbbseg_profile_get's total_ms).  Executed FLOPs of an op =
+ * sbbseg_op_info's flops_per_patch x these. */
+int sbbseg_op_executed(sbbseg_ctx* c, int op, double* exec_patches, double* timed_exec_patches);
 
 #ifdef __cplusplus
 }

@@ -32,6 +32,8 @@ EXPORTS = [
     "sbbseg_segment_pages",
     "sbbseg_profile_enable", "sbbseg_profile_reset", "sbbseg_profile_get",
     "sbbseg_debug_largest_contour_area2", "sbbseg_text_regions_present_dev", "sbbseg_run_page", "sbbseg_device_alloc", "sbbseg_device_free", "sbbseg_upload", "sbbseg_download", "sbbseg_download_labels",
+    "sbbseg_set_owned_regions", "sbbseg_owned_region_levels", "sbbseg_op_executed", "sbbseg_debug_owned_range", "sbbseg_debug_region_rows",
+    "sbbseg_debug_poison_activations",
 ]
 
 
@@ -146,12 +148,18 @@ def load_library(path: Optional[str] = None):
         "sbbseg_upload": [vp, vp, vp, C.c_size_t],
         "sbbseg_download": [vp, vp, vp, C.c_size_t],
         "sbbseg_download_labels": [vp, vp, vp, C.c_size_t, i32],
+        "sbbseg_set_owned_regions": [vp, i32],
+        "sbbseg_owned_region_levels": [vp, C.POINTER(C.c_int)],
+        "sbbseg_op_executed": [vp, i32, C.POINTER(C.c_double), C.POINTER(C.c_double)],
+        "sbbseg_debug_owned_range": [i32, i32, i32, i32, i32, C.POINTER(C.c_int), C.POINTER(C.c_int)],
+        "sbbseg_debug_region_rows": [i32, i32, i32, i32, i32, i32, vp, vp],
+        "sbbseg_debug_poison_activations": [vp, i32],
     }
     for name, args in sigs.items():
         fn = getattr(lib, name)
         fn.argtypes = args
         fn.restype = C.c_int
-    if lib.sbbseg_abi_version() != 4:
+    if lib.sbbseg_abi_version() != 5:
         raise RuntimeError("libsbbseg ABI version mismatch")
     if path is None:
         _lib = lib
@@ -309,6 +317,21 @@ class Context:
     def set_ksplit(self, on: bool):
         """Whole-image branch: split the K range of one-patch launches over the idle CUs (default on; see sbbseg.h)."""
         check(self.lib.sbbseg_set_ksplit(self.h, int(bool(on))), "sbbseg_set_ksplit")
+
+    def set_owned_regions(self, mode: int):
+        """Decoder launches over the region the page stitch keeps of every tile (+ halo) only: 0 = off, 1 = fused page paths
+        (default), 2 = the tile-range entry points too (their tile labels are then defined on the owned regions only).  See sbbseg.h."""
+        check(self.lib.sbbseg_set_owned_regions(self.h, int(mode)), "sbbseg_set_owned_regions")
+
+    def owned_region_levels(self) -> int:
+        """Decoder levels this plan runs as owned-region launches (0: everything is computed whole)."""
+        v = C.c_int(0)
+        check(self.lib.sbbseg_owned_region_levels(self.h, C.byref(v)), "sbbseg_owned_region_levels")
+        return int(v.value)
+
+    def poison_activations(self, byte_value: int = 0xFF):
+        """Test hook: fill every activation buffer and the tile-label scratch with a byte (0xFF = NaN in every 16-bit format)."""
+        check(self.lib.sbbseg_debug_poison_activations(self.h, int(byte_value)), "sbbseg_debug_poison_activations")
 
     def forwards(self) -> int:
         """Patches run through the plan on this handle so far."""
@@ -591,7 +614,11 @@ class Context:
         for i, op in enumerate(self.ops()):
             ms, ln, pt = C.c_double(), C.c_int64(), C.c_int64()
             check(self.lib.sbbseg_profile_get(self.h, i, C.byref(ms), C.byref(ln), C.byref(pt)))
-            op.update(total_ms=ms.value, launches=ln.value, patches=pt.value)
+            ex, tex = C.c_double(), C.c_double()
+            check(self.lib.sbbseg_op_executed(self.h, i, C.byref(ex), C.byref(tex)))
+            # exec_patches: whole-patch equivalents of the work launched since profile_reset (owned-region launches count the share of
+            # the output grid they walk); timed_exec_patches: the same over the launches total_ms covers
+            op.update(total_ms=ms.value, launches=ln.value, patches=pt.value, exec_patches=ex.value, timed_exec_patches=tex.value)
             out.append(op)
         return out
 
@@ -627,6 +654,24 @@ def run_page(border: "Context", layout: "Context", textline: "Context", page: np
     r = regions[:h * w * channels].reshape((h, w, 3) if channels == 3 else (h, w)).copy() if info.regions_ok else None
     t = lines[:h * w].reshape(h, w).copy() if info.textlines_ok else None
     return mask, r, t, info
+
+
+def owned_range(extent: int, tile: int, margin: int, n_tiles: int, t: int):
+    """[lo, hi) in tile coordinates of what the page stitch keeps of tile t of an axis (closed form of the owned-region launches; no GPU)."""
+    lib = load_library()
+    lo, hi = C.c_int(0), C.c_int(0)
+    check(lib.sbbseg_debug_owned_range(int(extent), int(tile), int(margin), int(n_tiles), int(t), C.byref(lo), C.byref(hi)), "sbbseg_debug_owned_range")
+    return int(lo.value), int(hi.value)
+
+
+def region_rows(extent: int, tile: int, margin: int, n_tiles: int, t: int, level_sizes):
+    """Rows [lo, hi) every decoder level must produce for tile t of an axis: one pair per level, level 0 = the network output (no GPU)."""
+    lib = load_library()
+    sizes = np.ascontiguousarray(level_sizes, dtype=np.int32)
+    out = np.zeros((len(sizes), 2), dtype=np.int32)
+    check(lib.sbbseg_debug_region_rows(int(extent), int(tile), int(margin), int(n_tiles), int(t), len(sizes), _ptr(sizes), _ptr(out)),
+          "sbbseg_debug_region_rows")
+    return out
 
 
 def host_largest_contour_area2(mask: np.ndarray) -> int:

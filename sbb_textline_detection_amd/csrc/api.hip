@@ -23,6 +23,7 @@
 #include <mutex>
 
 #include "internal.h"
+#include "region.h"
 
 using namespace sbbseg;
 
@@ -174,9 +175,22 @@ struct Op {
     std::vector<Op> parts;        // kBlock: the convs it fuses
     double prof_ms = 0;
     int64_t prof_launches = 0, prof_patches = 0;
+    int region_level = -1;        // >= 0: a decoder level of the owned-region chain (sbbseg_finalize: region_chain; region.h)
+    double exec_patches = 0;      // work executed since sbbseg_profile_reset, in whole-patch equivalents: a launch of n patches adds n, an
+                                  // owned-region launch n x (pixels walked / pixels of the whole grid)
+    double prof_exec_patches = 0; // the same, over the launches the profiling events timed (prof_ms)
 };
 
-struct PendingEvent { int op; hipEvent_t a, b; int patches; };
+struct PendingEvent { int op; hipEvent_t a, b; int patches; double exec; };
+
+// owned-region launches (region.h): tables of the chunk a lane is running
+struct RegionRun {
+    bool on = false;
+    int kind[kRegionMaxLevels] = {0};            // 0 = tile table, 1 = pixel map (what the level's kernel takes: dec_halo_* / tail vs conv_igemm_mfma)
+    int total[kRegionMaxLevels] = {0};           // entries (per class)
+    double frac[kRegionMaxLevels] = {0};         // pixels walked / pixels of the whole grid, over the chunk
+    uint32_t* tab[kRegionMaxLevels] = {nullptr};
+};
 
 }  // namespace
 
@@ -279,6 +293,14 @@ struct sbbseg_ctx {
     int num_cus = 256;
     std::vector<PendingEvent> pending;
     std::vector<hipEvent_t> free_events;
+    // owned-region launches of the decoder (region.h; sbbseg_set_owned_regions): 0 = off, 1 = the fused page paths (default), 2 = the
+    // tile-range entry points of the multi-rank protocol too (their tile labels are then defined on the owned regions only)
+    int owned_mode = 1;
+    int region_levels = 0;                        // decoder levels of the chain found by sbbseg_finalize (0: the plan has none)
+    int region_op[kRegionMaxLevels] = {0};        // op index per level (level 0 = the tail)
+    uint32_t* d_rtab[2][kRegionMaxLevels] = {{nullptr}, {nullptr}};     // per lane and level: the chunk's table (allocated on first use)
+    size_t rtab_cap[2][kRegionMaxLevels] = {{0}, {0}};
+    RegionRun rr;                                 // the chunk run_plan is launching (set by tile_range_impl around run_plan)
     std::vector<std::pair<void*, size_t>> user_bufs;      // sbbseg_device_alloc's buffers still alive (freed by sbbseg_destroy)
 };
 
@@ -376,12 +398,17 @@ int resolve_pending(sbbseg_ctx* c)
         op.prof_ms += ms;
         op.prof_launches += 1;
         op.prof_patches += pe.patches;
+        op.prof_exec_patches += pe.exec;
         c->free_events.push_back(pe.a);
         c->free_events.push_back(pe.b);
     }
     c->pending.clear();
     return 0;
 }
+
+// the 224 x 224 decoder conv takes the LDS-resident-halo kernel (dec_halo_x3 / dec_halo_f16) -- also decides which table an
+// owned-region chunk builds for that level (tile origins vs class-grid pixels)
+bool runs_dec_halo(const sbbseg_ctx* c, const ConvOp& co) { return co.d_halo_wfrag && !c->no_dec_halo && !(c->conv_variant & 3); }
 
 // ---- forward pass over n patches whose input forms are already filled -------------------------
 int launch_op(sbbseg_ctx* c, Op& op, int n, uint8_t* d_labels, float* d_probs)
@@ -401,7 +428,9 @@ int launch_op(sbbseg_ctx* c, Op& op, int n, uint8_t* d_labels, float* d_probs)
             bp.s3 = op.parts[2].conv.d_scale; bp.b3 = op.parts[2].conv.d_shift;
             bp.out = c->tensors[bo.out_tensor].data();
             bp.wmul1 = bo.wmul[0]; bp.wmul2 = bo.wmul[1]; bp.wmul3 = bo.wmul[2];
+#ifdef SBBSEG_PROBES
             { static const int blk_dbg = getenv("SBBSEG_BLOCK_DBG") ? atoi(getenv("SBBSEG_BLOCK_DBG")) : 0; bp.dbg = blk_dbg; }
+#endif
             if (c->precision == kF16X3) HIPCHK(launch_block_x3(bp, c->num_cus, c->stream));
             else HIPCHK(launch_bottleneck(bp, c->precision, c->num_cus, c->stream));
         } else if (op.type == kConv) {
@@ -436,8 +465,10 @@ int launch_op(sbbseg_ctx* c, Op& op, int n, uint8_t* d_labels, float* d_probs)
             p.variant = c->conv_variant & 3; p.persist_blocks = (c->conv_variant & 4) ? 0 : c->num_cus;
             p.M = n * co.Ho * co.Wo;
             p.variant_flags = ((c->conv_variant & 64) ? 1 : 0) | ((c->conv_variant & 128) ? 2 : 0) | (c->ph8 ? 4 : 0);
+#ifdef SBBSEG_PROBES
             { static const int probe_local = getenv("SBBSEG_CONV_PROBE_LOCAL") ? atoi(getenv("SBBSEG_CONV_PROBE_LOCAL")) : 0; if (probe_local) p.variant_flags |= 32; }
             { static const int probe_whot = getenv("SBBSEG_CONV_PROBE_WHOT") ? atoi(getenv("SBBSEG_CONV_PROBE_WHOT")) : 0; if (probe_whot) p.variant_flags |= 64; }
+#endif
             // XCD-grouped walk for single-class layers: measured neutral-to-slower (it removes the n_ct-fold
             // re-fetch of the pixel operand, but those layers are not bound by fetch bytes) -> opt-in, bit 5
             // (split mode: on by default -- twice the pixel bytes; +0.7 % page throughput in two runs, profiles/r03_experiments.md)
@@ -466,6 +497,10 @@ int launch_op(sbbseg_ctx* c, Op& op, int n, uint8_t* d_labels, float* d_probs)
             p.residual = co.d.residual_tensor >= 0 ? c->tensors[co.d.residual_tensor].data() : nullptr;
             p.raw_out = co.d.raw_out_tensor >= 0 ? c->tensors[co.d.raw_out_tensor].data() : nullptr;
             p.raw_scale = co.d_rscale; p.raw_shift = co.d_rshift; p.relu = co.d.relu;
+            // owned-region launch of a decoder level (region.h): the chunk's table replaces the walk over the whole output grid
+            const int rlv = c->rr.on ? op.region_level : -1;
+            if (rlv >= 0 && c->rr.total[rlv] == 0) return 0;                         // (no patch of the chunk keeps anything)
+            if (rlv >= 0 && c->rr.kind[rlv] == 1) { p.rmap = c->rr.tab[rlv]; p.M = c->rr.total[rlv]; }
             if (co.d_stem_wfrag && !(c->conv_variant & 3)) {
                 const Tensor& st = c->tensors[co.d.src[0].tensor];
                 StemParams sp;
@@ -496,15 +531,19 @@ int launch_op(sbbseg_ctx* c, Op& op, int n, uint8_t* d_labels, float* d_probs)
                 ep.w3frag = co.d_er_w3; ep.w1frag = co.d_er_w1;
                 ep.s3 = co.d_scale; ep.h3 = co.d_shift; ep.s1 = ro.d_scale; ep.h1 = ro.d_shift;
                 ep.wmul3 = co.wmul_cls[0]; ep.wmul1 = ro.wmul_cls[0];
+                ep.dbg = 0;
+#ifdef SBBSEG_PROBES
                 { static const int er_dbg = getenv("SBBSEG_ER_DBG") ? atoi(getenv("SBBSEG_ER_DBG")) : 0; ep.dbg = er_dbg; }
+#endif
                 HIPCHK(launch_expand_reduce_x3(ep, c->num_cus, c->stream));
-            } else if (co.d_halo_wfrag && !c->no_dec_halo && !(c->conv_variant & 3)) {
+            } else if (runs_dec_halo(c, co)) {
                 const Tensor& s0 = c->tensors[co.d.src[0].tensor];
                 DecHaloParams hp;
                 hp.src0 = s0.buf; hp.skip = c->tensors[co.d.src[1].tensor].buf; hp.PH = s0.H; hp.PW = s0.W; hp.n = n;
                 hp.wfrag = co.d_halo_wfrag; hp.taps = co.d_halo_taps; hp.scale = co.d_scale; hp.shift = co.d_shift;
                 for (int q = 0; q < 4; ++q) hp.wmul[q] = co.wmul_cls[q];
                 hp.relu = co.d.relu; hp.out = c->tensors[co.d.out_tensor].data();
+                if (rlv >= 0) { hp.ttab = c->rr.tab[rlv]; hp.n_tab = c->rr.total[rlv]; }
                 if (c->precision == kF16X3) HIPCHK(launch_dec_halo_x3(hp, c->num_cus, c->stream));
                 else HIPCHK(launch_dec_halo_f16(hp, c->num_cus, c->stream));
             } else {
@@ -546,6 +585,10 @@ int launch_op(sbbseg_ctx* c, Op& op, int n, uint8_t* d_labels, float* d_probs)
             tp.wfrag = to.d_wfrag; tp.scale = to.d_scale; tp.shift = to.d_shift; tp.classes = to.classes;
             tp.head_w = to.d_head_w; tp.head_scale = to.d_head_scale; tp.head_shift = to.d_head_shift;
             tp.labels = d_labels; tp.probs = d_probs;
+            if (c->rr.on && op.region_level >= 0) {
+                if (c->rr.total[op.region_level] == 0) return 0;
+                tp.ttab = c->rr.tab[op.region_level]; tp.n_tab = c->rr.total[op.region_level];
+            }
             HIPCHK(launch_tail(tp, c->precision, c->num_cus, c->stream));
         } else {
             const HeadOp& ho = op.head;
@@ -570,9 +613,11 @@ int run_plan(sbbseg_ctx* c, int n, uint8_t* d_labels, float* d_probs)
             HIPCHK(hipEventRecord(ea, c->stream));
         }
         if (launch_op(c, op, n, d_labels, d_probs)) return 1;
+        const double exec = (c->rr.on && op.region_level >= 0) ? n * c->rr.frac[op.region_level] : (double)n;
+        op.exec_patches += exec;
         if (c->profiling) {
             HIPCHK(hipEventRecord(eb, c->stream));
-            c->pending.push_back({(int)i, ea, eb, n});
+            c->pending.push_back({(int)i, ea, eb, n, exec});
         }
     }
     return 0;
@@ -855,6 +900,7 @@ int sbbseg_create(int device, int precision, sbbseg_ctx** out)
     if (const char* v = getenv("SBBSEG_STAGGER_MIN_TILES")) c->stagger_min_tiles = atoi(v);
     if (const char* v = getenv("SBBSEG_DEDUPE")) c->dedupe = v[0] != '0';
     if (const char* v = getenv("SBBSEG_KSPLIT")) c->ksplit = v[0] != '0';
+    if (const char* v = getenv("SBBSEG_OWNED_REGIONS")) c->owned_mode = v[0] == '0' ? 0 : (v[0] == '2' ? 2 : 1);
     *out = c;
     return 0;
     API_END
@@ -897,6 +943,8 @@ int sbbseg_destroy(sbbseg_ctx* c)
     (void)hipFree(c->d_page); (void)hipFree(c->d_page_labels); (void)hipFree(c->d_page_labels3); (void)hipFree(c->d_tile_labels);
     (void)hipFree(c->d_own_x); (void)hipFree(c->d_own_y); (void)hipFree(c->d_map); (void)hipFree(c->d_wmap);
     (void)hipFree(c->d_deskew);
+    for (int lane = 0; lane < 2; ++lane)
+        for (int L = 0; L < kRegionMaxLevels; ++L) (void)hipFree(c->d_rtab[lane][L]);
     (void)hipFree(c->d_run_page); (void)hipFree(c->d_run_mask); (void)hipFree(c->d_run_a); (void)hipFree(c->d_run_b);
     for (auto& ub : c->user_bufs) (void)hipFree(ub.first);
     for (int k = 0; k < 2; ++k) {
@@ -974,6 +1022,70 @@ int sbbseg_set_dedupe(sbbseg_ctx* c, int on)
     API_BEGIN
     REQUIRE(c && (on == 0 || on == 1), "dedupe must be 0 or 1");
     c->dedupe = on != 0;
+    return 0;
+    API_END
+}
+
+int sbbseg_set_owned_regions(sbbseg_ctx* c, int mode)
+{
+    API_BEGIN
+    REQUIRE(c && mode >= 0 && mode <= 2, "mode: 0 = off, 1 = fused page paths, 2 = tile-range entry points too");
+    c->owned_mode = mode;
+    return 0;
+    API_END
+}
+
+int sbbseg_owned_region_levels(sbbseg_ctx* c, int* levels)
+{
+    API_BEGIN
+    REQUIRE(c && levels, "bad arguments");
+    *levels = c->finalized ? c->region_levels : 0;
+    return 0;
+    API_END
+}
+
+int sbbseg_debug_owned_range(int extent, int tile, int margin, int n_tiles, int t, int* lo, int* hi)
+{
+    API_BEGIN
+    REQUIRE(lo && hi && tile > 2 * margin && margin >= 0 && extent >= tile && n_tiles >= 1 && t >= 0 && t < n_tiles, "bad arguments");
+    const RegionAxis a = {extent, tile, margin, tile - 2 * margin, n_tiles};
+    region_own(a, t, *lo, *hi);
+    return 0;
+    API_END
+}
+
+int sbbseg_debug_region_rows(int extent, int tile, int margin, int n_tiles, int t, int levels, const int32_t* level_size, int32_t* lo_hi)
+{
+    API_BEGIN
+    REQUIRE(lo_hi && level_size && levels >= 1 && levels <= kRegionMaxLevels && tile > 2 * margin && margin >= 0 && extent >= tile && n_tiles >= 1 &&
+            t >= 0 && t < n_tiles, "bad arguments");
+    const RegionAxis a = {extent, tile, margin, tile - 2 * margin, n_tiles};
+    int lo, hi;
+    region_own(a, t, lo, hi);
+    lo_hi[0] = lo; lo_hi[1] = hi;
+    for (int k = 1; k < levels; ++k) {
+        region_down(lo, hi, level_size[k]);
+        lo_hi[2 * k] = lo; lo_hi[2 * k + 1] = hi;
+    }
+    return 0;
+    API_END
+}
+
+int sbbseg_debug_poison_activations(sbbseg_ctx* c, int byte_value)
+{
+    API_BEGIN
+    if (check_ready(c)) return 1;
+    HIPCHK(hipDeviceSynchronize());
+    for (auto& t : c->tensors) {
+        if (t.is_input_form) continue;                     // (their zero borders are part of the form)
+        for (int lane = 0; lane < 2; ++lane) {
+            if (!t.lane_buf[lane]) continue;
+            const size_t n = t.elems_per_patch * (size_t)(lane == 0 ? c->max_batch : c->lane1_batch) * c->elem * c->planes;
+            HIPCHK(hipMemset(t.lane_buf[lane] + kZeroHeaderBytes, byte_value & 255, n));
+        }
+    }
+    if (c->d_tile_labels) HIPCHK(hipMemset(c->d_tile_labels, byte_value & 255, c->tile_labels_cap));
+    HIPCHK(hipDeviceSynchronize());
     return 0;
     API_END
 }
@@ -1767,6 +1879,76 @@ static int fuse_bottlenecks(sbbseg_ctx* c)
     return 0;
 }
 
+// ---- owned-region chain (region.h): the fused tail and, below it, every decoder conv of the form
+//   four output-parity classes of conv3x3([nearest-x2 upsampling of the level below, skip]) -> this level
+// whose output is read by the level above only.  Level 0 = the tail (network output), level k = the conv k steps below.  A level's rows
+// are the rows above dilated by one and halved (region_down), which is exact when class (py, px) reads rows {py - 1, py} / columns
+// {px - 1, px} of the level below -- checked here on the K-step records; anything else (unfused heads, fp32 handles, Conv2DTranspose
+// decoders whose classes read other taps) leaves the chain short or empty and those ops run whole.
+static void find_region_chain(sbbseg_ctx* c)
+{
+    c->region_levels = 0;
+    for (auto& op : c->ops) op.region_level = -1;
+    if (c->precision == kF32 || c->ops.empty() || c->ops.back().type != kTail) return;
+    if (c->max_batch > kRegionMaxPatches || c->in_H > 2 * kRegionMaxCoord || c->in_W > 2 * kRegionMaxCoord || (c->in_H & 15) || (c->in_W & 15)) return;
+    auto readers = [&](int tensor) {
+        int nrd = 0;
+        for (const Op& o : c->ops) {
+            if (o.type == kConv) {
+                for (int s = 0; s < o.conv.d.n_src; ++s) nrd += o.conv.d.src[s].tensor == tensor;
+                nrd += o.conv.d.residual_tensor == tensor;
+            } else if (o.type == kPool) nrd += o.pool.src == tensor;
+            else if (o.type == kHead) nrd += o.head.src == tensor;
+            else if (o.type == kTail) nrd += (o.tail.src0 == tensor) + (o.tail.img == tensor);
+            else if (o.type == kBlock) nrd += o.block.x_tensor == tensor;
+        }
+        return nrd;
+    };
+    int level = 0;
+    c->region_op[0] = (int)c->ops.size() - 1;
+    c->ops.back().region_level = 0;
+    int below = c->ops.back().tail.src0;              // the tensor the level above upsamples
+    {
+        const Tensor& t = c->tensors[below];
+        if (2 * t.H != c->in_H || 2 * t.W != c->in_W) { c->ops.back().region_level = -1; return; }
+    }
+    c->region_levels = 1;
+    while (level + 1 < kRegionMaxLevels) {
+        int oi = -1;
+        for (size_t i = 0; i < c->ops.size(); ++i)
+            if (c->ops[i].type == kConv && c->ops[i].conv.d.out_tensor == below) oi = oi < 0 ? (int)i : -2;
+        if (oi < 0 || readers(below) != 1) break;
+        const ConvOp& co = c->ops[oi].conv;
+        const sbbseg_conv_desc& d = co.d;
+        const Tensor& to = c->tensors[below];
+        if (co.n_cls != 4 || d.n_src != 2 || d.out_stride_y != 2 || d.out_stride_x != 2 || d.residual_tensor >= 0 || d.raw_out_tensor >= 0 ||
+            d.head_classes > 0 || d.src[0].stride_y != 1 || d.src[0].stride_x != 1 || d.src[0].up_shift != 0 || d.src[0].off_y || d.src[0].off_x ||
+            to.H != 2 * co.Ho || to.W != 2 * co.Wo || co.TH != to.H || co.TW != to.W || !co.fg_ok)
+            break;
+        const Tensor& t0 = c->tensors[d.src[0].tensor];
+        if (t0.H != co.Ho || t0.W != co.Wo || t0.is_input_form) break;
+        bool ok = true;
+        int seen = 0;
+        for (int q = 0; q < 4 && ok; ++q) {
+            const int py = co.ooy_cls[q], px = co.oox_cls[q];
+            ok = (py == 0 || py == 1) && (px == 0 || px == 1);
+            seen |= 1 << (py * 2 + px);
+            const int ks0 = co.ksteps[0];
+            ok = ok && (int)co.h_ksteps_cls[q].size() >= ks0;
+            for (int t = 0; t < ks0 && ok; ++t) {
+                const KStepRec& r = co.h_ksteps_cls[q][t];
+                ok = !r.irregular && (r.dy == py - 1 || r.dy == py) && (r.dx == px - 1 || r.dx == px);
+            }
+        }
+        if (!ok || seen != 15) break;
+        ++level;
+        c->region_op[level] = oi;
+        c->ops[oi].region_level = level;
+        c->region_levels = level + 1;
+        below = d.src[0].tensor;
+    }
+}
+
 int sbbseg_finalize(sbbseg_ctx* c, int max_batch)
 {
     API_BEGIN
@@ -1918,6 +2100,7 @@ int sbbseg_finalize(sbbseg_ctx* c, int max_batch)
     REQUIRE(max_batch >= 1, "max_batch must be >= 1");
     REQUIRE(c->classes > 0 && !c->ops.empty(), "plan must contain a head (head op or a conv with a fused head)");
     c->max_batch = max_batch;
+    find_region_chain(c);
     for (auto& t : c->tensors) {
         const size_t bytes = kZeroHeaderBytes + t.elems_per_patch * max_batch * c->elem * c->planes + 256;
         REQUIRE(bytes < ((size_t)1 << 32), "tensor %dx%dx%d x batch %d exceeds the 4 GiB gather window", t.H, t.W, t.C, max_batch);
@@ -2099,8 +2282,11 @@ static int fused_grid(const sbbseg_ctx* c, int Hp, int Wp, bool dedupe, int* nx,
 // Tiles [first_tile, first_tile + n_tiles) of the tile list of `n_pages` equally sized pages (page-major: tile g = page g / tpp,
 // grid index g % tpp) -> d_tile_labels[g - first_tile].  Chunks of <= max_batch tiles may span pages: big launches fill the chip's
 // persistent grids better than one page's 70 tiles (profiles/r02_experiments.md).
+// `owned`: the decoder of every tile is launched over the region the page stitch keeps of it (+ the halo the levels above need) only
+// (region.h) -- d_tile_labels is then defined on the owned regions, which is all stitch_impl reads.
 static int tile_range_impl(sbbseg_ctx* c, const void* const* d_pages, int n_pages, int src_Hp, int src_Wp, const int* d_map_y, const int* d_map_x,
-                           int Hp, int Wp, int first_tile, int n_tiles, void* d_tile_labels, const int* d_bin_thr = nullptr, bool dedupe = false)
+                           int Hp, int Wp, int first_tile, int n_tiles, void* d_tile_labels, const int* d_bin_thr = nullptr, bool dedupe = false,
+                           bool owned = false)
 {
     REQUIRE(d_pages && n_pages >= 1 && d_tile_labels && first_tile >= 0 && n_tiles >= 0, "bad arguments");
     for (int k = 0; k < n_pages; ++k) REQUIRE(d_pages[k], "null page pointer (page %d)", k);
@@ -2117,8 +2303,57 @@ static int tile_range_impl(sbbseg_ctx* c, const void* const* d_pages, int n_page
     ip.grid_nyf = ny; ip.grid_mid_x = c->in_W - 2 * margin; ip.grid_mid_y = c->in_H - 2 * margin;
     const size_t per = (size_t)c->in_H * c->in_W;
     const size_t act = (size_t)c->elem * c->planes;          // bytes per stored element
+    // owned-region launches: the page geometry in closed form; the tables of a chunk are built on its lane's stream in front of its forward
+    const bool regions = owned && c->region_levels > 0 && c->max_batch <= kRegionMaxPatches;
+    RegionGeom rg;
+    memset(&rg, 0, sizeof(rg));
+    if (regions) {
+        rg.ax = {Wp, c->in_W, margin, c->in_W - 2 * margin, nx};
+        rg.ay = {Hp, c->in_H, margin, c->in_H - 2 * margin, ny};
+        rg.tpp = tpp; rg.ny = ny; rg.n_levels = c->region_levels;
+        for (int L = 0; L < c->region_levels; ++L) {
+            const Op& lop = c->ops[c->region_op[L]];
+            if (L == 0) { rg.kind[L] = 0; rg.Rh[L] = c->in_H; rg.Rw[L] = c->in_W; rg.align_x[L] = 16; }
+            else {
+                const Tensor& to = c->tensors[lop.conv.d.out_tensor];
+                rg.kind[L] = runs_dec_halo(c, lop.conv) ? 0 : 1;
+                rg.Rh[L] = to.H; rg.Rw[L] = to.W; rg.align_x[L] = 2;
+            }
+        }
+    }
+    auto setup_regions = [&](int lane, int g_first, int nb) -> int {       // (inside the lane's scope: c->stream is the lane's stream)
+        RegionBuildParams bp;
+        memset(&bp, 0, sizeof(bp));
+        bp.g = rg; bp.g0 = g_first; bp.nb = nb;
+        RegionRun& rr = c->rr;
+        const size_t batch_cap = (size_t)(lane == 0 ? c->max_batch : c->lane1_batch);
+        for (int L = 0; L < rg.n_levels; ++L) {
+            long total = 0;
+            for (int q = 0; q < nb; ++q) {
+                const int local = (g_first + q) % tpp, i = local / ny, j = local - i * ny;
+                total += region_entries(rg, i, j, L);
+            }
+            const size_t need = 4 * (rg.kind[L] ? 4 * batch_cap * (size_t)(rg.Rh[L] / 2) * (size_t)(rg.Rw[L] / 2)
+                                                 : batch_cap * (size_t)(rg.Rh[L] / 16 + 1) * (size_t)(rg.Rw[L] / 16 + 1));
+            if (c->rtab_cap[lane][L] < need) {
+                HIPCHK(hipDeviceSynchronize());                  // (first use / a kind switched by an A/B knob: rare)
+                if (c->d_rtab[lane][L]) { HIPCHK(hipFree(c->d_rtab[lane][L])); c->device_bytes -= c->rtab_cap[lane][L]; c->d_rtab[lane][L] = nullptr; c->rtab_cap[lane][L] = 0; }
+                if (dmalloc(c, (void**)&c->d_rtab[lane][L], need)) return 1;
+                c->rtab_cap[lane][L] = need;
+            }
+            bp.out[L] = c->d_rtab[lane][L]; bp.total[L] = (int)total;
+            rr.kind[L] = rg.kind[L]; rr.total[L] = (int)total; rr.tab[L] = c->d_rtab[lane][L];
+            rr.frac[L] = (double)total * (rg.kind[L] ? 4.0 : 256.0) / ((double)nb * rg.Rh[L] * rg.Rw[L]);
+        }
+        HIPCHK(launch_region_build(bp, c->stream));
+        rr.on = true;
+        return 0;
+    };
+    struct RegionOff { sbbseg_ctx* c; ~RegionOff() { c->rr.on = false; } };
     auto run_chunk = [&](int lane, int first, int nb, bool halves = false) -> int {
         LaneScope scope(c, lane, halves);
+        RegionOff roff{c};
+        if (regions && setup_regions(lane, first_tile + first, nb)) return 1;
         IngestParams lp = ip;
         if (fill_ingest(c, lp)) return 1;          // (input-form pointers of this lane)
         char* const c8_base = (char*)lp.c8;
@@ -2229,7 +2464,7 @@ int sbbseg_segment_tile_range_dev(sbbseg_ctx* c, const void* d_page_hwc, int Hp,
 {
     API_BEGIN
     if (check_ready(c)) return 1;
-    return tile_range_impl(c, &d_page_hwc, 1, Hp, Wp, nullptr, nullptr, Hp, Wp, first_tile, n_tiles, d_tile_labels);
+    return tile_range_impl(c, &d_page_hwc, 1, Hp, Wp, nullptr, nullptr, Hp, Wp, first_tile, n_tiles, d_tile_labels, nullptr, false, c->owned_mode >= 2);
     API_END
 }
 
@@ -2286,7 +2521,7 @@ int sbbseg_segment_page_dev(sbbseg_ctx* c, const void* d_page_hwc, int Hp, int W
     int nx = 0, ny = 0;
     if (fused_grid(c, Hp, Wp, c->dedupe, &nx, &ny)) return 1;
     if (ensure(c, (void**)&c->d_tile_labels, &c->tile_labels_cap, (size_t)nx * ny * c->in_H * c->in_W)) return 1;
-    if (tile_range_impl(c, &d_page_hwc, 1, Hp, Wp, nullptr, nullptr, Hp, Wp, 0, nx * ny, c->d_tile_labels, nullptr, c->dedupe)) return 1;
+    if (tile_range_impl(c, &d_page_hwc, 1, Hp, Wp, nullptr, nullptr, Hp, Wp, 0, nx * ny, c->d_tile_labels, nullptr, c->dedupe, c->owned_mode >= 1)) return 1;
     return stitch_impl(c, c->d_tile_labels, Hp, Wp, d_labels_hw, c->dedupe);
     API_END
 }
@@ -2320,7 +2555,7 @@ int sbbseg_segment_pages_dev(sbbseg_ctx* c, int n_pages, const void* const* d_pa
     if (ensure(c, (void**)&c->d_tile_labels, &c->tile_labels_cap, tpp * G * per)) return 1;
     for (size_t g0 = 0; g0 < (size_t)n_pages; g0 += G) {
         const size_t np = g0 + G <= (size_t)n_pages ? G : (size_t)n_pages - g0;
-        if (tile_range_impl(c, d_pages_hwc + g0, (int)np, Hp, Wp, nullptr, nullptr, Hp, Wp, 0, (int)(tpp * np), c->d_tile_labels, nullptr, c->dedupe)) return 1;
+        if (tile_range_impl(c, d_pages_hwc + g0, (int)np, Hp, Wp, nullptr, nullptr, Hp, Wp, 0, (int)(tpp * np), c->d_tile_labels, nullptr, c->dedupe, c->owned_mode >= 1)) return 1;
         for (size_t k = 0; k < np; ++k)
             if (stitch_impl(c, c->d_tile_labels + k * tpp * per, Hp, Wp, d_labels_hw[g0 + k], c->dedupe)) return 1;
     }
@@ -2465,7 +2700,7 @@ int sbbseg_segment_page_scaled(sbbseg_ctx* c, const uint8_t* page_hwc, int Hs, i
     if (fused_grid(c, Hp, Wp, c->dedupe, &nx, &ny)) return 1;
     if (ensure(c, (void**)&c->d_tile_labels, &c->tile_labels_cap, (size_t)nx * ny * c->in_H * c->in_W)) return 1;
     const void* pg_ = c->d_page;
-    if (tile_range_impl(c, &pg_, 1, Hs, Ws, d_my, d_mx, Hp, Wp, 0, nx * ny, c->d_tile_labels, nullptr, c->dedupe)) return 1;
+    if (tile_range_impl(c, &pg_, 1, Hs, Ws, d_my, d_mx, Hp, Wp, 0, nx * ny, c->d_tile_labels, nullptr, c->dedupe, c->owned_mode >= 1)) return 1;
     if (stitch_impl(c, c->d_tile_labels, Hp, Wp, c->d_page_labels, c->dedupe)) return 1;
     if (labels_to_host(c, labels_hw, pix)) return 1;
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -2489,7 +2724,7 @@ int sbbseg_segment_tile_range_bin_dev(sbbseg_ctx* c, const void* d_page_hwc, int
     API_BEGIN
     if (check_ready(c)) return 1;
     REQUIRE(d_threshold, "bad arguments");
-    return tile_range_impl(c, &d_page_hwc, 1, Hp, Wp, nullptr, nullptr, Hp, Wp, first_tile, n_tiles, d_tile_labels, d_threshold);
+    return tile_range_impl(c, &d_page_hwc, 1, Hp, Wp, nullptr, nullptr, Hp, Wp, first_tile, n_tiles, d_tile_labels, d_threshold, false, c->owned_mode >= 2);
     API_END
 }
 
@@ -2523,7 +2758,7 @@ int sbbseg_segment_page_otsu(sbbseg_ctx* c, const uint8_t* page_hwc, int Hs, int
     if (fused_grid(c, Hp, Wp, c->dedupe, &nx, &ny)) return 1;
     if (ensure(c, (void**)&c->d_tile_labels, &c->tile_labels_cap, (size_t)nx * ny * c->in_H * c->in_W)) return 1;
     const void* pg_ = c->d_page;
-    if (tile_range_impl(c, &pg_, 1, Hs, Ws, d_my, d_mx, Hp, Wp, 0, nx * ny, c->d_tile_labels, d_thr, c->dedupe)) return 1;
+    if (tile_range_impl(c, &pg_, 1, Hs, Ws, d_my, d_mx, Hp, Wp, 0, nx * ny, c->d_tile_labels, d_thr, c->dedupe, c->owned_mode >= 1)) return 1;
     if (stitch_impl(c, c->d_tile_labels, Hp, Wp, c->d_page_labels, c->dedupe)) return 1;
     if (labels_to_host(c, labels_hw, pix)) return 1;
     int thr = 0;
@@ -2567,7 +2802,7 @@ int sbbseg_segment_crop_dev(sbbseg_ctx* c, const void* d_page_hwc, int Hs, int W
     int nx = 0, ny = 0;
     if (fused_grid(c, ch, cw, c->dedupe, &nx, &ny)) return 1;
     if (ensure(c, (void**)&c->d_tile_labels, &c->tile_labels_cap, (size_t)nx * ny * c->in_H * c->in_W)) return 1;
-    if (tile_range_impl(c, &d_page_hwc, 1, Hs, Ws, d_my, d_mx, ch, cw, 0, nx * ny, c->d_tile_labels, d_thr, c->dedupe)) return 1;
+    if (tile_range_impl(c, &d_page_hwc, 1, Hs, Ws, d_my, d_mx, ch, cw, 0, nx * ny, c->d_tile_labels, d_thr, c->dedupe, c->owned_mode >= 1)) return 1;
     return stitch_impl(c, c->d_tile_labels, ch, cw, d_labels_hw, c->dedupe);
     API_END
 }
@@ -3267,7 +3502,18 @@ int sbbseg_profile_reset(sbbseg_ctx* c)
     API_BEGIN
     REQUIRE(c, "null handle");
     if (resolve_pending(c)) return 1;
-    for (auto& op : c->ops) { op.prof_ms = 0; op.prof_launches = 0; op.prof_patches = 0; }
+    for (auto& op : c->ops) { op.prof_ms = 0; op.prof_launches = 0; op.prof_patches = 0; op.exec_patches = 0; op.prof_exec_patches = 0; }
+    return 0;
+    API_END
+}
+
+int sbbseg_op_executed(sbbseg_ctx* c, int op, double* exec_patches, double* timed_exec_patches)
+{
+    API_BEGIN
+    REQUIRE(c && op >= 0 && op < (int)c->ops.size(), "op index out of range");
+    if (resolve_pending(c)) return 1;
+    if (exec_patches) *exec_patches = c->ops[op].exec_patches;
+    if (timed_exec_patches) *timed_exec_patches = c->ops[op].prof_exec_patches;
     return 0;
     API_END
 }

@@ -147,7 +147,7 @@ __global__ __launch_bounds__(256, 1) void block_x3(const BlockParams p)
 
     // row rotation on the WRITE side: 2 slots per row like the reads (timing probe p.dbg & 1: 1 slot per row -- the 8-lane groups of
     // ds_write_b128 then hit eight different bank quads instead of four twice; the reads no longer find their data: results are wrong)
-    const int wrot = (p.dbg & 1) ? 1 : 2;
+    const int wrot = SBBSEG_PROBE(p.dbg & 1) ? 1 : 2;
     bool inimg[2];
     uint32_t xoff[2];
     auto locate = [&](int tile, bool (&in)[2], uint32_t (&off)[2]) __attribute__((always_inline)) {

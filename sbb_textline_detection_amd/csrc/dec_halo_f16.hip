@@ -93,7 +93,9 @@ __global__ __launch_bounds__(512, 2) void dec_halo_f16(const DecHaloParams p)
     const int H = 2 * p.PH, W = 2 * p.PW;
     const int tiles_x = W / 16, tiles_y = H / 16;
     const int tiles_per_patch = tiles_x * tiles_y;
-    const int n_tiles = p.n * tiles_per_patch;
+    // owned-region launch (DecHaloParams::ttab, region.h): the tiles are the table's entries, see dec_halo_x3
+    const int n_tiles = p.ttab ? p.n_tab : p.n * tiles_per_patch;
+    const __attribute__((address_space(4))) uint32_t* ttab = (const __attribute__((address_space(4))) uint32_t*)(uintptr_t)p.ttab;
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, GX = gridDim.x >> 3;
     const int per_xcd = (n_tiles + 7) >> 3;
     const int xcd_lo = xcd * per_xcd, xcd_hi = min(n_tiles, xcd_lo + per_xcd);
@@ -122,19 +124,25 @@ __global__ __launch_bounds__(512, 2) void dec_halo_f16(const DecHaloParams p)
         const int hy = 4 * (P >> 1) + (P & 1) + 2 * ((lane >> 3) & 1);        // 18, 19 (pair 8, 9, half 1): no such halo row -> zeros
         sk_e[m] = hy | (hx << 8) | ((((lane & 7) - (hx & ~1)) & 7) << 16) | (k << 24);
     }
-    auto tile_coords = [&](int tile, int& n, int& ty, int& tx) __attribute__((always_inline)) {
-        n = tile / tiles_per_patch;
-        const int rem = tile - n * tiles_per_patch;
-        ty = rem / tiles_x;
-        tx = rem - ty * tiles_x;
+    auto tile_coords = [&](int tile, int& n, int& y0, int& x0) __attribute__((always_inline)) {      // patch, origin of the 16 x 16 outputs
+        if (ttab) {
+            const uint32_t code = ttab[tile];
+            n = (int)(code >> 22); y0 = (int)((code >> 11) & 2047u) * 2; x0 = (int)(code & 2047u) * 2;
+        } else {
+            n = tile / tiles_per_patch;
+            const int rem = tile - n * tiles_per_patch;
+            const int ty = rem / tiles_x;
+            y0 = ty * 16;
+            x0 = (rem - ty * tiles_x) * 16;
+        }
     };
     auto issue_halos = [&](int tile, int buf) __attribute__((always_inline)) {            // kDma loads per wave
-        int n, ty, tx;
-        tile_coords(tile, n, ty, tx);
+        int n, y0, x0;
+        tile_coords(tile, n, y0, x0);
 #pragma unroll
         for (int m = 0; m < kS0PerWave; ++m) {
             const int e = s0_e[m];
-            const int Y = ty * 8 - 1 + (e & 255), X = tx * 8 - 1 + ((e >> 8) & 255);
+            const int Y = (y0 >> 1) - 1 + (e & 255), X = (x0 >> 1) - 1 + ((e >> 8) & 255);
             const bool ok = (unsigned)Y < (unsigned)p.PH && (unsigned)X < (unsigned)p.PW;
             const uint32_t off = ok ? (uint32_t)((n * p.PH + Y) * p.PW + X) * 256u + (uint32_t)(((e >> 16) & 15) * 16 + kZeroHeaderBytes) : 0u;
             const uint32_t dst = lds0 + (uint32_t)(buf * kS0Bytes) + (uint32_t)__builtin_amdgcn_readfirstlane(e >> 24) * 1024u;
@@ -144,7 +152,7 @@ __global__ __launch_bounds__(512, 2) void dec_halo_f16(const DecHaloParams p)
         for (int m = 0; m < kSkPerWave; ++m) {
             const int e = sk_e[m];
             const int hy = e & 255;
-            const int Y = ty * 16 - 1 + hy, X = tx * 16 - 1 + ((e >> 8) & 255);
+            const int Y = y0 - 1 + hy, X = x0 - 1 + ((e >> 8) & 255);
             const bool ok = hy < 18 && (unsigned)Y < (unsigned)H && (unsigned)X < (unsigned)W;
             const uint32_t off = ok ? (uint32_t)((n * H + Y) * W + X) * 128u + (uint32_t)(((e >> 16) & 15) * 16 + kZeroHeaderBytes) : 0u;
             const uint32_t dst = lds0 + (uint32_t)(2 * kS0Bytes + buf * kSkBytes) + (uint32_t)__builtin_amdgcn_readfirstlane(e >> 24) * 1024u;
@@ -284,11 +292,11 @@ __global__ __launch_bounds__(512, 2) void dec_halo_f16(const DecHaloParams p)
 
             if constexpr (t == kSteps - 1) {
                 // ---- epilogue: y = ReLU(scale * acc + shift) -> fp16, 16 bytes per pixel and 8-channel group.  EXACTLY kStores stores per wave.
-                int n, ty, tx;
-                tile_coords(tile_at(it + half), n, ty, tx);
+                int n, ty0, tx0;
+                tile_coords(tile_at(it + half), n, ty0, tx0);
 #pragma unroll
                 for (int ni = 0; ni < 4; ++ni) {
-                    const int oy = ty * 16 + 2 * (2 * ni + i0) + py, ox = tx * 16 + 2 * j0 + px;
+                    const int oy = ty0 + 2 * (2 * ni + i0) + py, ox = tx0 + 2 * j0 + px;
                     float y[8];
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
@@ -321,7 +329,8 @@ hipError_t launch_dec_halo_f16(const DecHaloParams& p, int num_cus, hipStream_t 
         if (e != hipSuccess) return e;
         attr_done[dev & 63] = true;
     }
-    const int n_tiles = p.n * (p.PH / 8) * (p.PW / 8);
+    const int n_tiles = p.ttab ? p.n_tab : p.n * (p.PH / 8) * (p.PW / 8);
+    if (n_tiles <= 0) return hipSuccess;
     const int grid = ((n_tiles < num_cus ? n_tiles : num_cus) + 7) & ~7;
     hipLaunchKernelGGL(dec_halo_f16, dim3(grid), dim3(512), kDecHaloF16LdsBytes, s, p);
     return hipGetLastError();

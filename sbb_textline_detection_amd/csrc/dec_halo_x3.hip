@@ -109,7 +109,10 @@ __global__ __launch_bounds__(512, 2) void dec_halo_x3(const DecHaloParams p)
     const int H = 2 * p.PH, W = 2 * p.PW;
     const int tiles_x = W / 16, tiles_y = H / 16;
     const int tiles_per_patch = tiles_x * tiles_y;
-    const int n_tiles = p.n * tiles_per_patch;
+    // owned-region launch (DecHaloParams::ttab, region.h): the tiles are the table's entries -- (patch, output origin / 2) -- instead of the
+    // 14 x 14 grid of every patch; an origin is any even pixel, tiles of one patch may overlap at its far edge (same values twice)
+    const int n_tiles = p.ttab ? p.n_tab : p.n * tiles_per_patch;
+    const __attribute__((address_space(4))) uint32_t* ttab = (const __attribute__((address_space(4))) uint32_t*)(uintptr_t)p.ttab;
     // XCD-contiguous walk (neighbouring tiles share halo lines in one L2)
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, GX = gridDim.x >> 3;
     const int per_xcd = (n_tiles + 7) >> 3;
@@ -139,33 +142,36 @@ __global__ __launch_bounds__(512, 2) void dec_halo_x3(const DecHaloParams p)
         const int hy = hp / 18, hx = hp - hy * 18;
         sk_hyx[m] = hy | (hx << 8) | ((((lane & 15) - hx) & 15) << 16) | (k << 24);
     }
-    auto tile_coords = [&](int tile, int& n, int& ty, int& tx) __attribute__((always_inline)) {
-        n = tile / tiles_per_patch;
-        const int rem = tile - n * tiles_per_patch;
-        ty = rem / tiles_x;
-        tx = rem - ty * tiles_x;
+    // tile -> patch and origin (y0, x0) of its 16 x 16 outputs (wave-uniform: the table entry comes through the scalar cache)
+    auto tile_coords = [&](int tile, int& n, int& y0, int& x0) __attribute__((always_inline)) {
+        if (ttab) {
+            const uint32_t code = ttab[tile];
+            n = (int)(code >> 22); y0 = (int)((code >> 11) & 2047u) * 2; x0 = (int)(code & 2047u) * 2;
+        } else {
+            n = tile / tiles_per_patch;
+            const int rem = tile - n * tiles_per_patch;
+            const int ty = rem / tiles_x;
+            y0 = ty * 16;
+            x0 = (rem - ty * tiles_x) * 16;
+        }
     };
     // src0 piece `pc` (channel groups 2 pc, 2 pc + 1 = bytes 256 pc .. of the 512-byte stored pixel): 4 loads per wave
-    auto issue_s0 = [&](int tile, int pc) __attribute__((always_inline)) {
-        int n, ty, tx;
-        tile_coords(tile, n, ty, tx);
+    auto issue_s0 = [&](int n, int y0, int x0, int pc) __attribute__((always_inline)) {
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
             const int e = s0_hyx[m];
-            const int Y = ty * 8 - 1 + (e & 255), X = tx * 8 - 1 + ((e >> 8) & 255);
+            const int Y = (y0 >> 1) - 1 + (e & 255), X = (x0 >> 1) - 1 + ((e >> 8) & 255);
             const bool ok = (unsigned)Y < (unsigned)p.PH && (unsigned)X < (unsigned)p.PW;
             const uint32_t off = ok ? (uint32_t)((n * p.PH + Y) * p.PW + X) * 512u + (uint32_t)(pc * 256 + ((e >> 16) & 15) * 16 + kZeroHeaderBytes) : 0u;
             const uint32_t dst = lds0 + (uint32_t)(pc * kS0Bytes) + (uint32_t)__builtin_amdgcn_readfirstlane(e >> 24) * 1024u;
             glds16_hidden(p.src0 + off, dst);
         }
     };
-    auto issue_sk = [&](int tile) __attribute__((always_inline)) {        // 11 loads per wave
-        int n, ty, tx;
-        tile_coords(tile, n, ty, tx);
+    auto issue_sk = [&](int n, int y0, int x0) __attribute__((always_inline)) {        // 11 loads per wave
 #pragma unroll
         for (int m = 0; m < 11; ++m) {
             const int e = sk_hyx[m];
-            const int Y = ty * 16 - 1 + (e & 255), X = tx * 16 - 1 + ((e >> 8) & 255);
+            const int Y = y0 - 1 + (e & 255), X = x0 - 1 + ((e >> 8) & 255);
             const bool ok = (unsigned)Y < (unsigned)H && (unsigned)X < (unsigned)W;
             const uint32_t off = ok ? (uint32_t)((n * H + Y) * W + X) * 256u + (uint32_t)(((e >> 16) & 15) * 16 + kZeroHeaderBytes) : 0u;
             const uint32_t dst = lds0 + (uint32_t)(2 * kS0Bytes) + (uint32_t)__builtin_amdgcn_readfirstlane(e >> 24) * 1024u;
@@ -230,9 +236,11 @@ __global__ __launch_bounds__(512, 2) void dec_halo_x3(const DecHaloParams p)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // (the compiler's own loads above are done before the hand-counted queue starts)
 
     // ---- prologue: the first tile's halos
-    issue_s0(tile_at(0), 0);
-    issue_s0(tile_at(0), 1);
-    issue_sk(tile_at(0));
+    int cn, cy0, cx0, nn, ny0, nx0;                            // this tile, the next one (decoded once per tile)
+    tile_coords(tile_at(0), cn, cy0, cx0);
+    issue_s0(cn, cy0, cx0, 0);
+    issue_s0(cn, cy0, cx0, 1);
+    issue_sk(cn, cy0, cx0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
@@ -254,6 +262,7 @@ __global__ __launch_bounds__(512, 2) void dec_halo_x3(const DecHaloParams p)
     load_b(0, bh[0], bl[0]);
 
     for (int it = 0; it < my_tiles; ++it) {
+        tile_coords(tile_at(it + 1), nn, ny0, nx0);
         // the fragment addresses of all 34 K-steps are tile-invariant: keep the compiler from hoisting 68 address registers (and as
         // many scalars) out of the tile loop -- they are recomputed per step (~10 VALU / SALU ops beside 24 MFMAs)
         asm volatile("" : "+v"(a0), "+v"(r0), "+v"(a1), "+v"(r1), "+v"(wlane));
@@ -307,20 +316,19 @@ __global__ __launch_bounds__(512, 2) void dec_halo_x3(const DecHaloParams p)
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
-                if constexpr (t == 7) issue_s0(tile_at(it + 1), 0);
-                else if constexpr (t == 15) issue_s0(tile_at(it + 1), 1);
-                else issue_sk(tile_at(it + 1));
+                if constexpr (t == 7) issue_s0(nn, ny0, nx0, 0);
+                else if constexpr (t == 15) issue_s0(nn, ny0, nx0, 1);
+                else issue_sk(nn, ny0, nx0);
             }
             __builtin_amdgcn_sched_barrier(0);                  // (keeps a step's loads from being scheduled many steps early: register pressure)
         });
 
         // ---- epilogue: y = ReLU(scale * acc + shift) -> hi | lo, 16 bytes each per pixel and 8-channel group (as conv_igemm_mfma's split
         // path).  EXACTLY 8 store instructions per wave: the wait counts of steps 0 and 1 include them.
-        int n, ty, tx;
-        tile_coords(tile_at(it), n, ty, tx);
+        const int n = cn;
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) {
-            const int oy = ty * 16 + 2 * (2 * ni + i0) + py, ox = tx * 16 + 2 * j0 + px;
+            const int oy = cy0 + 2 * (2 * ni + i0) + py, ox = cx0 + 2 * j0 + px;
             float y[8];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -337,6 +345,7 @@ __global__ __launch_bounds__(512, 2) void dec_halo_x3(const DecHaloParams p)
             asm volatile("global_store_dwordx4 %0, %1, off\n\tglobal_store_dwordx4 %0, %2, off offset:64\n\ts_nop 1"
                          :: "v"(dst), "v"(vh), "v"(vl) : "memory");
         }
+        cn = nn; cy0 = ny0; cx0 = nx0;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the surplus loads of the last tile land before the registers / LDS go away
 }
@@ -352,7 +361,8 @@ hipError_t launch_dec_halo_x3(const DecHaloParams& p, int num_cus, hipStream_t s
         if (e != hipSuccess) return e;
         attr_done[dev & 63] = true;
     }
-    const int n_tiles = p.n * (p.PH / 8) * (p.PW / 8);
+    const int n_tiles = p.ttab ? p.n_tab : p.n * (p.PH / 8) * (p.PW / 8);
+    if (n_tiles <= 0) return hipSuccess;
     const int grid = ((n_tiles < num_cus ? n_tiles : num_cus) + 7) & ~7;
     hipLaunchKernelGGL(dec_halo_x3, dim3(grid), dim3(512), kDecHaloLdsBytes, s, p);
     return hipGetLastError();

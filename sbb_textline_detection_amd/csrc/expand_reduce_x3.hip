@@ -192,7 +192,7 @@ __global__ __launch_bounds__(512, 2) void expand_reduce(const ExpRedParams p)
     u4_t xh[4], xl[4];                                          // the residual of the chunk ahead: [pixel block]
     auto issue_w = [&](int u, u4_t (&d)[4]) __attribute__((always_inline)) {             // u in [0, STEPS)
         const int j = u / (KS1 + G2S), r = u % (KS1 + G2S);
-        const uint32_t wm = (p.dbg & 1) ? 0u : 1u;                 // (timing probe: every request reads the first step's fragments)
+        const uint32_t wm = SBBSEG_PROBE(p.dbg & 1) ? 0u : 1u;                 // (timing probe: every request reads the first step's fragments)
         if (r < KS1) wload4(d[0], d[1], d[2], d[3], wlane + wm * (uint32_t)((j * KS1 + r) * 8 * 4096), w3rsrc);
         else if constexpr (MI2 == 2) wload4(d[0], d[1], d[2], d[3], wlane + wm * (uint32_t)((j * G2S + r - KS1) * 8 * 4096), w1rsrc);
         else wload2(d[0], d[1], wlane + wm * (uint32_t)((j * G2S + r - KS1) * 8 * 2048), w1rsrc);
@@ -200,7 +200,7 @@ __global__ __launch_bounds__(512, 2) void expand_reduce(const ExpRedParams p)
     auto issue_x = [&](int tile, int j) __attribute__((always_inline)) {                  // 8 loads (plain mode: 4)
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) {
-            const uint32_t off = ((p.dbg & 4) ? 0xf0000000u : 0u) + xlane + (uint32_t)(tile * 64 + ni * 16) * (uint32_t)PY + (uint32_t)(j * YROW);
+            const uint32_t off = (SBBSEG_PROBE(p.dbg & 4) ? 0xf0000000u : 0u) + xlane + (uint32_t)(tile * 64 + ni * 16) * (uint32_t)PY + (uint32_t)(j * YROW);
             if constexpr (X3) xload2(xh[ni], xl[ni], off, xrsrc);
             else asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=&v"(xh[ni]) : "v"(off), "s"(xrsrc) : "memory");
         }
@@ -346,7 +346,7 @@ __global__ __launch_bounds__(512, 2) void expand_reduce(const ExpRedParams p)
                         y[q] = __builtin_fmaf(acc1[0][ni][q], sc[q], sh[q]);
                         y[4 + q] = __builtin_fmaf(acc1[1][ni][q], sc[4 + q], sh[4 + q]);
                     }
-                    const uint32_t off = ((p.dbg & 2) ? 0xf0000000u : 0u) + xlane + (uint32_t)(tile * 64 + ni * 16) * (uint32_t)PY + (uint32_t)(j * YROW);
+                    const uint32_t off = (SBBSEG_PROBE(p.dbg & 2) ? 0xf0000000u : 0u) + xlane + (uint32_t)(tile * 64 + ni * 16) * (uint32_t)PY + (uint32_t)(j * YROW);
                     char* row = lds_y + (ni * 16 + frv) * YROW;
                     if constexpr (X3) {
                         const h8_t rh = __builtin_bit_cast(h8_t, xh[ni]), rl = __builtin_bit_cast(h8_t, xl[ni]);

@@ -108,6 +108,10 @@ struct ConvParams {
     int ks_shift;
     float* ks_ws;
     long ks_split_elems;      // floats per split = output pixels of the tensor x cout
+    // owned-region launch (region.h): the output grid is not walked whole -- pixel index m of class q is the rmap[q * M + m]-th entry of a
+    // per-launch table of (patch, oy, ox) triples (kRegionCode) that lists, patch by patch, only the class-grid pixels the page stitch
+    // will keep plus the halo the later decoder levels need; M = entries per class.  null = the whole grid (m = (n * Ho + oy) * Wo + ox)
+    const uint32_t* rmap;
 };
 
 // fused network tail: 3x3 conv over [nearest-x2-upsampled src0 (64 ch), image C8 (3 ch)] -> 32 ch
@@ -128,6 +132,10 @@ struct TailParams {
     const float* head_shift;
     uint8_t* labels;          // [n][2PH][2PW]
     float* probs;             // [n][2PH][2PW][classes] or null
+    // owned-region launch (region.h): the launch walks `n_tab` 16 x 16 output tiles listed in ttab (kRegionCode: patch, tile origin / 2)
+    // instead of every tile of every patch; null = all tiles
+    const uint32_t* ttab = nullptr;
+    int n_tab = 0;
 };
 
 // Network stem: 7x7 stride-2 conv on the image in the PAIRS input form (7 rows x 4 two-pixel granules
@@ -215,6 +223,8 @@ struct DecHaloParams {
     float wmul[4];            // per class: 2^-s of its power-of-two weight pre-scale
     int relu;
     void* out;                // data pointer [n][2 PH][2 PW][64] split layout
+    const uint32_t* ttab = nullptr;      // owned-region launch: see TailParams
+    int n_tab = 0;
 };
 
 // Split mode, stages 3 / 4 of the encoder: the last 1x1 conv of an identity bottleneck block (C -> 4C, BN, + residual, ReLU) and the first
@@ -272,6 +282,16 @@ struct IngestParams {
 // per pixel as [C hi][C lo] (4 bytes per element), weights per 32-channel K-step as [32 hi][32 lo] after a
 // power-of-two pre-scale that keeps their lo parts out of the fp16 subnormal range.
 enum Precision { kBF16 = 0, kF32 = 1, kF16 = 2, kF16X3 = 3 };
+
+// Timing probes that make a kernel compute WRONG results on purpose (every pixel gather an L2 hit, one weight block, stores dropped ...)
+// exist only in probe builds (`python -m sbb_textline_detection_amd._build --probes`: -DSBBSEG_PROBES, a separate library under
+// tools/probes/bin/); in the shipped library the conditions below are the constant `false` and the environment variables that used to
+// switch them (SBBSEG_CONV_PROBE_LOCAL / _WHOT, SBBSEG_BLOCK_DBG, SBBSEG_ER_DBG) are not read at all.
+#ifdef SBBSEG_PROBES
+#define SBBSEG_PROBE(cond) (cond)
+#else
+#define SBBSEG_PROBE(cond) (false)
+#endif
 inline bool is_split(int precision) { return precision == kF16X3; }
 
 // launchers implemented in kernels.hip ---------------------------------------------------------

@@ -314,6 +314,19 @@ void conv_igemm_mfma(const ConvParams p)
             ox = rem - oy * p.Wo;
         }
     };
+    // pixel index m of class `cls` -> (patch, oy, ox) on the op's output grid.  Owned-region launches (ConvParams::rmap, region.h) look the
+    // triple up in the launch's table -- the grid is walked only where the page stitch keeps the result (plus the later levels' halo);
+    // the table of a parity class is the one of its placement offset
+    auto decode_m = [&](int m, int cls, int& n, int& oy, int& ox) __attribute__((always_inline)) {
+        if (p.rmap) {
+            const int slot = p.n_cls > 1 ? p.ooy_cls[cls] * 2 + p.oox_cls[cls] : 0;
+            const uint32_t code = p.rmap[(size_t)slot * (size_t)p.M + (size_t)m];
+            n = (int)(code >> 22); oy = (int)((code >> 11) & 2047u); ox = (int)(code & 2047u);
+        } else {
+            n = fast_div(m, p.howo_magic, p.howo_shift);
+            decode_yx(m - n * HoWo, oy, ox);
+        }
+    };
 
     // both sources' descriptors live in SGPRs for the whole kernel
     const SrcDesc sd0 = p.src[0];
@@ -364,10 +377,8 @@ void conv_igemm_mfma(const ConvParams p)
             int my_a = 0, my_b = 0, my_c = -1;              // row past M: every tap out of bounds -> zero rows
             const int mm = ptile * BP + ((g8 < T::kPLoads ? g8 : 0) * NW + wave) * RPI + lrow;
             if (g8 < T::kPLoads && mm < p.M) {
-                const int n = fast_div(mm, p.howo_magic, p.howo_shift);
-                const int rem = mm - n * HoWo;
-                int oy, ox;
-                decode_yx(rem, oy, ox);
+                int n, oy, ox;
+                decode_m(mm, cls, n, oy, ox);
                 my_a = (int)((uint32_t)n * img0 + (uint32_t)(((oy << sd0.sy_shift) * sd0.PW + (ox << sd0.sx_shift)) * sd0.pix_bytes) +
                              (uint32_t)kZeroHeaderBytes);
                 // (fast_gather == 2: every tap is (0, 0) -- pointwise convs -- and in bounds for every real row)
@@ -396,11 +407,9 @@ void conv_igemm_mfma(const ConvParams p)
                 if (m < p.M) {
                     // (timing probe, variant flag bit 5 / SBBSEG_CONV_PROBE_LOCAL=1: every staged row gathers from the first 1 024 output pixels'
                     //  neighbourhood -- real data, but L2-resident: what the loop does when no pixel load misses.  Results are wrong.)
-                    const int mg = (p.variant_flags & 32) ? (m & 1023) : m;
-                    const int n = fast_div(mg, p.howo_magic, p.howo_shift);
-                    const int rem = mg - n * HoWo;
-                    int oy, ox;
-                    decode_yx(rem, oy, ox);
+                    const int mg = SBBSEG_PROBE(p.variant_flags & 32) ? (m & 1023) : m;
+                    int n, oy, ox;
+                    decode_m(mg, cls, n, oy, ox);
                     r_oy[j] = (int)((uint32_t)n * img0 + (uint32_t)(((oy << sd0.sy_shift) * sd0.PW + (ox << sd0.sx_shift)) * sd0.pix_bytes) +
                                     lane_part(sd0) + (uint32_t)kZeroHeaderBytes);
                     uint32_t inv = p.fast_gather == 2 ? 0u : oob_mask(sd0, oy, ox);
@@ -418,10 +427,8 @@ void conv_igemm_mfma(const ConvParams p)
                     r_n[j] = -1;                            // every tap out of bounds -> zero rows
                 }
             } else if (m < p.M) {
-                const int n = fast_div(m, p.howo_magic, p.howo_shift);
-                const int rem = m - n * HoWo;
-                int oy, ox;
-                decode_yx(rem, oy, ox);
+                int n, oy, ox;
+                decode_m(m, cls, n, oy, ox);
                 r_oy[j] = oy;
                 r_ox[j] = ox;
                 r_n[j] = n;
@@ -460,7 +467,7 @@ void conv_igemm_mfma(const ConvParams p)
             if (s1) rows(sd1.base - fg_bias1, sd1.bytes + fg_bias1, r_ox); else rows(sd0.base - fg_bias0, sd0.bytes + fg_bias0, r_oy);
             // (timing probe, variant flag bit 6 / SBBSEG_CONV_PROBE_WHOT=1: the weight rows of every K-step come from the tile's first sixteen
             //  K-steps -- an L2-resident 32-64 KB per channel tile.  Results are wrong.)
-            const uint32_t woff = (uint32_t)(((p.variant_flags & 64) ? (t & 15) : t) * (kBK * 2) + l_h * GS * 16);
+            const uint32_t woff = (uint32_t)((SBBSEG_PROBE(p.variant_flags & 64) ? (t & 15) : t) * (kBK * 2) + l_h * GS * 16);
 #pragma unroll
             for (int j = 0; j < T::kWLoads; ++j)
                 buffer_load_lds16(wbase, 0x7fffffffu, (LDS_AS void*)(lds_w + (j * NW + wave) * 1024), w_off[j], woff);
@@ -534,13 +541,11 @@ void conv_igemm_mfma(const ConvParams p)
     // gives, so the two MFMA row blocks (2s, 2s+1) of a lane hold 8 CONSECUTIVE channels of one
     // pixel: 16-byte NHWC stores / residual loads, 64 contiguous bytes per pixel per instruction.
     // linear pixel index inside the output tensor(s) for output-grid pixel m (placement: see ConvParams)
-    const bool placed = (p.osy != 1) | (p.osx != 1) | (p.ooy != 0) | (p.oox != 0) | (p.TH != p.Ho) | (p.TW != p.Wo) | (p.n_cls > 1);
+    const bool placed = (p.osy != 1) | (p.osx != 1) | (p.ooy != 0) | (p.oox != 0) | (p.TH != p.Ho) | (p.TW != p.Wo) | (p.n_cls > 1) | (p.rmap != nullptr);
     auto out_pixel = [&](int m, int cls) __attribute__((always_inline)) -> int {
         if (!placed) return m;
-        const int n = fast_div(m, p.howo_magic, p.howo_shift);
-        const int rem = m - n * HoWo;
-        int oy, ox;
-        decode_yx(rem, oy, ox);
+        int n, oy, ox;
+        decode_m(m, cls, n, oy, ox);
         const int ooy = p.n_cls > 1 ? p.ooy_cls[cls] : p.ooy, oox = p.n_cls > 1 ? p.oox_cls[cls] : p.oox;
         return (n * p.TH + oy * p.osy + ooy) * p.TW + ox * p.osx + oox;
     };
@@ -885,10 +890,8 @@ void conv_igemm_mfma(const ConvParams p)
                 const int rho = ((j & 1) * 8 + wave) * 8 + lrow;            // row inside the half-tile
                 const int m = ptile * BP + (rho >> 6) * 128 + (j >> 1) * 64 + (rho & 63);
                 if (m < p.M) {
-                    const int n = fast_div(m, p.howo_magic, p.howo_shift);
-                    const int rem = m - n * HoWo;
-                    int oy, ox;
-                    decode_yx(rem, oy, ox);
+                    int n, oy, ox;
+                    decode_m(m, cls, n, oy, ox);
                     q_oy[j] = oy; q_ox[j] = ox; q_n[j] = n;
                 } else {
                     q_oy[j] = -(1 << 20); q_ox[j] = 0; q_n[j] = 0;
@@ -1554,7 +1557,22 @@ __global__ __launch_bounds__(256, 2) void dec_tail_fused(const TailParams p)
     const int H = 2 * p.PH, W = 2 * p.PW;
     const int tiles_x = W / 16, tiles_y = H / 16;
     const int tiles_per_patch = tiles_x * tiles_y;
-    const int n_tiles = p.n * tiles_per_patch;
+    // owned-region launch (TailParams::ttab, region.h): the tiles are the table's entries -- (patch, output origin / 2), x origins multiples
+    // of 16 (label rows are stored 16 bytes at a time) -- instead of every 16 x 16 tile of every patch
+    const int n_tiles = p.ttab ? p.n_tab : p.n * tiles_per_patch;
+    const __attribute__((address_space(4))) uint32_t* ttab = (const __attribute__((address_space(4))) uint32_t*)(uintptr_t)p.ttab;
+    auto tile_origin = [&](int tile, int& n, int& y0, int& x0) __attribute__((always_inline)) {
+        if (ttab) {
+            const uint32_t code = ttab[tile];
+            n = (int)(code >> 22); y0 = (int)((code >> 11) & 2047u) * 2; x0 = (int)(code & 2047u) * 2;
+        } else {
+            n = tile / tiles_per_patch;
+            const int rem = tile - n * tiles_per_patch;
+            const int ty = rem / tiles_x;
+            y0 = ty * 16;
+            x0 = (rem - ty * tiles_x) * 16;
+        }
+    };
     // XCD-contiguous walk (grid = a multiple of 8 blocks): XCD x = block % 8 owns tiles [x * per_xcd, (x + 1) * per_xcd), so the
     // halo pixels neighbouring tiles share are fetched into one L2 once instead of once per XCD (a round-robin walk
     // re-fetched them from HBM: 1.8x the input bytes, L2 hit rate 2 %)
@@ -1606,10 +1624,8 @@ __global__ __launch_bounds__(256, 2) void dec_tail_fused(const TailParams p)
         }
 
     auto issue_tile = [&](int tile, int buf) __attribute__((always_inline)) {
-        const int n = tile / tiles_per_patch;
-        const int rem = tile - n * tiles_per_patch;
-        const int ty = rem / tiles_x, tx = rem - ty * tiles_x;
-        const int y0 = ty * 16, x0 = tx * 16;
+        int n, y0, x0;
+        tile_origin(tile, n, y0, x0);
         char* lds_src = smem + buf * kTailBufBytes;
         char* lds_img = lds_src + kTailSrcBytes;
         // src0 halo: 10 rows x 16 px (10 needed) x 8 granules = 20 wave-instructions of 8 px
@@ -1689,9 +1705,8 @@ __global__ __launch_bounds__(256, 2) void dec_tail_fused(const TailParams p)
         }
 
         // ---- epilogue: BN/ReLU, head, softmax, argmax
-        const int n = tile / tiles_per_patch;
-        const int rem = tile - n * tiles_per_patch;
-        const int tyy = rem / tiles_x, txx = rem - tyy * tiles_x;
+        int n, ty0, tx0;
+        tile_origin(tile, n, ty0, tx0);
         // (channel constants are read once per tile -- q outer, the four pixel blocks inner -- not once per pixel block)
         float lg[4][NC];
 #pragma unroll
@@ -1747,7 +1762,7 @@ __global__ __launch_bounds__(256, 2) void dec_tail_fused(const TailParams p)
             const int oy = 2 * (i >> 3) + py, ox = 2 * (i & 7) + px;             // inside the 16x16 tile
             lbl_tile[oy * 16 + ox] = (char)best;
             if (p.probs) {
-                float* dst = p.probs + ((size_t)(n * H + tyy * 16 + oy) * W + txx * 16 + ox) * p.classes;
+                float* dst = p.probs + ((size_t)(n * H + ty0 + oy) * W + tx0 + ox) * p.classes;
 #pragma unroll
                 for (int c = 0; c < NC; ++c)
                     if (c < p.classes) dst[c] = pr[c];
@@ -1755,7 +1770,7 @@ __global__ __launch_bounds__(256, 2) void dec_tail_fused(const TailParams p)
         }
         __syncthreads();
         if (tid < 16)
-            *(uint4*)(p.labels + (size_t)(n * H + tyy * 16 + tid) * W + txx * 16) = *(const uint4*)(lbl_tile + tid * 16);
+            *(uint4*)(p.labels + (size_t)(n * H + ty0 + tid) * W + tx0) = *(const uint4*)(lbl_tile + tid * 16);
     }
 }
 
@@ -1814,7 +1829,21 @@ __global__ __launch_bounds__(512, 2) void dec_tail_fused_x3ps(const TailParams p
     const int H = 2 * p.PH, W = 2 * p.PW;
     const int tiles_x = W / 16, tiles_y = H / 16;
     const int tiles_per_patch = tiles_x * tiles_y;
-    const int n_tiles = p.n * tiles_per_patch;
+    // owned-region launch (TailParams::ttab): see dec_tail_fused
+    const int n_tiles = p.ttab ? p.n_tab : p.n * tiles_per_patch;
+    const __attribute__((address_space(4))) uint32_t* ttab = (const __attribute__((address_space(4))) uint32_t*)(uintptr_t)p.ttab;
+    auto tile_origin = [&](int tile, int& n, int& y0, int& x0) __attribute__((always_inline)) {
+        if (ttab) {
+            const uint32_t code = ttab[tile];
+            n = (int)(code >> 22); y0 = (int)((code >> 11) & 2047u) * 2; x0 = (int)(code & 2047u) * 2;
+        } else {
+            n = tile / tiles_per_patch;
+            const int rem = tile - n * tiles_per_patch;
+            const int ty = rem / tiles_x;
+            y0 = ty * 16;
+            x0 = (rem - ty * tiles_x) * 16;
+        }
+    };
     // XCD-contiguous walk, as in the other tail kernels
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, GX = gridDim.x >> 3;
     const int per_xcd = (n_tiles + 7) >> 3;
@@ -1887,11 +1916,7 @@ __global__ __launch_bounds__(512, 2) void dec_tail_fused_x3ps(const TailParams p
     const int img_x = img_v < 9 ? 2 * img_v : 2 * (img_v - 12) + 1;
     const uint32_t voff_img = (uint32_t)(((lane >> 5) * W + img_x) * 32);
     const uint32_t src_img_bytes = (uint32_t)(p.PH * p.PW) * 256u, img_img_bytes = (uint32_t)(H * W) * 32u;
-    auto issue_src = [&](int tile, int buf) __attribute__((always_inline)) {           // group A: ten pieces per wave
-        const int n = tile / tiles_per_patch;
-        const int rem = tile - n * tiles_per_patch;
-        const int ty = rem / tiles_x, tx = rem - ty * tiles_x;
-        const int y0 = ty * 16, x0 = tx * 16;
+    auto issue_src = [&](int n, int y0, int x0, int buf) __attribute__((always_inline)) {           // group A: ten pieces per wave
         char* lds_src = smem + buf * kT3BufBytes;
         const char* sbase = p.src0 + kZeroHeaderBytes - 256 + (size_t)n * src_img_bytes;
         const uint32_t vs = ((unsigned)((x0 >> 1) - 1 + c_src) < (unsigned)p.PW && c_src < 10) ? voff_src : 0x80000000u;
@@ -1903,11 +1928,7 @@ __global__ __launch_bounds__(512, 2) void dec_tail_fused_x3ps(const TailParams p
             buffer_load_lds16(sbase, src_img_bytes + 256u, (LDS_AS void*)(lds_src + (par + 4 * j) * 1024), yok ? vs : 0x80000000u, soff);
         }
     };
-    auto issue_img = [&](int tile, int buf) __attribute__((always_inline)) {           // group B: two or three pieces per wave
-        const int n = tile / tiles_per_patch;
-        const int rem = tile - n * tiles_per_patch;
-        const int ty = rem / tiles_x, tx = rem - ty * tiles_x;
-        const int y0 = ty * 16, x0 = tx * 16;
+    auto issue_img = [&](int n, int y0, int x0, int buf) __attribute__((always_inline)) {           // group B: two or three pieces per wave
         char* lds_img = smem + buf * kT3BufBytes + kT3SrcBytes;
         // image: piece q = par + 4 j (< 9) = halo rows 2 q, 2 q + 1 (32 units each); one row + one pixel of bias
         const char* ibase = p.img + kZeroHeaderBytes + (size_t)n * img_img_bytes - (size_t)(W + 1) * 32;
@@ -2006,12 +2027,6 @@ __global__ __launch_bounds__(512, 2) void dec_tail_fused_x3ps(const TailParams p
             tot[c] = (o2 ? k1 : k0) + __shfl_xor(o2 ? k0 : k1, 32);
         }
     };
-    auto tile_coords = [&](int tile, int& n, int& tyy, int& txx) __attribute__((always_inline)) {
-        n = tile / tiles_per_patch;
-        const int rem = tile - n * tiles_per_patch;
-        tyy = rem / tiles_x;
-        txx = rem - tyy * tiles_x;
-    };
     // group B: finish tile `it` (its accumulators are still in this wave's registers; A's half came through part[it & 1])
     auto finish = [&](int it) __attribute__((always_inline)) {
         float tot[NC];
@@ -2039,9 +2054,9 @@ __global__ __launch_bounds__(512, 2) void dec_tail_fused_x3ps(const TailParams p
         const int oy = 2 * (i >> 3) + py, ox = 2 * (i & 7) + px;
         lbl_tile[(it & 1) * 256 + oy * 16 + ox] = (char)best;
         if (p.probs) {
-            int n, tyy, txx;
-            tile_coords(tile_at(it), n, tyy, txx);
-            float* dst = p.probs + ((size_t)(n * H + tyy * 16 + oy) * W + txx * 16 + ox) * p.classes;
+            int n, ty0, tx0;
+            tile_origin(tile_at(it), n, ty0, tx0);
+            float* dst = p.probs + ((size_t)(n * H + ty0 + oy) * W + tx0 + ox) * p.classes;
 #pragma unroll
             for (int c = 0; c < NC; ++c)
                 if (c < p.classes) dst[c] = pr[c];
@@ -2049,13 +2064,17 @@ __global__ __launch_bounds__(512, 2) void dec_tail_fused_x3ps(const TailParams p
     };
     auto store_labels = [&](int it) __attribute__((always_inline)) {       // (wave 4, after the barrier that follows finish(it))
         if (wave == 4 && lane < 16) {
-            int n, tyy, txx;
-            tile_coords(tile_at(it), n, tyy, txx);
-            *(uint4*)(p.labels + (size_t)(n * H + tyy * 16 + lane) * W + txx * 16) = *(const uint4*)(lbl_tile + (it & 1) * 256 + lane * 16);
+            int n, ty0, tx0;
+            tile_origin(tile_at(it), n, ty0, tx0);
+            *(uint4*)(p.labels + (size_t)(n * H + ty0 + lane) * W + tx0) = *(const uint4*)(lbl_tile + (it & 1) * 256 + lane * 16);
         }
     };
 
-    if (mh == 0) { issue_src(tile_at(0), 0); issue_img(tile_at(0), 0); }
+    if (mh == 0) {
+        int n, y0, x0;
+        tile_origin(tile_at(0), n, y0, x0);
+        issue_src(n, y0, x0, 0); issue_img(n, y0, x0, 0);
+    }
     for (int it = 0; it < my_tiles; ++it) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -2067,7 +2086,11 @@ __global__ __launch_bounds__(512, 2) void dec_tail_fused_x3ps(const TailParams p
         if (mh == 0) {
             // all of the next tile's halo pieces (before the epilogue: more time to land).  Moving the image pieces to group B --
             // before or after its epilogue -- made B the longer group: a piece costs its wave 200-400 cycles there
-            if (it + 1 < my_tiles) { issue_src(tile_at(it + 1), (it + 1) & 1); issue_img(tile_at(it + 1), (it + 1) & 1); }
+            if (it + 1 < my_tiles) {
+                int n, y0, x0;
+                tile_origin(tile_at(it + 1), n, y0, x0);
+                issue_src(n, y0, x0, (it + 1) & 1); issue_img(n, y0, x0, (it + 1) & 1);
+            }
             float tot[NC];
             partial_logits(tot);
             float* pa = part + (((it & 1) * 4 + par) * 64 + lane) * NC;
@@ -2086,7 +2109,8 @@ __global__ __launch_bounds__(512, 2) void dec_tail_fused_x3ps(const TailParams p
 
 hipError_t launch_tail(const TailParams& p, int precision, int num_cus, hipStream_t s)
 {
-    const int n_tiles = p.n * (p.PH / 8) * (p.PW / 8);
+    const int n_tiles = p.ttab ? p.n_tab : p.n * (p.PH / 8) * (p.PW / 8);
+    if (n_tiles <= 0) return hipSuccess;
     const int grid = ((n_tiles < 2 * num_cus ? n_tiles : 2 * num_cus) + 7) & ~7;      // (the XCD-contiguous walk: a multiple of 8)
     auto go = [&](auto kern) -> hipError_t {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, kTailLdsBytes);

@@ -29,7 +29,7 @@ def test_exports_match_header(lib):
 
 
 def test_abi_version(lib):
-    assert lib.sbbseg_abi_version() == 4
+    assert lib.sbbseg_abi_version() == 5
 
 
 @pytest.mark.parametrize("case", GOLD, ids=lambda c: f"{c['page_h']}x{c['page_w']}_m{c['model_h']}x{c['model_w']}")
@@ -89,3 +89,27 @@ def test_documents_name_only_entry_points_that_exist(lib):
                 continue
             candidates = {name, name + "_dev"}
             assert candidates & exports or any(e.startswith(name) for e in exports), f"{doc} names {name}, which libsbbseg does not export"
+
+
+def test_shipped_library_has_no_wrong_answer_probes(lib):
+    """The timing probes that make kernels compute WRONG results on purpose (gathers forced into L2, one weight block, dropped stores:
+    SBBSEG_CONV_PROBE_LOCAL / _WHOT, SBBSEG_BLOCK_DBG, SBBSEG_ER_DBG) compile only under -DSBBSEG_PROBES (`_build --probes`, a separate
+    library under tools/probes/bin/): the library a maintainer binds must not even contain the names of their switches."""
+    blob = open(_capi.LIB_PATH, "rb").read()
+    for name in (b"SBBSEG_CONV_PROBE_LOCAL", b"SBBSEG_CONV_PROBE_WHOT", b"SBBSEG_BLOCK_DBG", b"SBBSEG_ER_DBG", b"SBBSEG_PROBES"):
+        assert name not in blob, name.decode()
+    for src in ("api.hip", "kernels.hip", "block_x3.hip", "expand_reduce_x3.hip"):
+        text = open(os.path.join(ROOT, "sbb_textline_detection_amd", "csrc", src)).read()
+        # every use of the probe bits in device code goes through SBBSEG_PROBE(...) (constant false in the shipped build) ...
+        for m in re.finditer(r"(variant_flags & (?:32|64)|p\.dbg & \d)", text):
+            line = text[text.rfind("\n", 0, m.start()) + 1:text.find("\n", m.end())]
+            assert "SBBSEG_PROBE(" in line or line.lstrip().startswith("//"), (src, line.strip())
+        # ... and every getenv of a probe switch sits inside an #ifdef SBBSEG_PROBES block
+        depth = 0
+        for line in text.splitlines():
+            if line.strip().startswith("#ifdef SBBSEG_PROBES"):
+                depth += 1
+            elif line.strip().startswith("#endif") and depth:
+                depth -= 1
+            if re.search(r'getenv\("SBBSEG_(CONV_PROBE|BLOCK_DBG|ER_DBG)', line):
+                assert depth > 0, (src, line.strip())
