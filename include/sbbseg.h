@@ -107,9 +107,9 @@ int sbbseg_set_ksplit(sbbseg_ctx* c, int on);
  *   DEFINED ONLY ON EACH TILE'S OWNED REGION (everything sbbseg_stitch_dev reads); a repeated clamped tile owns nothing.
  * sbbseg_predict, sbbseg_segment_tiles_dev and the whole-image branch always compute whole patches. */
 int sbbseg_set_owned_regions(sbbseg_ctx* c, int mode);
-/* decoder levels (the fused tail + the parity-split decoder convs below it) the handle's plan runs as owned-region launches; 0 = none
- * (fp32 handles, unfused heads, decoders of another shape: everything is computed whole) */
-int sbbseg_owned_region_levels(sbbseg_ctx* c, int* levels);
+/* the mode in force, and the decoder levels (the fused tail + the parity-split decoder convs below it) the handle's plan runs as
+ * owned-region launches; 0 levels = none (fp32 handles, unfused heads, decoders of another shape: everything is computed whole) */
+int sbbseg_owned_region_info(sbbseg_ctx* c, int* mode, int* levels);
 
 /* ---- plan building: the host-side planner (planner.py) lowers the Keras model_config that the
  * reference would have handed to keras.models.load_model (main.py:221) into these calls, in

@@ -32,7 +32,7 @@ EXPORTS = [
     "sbbseg_segment_pages",
     "sbbseg_profile_enable", "sbbseg_profile_reset", "sbbseg_profile_get",
     "sbbseg_debug_largest_contour_area2", "sbbseg_text_regions_present_dev", "sbbseg_run_page", "sbbseg_device_alloc", "sbbseg_device_free", "sbbseg_upload", "sbbseg_download", "sbbseg_download_labels",
-    "sbbseg_set_owned_regions", "sbbseg_owned_region_levels", "sbbseg_op_executed", "sbbseg_debug_owned_range", "sbbseg_debug_region_rows",
+    "sbbseg_set_owned_regions", "sbbseg_owned_region_info", "sbbseg_op_executed", "sbbseg_debug_owned_range", "sbbseg_debug_region_rows",
     "sbbseg_debug_poison_activations",
 ]
 
@@ -149,7 +149,7 @@ def load_library(path: Optional[str] = None):
         "sbbseg_download": [vp, vp, vp, C.c_size_t],
         "sbbseg_download_labels": [vp, vp, vp, C.c_size_t, i32],
         "sbbseg_set_owned_regions": [vp, i32],
-        "sbbseg_owned_region_levels": [vp, C.POINTER(C.c_int)],
+        "sbbseg_owned_region_info": [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)],
         "sbbseg_op_executed": [vp, i32, C.POINTER(C.c_double), C.POINTER(C.c_double)],
         "sbbseg_debug_owned_range": [i32, i32, i32, i32, i32, C.POINTER(C.c_int), C.POINTER(C.c_int)],
         "sbbseg_debug_region_rows": [i32, i32, i32, i32, i32, i32, vp, vp],
@@ -325,9 +325,13 @@ class Context:
 
     def owned_region_levels(self) -> int:
         """Decoder levels this plan runs as owned-region launches (0: everything is computed whole)."""
-        v = C.c_int(0)
-        check(self.lib.sbbseg_owned_region_levels(self.h, C.byref(v)), "sbbseg_owned_region_levels")
-        return int(v.value)
+        return self.owned_region_info()[1]
+
+    def owned_region_info(self):
+        """(mode in force, decoder levels the plan runs as owned-region launches)."""
+        mode, levels = C.c_int(0), C.c_int(0)
+        check(self.lib.sbbseg_owned_region_info(self.h, C.byref(mode), C.byref(levels)), "sbbseg_owned_region_info")
+        return int(mode.value), int(levels.value)
 
     def poison_activations(self, byte_value: int = 0xFF):
         """Test hook: fill every activation buffer and the tile-label scratch with a byte (0xFF = NaN in every 16-bit format)."""

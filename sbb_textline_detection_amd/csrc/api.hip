@@ -1035,11 +1035,12 @@ int sbbseg_set_owned_regions(sbbseg_ctx* c, int mode)
     API_END
 }
 
-int sbbseg_owned_region_levels(sbbseg_ctx* c, int* levels)
+int sbbseg_owned_region_info(sbbseg_ctx* c, int* mode, int* levels)
 {
     API_BEGIN
-    REQUIRE(c && levels, "bad arguments");
-    *levels = c->finalized ? c->region_levels : 0;
+    REQUIRE(c, "null handle");
+    if (mode) *mode = c->owned_mode;
+    if (levels) *levels = c->finalized ? c->region_levels : 0;
     return 0;
     API_END
 }

@@ -51,7 +51,16 @@ class DeviceBackend:
     def tile_range(self, d_page, first: int, count: int, out_tiles) -> None:
         Hp, Wp = int(d_page.shape[0]), int(d_page.shape[1])
         if count:
-            self.ctx.segment_tile_range_dev(d_page.data_ptr(), Hp, Wp, first, count, out_tiles.data_ptr())
+            # the tile labels of a shard are only ever stitched (main.py:294-364 keeps each tile's owned region): let the decoder skip the
+            # rest (sbbseg_set_owned_regions mode 2), unless the caller switched owned-region launches off altogether
+            mode = self.ctx.owned_region_info()[0]
+            if mode == 1:
+                self.ctx.set_owned_regions(2)
+            try:
+                self.ctx.segment_tile_range_dev(d_page.data_ptr(), Hp, Wp, first, count, out_tiles.data_ptr())
+            finally:
+                if mode == 1:
+                    self.ctx.set_owned_regions(1)
 
     def stitch(self, all_tiles, Hp: int, Wp: int, out_page) -> None:
         self.ctx.stitch_dev(all_tiles.data_ptr(), Hp, Wp, out_page.data_ptr())

@@ -17,7 +17,7 @@ def _run(args, env_extra=None, timeout=240):
     return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, env=env, timeout=timeout, cwd=ROOT)
 
 
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2, 4, 8])
 def test_plain_invocation_spawns_its_own_ranks(world):
     res = _run(["--gpus", str(world), "--plumbing-check"])
     assert res.returncode == 0, res.stderr[-2000:]

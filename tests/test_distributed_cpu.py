@@ -21,8 +21,11 @@ GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "tiling_
 class NumpyBackend:
     """CPU stand-in for DeviceBackend: FakeModel's label rule per tile, oracle owner map for the stitch."""
 
-    def __init__(self, H, W, classes=16):
+    def __init__(self, H, W, classes=16, owned_only=False):
         self.H, self.W, self.classes = H, W, classes
+        # owned_only: what sbbseg_segment_tile_range_dev returns under sbbseg_set_owned_regions(2) -- a tile's labels are defined on the
+        # region the page stitch keeps of it (the library's closed form, csrc/region.h) and are junk (0xEE) everywhere else
+        self.owned_only = owned_only
 
     def empty(self, shape):
         return torch.zeros(shape, dtype=torch.uint8)
@@ -37,7 +40,18 @@ class NumpyBackend:
         for k in range(count):
             t = tiles[first + k]
             p = page[t["y0"]:t["y0"] + self.H, t["x0"]:t["x0"] + self.W]
-            out_tiles[k] = torch.from_numpy((((first + k) * 5 + yy * 3 + xx * 7 + p[:, :, 0] + 2 * p[:, :, 1]) % self.classes).astype(np.uint8))
+            lab = (((first + k) * 5 + yy * 3 + xx * 7 + p[:, :, 0] + 2 * p[:, :, 1]) % self.classes).astype(np.uint8)
+            if self.owned_only:
+                from sbb_textline_detection_amd import _capi
+                margin = int(0.1 * self.W)
+                nx = max(tt["i"] for tt in tiles) + 1
+                ny = max(tt["j"] for tt in tiles) + 1
+                ylo, yhi = _capi.owned_range(page.shape[0], self.H, margin, ny, t["j"])
+                xlo, xhi = _capi.owned_range(page.shape[1], self.W, margin, nx, t["i"])
+                junk = np.full_like(lab, 0xEE)
+                junk[ylo:yhi, xlo:xhi] = lab[ylo:yhi, xlo:xhi]
+                lab = junk
+            out_tiles[k] = torch.from_numpy(lab)
 
     def stitch(self, all_tiles, Hp, Wp, out_page):
         own = tiling.owner_map(Hp, Wp, self.H, self.W)
@@ -139,3 +153,57 @@ def test_sharded_pages_world4_with_padding_rows(n_pages):
     assert all(ok for _, ok, _ in res)
     counts = {rank: blk[1] for rank, _, blk in res}
     assert sum(counts.values()) == n_pages and counts[3] == 0 and all(blk[2] == 2 for _, _, blk in res)
+
+
+def _worker_w8(rank, world, port, case, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        # every rank returns its tiles' OWNED regions only (sbbseg_set_owned_regions(2): what DeviceBackend.tile_range asks for)
+        be = NumpyBackend(case["model_h"], case["model_w"], case["classes"], owned_only=True)
+        page = tiling.coord_page(case["page_h"], case["page_w"])
+        out = D.segment_page_sharded(be, be.to_device(page), case["n_calls"]).numpy()
+        crc = zlib.crc32(np.ascontiguousarray(out).tobytes()) & 0xFFFFFFFF
+        q.put((rank, crc, int(out.astype(np.int64).sum()), D.shard_block(case["n_calls"], rank, world)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_3500x2500_page_world8_uneven_tail_owned_regions_only():
+    """BASELINE configs[1]'s page over EIGHT ranks: 70 tiles -> 9 / 9 / ... / 9 / 7 (shard_block pads the last rank's contribution to the
+    block of 9), every rank hands the all-gather only the OWNED region of each of its tiles (junk elsewhere), and the stitched mask on
+    every rank still reproduces the CRC captured from the reference's own loop (tiling_golden.json)."""
+    case = [c for c in GOLD if (c["page_h"], c["page_w"]) == (3500, 2500)][0]
+    world = 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_w8, args=(r, world, port, case, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    counts = {}
+    for rank, crc, total, blk in res:
+        assert crc == case["out_crc32"] and total == case["out_sum"], f"rank {rank}"
+        counts[rank] = blk[1]
+    assert [counts[r] for r in range(world)] == [9] * 7 + [7]
+
+
+def test_sharded_64_pages_world8():
+    """BASELINE configs[3]'s sharding: 64 pages over eight ranks = 8 whole pages per rank, one all-gather of the masks."""
+    world, n_pages = 8, 64
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_pages, args=(r, world, port, n_pages, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=900) for _ in procs]
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _ in res)
+    assert all(blk[1] == 8 and blk[2] == 8 for _, _, blk in res)
