@@ -188,34 +188,54 @@ def install_contour_tree_stubs(cv2, ref):
         assert mode == cv2.RETR_TREE and method == cv2.CHAIN_APPROX_SIMPLE
         fg = mask > 0
         lab, n = ndimage.label(fg, structure=np.ones((3, 3), int))
-        # [EXT] the outer border of every 8-connected component, as the oracle traces it; hole borders are left out of the list
-        # (their parent is never -1, the only thing the reference asks of them); a component lying in a hole of another gets that
-        # component's index as its parent, every other one -1
+        # [EXT, a restatement -- NOT OpenCV] RETR_TREE as a list: the outer border of every 8-connected component as the oracle traces it,
+        # followed by the borders of its holes (the component's pixels around each hole); hierarchy[..][3] = parent: -1 for a component
+        # that touches the outer background, the hole it lies in for an island, the component for a hole.  Components in reverse discovery
+        # order, as in the extract_page stub.  Hole contours are in the list since round 6: they never pass the reference's
+        # `parent == -1` test, but they do advance its `jv` counter (main.py:80-92), which indexes the hierarchy by the contours that were
+        # NOT skipped for having fewer than three points -- with them in the list a skipped contour would shift every later lookup.
         bg = np.pad(~fg, 1, constant_values=True)
-        blab, _ = ndimage.label(bg, structure=[[0, 1, 0], [1, 1, 1], [0, 1, 0]])
+        blab, _nb = ndimage.label(bg, structure=[[0, 1, 0], [1, 1, 1], [0, 1, 0]])
         outer_bg = blab == blab[0, 0]
         pl = np.pad(lab, 1, constant_values=0)
         touch = np.zeros(n + 1, bool)
         for dy, dx in ((0, 1), (0, -1), (1, 0), (-1, 0)):
             sh = np.roll(outer_bg, (dy, dx), axis=(0, 1))
             touch[np.unique(pl[sh & (pl > 0)])] = True
-        filled = [ndimage.binary_fill_holes(lab == k + 1) for k in range(n)]
-        contours, hier = [], []
-        order = list(range(n, 0, -1))                     # reverse discovery order, as in the extract_page stub
+        hole_lab = blab[1:-1, 1:-1].copy()
+        hole_lab[outer_bg[1:-1, 1:-1]] = 0                 # > 0: a 4-connected background region enclosed by foreground
+        order = list(range(n, 0, -1))
+
+        def trace(region):
+            ys, xs = np.nonzero(region)
+            y0, x0 = ys.min(), xs.min()
+            chain = sg.outer_contour_chain(region[y0:ys.max() + 1, x0:xs.max() + 1])
+            return np.array([[[x + x0, y + y0]] for (x, y) in approx_simple(chain)], np.int32)
+        # holes of each component: the enclosed background regions lying inside its filled shape and bordered by its pixels
+        filled = {k: ndimage.binary_fill_holes(lab == k) for k in order}
+        holes_of = {k: [] for k in order}
+        for hid in [int(h) for h in np.unique(hole_lab) if h > 0]:
+            hole = hole_lab == hid
+            ring = ndimage.binary_dilation(hole, structure=np.ones((3, 3), bool)) & fg
+            owners = [int(o) for o in np.unique(lab[ring]) if filled[int(o)][hole].all()]
+            assert len(owners) == 1
+            holes_of[owners[0]].append((hid, ring & (lab == owners[0])))
+        contours, hier, index_of_comp, index_of_hole = [], [], {}, {}
         for k in order:
-            sl = ndimage.find_objects(lab)[k - 1]
-            chain = sg.outer_contour_chain(lab[sl] == k)
-            pts = np.array([[[x + sl[1].start, y + sl[0].start]] for (x, y) in approx_simple(chain)], np.int32)
-            parent = -1
+            index_of_comp[k] = len(contours)
+            contours.append(trace(lab == k))
+            hier.append([-1, -1, -1, -1])
+            for hid, ring in holes_of[k]:
+                index_of_hole[hid] = len(contours)
+                contours.append(trace(ring))
+                hier.append([-1, -1, -1, index_of_comp[k]])
+        for k in order:                                    # an island's parent is the hole it lies in
             if not touch[k]:
-                ys, xs = np.nonzero(lab == k)
-                for j in order:
-                    if j != k and filled[j - 1][ys[0], xs[0]]:
-                        parent = order.index(j)
-                        break
-                assert parent >= 0
-            contours.append(pts)
-            hier.append([-1, -1, -1, parent])
+                around = ndimage.binary_dilation(lab == k, structure=[[0, 1, 0], [1, 1, 1], [0, 1, 0]]) & ~fg
+                hid = int(hole_lab[around].max())
+                assert hid > 0
+                hier[index_of_comp[k]][3] = index_of_hole[hid]
+        find_contours.last = (len(contours), sum(1 for h in hier if h[3] >= 0), min((len(c) for c in contours), default=0))
         return contours, np.array([hier], np.int32)
     cv2.findContours = find_contours
 
