@@ -534,12 +534,14 @@ class Context:
 
     def text_regions_present(self, regions: np.ndarray, label: int = 1, min_area: float = 0.00001) -> bool:
         plane = np.ascontiguousarray(regions[:, :, 0] if regions.ndim == 3 else regions, np.uint8)
-        d = self.device_alloc(plane.size)
-        try:
-            self.upload(d, plane)
-            return self.text_regions_present_dev(d, plane.shape[0], plane.shape[1], label, min_area)
-        finally:
-            self.device_free(d)
+        # staging buffer cached on the Context (grown on demand, released with the handle): sbbseg_device_free synchronises the device
+        cap = getattr(self, "_gate_cap", 0)
+        if cap < plane.size:
+            if cap:
+                self.device_free(self._gate_buf)
+            self._gate_buf, self._gate_cap = self.device_alloc(plane.size), plane.size
+        self.upload(self._gate_buf, plane)
+        return self.text_regions_present_dev(self._gate_buf, plane.shape[0], plane.shape[1], label, min_area)
 
     def page_box_dev(self, d_mask: int, H: int, W: int):
         """((x, y, w, h), pixels) of the largest component of the dilated mask (main.py:394-404); pixels == 0: empty mask."""

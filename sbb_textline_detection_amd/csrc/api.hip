@@ -2431,7 +2431,7 @@ static int tile_range_impl(sbbseg_ctx* c, const void* const* d_pages, int n_page
                 HIPCHK(hipStreamWaitEvent(c->stream, c->ev_half[0], 0));
                 continue;
             }
-            if (run_chunk(0, done, nb)) return 1;
+            if (run_chunk(0, done, nb)) return 1;               // (not forked here: a fork in front was joined above)
             continue;
         }
         const int na = (nb + 1) / 2, nb2 = nb - na;            // nb2 <= lane1_batch
@@ -2445,8 +2445,16 @@ static int tile_range_impl(sbbseg_ctx* c, const void* const* d_pages, int n_page
             HIPCHK(hipStreamWaitEvent(c->lane_stream, c->ev_fork, 0));
             forked = true;
         }
-        if (run_chunk(0, done, na)) return 1;
-        if (run_chunk(1, done + na, nb2)) return 1;           // (starting lane 1 later -- after lane 0's op k -- measured 3-14 % slower)
+        // (a failure from here on must still join the lanes: earlier chunks of this range are in flight on lane_stream, unordered against
+        //  whatever the caller does next on the handle's stream -- stitch, reuse of d_tile_labels, destroy)
+        auto join_on_error = [&]() -> int {
+            if (hipEventRecord(c->ev_join, c->lane_stream) != hipSuccess || hipStreamWaitEvent(c->stream, c->ev_join, 0) != hipSuccess)
+                (void)hipStreamSynchronize(c->lane_stream);
+            (void)hipGetLastError();
+            return 1;
+        };
+        if (run_chunk(0, done, na)) return join_on_error();
+        if (run_chunk(1, done + na, nb2)) return join_on_error();           // (starting lane 1 later -- after lane 0's op k -- measured 3-14 % slower)
         if (join_per_chunk) {
             HIPCHK(hipEventRecord(c->ev_join, c->lane_stream));
             HIPCHK(hipStreamWaitEvent(c->stream, c->ev_join, 0));
@@ -2938,7 +2946,9 @@ int sbbseg_morph(sbbseg_ctx* c, const uint8_t* src_hw, int H, int W, int op, int
 // the candidates on the device's label plane (parent[i] = root = the component's first pixel in raster order): 4 bytes per pixel of
 // D2H + the candidates' perimeters.  box = {x0, y0, x1, y1, pixels} of the winner; *any = false for an empty plane; *area2 = twice the
 // winner's contour area (exact when traced, else the device's lower bound; *traced says which).
-static int rank_contours(sbbseg_ctx* c, int H, int W, bool exact, int (&box)[5], bool* any, long long* area2, bool* traced)
+// exact_below2: trace on the host (exact area) also when the device's lower bound of TWICE the winner's area is below this -- the caller's
+// threshold: one labelling pass and one copy of the label plane decide "too small", not two
+static int rank_contours(sbbseg_ctx* c, int H, int W, bool exact, int (&box)[5], bool* any, long long* area2, bool* traced, double exact_below2 = -1.0)
 {
     const size_t pix = (size_t)H * W;
     if (ensure(c, (void**)&c->d_cc_parent, &c->cc_parent_cap, pix * sizeof(int)) || ensure(c, (void**)&c->d_cc_count, &c->cc_count_cap, pix * sizeof(int))) return 1;
@@ -2958,7 +2968,7 @@ static int rank_contours(sbbseg_ctx* c, int H, int W, bool exact, int (&box)[5],
     *any = out[2] >= 0;
     *area2 = (long long)(key >> 32);
     *traced = false;
-    if (*any && (out[5] > 0 || exact || c->force_host_contours)) {
+    if (*any && (out[5] > 0 || exact || c->force_host_contours || (double)*area2 < exact_below2)) {
         alloc_check();
         std::vector<int> lab(pix);
         HIPCHK(hipMemcpy(lab.data(), c->d_cc_parent, pix * sizeof(int), hipMemcpyDeviceToHost));
@@ -3036,11 +3046,8 @@ int sbbseg_text_regions_present_dev(sbbseg_ctx* c, const void* d_regions_hw, int
     int box[5];
     bool any = false, traced = false;
     long long area2 = 0;
-    if (rank_contours(c, H, W, false, box, &any, &area2, &traced)) return 1;
-    if (any && !traced && (double)area2 * 0.5 < need) {
-        // the device's figure is a lower bound (holes not filled): only the exact area can say "too small"
-        if (rank_contours(c, H, W, true, box, &any, &area2, &traced)) return 1;
-    }
+    // the device's figure is a lower bound (holes not filled): only the exact area can say "too small" -- traced in the same pass
+    if (rank_contours(c, H, W, false, box, &any, &area2, &traced, 2.0 * need)) return 1;
     *present = (any && (double)area2 * 0.5 >= need) ? 1 : 0;
     return 0;
     API_END
@@ -3073,7 +3080,8 @@ int sbbseg_device_free(sbbseg_ctx* c, void* d_ptr)
     for (size_t i = 0; i < c->user_bufs.size(); ++i)
         if (c->user_bufs[i].first == d_ptr) {
             HIPCHK(hipSetDevice(c->device));
-            HIPCHK(hipDeviceSynchronize());            // other handles' streams may still be reading it
+            HIPCHK(hipDeviceSynchronize());            // DEVICE-wide on purpose: any handle on the device may use the buffer (sbbseg.h), so
+                                                       // other handles' streams may still be reading it; a free is not a hot-path call
             HIPCHK(hipFree(d_ptr));
             c->device_bytes -= c->user_bufs[i].second;
             c->user_bufs.erase(c->user_bufs.begin() + (long)i);
@@ -3179,8 +3187,21 @@ int sbbseg_run_page(sbbseg_ctx* border, sbbseg_ctx* layout, sbbseg_ctx* textline
     if (page_mask_out && sbbseg_download_labels(border, page_mask_out, border->d_run_mask, pix, channels)) return 1;
     const int x = info->box_xywh[0], y = info->box_xywh[1], w = info->box_xywh[2], h = info->box_xywh[3];
     const size_t cpix = (size_t)w * h;
+    // A failed stage: wait for whatever it had queued (its kernels read border->d_run_page and the handle's d_run_a / d_run_b, which the next
+    // call overwrites / may reallocate), then decide what the failure is.  Only a crop that cannot hold one model input -- what makes the
+    // reference's own loop raise inside its bare try / except (main.py:278-281 under 2069-2091 / 2152-2157) -- degrades to "no regions" /
+    // "no lines"; a device or allocation error fails the call with its message in sbbseg_last_error(): a fault must not look like an empty page.
+    auto stage_failed = [&](sbbseg_ctx* h) -> bool {          // true: a geometry failure (swallowed, as the reference swallows it)
+        const std::string msg = g_err;
+        (void)hipStreamSynchronize(h->stream);
+        if (h->lane_stream) (void)hipStreamSynchronize(h->lane_stream);
+        (void)hipGetLastError();
+        g_err = msg;
+        return msg.find("smaller than the model input") != std::string::npos;
+    };
     // layout stage + its post-processing: the reference's bare try / except (main.py:2069-2091)
     int present = 0;
+    bool ok = false;
     do {
         if (ensure(layout, (void**)&layout->d_run_a, &layout->run_a_cap, cpix + 4) || ensure(layout, (void**)&layout->d_run_b, &layout->run_b_cap, cpix + 4)) break;
         int* d_thr = (int*)(layout->d_hist + 256);
@@ -3191,15 +3212,20 @@ int sbbseg_run_page(sbbseg_ctx* border, sbbseg_ctx* layout, sbbseg_ctx* textline
         if (sbbseg_download(layout, &info->otsu_threshold, d_thr, sizeof(int))) break;
         if (sbbseg_download_labels(layout, regions_out, layout->d_run_b, cpix, channels)) break;
         info->regions_ok = 1;
+        ok = true;
     } while (0);
+    if (!ok && !stage_failed(layout)) return 1;
     info->text_present = info->regions_ok ? present : 0;
     if (info->text_present) {                                  // main.py:2096-2107; a failure = the outer except (2152-2157): no lines
+        ok = false;
         do {
             if (ensure(textline, (void**)&textline->d_run_a, &textline->run_a_cap, cpix + 4)) break;
             if (sbbseg_segment_crop_dev(textline, border->d_run_page, Hp, Wp, Hs, Ws, x, y, w, h, 0, textline->d_run_a, nullptr)) break;
             if (sbbseg_download_labels(textline, textlines_out, textline->d_run_a, cpix, 1)) break;
             info->textlines_ok = 1;
+            ok = true;
         } while (0);
+        if (!ok && !stage_failed(textline)) return 1;
     }
     return 0;
     API_END
