@@ -1317,6 +1317,14 @@ static hipError_t launch_conv_impl(const ConvParams& p, hipStream_t s)
     // the 8-wave ones); p.persist_blocks == 0 -> one block per tile (A/B)
     const int resident = p.persist_blocks > 0 ? p.persist_blocks * T::kBlocksPerCU : n_tiles;
     int grid = n_tiles < resident ? n_tiles : resident;
+    // Balanced rounds (round 6, SBBSEG_BALANCED_GRID=1, off by default: an experiment): a launch of R = ceil(tiles / resident) rounds runs on
+    // ceil(tiles / R) blocks instead of all resident ones -- every block walks R tiles (+- 1), no CU idles through a last partial round
+    // while its neighbours finish it, and the CUs the launch does not occupy are free for the other lane's kernel from the start.
+    static const bool balanced = getenv("SBBSEG_BALANCED_GRID") && getenv("SBBSEG_BALANCED_GRID")[0] == '1';
+    if (balanced && p.persist_blocks > 0 && n_tiles > resident) {
+        const int rounds = (n_tiles + resident - 1) / resident;
+        grid = (n_tiles + rounds - 1) / rounds;
+    }
     if (p.tile_map >= 1) grid = (grid + 7) & ~7;          // the XCD-grouped walk needs a multiple of 8 blocks
     ConvParams q = p;
     make_fast_div((uint32_t)(p.Ho * p.Wo), &q.howo_magic, &q.howo_shift);

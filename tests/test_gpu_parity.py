@@ -1663,3 +1663,28 @@ def test_run_page_one_call_equals_the_piecewise_device_calls(tmp_path):
     with pytest.raises(RuntimeError, match="not allocated by this handle"):
         cl.device_free(cb.device_alloc(64))
     clear_session()
+
+
+def test_probe_switches_do_nothing_in_the_shipped_library():
+    """SBBSEG_CONV_PROBE_LOCAL / _WHOT, SBBSEG_BLOCK_DBG, SBBSEG_ER_DBG made round 5's library return WRONG labels with rc 0 (timing probes).
+    They compile only under -DSBBSEG_PROBES now: a process that sets all of them gets the same label map, byte for byte, in both modes."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, zlib; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "from gpu_common import make_model\n"
+            "from sbb_textline_detection_amd.synthetic import synthetic_page\n"
+            "page = synthetic_page(1000, 1234, seed=5)\n"
+            "for prec in ('f16x3', 'f16'):\n"
+            "    m = make_model(2, 448, 448, seed=0, precision=prec, max_batch=16)[3]\n"
+            "    print('CRC', prec, zlib.crc32(m.segment_page(page).tobytes()) & 0xFFFFFFFF)\n"
+            "    m.release()\n") % (root, os.path.join(root, "tests"))
+    outs = []
+    for probes in (False, True):
+        env = {k: v for k, v in os.environ.items() if not k.startswith("SBBSEG_")}
+        if probes:
+            env.update(SBBSEG_CONV_PROBE_LOCAL="1", SBBSEG_CONV_PROBE_WHOT="1", SBBSEG_BLOCK_DBG="1", SBBSEG_ER_DBG="7")
+        res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=900, cwd=root)
+        assert res.returncode == 0, res.stderr[-2000:]
+        outs.append([l for l in res.stdout.splitlines() if l.startswith("CRC")])
+    assert len(outs[0]) == 2 and outs[0] == outs[1], outs
