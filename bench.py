@@ -759,7 +759,7 @@ def main():
         for k, v in modes.items():
             lm = v.get("label_match") or {}
             rr = roofline if k == args.precision else v.get("roofline", {})
-            summary[k] = {"patches_per_s": v["patches_per_s"],
+            summary[k] = {"patches_per_s": v["patches_per_s"], "label_exact_mode": k == "f16x3",
                           "conv3x3_frac": rr.get("conv3x3_stages", {}).get("frac"),
                           "conv3x3_frac_incl_stage2": rr.get("conv3x3_stages_incl_stage2", {}).get("frac"),
                           "all_convs_frac": rr.get("all_convs", {}).get("frac"),

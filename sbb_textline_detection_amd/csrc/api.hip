@@ -301,6 +301,8 @@ struct sbbseg_ctx {
     uint32_t* d_rtab[2][kRegionMaxLevels] = {{nullptr}, {nullptr}};     // per lane and level: the chunk's table (allocated on first use)
     size_t rtab_cap[2][kRegionMaxLevels] = {{0}, {0}};
     RegionRun rr;                                 // the chunk run_plan is launching (set by tile_range_impl around run_plan)
+    double last_exec_frac = 1.0;                  // share of its output grid the op being launched walks (run_plan's accounting; launch_op resets
+                                                  // it to 1 when an A/B knob takes a level off its owned-region form)
     std::vector<std::pair<void*, size_t>> user_bufs;      // sbbseg_device_alloc's buffers still alive (freed by sbbseg_destroy)
 };
 
@@ -500,7 +502,12 @@ int launch_op(sbbseg_ctx* c, Op& op, int n, uint8_t* d_labels, float* d_probs)
             // owned-region launch of a decoder level (region.h): the chunk's table replaces the walk over the whole output grid
             const int rlv = c->rr.on ? op.region_level : -1;
             if (rlv >= 0 && c->rr.total[rlv] == 0) return 0;                         // (no patch of the chunk keeps anything)
-            if (rlv >= 0 && c->rr.kind[rlv] == 1) { p.rmap = c->rr.tab[rlv]; p.M = c->rr.total[rlv]; }
+            if (rlv >= 0 && c->rr.kind[rlv] == 1) {
+                // the pixel table is read by the fast-gather form of conv_igemm_mfma, 2-stage whole-K-step tiles only (what every decoder conv
+                // runs by default); under an A/B knob that takes the level elsewhere it is launched whole -- a superset, same results
+                if (p.fast_gather && !p.half_stages && p.variant != 2 && !(p.variant_flags & 4)) { p.rmap = c->rr.tab[rlv]; p.M = c->rr.total[rlv]; }
+                else c->last_exec_frac = 1.0;
+            }
             if (co.d_stem_wfrag && !(c->conv_variant & 3)) {
                 const Tensor& st = c->tensors[co.d.src[0].tensor];
                 StemParams sp;
@@ -612,8 +619,9 @@ int run_plan(sbbseg_ctx* c, int n, uint8_t* d_labels, float* d_probs)
             if (get_event(c, &ea) || get_event(c, &eb)) return 1;
             HIPCHK(hipEventRecord(ea, c->stream));
         }
+        c->last_exec_frac = (c->rr.on && op.region_level >= 0) ? c->rr.frac[op.region_level] : 1.0;
         if (launch_op(c, op, n, d_labels, d_probs)) return 1;
-        const double exec = (c->rr.on && op.region_level >= 0) ? n * c->rr.frac[op.region_level] : (double)n;
+        const double exec = n * c->last_exec_frac;
         op.exec_patches += exec;
         if (c->profiling) {
             HIPCHK(hipEventRecord(eb, c->stream));

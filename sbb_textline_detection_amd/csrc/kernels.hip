@@ -317,8 +317,10 @@ void conv_igemm_mfma(const ConvParams p)
     // pixel index m of class `cls` -> (patch, oy, ox) on the op's output grid.  Owned-region launches (ConvParams::rmap, region.h) look the
     // triple up in the launch's table -- the grid is walked only where the page stitch keeps the result (plus the later levels' halo);
     // the table of a parity class is the one of its placement offset
+    // (fast-gather kernels only -- every decoder conv takes them; the plain-gather tiles have no registers for the lookup and the host
+    //  never hands them a table: launch_op)
     auto decode_m = [&](int m, int cls, int& n, int& oy, int& ox) __attribute__((always_inline)) {
-        if (p.rmap) {
+        if (FG && p.rmap) {
             const int slot = p.n_cls > 1 ? p.ooy_cls[cls] * 2 + p.oox_cls[cls] : 0;
             const uint32_t code = p.rmap[(size_t)slot * (size_t)p.M + (size_t)m];
             n = (int)(code >> 22); oy = (int)((code >> 11) & 2047u); ox = (int)(code & 2047u);
@@ -541,7 +543,7 @@ void conv_igemm_mfma(const ConvParams p)
     // gives, so the two MFMA row blocks (2s, 2s+1) of a lane hold 8 CONSECUTIVE channels of one
     // pixel: 16-byte NHWC stores / residual loads, 64 contiguous bytes per pixel per instruction.
     // linear pixel index inside the output tensor(s) for output-grid pixel m (placement: see ConvParams)
-    const bool placed = (p.osy != 1) | (p.osx != 1) | (p.ooy != 0) | (p.oox != 0) | (p.TH != p.Ho) | (p.TW != p.Wo) | (p.n_cls > 1) | (p.rmap != nullptr);
+    const bool placed = (p.osy != 1) | (p.osx != 1) | (p.ooy != 0) | (p.oox != 0) | (p.TH != p.Ho) | (p.TW != p.Wo) | (p.n_cls > 1) | (FG && p.rmap != nullptr);
     auto out_pixel = [&](int m, int cls) __attribute__((always_inline)) -> int {
         if (!placed) return m;
         int n, oy, ox;
@@ -890,8 +892,11 @@ void conv_igemm_mfma(const ConvParams p)
                 const int rho = ((j & 1) * 8 + wave) * 8 + lrow;            // row inside the half-tile
                 const int m = ptile * BP + (rho >> 6) * 128 + (j >> 1) * 64 + (rho & 63);
                 if (m < p.M) {
-                    int n, oy, ox;
-                    decode_m(m, cls, n, oy, ox);
+                    // (no owned-region table on this schedule: ph8_ok() keeps launches with a table off it -- the lookup's registers spill here)
+                    const int n = fast_div(m, p.howo_magic, p.howo_shift);
+                    const int rem = m - n * HoWo;
+                    int oy, ox;
+                    decode_yx(rem, oy, ox);
                     q_oy[j] = oy; q_ox[j] = ox; q_n[j] = n;
                 } else {
                     q_oy[j] = -(1 << 20); q_ox[j] = 0; q_n[j] = 0;
@@ -1346,6 +1351,7 @@ static hipError_t launch_conv_t(const ConvParams& p, hipStream_t s)
     if constexpr (!PH8 && GS == 8 && NS == 2) {        // (the opt-in half-stage, 3-stage and 8-phase forms keep the plain gather)
         if (p.fast_gather) return launch_conv_impl<BP, BC, WP, WC, NS, F16, GS, PH8, X3, true>(p, s);
     }
+    if (p.rmap) return hipErrorInvalidValue;           // an owned-region table needs the fast-gather form (launch_op checks before it sets one)
     return launch_conv_impl<BP, BC, WP, WC, NS, F16, GS, PH8, X3, false>(p, s);
 }
 
@@ -1355,7 +1361,7 @@ static hipError_t launch_conv_t(const ConvParams& p, hipStream_t s)
 // the 8-phase schedule of the 256x256 tile: regular K-steps only (>= 64-channel sources), at least 2 K-steps
 static bool ph8_ok(const ConvParams& p)
 {
-    if (!(p.variant_flags & 4) || p.total_ksteps < 2 || p.half_stages) return false;      // opt-in: conv variant bit 16
+    if (!(p.variant_flags & 4) || p.total_ksteps < 2 || p.half_stages || p.rmap) return false;      // opt-in: conv variant bit 16; never with an owned-region table
     for (int i = 0; i < p.n_src; ++i)
         if (p.src[i].pix_bytes < 128) return false;
     return true;

@@ -2,7 +2,7 @@
 # stats + per-op trace table + three PMC passes.
 # usage: bash tools/collect_profiles.sh <tag> [precision: f16x3 | f16] [skip-tests]
 # (results under gpurun_out/; copy what should be judged into profiles/)
-TAG=${1:-r03}
+TAG=${1:-r06}
 PREC=${2:-f16x3}
 mkdir -p gpurun_out
 if [ "$3" != "skip-tests" ]; then
@@ -13,7 +13,7 @@ if [ "$3" != "skip-tests" ]; then
 import json
 d=json.load(open("gpurun_out/bench_$TAG.json"))
 print("BENCH", d["dtype"], d["value"], d["unit"], d["ms_per_step"], "ms/step; roofline", d["roofline"]["kernel"], d["roofline"]["frac"], d["roofline"].get("frac_issued"))
-print("  modes", {k: (v["patches_per_s"], v["label_match"]) for k, v in (d.get("modes") or {}).items()})
+print("  modes", (d.get("roofline") or {}).get("modes"))
 print("  extras", d.get("extras")); print("  cpu", d["cpu_baseline"]["value"] if d.get("cpu_baseline") else None)
 PY
 fi

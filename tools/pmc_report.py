@@ -23,7 +23,8 @@ def csrc_sha():
     import hashlib
     h = hashlib.sha1()
     base = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "sbb_textline_detection_amd", "csrc")
-    for name in ("kernels.hip", "block_x3.hip", "stem_pool_x3.hip", "dec_halo_x3.hip", "dec_halo_f16.hip", "expand_reduce_x3.hip", "api.hip", "internal.h"):
+    for name in ("kernels.hip", "block_x3.hip", "stem_pool_x3.hip", "dec_halo_x3.hip", "dec_halo_f16.hip", "expand_reduce_x3.hip", "region.hip", "region.h",
+                 "api.hip", "internal.h"):
         with open(os.path.join(base, name), "rb") as f:
             h.update(f.read())
     return h.hexdigest()[:12]
