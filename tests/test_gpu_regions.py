@@ -182,3 +182,23 @@ def test_generic_kernel_levels_and_tile_families(model448):
             # another tile family rounds nothing differently (same K order per accumulator): still the same map
             pass
         assert np.array_equal(got, ref), hex(variant)
+
+
+@pytest.mark.parametrize("precision", ["f16x3", "f16"])
+def test_random_page_sizes_owned_equals_whole(precision):
+    """Randomised geometry sweep on the 224 x 224 model (margin 22, mid 180): page extents that land in every regime of the clamp --
+    exact multiples of mid, one pixel more, a repeated clamped tile (extent % 180 in (0, 44]: the dedupe paths), a last tile that owns a
+    few columns only -- owned-region launches against whole-tile launches, byte for byte, with the reference's call list (dedupe off) too."""
+    cfg, w, g, model = make_model(4, 224, 224, seed=9, precision=precision, max_batch=20, calib_hw=160)
+    try:
+        rng = np.random.RandomState(4321)
+        sizes = [(224, 224), (225, 224 * 3), (180 * 3, 180 * 4), (180 * 3 + 1, 180 * 4 - 1), (180 * 2 + 44, 180 * 3 + 45), (404, 405), (583, 227)]
+        sizes += [(int(rng.randint(224, 1000)), int(rng.randint(224, 1000))) for _ in range(6)]
+        for hp, wp in sizes:
+            page = synthetic_page(hp, wp, seed=hp * 7 + wp)
+            for dedupe in (True, False):
+                model.ctx.set_dedupe(dedupe)
+                full, owned = _both(model, lambda: model.segment_page(page))
+                assert np.array_equal(full, owned), (hp, wp, dedupe, int((full != owned).sum()))
+    finally:
+        model.release()

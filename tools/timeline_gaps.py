@@ -14,11 +14,15 @@ with open(sys.argv[1]) as f:
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r.get("Queue_Id", "?"), r["Kernel_Name"].split("(")[0][-70:],
                      any(s in r["Kernel_Name"] for s in PLAN)))
 rows.sort()
+if not rows:
+    sys.exit(f"{sys.argv[1]}: empty kernel trace")
 f0 = float(sys.argv[2]) if len(sys.argv) > 2 else 0.5
 f1 = float(sys.argv[3]) if len(sys.argv) > 3 else 0.9
 t_lo = rows[0][0] + (rows[-1][1] - rows[0][0]) * f0
 t_hi = rows[0][0] + (rows[-1][1] - rows[0][0]) * f1
 sel = [r for r in rows if r[0] >= t_lo and r[1] <= t_hi]
+if not sel:
+    sys.exit(f"{sys.argv[1]}: no kernel inside the [{f0}, {f1}] slice of the trace ({len(rows)} rows in all)")
 span = sel[-1][1] - sel[0][0]
 print(f"{len(sel)} kernels in a {span / 1e6:.2f} ms slice; {sum(1 for r in sel if r[4])} of them plan ops")
 byq = defaultdict(list)
