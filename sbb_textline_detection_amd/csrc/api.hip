@@ -909,6 +909,9 @@ int sbbseg_create(int device, int precision, sbbseg_ctx** out)
     if (const char* v = getenv("SBBSEG_DEDUPE")) c->dedupe = v[0] != '0';
     if (const char* v = getenv("SBBSEG_KSPLIT")) c->ksplit = v[0] != '0';
     if (const char* v = getenv("SBBSEG_OWNED_REGIONS")) c->owned_mode = v[0] == '0' ? 0 : (v[0] == '2' ? 2 : 1);
+    // experiment (round 6): persistent grids sized for this many CUs instead of the device's -- with two lanes, grids of half the chip let both
+    // lanes' kernels run side by side for their whole duration (no CU masks: the dispatcher places the blocks)
+    if (const char* v = getenv("SBBSEG_GRID_CUS")) { const int n = atoi(v); if (n >= 8 && n <= c->num_cus) c->num_cus = n & ~7; }
     *out = c;
     return 0;
     API_END
