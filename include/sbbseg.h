@@ -406,7 +406,8 @@ int sbbseg_debug_read_tensor(sbbseg_ctx* c, int tensor_id, int n, float* out, si
  * bit 22 = split mode: stem and max-pool as two launches (stem_conv_pairs_x3 + maxpool_kernel) instead of stem_pool_x3;
  * bit 23 = the 224 x 224 decoder conv on conv_igemm_mfma instead of dec_halo_x3 / dec_halo_f16 (LDS-resident halos);
  * bit 24 = split mode: an identity block's last 1x1 conv and the next block's first 1x1 conv (encoder stages 3 / 4) as two
- * conv_igemm_mfma launches instead of expand_reduce_x3 */
+ * conv_igemm_mfma launches instead of expand_reduce_x3; bit 25 = the 3x3 conv of a stage-3 identity block as its own launch in front
+ * of expand_reduce instead of inside conv3_expand_reduce */
 int sbbseg_debug_set_conv_variant(sbbseg_ctx* c, int variant);
 /* the exact host-side contour ranking of sbbseg_page_box_dev on a host mask that is ALREADY dilated (no GPU needed; tests) */
 int sbbseg_debug_largest_contour(const uint8_t* mask_hw, int H, int W, int32_t* box_xywh, int64_t* pixels);

@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ_DIR = os.path.join(HERE, "_obj")          # package-local (git- and gpurun-ignored): an installed copy never writes outside itself
 LIB = os.path.join(HERE, "libsbbseg.so")
-SOURCES = ["kernels.hip", "block_x3.hip", "stem_pool_x3.hip", "dec_halo_x3.hip", "dec_halo_f16.hip", "expand_reduce_x3.hip", "region.hip", "api.hip", "loader.cpp"]
+SOURCES = ["kernels.hip", "block_x3.hip", "stem_pool_x3.hip", "dec_halo_x3.hip", "dec_halo_f16.hip", "expand_reduce_x3.hip", "conv3_expand_reduce.hip", "region.hip", "api.hip", "loader.cpp"]
 HEADERS = [os.path.join(CSRC, "internal.h"), os.path.join(CSRC, "region.h"), os.path.join(HERE, "..", "include", "sbbseg.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
 

@@ -127,6 +127,11 @@ struct ConvOp {
                                           // (expand_reduce_x3.hip; sbbseg_finalize), or -1
     uint16_t *d_er_w3 = nullptr, *d_er_w1 = nullptr;      //   ... the two convs' packed rows as MFMA A fragments
     bool fused_into_expand = false;       // split mode: this op's output is written by the launch of the op before it; it launches nothing
+    int fused_conv3 = -1;                 // on an expand conv with fused_reduce: index of the block's 3x3 conv, which the same launch computes too
+                                          // (conv3_expand_reduce.hip; sbbseg_finalize), or -1
+    uint16_t* d_c3_w2 = nullptr;          //   ... the 3x3 conv's packed rows as MFMA A fragments, and its K-steps (taps / channel groups) in order
+    int* d_c3_k0 = nullptr;
+    bool fused_into_c3 = false;           // the 3x3 conv of such a block: its output tensor lives in LDS only, the op launches nothing
     std::vector<float> h_w[2];            // host copy of a small 1x1 conv's weights ([cin][cout] per source): bottleneck fusion
                                           // (sbbseg_finalize) repacks them as MFMA A fragments
     bool fg_ok = true;                    // every K-step (of every class) regular: the fast gather of conv_igemm_mfma applies
@@ -287,6 +292,7 @@ struct sbbseg_ctx {
     bool unfuse_stem_pool = false;     // A/B: stem and max-pool as two launches (conv variant bit 22)
     bool no_dec_halo = false;          // A/B: the 224 x 224 decoder conv on the generic kernel (conv variant bit 23)
     bool no_expand_reduce = false;     // A/B: expand + next reduce 1x1 convs as two launches (conv variant bit 24)
+    bool no_c3er = false;              // A/B: the 3x3 conv of a stage-3 identity block as its own launch in front of expand_reduce (conv variant bit 25)
     bool plain_gather = false;   // A/B: per-load address arithmetic instead of the fast gather (conv variant bit 17)
     int contig_max_k = 0;        // short-K layers up to this K walk their tiles in per-block contiguous runs (tile map 2)
     int fused_heads = 0;
@@ -438,6 +444,7 @@ int launch_op(sbbseg_ctx* c, Op& op, int n, uint8_t* d_labels, float* d_probs)
         } else if (op.type == kConv) {
             const ConvOp& co = op.conv;
             if (co.fused_into_expand && !c->no_expand_reduce && !(c->conv_variant & 3)) return 0;      // written by the expand conv's launch (expand_reduce_x3)
+            if (co.fused_into_c3 && !c->no_c3er && !c->no_expand_reduce && !(c->conv_variant & 3)) return 0;     // computed by the expand conv's launch (conv3_expand_reduce)
             ConvParams p;
             p.ks_shift = 0; p.ks_ws = nullptr; p.ks_split_elems = 0;
             memset(&p, 0, sizeof(p));
@@ -474,8 +481,11 @@ int launch_op(sbbseg_ctx* c, Op& op, int n, uint8_t* d_labels, float* d_probs)
             // XCD-grouped walk for single-class layers: measured neutral-to-slower (it removes the n_ct-fold
             // re-fetch of the pixel operand, but those layers are not bound by fetch bytes) -> opt-in, bit 5
             // (split mode: on by default -- twice the pixel bytes; +0.7 % page throughput in two runs, profiles/r03_experiments.md)
+            // (SBBSEG_PSHARE_MAX_MB: weight-matrix size up to which the pixel-sharing walk is taken; round 6 experiment -- the K >= 768 merge / reduce
+            //  convs of stages 4 / 5 and dec0 re-fetch their pixel operand once per channel tile under map 0: PMC FETCH = n_ct x the input)
+            static const size_t pshare_max = (size_t)(getenv("SBBSEG_PSHARE_MAX_MB") ? atoi(getenv("SBBSEG_PSHARE_MAX_MB")) : 2) << 20;
             p.tile_map = (((c->conv_variant & 32) || c->precision == kF16X3) && !(c->conv_variant & 8) && (c->conv_variant & 4) == 0 && co.d.cout > conv_tile_bc(co.d.cout) && p.M >= 256 * 128 &&
-                          (size_t)co.cout_pad * co.Ktot * c->elem <= ((size_t)2 << 20)) ? 1 : 0;
+                          (size_t)co.cout_pad * co.Ktot * c->elem <= pshare_max) ? 1 : 0;
             if (p.tile_map == 1 && co.n_cls == 1 && co.Ktot <= c->contig_max_k) p.tile_map = 2;
             p.w = co.d_w; p.Ktot = co.Ktot; p.total_ksteps = co.total_ksteps;
             p.Ho = co.Ho; p.Wo = co.Wo; p.M = n * co.Ho * co.Wo;
@@ -531,6 +541,20 @@ int launch_op(sbbseg_ctx* c, Op& op, int n, uint8_t* d_labels, float* d_probs)
                 HIPCHK(launch_direct64(dp, c->precision, c->num_cus, c->stream));
             } else if (co.fused_reduce >= 0 && !c->no_expand_reduce && !(c->conv_variant & 3)) {
                 const ConvOp& ro = c->ops[co.fused_reduce].conv;
+                if (co.fused_conv3 >= 0 && !c->no_c3er) {
+                    const ConvOp& k3 = c->ops[co.fused_conv3].conv;
+                    const Tensor& ta = c->tensors[k3.d.src[0].tensor];
+                    C3ERParams cp;
+                    cp.a = ta.buf; cp.x = c->tensors[co.d.residual_tensor].buf;
+                    cp.y = c->tensors[co.d.out_tensor].buf; cp.a2 = c->tensors[ro.d.out_tensor].buf;
+                    cp.n = n; cp.H = ta.H; cp.W = ta.W; cp.C = co.d.src[0].channels; cp.x3 = c->precision == kF16X3;
+                    cp.w2frag = co.d_c3_w2; cp.w3frag = co.d_er_w3; cp.w1frag = co.d_er_w1;
+                    cp.s2 = k3.d_scale; cp.h2 = k3.d_shift; cp.s3 = co.d_scale; cp.h3 = co.d_shift; cp.s1 = ro.d_scale; cp.h1 = ro.d_shift;
+                    cp.wmul2 = k3.wmul_cls[0]; cp.wmul3 = co.wmul_cls[0]; cp.wmul1 = ro.wmul_cls[0];
+                    cp.k0 = co.d_c3_k0;
+                    HIPCHK(launch_conv3_expand_reduce(cp, c->num_cus, c->stream));
+                    return 0;
+                }
                 ExpRedParams ep;
                 ep.b = c->tensors[co.d.src[0].tensor].buf; ep.x = c->tensors[co.d.residual_tensor].buf;
                 ep.y = c->tensors[co.d.out_tensor].buf; ep.a2 = c->tensors[ro.d.out_tensor].buf;
@@ -944,6 +968,7 @@ int sbbseg_destroy(sbbseg_ctx* c)
         (void)hipFree(op.conv.d_head_w); (void)hipFree(op.conv.d_head_scale); (void)hipFree(op.conv.d_head_shift); (void)hipFree(op.conv.d_stem_wfrag); (void)hipFree(op.conv.d_d64_wfrag);
         (void)hipFree(op.conv.d_halo_wfrag); (void)hipFree(op.conv.d_halo_taps);
         (void)hipFree(op.conv.d_er_w3); (void)hipFree(op.conv.d_er_w1);
+        (void)hipFree(op.conv.d_c3_w2); (void)hipFree(op.conv.d_c3_k0);
         for (int q = 1; q < 4; ++q) { (void)hipFree(op.conv.d_w_cls[q]); (void)hipFree(op.conv.d_kstep_cls[q]); (void)hipFree(op.conv.d_ktab_cls[q]); }
         (void)hipFree(op.head.d_w); (void)hipFree(op.head.d_scale); (void)hipFree(op.head.d_shift);
         (void)hipFree(op.pool.d_pre_scale); (void)hipFree(op.pool.d_pre_shift);
@@ -2086,6 +2111,67 @@ int sbbseg_finalize(sbbseg_ctx* c, int max_batch)
             if (upload(c, &e.d_er_w3, f3.data(), f3.size()) || upload(c, &e.d_er_w1, f1.data(), f1.size())) return 1;
             e.fused_reduce = (int)(i + 1);
             r.fused_into_expand = true;
+        }
+        // Round 6, stage 3 (C = 128; H, W multiples of 8): the identity block's 3x3 conv in front of such a pair joins the launch
+        // (conv3_expand_reduce.hip: b stays in LDS).  The conv's packed rows are re-laid as A fragments in ITS K-step order, the taps and
+        // channel groups of the K-steps go along as a table.  SBBSEG_C3ER=0 keeps the 3x3 conv's own launch.
+        const char* env3 = getenv("SBBSEG_C3ER");
+        auto readers_of = [&](int tensor) {
+            int nrd = 0;
+            for (const Op& o : c->ops) {
+                if (o.type == kConv) {
+                    for (int s = 0; s < o.conv.d.n_src; ++s) nrd += o.conv.d.src[s].tensor == tensor;
+                    nrd += o.conv.d.residual_tensor == tensor;
+                } else if (o.type == kPool) nrd += o.pool.src == tensor;
+                else if (o.type == kHead) nrd += o.head.src == tensor;
+                else if (o.type == kTail) nrd += (o.tail.src0 == tensor) + (o.tail.img == tensor);
+                else if (o.type == kBlock) nrd += o.block.x_tensor == tensor;
+            }
+            return nrd;
+        };
+        for (size_t i = 1; (x3 || c->precision == kF16) && !(env && env[0] == '0') && !(env3 && env3[0] == '0') && i < c->ops.size(); ++i) {
+            if (c->ops[i].type != kConv || c->ops[i - 1].type != kConv) continue;
+            ConvOp& e = c->ops[i].conv;
+            ConvOp& k3 = c->ops[i - 1].conv;
+            if (e.fused_reduce < 0) continue;
+            const int C = e.d.src[0].channels;
+            const sbbseg_conv_desc& d = k3.d;
+            const int ks0 = 9 * C / kch;
+            if (C != 128 || k3.n_cls != 1 || d.n_src != 1 || d.cout != C || d.src[0].channels != C || d.src[0].kh != 3 || d.src[0].kw != 3 ||
+                d.src[0].stride_y != 1 || d.src[0].stride_x != 1 || d.src[0].pad_top != 1 || d.src[0].pad_left != 1 || d.src[0].up_shift || d.src[0].off_y ||
+                d.src[0].off_x || !d.relu || d.residual_tensor >= 0 || d.raw_out_tensor >= 0 || d.head_classes > 0 || d.out_tensor != e.d.src[0].tensor ||
+                d.out_stride_y != 1 || d.out_stride_x != 1 || d.out_off_y || d.out_off_x || k3.d_stem_wfrag || k3.d_d64_wfrag || k3.d_halo_wfrag ||
+                k3.fused_into_expand || k3.fused_reduce >= 0 || k3.total_ksteps != ks0 || k3.Ktot != ks0 * 64 || k3.cout_pad < C ||
+                (int)k3.h_ksteps_cls[0].size() != ks0 || readers_of(d.out_tensor) != 1)
+                continue;
+            const Tensor &ta = c->tensors[d.src[0].tensor], &tb = c->tensors[d.out_tensor];
+            if (ta.C != C || ta.is_input_form || ta.H != d.out_h || ta.W != d.out_w || tb.H != ta.H || tb.W != ta.W || (ta.H & 7) || (ta.W & 7)) continue;
+            std::vector<int> k0(ks0);
+            bool ok = true;
+            for (int t = 0; t < ks0 && ok; ++t) {
+                const KStepRec& r = k3.h_ksteps_cls[0][t];
+                ok = !r.irregular && r.dy >= -1 && r.dy <= 1 && r.dx >= -1 && r.dx <= 1 && r.coff >= 0 && r.coff % 128 == 0 && r.coff / 128 < C / kch;
+                k0[t] = (r.dy & 255) | ((r.dx & 255) << 8) | ((r.coff / 128) << 16);
+            }
+            if (!ok) continue;
+            alloc_check();
+            const int MI0 = C / 128;
+            std::vector<uint16_t> m2((size_t)k3.cout_pad * k3.Ktot);
+            HIPCHK(hipMemcpy(m2.data(), k3.d_w, m2.size() * sizeof(uint16_t), hipMemcpyDeviceToHost));
+            std::vector<uint16_t> f2((size_t)ks0 * 8 * MI0 * 2 * 64 * 8);
+            for (int t = 0; t < ks0; ++t)
+                for (int w = 0; w < 8; ++w)
+                    for (int m = 0; m < MI0; ++m)
+                        for (int lo = 0; lo < 2; ++lo)
+                            for (int l = 0; l < 64; ++l) {
+                                const int row = (w * MI0 + m) * 16 + (l & 15);
+                                const uint16_t* src = &m2[(size_t)row * k3.Ktot + (size_t)t * 64 + lo * 32 + (l >> 4) * 8];
+                                uint16_t* dst = &f2[(((((size_t)t * 8 + w) * MI0 + m) * 2 + lo) * 64 + l) * 8];
+                                for (int q = 0; q < 8; ++q) dst[q] = src[q];
+                            }
+            if (upload(c, &e.d_c3_w2, f2.data(), f2.size()) || upload(c, &e.d_c3_k0, k0.data(), k0.size())) return 1;
+            e.fused_conv3 = (int)(i - 1);
+            k3.fused_into_c3 = true;
         }
     }
     // split and plain fp16 modes: the stem (dedicated kernel, raw output only) directly followed by the 3x3 / stride-2 max-pool of that tensor with an
@@ -3508,7 +3594,7 @@ int sbbseg_debug_counter(sbbseg_ctx* c, int which, int64_t* value)
 int sbbseg_debug_set_conv_variant(sbbseg_ctx* c, int variant)
 {
     API_BEGIN
-    REQUIRE(c && variant >= 0 && variant <= 0x1ffffff, "variant: bits 0-1 = 0 auto | 1 4-wave/2-stage | 2 8-wave/3-stage; bit 2 = one block per tile (non-persistent); bit 3 = no XCD-grouped tile walk; bit 4 = half-K-step stages; bit 5 = XCD-grouped walk on single-class layers; bit 6 = drain epilogue stores; bit 7 = half-line epilogue stores; bits 8-15 = contiguous-run K limit / 64; bit 16 = 8-phase schedule on the 256x256 tile; bit 17 = plain gather everywhere; bit 18 = fused bottleneck blocks run as their three convs; bit 19 = XCD-contiguous walk for grouped launches; bit 20 = one-group form of the fused block kernel; bit 21 = extract_page ranks contours on the host always; bit 22 = stem and max-pool as two launches; bit 23 = the 224 x 224 decoder conv on the generic kernel; bit 24 = expand + next reduce 1x1 convs as two launches");
+    REQUIRE(c && variant >= 0 && variant <= 0x3ffffff, "variant: bits 0-1 = 0 auto | 1 4-wave/2-stage | 2 8-wave/3-stage; bit 2 = one block per tile (non-persistent); bit 3 = no XCD-grouped tile walk; bit 4 = half-K-step stages; bit 5 = XCD-grouped walk on single-class layers; bit 6 = drain epilogue stores; bit 7 = half-line epilogue stores; bits 8-15 = contiguous-run K limit / 64; bit 16 = 8-phase schedule on the 256x256 tile; bit 17 = plain gather everywhere; bit 18 = fused bottleneck blocks run as their three convs; bit 19 = XCD-contiguous walk for grouped launches; bit 20 = one-group form of the fused block kernel; bit 21 = extract_page ranks contours on the host always; bit 22 = stem and max-pool as two launches; bit 23 = the 224 x 224 decoder conv on the generic kernel; bit 24 = expand + next reduce 1x1 convs as two launches");
     c->conv_variant = variant & 0xff;
     c->ph8 = (variant >> 16) & 1;
     c->plain_gather = (variant >> 17) & 1;
@@ -3519,6 +3605,7 @@ int sbbseg_debug_set_conv_variant(sbbseg_ctx* c, int variant)
     c->unfuse_stem_pool = (variant >> 22) & 1;
     c->no_dec_halo = (variant >> 23) & 1;
     c->no_expand_reduce = (variant >> 24) & 1;
+    c->no_c3er = (variant >> 25) & 1;
     if ((variant >> 8) & 0xff) c->contig_max_k = ((variant >> 8) & 0xff) * 64;
     return 0;
     API_END

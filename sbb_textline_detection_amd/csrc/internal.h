@@ -245,6 +245,26 @@ struct ExpRedParams {
     int dbg;                  // timing probes (SBBSEG_ER_DBG; results are WRONG with any bit set): 1 = one weight block, 2 = y stores dropped, 4 = x reads dropped
 };
 
+// Encoder stage 3: an identity block's 3x3 conv + its last 1x1 conv + the next block's first 1x1 conv in one launch
+// (conv3_expand_reduce.hip): b = ReLU(BN(W2 * a)) lives in LDS only.
+struct C3ERParams {
+    const char* a;            // buffer start (zero header), [n][H][W][C]: the 3x3 conv's input
+    const char* x;            // buffer start (zero header), [n][H][W][4C]: the residual
+    char* y;                  // buffer start (zero header), [n][H][W][4C]
+    char* a2;                 // buffer start (zero header), [n][H][W][C]: the reduce's output
+    int n, H, W;              // H, W multiples of 8
+    int C;                    // 128
+    int x3;                   // 1: split mode; 0: plain fp16
+    const void* w2frag;       // [9 C / KCH K-steps][8 waves][C / 128 row blocks][hi | lo][64 lanes] x 16 B: A fragments of the 3x3 conv's packed rows, its K order
+    const void* w3frag;       // as ExpRedParams
+    const void* w1frag;
+    const float *s2, *h2;     // [C] scale / shift of the 3x3 conv
+    const float *s3, *h3;     // [4C]
+    const float *s1, *h1;     // [C]
+    float wmul2, wmul3, wmul1;
+    const int* k0;            // device [9 C / KCH]: the 3x3 conv's K-steps in its own order: (dy & 255) | (dx & 255) << 8 | channel group << 16
+};
+
 struct HeadParams {
     const void* src;          // [M][cin] activations (data pointer)
     int cin;                  // <= 64, multiple of 8
@@ -306,6 +326,7 @@ hipError_t launch_tail(const TailParams& p, int precision, int num_cus, hipStrea
 hipError_t launch_stem(const StemParams& p, int precision, int num_cus, hipStream_t s);
 hipError_t launch_dec_halo_x3(const DecHaloParams& p, int num_cus, hipStream_t s);     // split mode: dec4 with LDS-resident halos (dec_halo_x3.hip)
 hipError_t launch_dec_halo_f16(const DecHaloParams& p, int num_cus, hipStream_t s);
+hipError_t launch_conv3_expand_reduce(const C3ERParams& p, int num_cus, hipStream_t s);   // 3x3 + expand + next reduce (conv3_expand_reduce.hip)
 hipError_t launch_expand_reduce_x3(const ExpRedParams& p, int num_cus, hipStream_t s);   // split mode: expand + next reduce 1x1 (expand_reduce_x3.hip)    // ... plain fp16 mode (dec_halo_f16.hip)
 hipError_t launch_stem_pool_x3(const StemParams& p, int num_cus, hipStream_t s);      // split mode: stem + max-pool in one launch (stem_pool_x3.hip)
 hipError_t launch_direct64(const Direct64Params& p, int precision, int num_cus, hipStream_t s);

@@ -68,7 +68,7 @@ def _kernel_bodies(text):
 
 @pytest.mark.skipif(shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"), reason="hipcc not available")
 @pytest.mark.parametrize("source,hand_counted", [("stem_pool_x3.hip", True), ("dec_halo_x3.hip", True), ("dec_halo_f16.hip", True),
-                                                  ("expand_reduce_x3.hip", True), ("block_x3.hip", False)])
+                                                  ("expand_reduce_x3.hip", True), ("conv3_expand_reduce.hip", True), ("block_x3.hip", False)])
 def test_tile_loops_are_not_drained_by_the_compiler(tmp_path, source, hand_counted):
     """The round-4 kernels keep loads in flight across MFMA phases; hipcc's own s_waitcnt insertion drains them (vmcnt(0) inside the
     tile loop) when a one-time load is first used inside the loop, when loads are pending at the loop entry, around conditional

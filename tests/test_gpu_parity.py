@@ -286,12 +286,13 @@ def test_expand_reduce_x3_matches_the_two_launches(hw, nb, precision):
             t = model.plan.tensors[tid]
             out[name] = model.ctx.debug_read_tensor(tid, nb, (t.H, t.W, t.C))
         return out
+    model.ctx.set_conv_variant(1 << 25)              # (the 3x3 conv in front of a stage-3 pair keeps its own launch here: conv3_expand_reduce has its own test)
     got_fused = model.predict(x)
     t_fused = read_all()
-    model.ctx.set_conv_variant(1 << 24)
+    model.ctx.set_conv_variant((1 << 24) | (1 << 25))
     got_two = model.predict(x)
     t_two = read_all()
-    model.ctx.set_conv_variant(0)
+    model.ctx.set_conv_variant(1 << 25)
     for name in t_fused:
         assert np.array_equal(t_fused[name], t_two[name]), (name, float(np.abs(t_fused[name] - t_two[name]).max()))
     assert np.array_equal(got_fused, got_two)
@@ -302,6 +303,53 @@ def test_expand_reduce_x3_matches_the_two_launches(hw, nb, precision):
         assert float(np.abs(got_fused[:2] - ref).max()) < TOL_SOFTMAX["f16x3"] and exact_label_check(ref, got_fused[:2])[1] == 0
     else:
         assert float(np.abs(got_fused[:2] - ref).max()) < 0.2
+    model.release()
+
+
+@pytest.mark.parametrize("precision", ["f16x3", "f16"])
+@pytest.mark.parametrize("hw,nb", [((64, 64), 5), ((128, 192), 4), ((448, 448), 9), ((448, 448), 2)])
+def test_conv3_expand_reduce_matches_the_three_launches(hw, nb, precision):
+    """Encoder stage 3 (C = 128, maps whose sides are multiples of 8): an identity block's 3x3 conv, its last 1x1 conv (+ residual, ReLU) and
+    the next block's first 1x1 conv run as ONE launch (csrc/conv3_expand_reduce.hip: the 3x3's output b lives in LDS only).  Against the
+    3x3 conv's own launch in front of expand_reduce (conv variant bit 25) and against three conv_igemm_mfma launches (bits 24 + 25) every
+    tensor the fused plan still writes must be the same bits; the tensors it no longer writes are exactly the two b's (activation buffers
+    are filled with NaNs before the fused run).  64 x 64 patches: one 8 x 8 tile per patch, every halo pixel outside the image."""
+    h, wd = hw
+    cfg, w, g, model = make_model(2, h, wd, seed=11, precision=precision, max_batch=nb + 2, calib_hw=min(160, max(h, wd)))
+    x = (patches_from_page(h, wd, nb, seed=31) / 255.0).astype(np.float32)
+
+    def read_all():
+        out = {}
+        for name, tid in model.plan.layer_tensor.items():
+            t = model.plan.tensors[tid]
+            out[name] = model.ctx.debug_read_tensor(tid, nb, (t.H, t.W, t.C))
+        return out
+    model.ctx.poison_activations(0xFF)
+    got_fused = model.predict(x)
+    t_fused = read_all()
+    model.ctx.set_conv_variant(1 << 25)
+    got_pair = model.predict(x)
+    t_pair = read_all()
+    model.ctx.set_conv_variant((1 << 24) | (1 << 25))
+    got_three = model.predict(x)
+    t_three = read_all()
+    model.ctx.set_conv_variant(0)
+    skipped = []
+    for name in t_fused:
+        # (tensors inside the fused stage-2 blocks are written by none of the three runs: NaN everywhere, in all of them)
+        assert np.array_equal(t_pair[name], t_three[name], equal_nan=True), name
+        if np.isnan(t_fused[name]).all() and not np.isnan(t_three[name]).any():
+            skipped.append(name)
+            continue
+        assert np.array_equal(t_fused[name], t_three[name], equal_nan=True), (name, float(np.nanmax(np.abs(t_fused[name] - t_three[name]))))
+    shapes = {model.plan.tensors[model.plan.layer_tensor[n]].C for n in skipped}
+    assert len(skipped) == 2 and shapes == {128}, skipped            # blocks 2 and 3 of stage 3: their 3x3 outputs never reach HBM
+    assert np.array_equal(got_fused, got_three) and np.array_equal(got_pair, got_three)
+    for _ in range(3):                                               # the hand-placed waits must not race
+        assert np.array_equal(model.predict(x), got_fused)
+    ref = kf.forward(g, w, x[:2])
+    if precision == "f16x3" and hw == (448, 448):
+        assert float(np.abs(got_fused[:2] - ref).max()) < TOL_SOFTMAX["f16x3"] and exact_label_check(ref, got_fused[:2])[1] == 0
     model.release()
 
 
