@@ -2214,6 +2214,15 @@ int sbbseg_finalize(sbbseg_ctx* c, int max_batch)
             if (dmalloc(c, (void**)&t.lane_buf[1], bytes)) return 1;
             HIPCHK(hipMemset(t.lane_buf[1], 0, t.is_input_form ? bytes : (size_t)kZeroHeaderBytes));
         }
+    // a 3x3 conv that conv3_expand_reduce computes never writes its output tensor: give the buffers a defined content (zeros) -- the debug
+    // read-back of a plan tensor and the tests that compare whole plans then see the same bytes in every run
+    for (const Op& op : c->ops)
+        if (op.type == kConv && op.conv.fused_into_c3 && op.conv.d.out_tensor >= 0) {
+            Tensor& t = c->tensors[op.conv.d.out_tensor];
+            for (int lane = 0; lane < 2; ++lane)
+                if (t.lane_buf[lane])
+                    HIPCHK(hipMemset(t.lane_buf[lane], 0, kZeroHeaderBytes + t.elems_per_patch * (size_t)(lane == 0 ? max_batch : c->lane1_batch) * c->elem * c->planes));
+        }
     float lut[256];
     for (int v = 0; v < 256; ++v) lut[v] = (float)((double)v / 255.0);   // main.py:239 in f64, then Keras' f32 feed
     if (upload(c, &c->d_lut, lut, 256)) return 1;
