@@ -61,7 +61,7 @@ def csrc_sha():
     """Hash of the device / host sources libsbbseg is built from: ties a committed PMC summary to the kernels it measured."""
     import hashlib
     h = hashlib.sha1()
-    for name in ("kernels.hip", "block_x3.hip", "stem_pool_x3.hip", "dec_halo_x3.hip", "dec_halo_f16.hip", "expand_reduce_x3.hip", "region.hip", "region.h",
+    for name in ("kernels.hip", "block_x3.hip", "stem_pool_x3.hip", "dec_halo_x3.hip", "dec_halo_f16.hip", "expand_reduce_x3.hip", "conv3_expand_reduce.hip", "region.hip", "region.h",
                  "api.hip", "internal.h"):
         with open(os.path.join(ROOT, "sbb_textline_detection_amd", "csrc", name), "rb") as f:
             h.update(f.read())

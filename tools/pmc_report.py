@@ -23,7 +23,7 @@ def csrc_sha():
     import hashlib
     h = hashlib.sha1()
     base = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "sbb_textline_detection_amd", "csrc")
-    for name in ("kernels.hip", "block_x3.hip", "stem_pool_x3.hip", "dec_halo_x3.hip", "dec_halo_f16.hip", "expand_reduce_x3.hip", "region.hip", "region.h",
+    for name in ("kernels.hip", "block_x3.hip", "stem_pool_x3.hip", "dec_halo_x3.hip", "dec_halo_f16.hip", "expand_reduce_x3.hip", "conv3_expand_reduce.hip", "region.hip", "region.h",
                  "api.hip", "internal.h"):
         with open(os.path.join(base, name), "rb") as f:
             h.update(f.read())
