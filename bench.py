@@ -568,9 +568,13 @@ def main():
         ach, iss = rate([dom]), rate([dom], "issued_flops")
         s2_fl, s2_iss, s2_ms = stage2_3x3()
         f3_fl, f3_iss, f3_ms = fused_3x3()
-        k3_ms = sum(o["total_ms"] for o in k3) + f3_ms
-        k3_fl = sum(o["flops"] * o["timed_exec_patches"] for o in k3) + f3_fl
-        k3_iss = sum(o["issued_flops"] * o["timed_exec_patches"] for o in k3) + f3_iss
+        k3_ms = sum(o["total_ms"] for o in k3)
+        k3_fl = sum(o["flops"] * o["timed_exec_patches"] for o in k3)
+        k3_iss = sum(o["issued_flops"] * o["timed_exec_patches"] for o in k3)
+        # `conv3x3_stages` = the 3x3 convs with a launch of their own; `conv3x3_stages_incl_stage2` adds every 3x3 conv that runs inside
+        # another launch -- the three of stage 2 (fused blocks) and the two of stage 3 that ride in conv3_expand_reduce -- with the share of
+        # that launch's time that their share of its (issued) FLOPs is
+        s2_fl, s2_iss, s2_ms = s2_fl + f3_fl, s2_iss + f3_iss, s2_ms + f3_ms
         # (what the numbers mean -- algorithmic vs issued vs executed FLOPs, the profiling pass, peak / 3 in the split mode -- is
         #  written up in DESIGN.md section 6: the line carries numbers only, so that the driver's record keeps all of it)
         r = {

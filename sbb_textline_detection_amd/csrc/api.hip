@@ -2116,6 +2116,8 @@ int sbbseg_finalize(sbbseg_ctx* c, int max_batch)
         // (conv3_expand_reduce.hip: b stays in LDS).  The conv's packed rows are re-laid as A fragments in ITS K-step order, the taps and
         // channel groups of the K-steps go along as a table.  SBBSEG_C3ER=0 keeps the 3x3 conv's own launch.
         const char* env3 = getenv("SBBSEG_C3ER");
+        const char* envfb = getenv("SBBSEG_FUSE_BLOCKS");          // (= 0: "keep every plan tensor materialised" -- the per-layer tests; b would not be)
+        if (envfb && envfb[0] == '0') env3 = "0";
         auto readers_of = [&](int tensor) {
             int nrd = 0;
             for (const Op& o : c->ops) {
