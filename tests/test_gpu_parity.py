@@ -705,7 +705,7 @@ def test_c_abi_error_paths_do_not_abort(stitch_model):
     with pytest.raises(RuntimeError):
         m.ctx.debug_read_tensor(0, 10 ** 6, (1, 1, 1))
     with pytest.raises(RuntimeError, match="variant"):
-        m.ctx.set_conv_variant(1 << 25)
+        m.ctx.set_conv_variant(1 << 26)
     page = synthetic_page(448, 448, seed=1)              # 448x448 page -> 4 identical clamped tiles
     lab = m.segment_page(page)
     assert lab.shape == (448, 448)
