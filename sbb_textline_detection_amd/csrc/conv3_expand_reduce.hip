@@ -14,14 +14,15 @@
 // K-steps of the conv it replaces in that conv's order (taken from its K-step records) with its epilogue arithmetic: b, y and a' are
 // bit-identical to the three launches (tests/test_gpu_parity.py).  b itself is never written to HBM.
 // Every vector-memory operation of the loop is issued from inline asm and waited for by a hand-counted vmcnt (see dec_halo_x3.hip).
-// One count is deliberately NOT the tight one: GEMM 0's first two steps wait `vmcnt(weights of the next step)` although the previous tile's
-// a' stores (epilogue 2) are younger than their own weight request and could be left in flight.  With the stores allowed for, one tile in
-// ~10^5 came out wrong in the plain fp16 mode (tools/first_run_probe.py: a whole patch's labels, run to run): GEMM 0's weights are the one
-// stream of this kernel that misses L2 now and then, and the count `loads of the next step + 4 stores` was reached with the stores
-// acknowledged and the OLDER weight loads still out -- vmcnt does not retire a store behind an older load.  (expand_reduce has the same
-// count at its tile top; its weights are re-read by every tile and have never been seen to lose that race.)  And the two waits are one
-// statement, not an `if (first tile) ... else ...` pair: the `"+v"` ties of two asm statements in two branches make the compiler copy the
-// weight registers in front of one of them -- a copy of registers whose loads are still in flight.
+// One count is deliberately NOT the tight steady-state one: GEMM 0's first two steps wait `vmcnt(weights of the next step)` although the
+// previous tile's a' stores (epilogue 2) are younger than their own weight request and could be left in flight.  The tight count
+// `next step + 4 stores` is only right from a block's second tile on: its FIRST tile has no epilogue in front of it, the count is then
+// looser than what is in flight, and steps 0 / 1 multiplied weight registers whose loads had not landed whenever those loads missed L2 --
+// one tile in ~10^5 in the plain fp16 mode (tools/first_run_probe.py: a whole patch's labels, run to run; with the first tile drained in
+// the prologue and the stores allowed for again: 0 of 144, profiles/r06_experiments.md section 7).  `vmcnt(next step)` is right for every
+// tile and costs nothing measurable (the stores are acknowledged by then).  expand_reduce had the same tile top since round 4.  And the
+// wait is one statement, not an `if (first tile) ... else ...` pair: the `"+v"` ties of two asm statements in two branches make the
+// compiler copy the weight registers in front of one of them -- a copy of registers whose loads are still in flight.
 #include "internal.h"
 
 namespace sbbseg {
@@ -335,8 +336,8 @@ __global__ __launch_bounds__(512, 2) void conv3_expand_reduce(const C3ERParams p
             if constexpr (!g0 && !g1 && k + 1 < G2S) load_frags(lds_y, YROW, SLY, k + 1, bh[set ^ 1], bl[set ^ 1]);
             u4_t (&cw)[4] = w[set];
             if constexpr (g0 && k < 2) {
-                // (the a' stores of the previous tile's epilogue 2 sit between this step's weight request and here; they are NOT allowed for
-                //  in the count -- see the header: a store may be acknowledged before an older load has returned)
+                // (the a' stores of the previous tile's epilogue 2 sit between this step's weight request and here -- but not on a block's
+                //  first tile: they are NOT allowed for in the count, see the header)
                 wait4<Lnext>(cw[0], cw[1], cw[2], cw[3]);
             } else {
                 wait4<Lnext + extra>(cw[0], cw[1], cw[2], cw[3]);

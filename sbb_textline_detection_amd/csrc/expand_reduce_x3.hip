@@ -263,10 +263,11 @@ __global__ __launch_bounds__(512, 2) void expand_reduce(const ExpRedParams p)
             if constexpr (!g1 && k + 1 < G2S) load_frags(lds_y, YROW, SLY, k + 1, bh[set ^ 1], bl[set ^ 1]);
             u4_t (&cw)[4] = w[set];
             if constexpr (g1 && j == 0 && k < 2) {
-                // (round 6: the previous tile's a' stores are younger than this step's weight request but are NOT allowed for in the count --
-                //  vmcnt does not retire a store behind an older load; conv3_expand_reduce, which has the same tile top, lost that race once
-                //  in ~1e5 tiles when its weight loads missed L2: profiles/r06_experiments.md section 7.  One statement, not an if / else pair
-                //  of two asm waits: see there too)
+                // (round 6: the previous tile's a' stores are younger than this step's weight request but are NOT allowed for in the count:
+                //  a block's FIRST tile has no epilogue in front of it, the count with the stores in was looser than what is in flight there, and
+                //  steps 0 / 1 could multiply weights still on their way.  conv3_expand_reduce, which has the same tile top, lost that race once in
+                //  ~1e5 tiles when its weight loads missed L2: profiles/r06_experiments.md section 7.  One statement, not an if / else pair of
+                //  two asm waits: see there too)
                 wait4<Lnext>(cw[0], cw[1], cw[2], cw[3]);
             } else {
                 wait4<Lnext + extra>(cw[0], cw[1], cw[2], cw[3]);

@@ -24,6 +24,12 @@ page = synthetic_page(H, W, seed=0)
 d_page = torch.from_numpy(page).cuda()
 d_out = torch.empty((324, 448, 448), dtype=torch.uint8, device="cuda")
 ctx = m.ctx
+if os.environ.get("PROBE_LANES"):
+    ctx.set_lanes(int(os.environ["PROBE_LANES"]))
+    print("lanes", os.environ["PROBE_LANES"])
+if os.environ.get("PROBE_OWNED"):
+    ctx.set_owned_regions(int(os.environ["PROBE_OWNED"]))      # 2: the tile-range entry point computes owned regions too
+    print("owned regions mode", os.environ["PROBE_OWNED"])
 if variant:
     ctx.set_conv_variant(variant)
     print(f"conv variant {variant:#x}")
