@@ -6,7 +6,7 @@ TAG=${1:-r06}
 PREC=${2:-f16x3}
 mkdir -p gpurun_out
 if [ "$3" != "skip-tests" ]; then
-  timeout -k 5 2700 python -m pytest tests -m gpu -q > gpurun_out/pytest_gpu_$TAG.log 2>&1; echo "pytest rc=$?"; tail -3 gpurun_out/pytest_gpu_$TAG.log
+  timeout -k 5 2700 python -m pytest tests -m gpu -q --durations=25 > gpurun_out/pytest_gpu_$TAG.log 2>&1; echo "pytest rc=$?"; tail -3 gpurun_out/pytest_gpu_$TAG.log
   python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3
   timeout -k 5 900 python bench.py --steps 20 --warmup 5 > gpurun_out/bench_$TAG.log 2>&1; tail -1 gpurun_out/bench_$TAG.log > gpurun_out/bench_$TAG.json
   python - <<PY
